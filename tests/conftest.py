@@ -1,0 +1,60 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Golden:
+    """One golden case: seeded inputs + the reference's stage-by-stage outputs
+    (tests/golden/gen_golden.py)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.pred = self.z["pred_f16"].astype(np.float32)
+        self.foreground = self.z["foreground"]
+        self.numinst = self.z["numinst"]
+        self.patchshape = [int(p) for p in self.z["patchshape"]]
+        self.kw = json.loads(str(self.z["flags"]))
+        self.kw.setdefault("max_total_patch_distance_in_ps_multiples", 2)
+        self.overlap_mask = 1 * (self.numinst > 1)
+
+    def has(self, key):
+        return key in self.z.files
+
+    def __getitem__(self, key):
+        return self.z[key]
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    return Golden(request.param)
+
+
+def same_partition(a, b):
+    """True if label volumes a and b are equal up to a permutation of the ids."""
+    a = np.asarray(a).ravel().astype(np.int64)
+    b = np.asarray(b).ravel().astype(np.int64)
+    if a.shape != b.shape or not np.array_equal(a == 0, b == 0):
+        return False
+    pairs = np.unique(np.stack([a, b], axis=1), axis=0)
+    return len(np.unique(pairs[:, 0])) == len(pairs) and \
+        len(np.unique(pairs[:, 1])) == len(pairs)
