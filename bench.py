@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxels/s assembled by vote_instances on MI355X (BASELINE.json metric).
+
+One "step" = one full pass of the hot path (consensus -> ranking -> cover -> pairs ->
+patch graph -> labelling) over one synthetic prediction volume that is already resident in
+HBM when the timed region starts.  Prints ONE JSON line ("Measurement").
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: every rank assembles its own
+z-slab tile of an N-times larger volume (weak scaling, no collective on the data path in
+this round -- see DESIGN.md "Multi-GPU").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (shape, patchshape, cell size of the synthetic instances)
+    # BASELINE.json configs[1]: flylight setup01 3-d crop 140^3, 7x7x7 patch
+    "flylight140_p7": ((140, 140, 140), (7, 7, 7), (18, 18, 18)),
+    # reduced variants for quick checks
+    "synth64_p5": ((64, 64, 64), (5, 5, 5), (12, 12, 12)),
+    "synth96_p7": ((96, 96, 96), (7, 7, 7), (18, 18, 18)),
+    # BASELINE.json configs[2] (needs the tiled consensus path)
+    "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
+}
+CPU_SAMPLE = {"flylight140_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
+              "synth64_p5": (24, 24, 24), "synth512_p9": (26, 26, 26)}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def device_labels(torch, shape, cell, seed, z_offset=0):
+    """patchperpix_amd.synth.cell_labels evaluated with torch ops on the device (plumbing
+    for the synthetic input; not part of the measured path)."""
+    def hash_u32(x):
+        m = 0xFFFFFFFF
+        x = x & m
+        x = (x ^ (x >> 16)) & m
+        x = (x * 0x7FEB352D) & m
+        x = (x ^ (x >> 15)) & m
+        x = (x * 0x846CA68B) & m
+        x = (x ^ (x >> 16)) & m
+        return x
+    dev = "cuda"
+    zz = torch.arange(shape[0], device=dev, dtype=torch.int64).view(-1, 1, 1) + z_offset
+    yy = torch.arange(shape[1], device=dev, dtype=torch.int64).view(1, -1, 1)
+    xx = torch.arange(shape[2], device=dev, dtype=torch.int64).view(1, 1, -1)
+    cz = zz // cell[0]
+    sy = hash_u32(cz * 7919 + seed) % max(1, cell[1])
+    cy = (yy + sy) // cell[1]
+    sx = hash_u32((cz * 131 + cy) * 104729 + seed + 1) % max(1, cell[2])
+    cx = (xx + sx) // cell[2]
+    key = ((cz * 1000003 + cy) * 1000003 + cx) & 0xFFFFFFFF
+    h = hash_u32(key + (seed * 2654435761) % (1 << 32))
+    lab = (h % 65000) + 1
+    lab = torch.where(((h >> 16) % 16) == 0, torch.zeros_like(lab), lab)
+    return lab.to(torch.int32).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="flylight140_p7", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from patchperpix_amd import backend
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import vote_instances as vi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL
+    n_gpus = max(args.gpus, world)
+
+    shape, ps, cell = WORKLOADS[args.workload]
+    kw = dict(FLYLIGHT)
+    P = backend.make_params(shape, ps, **kw)
+    # every rank: its own z-slab of an N-times taller volume (distinct instances per rank)
+    labels = device_labels(torch, shape, cell, seed=0, z_offset=rank * shape[0])
+    pred = backend.synth_pred(labels, P, seed=rank, f16=True)       # resident in HBM
+    fg_host = (labels != 0).cpu().numpy()
+    numinst = fg_host.astype(np.uint8)
+    torch.cuda.synchronize()
+
+    def step():
+        inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps, **kw)
+        return inst
+
+    for _ in range(args.warmup):
+        inst = step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    backend.EVENTS = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        inst = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ev = backend.event_times_ms()
+    backend.EVENTS = None
+
+    V = float(np.prod(shape))
+    C = int(np.prod(ps))
+    value = n_gpus * V * args.steps / dt / 1e6
+    # roofline of the dominant kernel (S1 consensus): algorithmic bytes = prediction block
+    # read once (f16 resident: 2*C*V) + overlap mask (V); outputs excluded
+    s1_ms = float(np.mean(ev["consensus"])) if ev.get("consensus") else None
+    alg_bytes = 2.0 * C * V + V
+    roofline = None
+    if s1_ms:
+        achieved = alg_bytes / (s1_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "consensus_gather_kernel", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes": alg_bytes, "avg_ms": s1_ms}
+
+    if rank == 0:
+        out = {
+            "metric": "Mvoxels/sec assembled (vote_instances)", "value": value,
+            "unit": "Mvoxels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "volume": list(shape), "patchshape": list(ps),
+                       "pred_dtype": "f16 resident, widened to f32 in registers",
+                       "flags": "flylight default.toml [vote_instances]",
+                       "instances_found": int(len(np.unique(inst)) - 1),
+                       "parallelism": "tiles%d" % n_gpus},
+            "roofline": roofline,
+            "stage_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, ps, cell, kw)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(workload, ps, cell, kw):
+    """The CPU oracle (a port of the reference's kernel arithmetic + host stages) timed on a
+    bounded sample of the same generator, one host core."""
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd import synth
+    sshape = CPU_SAMPLE[workload]
+    lab = synth.cell_labels(sshape, cell, seed=0)
+    pred = synth.pred_from_labels(lab, ps, seed=0)
+    fg = lab != 0
+    orc.lib()
+    t0 = time.perf_counter()
+    orc.to_instance_seg(pred, fg, fg.copy(), fg.astype(np.uint8), ps, **kw)
+    dt = time.perf_counter() - t0
+    return {"value": float(np.prod(sshape)) / dt / 1e6, "unit": "Mvoxels/s", "cores": 1,
+            "kind": "port", "seconds": dt,
+            "sample": "%s sub-volume of the same generator, %s patch, full pipeline "
+                      "(oracle/ppp_oracle)" % ("x".join(map(str, sshape)), "x".join(map(str, ps)))}
+
+
+if __name__ == "__main__":
+    main()

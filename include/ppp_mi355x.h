@@ -1,0 +1,203 @@
+/*
+ * ppp_mi355x.h -- C ABI of libppp_mi355x.so: the MI355X (gfx950) implementation of
+ * PatchPerPix's vote_instances device path.
+ *
+ * This is the drop-in boundary.  In the reference the plug is the pycuda shim
+ * PatchPerPix/vote_instances/cuda_code.py:5-59 (make_kernel / alloc_zero_array / sync)
+ * plus the four JIT-templated kernels under PatchPerPix/vote_instances/cuda/.  Here the
+ * kernels are compiled ahead of time for gfx950; shapes, thresholds and the
+ * reference's -D build flags are run-time fields of ppp_params.
+ *
+ * Conventions
+ *  - every pointer named d_* is a DEVICE pointer owned by the caller (the Python
+ *    host code carries them as torch-ROCm tensors); the library never allocates,
+ *    frees or retains them.  h_* pointers are host pointers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *    asynchronous on that stream unless stated otherwise.
+ *  - return value 0 = success, negative = error; ppp_last_error() gives the message
+ *    (thread-local).  Nothing falls back to the CPU: without a HIP device every
+ *    compute entry point fails with PPP_ERR_NO_DEVICE.
+ *  - volumes are (Z, Y, X) C-contiguous; predictions are (C, Z, Y, X) with
+ *    C = pz*py*px, channel r = (z*py + y)*px + x of the patch, float32 or float16
+ *    (the zarr dtype written by experiments/flylight/setups/setup01/predict_no_gp.py:
+ *    243-257; widening to f32 is exact, which is what the reference does on load,
+ *    vote_instances.py:193-200).
+ *
+ * Consensus layout (ppp_params.cons_layout)
+ *  PPP_CONS_COMPACT   [n_planes][bz][by][bx] float32 over the base-voxel box cons_box,
+ *                     one plane per lexicographically positive pixel offset
+ *                     d = (dz,dy,dx), |d_i| <= p_i-1: plane = L-1 with
+ *                     L = (dz*(2py-1) + dy)*(2px-1) + dx  (L > 0 <=> d positive).
+ *                     These are exactly the planes the reference ever writes.
+ *  PPP_CONS_REFERENCE [NSZ][NSY][NSX][Z][Y][X] float32, index o = d + p - 1,
+ *                     NS = 2p (NSZ = 1 when pz == 1): the reference's array
+ *                     (consensus_array.py:99-106); cons_box must be the whole volume.
+ */
+#ifndef PPP_MI355X_H
+#define PPP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPP_ABI_VERSION 1
+
+enum ppp_error {
+    PPP_OK = 0,
+    PPP_ERR_INVALID_ARG = -1,
+    PPP_ERR_NO_DEVICE = -2,
+    PPP_ERR_HIP = -3,
+    PPP_ERR_UNSUPPORTED = -4,
+    PPP_ERR_WORKSPACE = -5
+};
+
+enum ppp_dtype { PPP_F32 = 0, PPP_F16 = 1 };
+
+/* background rule for the second pixel of a pair: -DUSE_INV_TH / -DUSE_HALF_TH /
+ * -DUSE_LESS_THAN_TH (utilVoteInstances.py:389-406) */
+enum ppp_bg_rule { PPP_BG_INV_TH = 0, PPP_BG_HALF_TH = 1, PPP_BG_LESS_THAN_TH = 2 };
+/* vote value: (none = 1) / -DPROB_PRODUCT / -DNORM_PROB_PRODUCT (utilVoteInstances.py:412-427) */
+enum ppp_value_rule { PPP_VAL_COUNT = 0, PPP_VAL_PROB_PRODUCT = 1, PPP_VAL_NORM_PROB_PRODUCT = 2 };
+enum ppp_cons_layout { PPP_CONS_COMPACT = 0, PPP_CONS_REFERENCE = 1 };
+
+typedef struct ppp_box {
+    int32_t z0, y0, x0; /* inclusive */
+    int32_t z1, y1, x1; /* exclusive */
+} ppp_box;
+
+typedef struct ppp_params {
+    int32_t abi_version;   /* PPP_ABI_VERSION */
+    int32_t Z, Y, X;       /* DATAZSIZE, DATAYSIZE, DATAXSIZE                            */
+    int32_t pz, py, px;    /* PSZ, PSY, PSX (odd)                                        */
+    double th;             /* TH  = patch_threshold, compared in double like the         */
+    double thi;            /* THI   reference's literal (utilVoteInstances.py:361-375)   */
+    int32_t bg_rule;       /* enum ppp_bg_rule                                           */
+    int32_t value_rule;    /* enum ppp_value_rule                                        */
+    int32_t use_overlap;   /* -DOVERLAP: skip pixels whose overlap mask is non-zero      */
+    int32_t normalise;     /* consensus_norm_aff: cons /= count (normConsensusArray.cu)  */
+    int32_t norm_rank;     /* -DNORM_PATCH_RANK                                          */
+    int32_t count_pos_neg; /* -DCOUNT_POS_NEG                                            */
+    int32_t norm_aff;      /* -DNORM_PATCH_AFFINITY                                      */
+    int32_t cons_layout;   /* enum ppp_cons_layout                                       */
+    ppp_box cons_box;      /* base voxels held by the consensus buffer (tile)            */
+} ppp_params;
+
+/* --- library / device ------------------------------------------------------------- */
+int ppp_abi_version(void);
+const char *ppp_last_error(void);
+/* number of HIP devices visible; 0 if none (never fails) */
+int ppp_device_count(void);
+
+/* number of consensus planes and floats of a consensus buffer for these params */
+int64_t ppp_cons_planes(const ppp_params *p);
+int64_t ppp_cons_elems(const ppp_params *p);
+
+/* --- S1: consensus = scoring + vote + (count) + normalise ---------------------------
+ * replaces  create_consensus_array_cuda (consensus_array.py:71-206) and the kernels
+ * fillConsensusArray_allPatches (cuda/fillConsensusArray.cu:179-218, run once or twice)
+ * + normConsensusArray (cuda/normConsensusArray.cu:32-43).
+ * Deterministic: every consensus entry is the float sum of its votes in raster order of
+ * the voting patch centres (a legal serialisation of the reference's atomicAdd).
+ * d_cons : out, layout per p->cons_layout, fully overwritten (no pre-zeroing needed)
+ * d_count: optional out (same layout), the vote counts (-DOUTPUT_CNT pass); may be NULL
+ * d_overlap: uint8 (Z,Y,X) or NULL when !use_overlap                                   */
+int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
+                  float *d_count, const ppp_params *p, void *stream);
+
+/* --- S2: patch ranking ---------------------------------------------------------------
+ * replaces rank_patches_cuda (ranked_patches.py:33-74) + kernel rankPatches
+ * (cuda/rankPatches.cu:1-161).  Scores are written for the voxels of `score_box`
+ * (NULL = whole volume) into d_score (Z,Y,X) float32; border voxels get -1 / -9999999,
+ * interior non-foreground voxels 0.  The consensus buffer must cover score_box grown by
+ * the patch radius (clipped to the volume).                                             */
+int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
+                     const uint8_t *d_overlap, float *d_score, const ppp_box *score_box,
+                     const ppp_params *p, void *stream);
+
+/* --- S5: patch graph (edge emission) --------------------------------------------------
+ * replaces computePatchGraph_cuda (aff_patch_graph.py:113-187) + kernel computePatchGraph
+ * (cuda/computePatchGraph.cu:3-136).  d_pairs u32[n_pairs][6] = (z,y,x) of patch A and B,
+ * d_aff f32[n_pairs] out.  The reference's 512-pairs-per-launch loop with its `offset`
+ * argument (aff_patch_graph.py:137-159) is one launch here.                             */
+int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
+                    const uint32_t *d_pairs, uint64_t n_pairs, float *d_aff,
+                    const ppp_params *p, void *stream);
+
+/* --- S6: labelling -------------------------------------------------------------------
+ * replaces setAffgraph (aff_patch_graph.py:31-40) + the connected-components branch of
+ * affGraphToInstances (graph_to_labeling.py:50-54,61-86).
+ *
+ * ppp_label_components: union-find (global atomics) over the rows with aff > 0; nodes are
+ * patch centres identified by their linear voxel index.  Outputs, per pair row i:
+ *   d_cc_key[2*i+0], d_cc_key[2*i+1] (uint32): the ORDER KEY of the component that the
+ *   A / B patch of row i belongs to, or 0xFFFFFFFF if that patch is in no component
+ *   (no positive edge).  The key of a component is the smallest position 2*row+side at
+ *   which any of its members first appears among the rows with aff != 0 -- sorting the
+ *   distinct keys ascending reproduces networkx's component enumeration order.
+ * d_work: workspace of ppp_label_workspace_bytes(p) bytes.                              */
+size_t ppp_label_workspace_bytes(const ppp_params *p);
+int ppp_label_components(const uint32_t *d_pairs, const float *d_aff, uint64_t n_pairs,
+                         uint32_t *d_cc_key, void *d_work, const ppp_params *p, void *stream);
+
+/* ppp_paint_instances: for every node k (d_nodes u32[n_nodes][3]) with label
+ * d_labels[k] > 0, write the label into every voxel of its window whose patch value is
+ * > TH, keeping the maximum label per voxel ("later components overwrite earlier ones",
+ * graph_to_labeling.py:73-84, with labels = component rank + 1).  d_instances u32 (Z,Y,X)
+ * is updated in place (caller zero-initialises).                                        */
+int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_nodes,
+                        const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
+                        const ppp_params *p, void *stream);
+
+/* --- layout helper ---------------------------------------------------------------------
+ * expand a whole-volume COMPACT consensus into the reference's [NSZ][NSY][NSX][Z][Y][X]
+ * array (what create_consensus_array_cuda returns / save_consensus writes).             */
+int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
+                          const ppp_params *p, void *stream);
+
+/* --- foreground / patch bit helpers used by the host stages --------------------------
+ * ppp_patch_bits: for n centres (d_centres u32[n][3]) pack (pred[r][c] > thresh) for
+ * r = 0..C-1 into ceil(C/32) uint32 words each (bit r%32 of word r/32), d_bits
+ * u32[n][ceil(C/32)].  The compare is float32 against (float)thresh, which is how NumPy
+ * evaluates `patch > fc_threshold` for a float32 patch (foreground_cover.py:156-158).      */
+int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres,
+                   uint64_t n, double thresh, uint32_t *d_bits, const ppp_params *p,
+                   void *stream);
+
+/* --- host stages (host pointers; they are host code in the reference as well) ---------
+ * ppp_host_rank_order: all_patches + rank_patches_by_score (vote_instances.py:276,286-287,
+ *   ranked_patches.py:21-30): interior foreground voxels in raster order, stably sorted by
+ *   score descending.  out_lin holds linear voxel indices (capacity Z*Y*X); returns count. */
+int64_t ppp_host_rank_order(const float *h_score, const uint8_t *h_foreground, const int32_t *vol,
+                            const int32_t *patchshape, int64_t *out_lin);
+/* ppp_host_cover_pass: one computeForegroundCoverLoop pass (foreground_cover.py:111-180) over
+ *   n ranked patches; bits from ppp_patch_bits with fc_threshold; selected / mask / remaining
+ *   are updated in place; score_threshold NaN = off, *stopped = 1 when it ended the pass.
+ *   Returns #newly selected.                                                               */
+int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, const int32_t *vol,
+                            const int32_t *patchshape, const int64_t *ranked_lin,
+                            const float *ranked_score, const uint32_t *bits, int64_t n,
+                            int32_t pix_th, double score_threshold, uint8_t *selected,
+                            int64_t *remaining, int32_t *stopped);
+/* ppp_host_thin_cover: thinOutForegroundCover (foreground_cover.py:183-256), keep[n] out.   */
+int64_t ppp_host_thin_cover(const uint8_t *h_mask, const int32_t *vol, const int32_t *patchshape,
+                            const int64_t *sel_lin, const uint32_t *bits, int64_t n,
+                            uint8_t *keep);
+/* ppp_host_patch_pairs: computeAndStorePatchPairs (aff_patch_graph.py:43-110) with a grid
+ *   hash instead of cKDTree; canonical row order (see file header of ppp_host.cpp).
+ *   pairs == NULL returns the row count only.                                               */
+int64_t ppp_host_patch_pairs(const int32_t *sel_zyx, int64_t n, const int32_t *patchshape,
+                             int32_t max_ps_dist, int32_t include_single, int32_t *sorted_zyx,
+                             uint32_t *pairs);
+
+/* --- synthetic input (bench / tests only; same hash as patchperpix_amd/synth.py) ------
+ * fills d_pred (C,Z,Y,X) from a label volume d_labels int32 (Z,Y,X).                    */
+int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
+                   float hi, float lo, float noise, const ppp_params *p, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPP_MI355X_H */

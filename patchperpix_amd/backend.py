@@ -1,0 +1,417 @@
+"""ctypes binding of libppp_mi355x.so (include/ppp_mi355x.h).
+
+This module replaces the reference's device shim ``PatchPerPix/vote_instances/cuda_code.py``
+(pycuda JIT + managed memory) for this package: device buffers are torch-ROCm tensors
+(PyTorch is only the buffer / stream carrier), every computation happens inside the
+hand-written HIP kernels of the shared library.  There is NO fallback: if the library is
+missing, or no GPU is present, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+F32, F16 = 0, 1
+BG_INV_TH, BG_HALF_TH, BG_LESS_THAN_TH = 0, 1, 2
+VAL_COUNT, VAL_PROB_PRODUCT, VAL_NORM_PROB_PRODUCT = 0, 1, 2
+CONS_COMPACT, CONS_REFERENCE = 0, 1
+ABI_VERSION = 1
+NONE_KEY = 0xFFFFFFFF
+
+
+class Box(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("z0", "y0", "x0", "z1", "y1", "x1")]
+
+    def shape(self):
+        return (self.z1 - self.z0, self.y1 - self.y0, self.x1 - self.x0)
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32),
+                ("Z", ctypes.c_int32), ("Y", ctypes.c_int32), ("X", ctypes.c_int32),
+                ("pz", ctypes.c_int32), ("py", ctypes.c_int32), ("px", ctypes.c_int32),
+                ("th", ctypes.c_double), ("thi", ctypes.c_double),
+                ("bg_rule", ctypes.c_int32), ("value_rule", ctypes.c_int32),
+                ("use_overlap", ctypes.c_int32), ("normalise", ctypes.c_int32),
+                ("norm_rank", ctypes.c_int32), ("count_pos_neg", ctypes.c_int32),
+                ("norm_aff", ctypes.c_int32), ("cons_layout", ctypes.c_int32),
+                ("cons_box", Box)]
+
+    @property
+    def shape(self):
+        return (self.Z, self.Y, self.X)
+
+    @property
+    def patchshape(self):
+        return (self.pz, self.py, self.px)
+
+    def copy(self):
+        q = Params()
+        ctypes.memmove(ctypes.byref(q), ctypes.byref(self), ctypes.sizeof(Params))
+        return q
+
+
+_LIB = None
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "ppp_abi_version": (ctypes.c_int, []),
+    "ppp_last_error": (ctypes.c_char_p, []),
+    "ppp_device_count": (ctypes.c_int, []),
+    "ppp_cons_planes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
+    "ppp_cons_elems": (ctypes.c_int64, [ctypes.POINTER(Params)]),
+    "ppp_consensus": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_rank_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.POINTER(Box), ctypes.POINTER(Params),
+                                        ctypes.c_void_p]),
+    "ppp_patch_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_label_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
+    "ppp_label_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                            ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_paint_instances": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                           ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_cons_to_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p,
+                                      ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_synth_pred": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_float, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_host_rank_order": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p]),
+    "ppp_host_cover_pass": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_double, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_int64),
+                                             ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_host_thin_cover": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                             ctypes.c_void_p]),
+    "ppp_host_patch_pairs": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                              ctypes.c_void_p]),
+}
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load libppp_mi355x.so; raise (never fall back) if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "HIP library %s is missing -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(patchperpix_amd has no CPU fallback)" % path)
+        L = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        if L.ppp_abi_version() != ABI_VERSION:
+            raise RuntimeError("libppp_mi355x.so ABI %d != %d" % (L.ppp_abi_version(), ABI_VERSION))
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libppp_mi355x: %s (code %d)" % (lib().ppp_last_error().decode(), rc))
+
+
+def device_count():
+    return lib().ppp_device_count()
+
+
+# ----------------------------------------------------------------------------------------
+# parameters from the reference's kwargs (utilVoteInstances.py:340-449)
+# ----------------------------------------------------------------------------------------
+def make_params(shape_zyx, patchshape, cons_box=None, cons_layout=CONS_COMPACT, **kw):
+    """Translate the reference's keyword flags into ppp_params.
+
+    Mirrors loadKernelFromFile's TH/THI substitution and setKernelBuildOptions' -D flags,
+    including its defaults (vi_bg_use_inv_th defaults to True when absent) and its error
+    for an undefined background rule."""
+    th = float(kw["patch_threshold"])
+    P = Params()
+    P.abi_version = ABI_VERSION
+    P.Z, P.Y, P.X = [int(s) for s in shape_zyx]
+    P.pz, P.py, P.px = [int(p) for p in patchshape]
+    P.th = th
+    P.thi = th if th < 0.5 else 1.0 - th
+    if kw.get("vi_bg_use_inv_th", True):
+        P.bg_rule = BG_LESS_THAN_TH if th < 0.5 else BG_INV_TH
+    elif kw.get("vi_bg_use_half_th", False):
+        P.bg_rule = BG_HALF_TH
+    elif kw.get("vi_bg_use_less_than_th", False):
+        P.bg_rule = BG_LESS_THAN_TH
+    else:
+        raise RuntimeError("how is bg defined for vote instances?")
+    P.use_overlap = 1 if kw.get("overlapping_inst", False) else 0
+    if kw.get("consensus_norm_prob_product", True):
+        P.value_rule = VAL_NORM_PROB_PRODUCT
+    elif kw.get("consensus_prob_product", True):
+        P.value_rule = VAL_PROB_PRODUCT
+    else:
+        assert \
+            not kw.get("consensus_norm_aff", True) and \
+            not kw.get("consensus_interleaved_cnt", True), \
+            "no normalizing for accumulate consensus counter available"
+        P.value_rule = VAL_COUNT
+    P.normalise = 1 if kw.get("consensus_norm_aff", True) else 0
+    P.norm_rank = 1 if kw.get("rank_norm_patch_score", True) else 0
+    P.count_pos_neg = 1 if kw.get("rank_int_counter", False) else 0
+    P.norm_aff = 1 if kw.get("patch_graph_norm_aff", True) else 0
+    P.cons_layout = cons_layout
+    if cons_box is None:
+        cons_box = (0, 0, 0, P.Z, P.Y, P.X)
+    P.cons_box = Box(*[int(v) for v in cons_box])
+    return P
+
+
+def params_from_kwargs(shape_zyx, patchshape, kwargs):
+    """make_params for a reference-style kwargs dict (which may carry this package's own
+    ``cons_box`` / ``cons_layout`` entries next to the reference's flags)."""
+    kw = {k: v for k, v in kwargs.items() if k not in ("cons_box", "cons_layout")}
+    return make_params(shape_zyx, patchshape, cons_box=kwargs.get("cons_box"),
+                       cons_layout=kwargs.get("cons_layout", CONS_COMPACT), **kw)
+
+
+# ----------------------------------------------------------------------------------------
+# torch plumbing
+# ----------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _dev_ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors must be contiguous and on the GPU"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+# Optional per-kernel timing with HIP events on the stream the kernels are launched on
+# (bench.py switches it on): EVENTS = {} collects name -> [(start, stop), ...].
+EVENTS = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if EVENTS is not None:
+            torch = _torch()
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if EVENTS is not None:
+            self.b.record(_torch().cuda.current_stream())
+            EVENTS.setdefault(self.name, []).append((self.a, self.b))
+
+
+def event_times_ms():
+    """name -> list of elapsed ms (call after a synchronize)."""
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (EVENTS or {}).items()}
+
+
+def pred_dtype_code(t):
+    torch = _torch()
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError("pred must be float32 or float16, got %s" % t.dtype)
+
+
+def to_device_pred(pred, device="cuda", keep_f16=True):
+    """Host ndarray / tensor -> contiguous device tensor (f16 stays f16: widening is exact
+    and happens in registers)."""
+    torch = _torch()
+    if isinstance(pred, np.ndarray):
+        if pred.dtype not in (np.float32, np.float16):
+            pred = pred.astype(np.float32)
+        pred = torch.from_numpy(np.ascontiguousarray(pred))
+    if pred.dtype not in (torch.float32, torch.float16):
+        pred = pred.float()
+    if pred.dtype == torch.float16 and not keep_f16:
+        pred = pred.float()
+    return pred.to(device).contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+# device stages
+# ----------------------------------------------------------------------------------------
+def consensus(pred, overlap, P, want_count=False):
+    """S1.  Returns cons (and count) as device float32 tensors shaped
+    [planes, bz, by, bx] (compact) or [NSZ, NSY, NSX, Z, Y, X] (reference layout)."""
+    torch = _torch()
+    L = lib()
+    if P.cons_layout == CONS_REFERENCE:
+        shape = (2 * P.pz if P.pz > 1 else 1, 2 * P.py, 2 * P.px, P.Z, P.Y, P.X)
+    else:
+        shape = (int(L.ppp_cons_planes(ctypes.byref(P))),) + P.cons_box.shape()
+    cons = torch.empty(shape, dtype=torch.float32, device=pred.device)
+    cnt = torch.empty(shape, dtype=torch.float32, device=pred.device) if want_count else None
+    with _timed("consensus"):
+        check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
+                              _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
+    return (cons, cnt) if want_count else cons
+
+
+def rank_patches(pred, cons, overlap, P, score_box=None, out=None):
+    """S2.  Returns the (Z, Y, X) float32 score volume on the device."""
+    torch = _torch()
+    if out is None:
+        out = torch.zeros(P.shape, dtype=torch.float32, device=pred.device)
+    box = None if score_box is None else ctypes.byref(Box(*[int(v) for v in score_box]))
+    with _timed("rank_patches"):
+        check(lib().ppp_rank_patches(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons),
+                                     _dev_ptr(overlap), _dev_ptr(out), box, ctypes.byref(P),
+                                     _stream()))
+    return out
+
+
+def patch_graph(pred, cons, pairs, P):
+    """S5.  pairs: device uint32-as-int32 [N, 6]; returns float32 [N]."""
+    torch = _torch()
+    n = int(pairs.shape[0])
+    aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
+    with _timed("patch_graph"):
+        check(lib().ppp_patch_graph(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons),
+                                    _dev_ptr(pairs), n, _dev_ptr(aff), ctypes.byref(P),
+                                    _stream()))
+    return aff
+
+
+def label_components(pairs, aff, P):
+    """S6 (components).  Returns int64 [N, 2] order keys (NONE_KEY = not in a component)."""
+    torch = _torch()
+    n = int(pairs.shape[0])
+    keys = torch.empty((n, 2), dtype=torch.int32, device=pairs.device)
+    nbytes = int(lib().ppp_label_workspace_bytes(ctypes.byref(P)))
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=pairs.device)
+    check(lib().ppp_label_components(_dev_ptr(pairs), _dev_ptr(aff), n, _dev_ptr(keys),
+                                     _dev_ptr(work), ctypes.byref(P), _stream()))
+    return keys.to(torch.int64) & 0xFFFFFFFF
+
+
+def paint_instances(pred, nodes, labels, instances, P):
+    """S6 (paint).  nodes int32 [K, 3], labels int32 [K], instances int32 (Z, Y, X) in place."""
+    check(lib().ppp_paint_instances(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(nodes),
+                                    _dev_ptr(labels), int(nodes.shape[0]), _dev_ptr(instances),
+                                    ctypes.byref(P), _stream()))
+    return instances
+
+
+def cons_to_reference(cons_compact, P):
+    torch = _torch()
+    shape = (2 * P.pz if P.pz > 1 else 1, 2 * P.py, 2 * P.px, P.Z, P.Y, P.X)
+    ref = torch.empty(shape, dtype=torch.float32, device=cons_compact.device)
+    check(lib().ppp_cons_to_reference(_dev_ptr(cons_compact), _dev_ptr(ref), ctypes.byref(P),
+                                      _stream()))
+    return ref
+
+
+def patch_bits(pred, centres, thresh, P):
+    """Bit r of row k = (pred[r][centre k] > float32(thresh)).  centres int32 [n, 3] on the
+    device; returns int32 [n, ceil(C/32)] on the device."""
+    torch = _torch()
+    n = int(centres.shape[0])
+    words = (P.pz * P.py * P.px + 31) // 32
+    bits = torch.empty((n, words), dtype=torch.int32, device=pred.device)
+    check(lib().ppp_patch_bits(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(centres), n,
+                               float(thresh), _dev_ptr(bits), ctypes.byref(P), _stream()))
+    return bits
+
+
+def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True):
+    """Procedural prediction volume on the device (bench / tests)."""
+    torch = _torch()
+    C = P.pz * P.py * P.px
+    pred = torch.empty((C,) + P.shape, dtype=torch.float16 if f16 else torch.float32,
+                       device=labels.device)
+    check(lib().ppp_synth_pred(_dev_ptr(labels), _dev_ptr(pred), F16 if f16 else F32,
+                               int(seed) & 0xFFFFFFFF, hi, lo, noise, ctypes.byref(P), _stream()))
+    return pred
+
+
+# ----------------------------------------------------------------------------------------
+# host stages (NumPy arrays in, NumPy arrays out)
+# ----------------------------------------------------------------------------------------
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(seq):
+    return np.ascontiguousarray(np.array(seq, dtype=np.int32))
+
+
+def host_rank_order(score, foreground, patchshape):
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    fg = np.ascontiguousarray(foreground).astype(np.uint8)
+    out = np.empty(score.size, dtype=np.int64)
+    vol, ps = _i32(score.shape), _i32(patchshape)
+    n = lib().ppp_host_rank_order(_np_ptr(score), _np_ptr(fg), _np_ptr(vol), _np_ptr(ps),
+                                  _np_ptr(out))
+    return out[:n].copy()
+
+
+def host_cover_pass(mask_running, overlap, patchshape, ranked_lin, ranked_score, bits, pix_th,
+                    score_threshold, selected, remaining):
+    """In place on mask_running (uint8) and selected (uint8); returns (new `remaining`,
+    stopped-by-score-threshold)."""
+    vol, ps = _i32(mask_running.shape), _i32(patchshape)
+    rem = ctypes.c_int64(int(remaining))
+    stopped = ctypes.c_int32(0)
+    thr = float("nan") if score_threshold is None else float(score_threshold)
+    lib().ppp_host_cover_pass(_np_ptr(mask_running), _np_ptr(overlap), _np_ptr(vol), _np_ptr(ps),
+                              _np_ptr(ranked_lin), _np_ptr(ranked_score), _np_ptr(bits),
+                              len(ranked_lin), int(pix_th), thr, _np_ptr(selected),
+                              ctypes.byref(rem), ctypes.byref(stopped))
+    return rem.value, bool(stopped.value)
+
+
+def host_thin_cover(mask, patchshape, sel_lin, bits):
+    vol, ps = _i32(mask.shape), _i32(patchshape)
+    keep = np.zeros(len(sel_lin), dtype=np.uint8)
+    lib().ppp_host_thin_cover(_np_ptr(mask), _np_ptr(vol), _np_ptr(ps), _np_ptr(sel_lin),
+                              _np_ptr(bits), len(sel_lin), _np_ptr(keep))
+    return keep.astype(bool)
+
+
+def host_patch_pairs(sel_zyx, patchshape, max_ps_dist=2, include_single=True):
+    sel = np.ascontiguousarray(np.asarray(sel_zyx).reshape(-1, 3), dtype=np.int32)
+    ps = _i32(patchshape)
+    n = len(sel)
+    sorted_zyx = np.empty((n, 3), dtype=np.int32)
+    rows = lib().ppp_host_patch_pairs(_np_ptr(sel), n, _np_ptr(ps), int(max_ps_dist),
+                                      1 if include_single else 0, _np_ptr(sorted_zyx), None)
+    if rows == 0:
+        return sorted_zyx, None
+    pairs = np.empty((rows, 6), dtype=np.uint32)
+    lib().ppp_host_patch_pairs(_np_ptr(sel), n, _np_ptr(ps), int(max_ps_dist),
+                               1 if include_single else 0, _np_ptr(sorted_zyx), _np_ptr(pairs))
+    return sorted_zyx, pairs

@@ -1,0 +1,45 @@
+"""Ahead-of-time build of libppp_mi355x.so (hand-written HIP kernels + C ABI) for gfx950.
+
+hipcc cross-compiles without a GPU; the built library stays in-tree
+(patchperpix_amd/csrc/libppp_mi355x.so, git-ignored) so that it travels to the GPU box.
+"""
+import glob
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libppp_mi355x.so")
+ARCH = "gfx950"
+# -ffp-contract=off: the float arithmetic must round exactly like the reference's
+# (no fused multiply-add across the statements being restated).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH,
+         "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + \
+        sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+        [os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "ppp_mi355x.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

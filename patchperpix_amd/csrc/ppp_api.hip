@@ -1,0 +1,255 @@
+// ppp_api.hip -- the extern "C" entry points declared in include/ppp_mi355x.h.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "ppp_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(PPP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+// largest float <= t  /  smallest float >= t
+float round_down_f32(double t) {
+    float f = (float)t;
+    if ((double)f > t) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+float round_up_f32(double t) {
+    float f = (float)t;
+    if ((double)f < t) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+int make_geo(const ppp_params *p, ppp::Geo *G) {
+    if (!p) return fail(PPP_ERR_INVALID_ARG, "params is NULL");
+    if (p->abi_version != PPP_ABI_VERSION)
+        return fail(PPP_ERR_INVALID_ARG, "abi_version %d != %d", p->abi_version, PPP_ABI_VERSION);
+    if (p->Z <= 0 || p->Y <= 0 || p->X <= 0)
+        return fail(PPP_ERR_INVALID_ARG, "bad volume %d x %d x %d", p->Z, p->Y, p->X);
+    if (p->pz <= 0 || p->py <= 0 || p->px <= 0 || !(p->pz & 1) || !(p->py & 1) || !(p->px & 1))
+        return fail(PPP_ERR_INVALID_ARG, "patch shape must be positive and odd (%d,%d,%d)", p->pz,
+                    p->py, p->px);
+    if (!(p->th > 0.0 && p->th < 1.0)) return fail(PPP_ERR_INVALID_ARG, "th must be in (0,1)");
+    if ((long long)p->Z * p->Y * p->X >= (1ll << 31))
+        return fail(PPP_ERR_UNSUPPORTED, "volumes of 2^31 voxels or more are not supported");
+    ppp::Geo g;
+    memset(&g, 0, sizeof(g));
+    g.Z = p->Z; g.Y = p->Y; g.X = p->X;
+    g.pz = p->pz; g.py = p->py; g.px = p->px;
+    g.rz = p->pz / 2; g.ry = p->py / 2; g.rx = p->px / 2;
+    g.C = p->pz * p->py * p->px;
+    g.mid = g.C / 2;
+    g.V = (long long)p->Z * p->Y * p->X;
+    g.th_gt = round_down_f32(p->th);
+    double bg;
+    switch (p->bg_rule) {
+    case PPP_BG_INV_TH: bg = p->thi; break;
+    case PPP_BG_HALF_TH: bg = p->th / 2; break;
+    case PPP_BG_LESS_THAN_TH: bg = p->th; break;
+    default: return fail(PPP_ERR_INVALID_ARG, "how is bg defined for vote instances? (bg_rule %d)", p->bg_rule);
+    }
+    g.bg_lt = round_up_f32(bg);
+    g.th_rn = (float)p->th;
+    g.th2 = p->th * p->th;
+    g.den = 1.0 - p->th * p->th;
+    if (p->value_rule < PPP_VAL_COUNT || p->value_rule > PPP_VAL_NORM_PROB_PRODUCT)
+        return fail(PPP_ERR_INVALID_ARG, "bad value_rule %d", p->value_rule);
+    g.value_rule = p->value_rule;
+    g.use_overlap = p->use_overlap != 0;
+    g.normalise = p->normalise != 0;
+    g.norm_rank = p->norm_rank != 0;
+    g.count_pos_neg = p->count_pos_neg != 0;
+    g.norm_aff = p->norm_aff != 0;
+    g.layout = p->cons_layout;
+    const ppp_box &b = p->cons_box;
+    if (b.z0 < 0 || b.y0 < 0 || b.x0 < 0 || b.z1 > p->Z || b.y1 > p->Y || b.x1 > p->X ||
+        b.z1 <= b.z0 || b.y1 <= b.y0 || b.x1 <= b.x0)
+        return fail(PPP_ERR_INVALID_ARG, "cons_box outside the volume or empty");
+    if (g.layout == PPP_CONS_REFERENCE) {
+        if (b.z0 || b.y0 || b.x0 || b.z1 != p->Z || b.y1 != p->Y || b.x1 != p->X)
+            return fail(PPP_ERR_INVALID_ARG, "reference layout needs cons_box = whole volume");
+    } else if (g.layout != PPP_CONS_COMPACT) {
+        return fail(PPP_ERR_INVALID_ARG, "bad cons_layout %d", p->cons_layout);
+    }
+    g.bz0 = b.z0; g.by0 = b.y0; g.bx0 = b.x0;
+    g.bZ = b.z1 - b.z0; g.bY = b.y1 - b.y0; g.bX = b.x1 - b.x0;
+    g.BV = (long long)g.bZ * g.bY * g.bX;
+    g.nsy = 2 * p->py; g.nsx = 2 * p->px;
+    g.wy = 2 * p->py - 1; g.wx = 2 * p->px - 1;
+    g.n_planes = ((2 * p->pz - 1) * g.wy * g.wx - 1) / 2;
+    *G = g;
+    return PPP_OK;
+}
+
+int need_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(PPP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    return PPP_OK;
+}
+
+int check_dtype(int dt) {
+    if (dt != PPP_F32 && dt != PPP_F16) return fail(PPP_ERR_INVALID_ARG, "bad pred dtype %d", dt);
+    return PPP_OK;
+}
+
+}  // namespace
+
+#define PPP_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != PPP_OK) return rc_; \
+    } while (0)
+
+extern "C" {
+
+int ppp_abi_version(void) { return PPP_ABI_VERSION; }
+const char *ppp_last_error(void) { return g_err; }
+
+int ppp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t ppp_cons_planes(const ppp_params *p) {
+    if (!p) return -1;
+    if (p->cons_layout == PPP_CONS_REFERENCE)
+        return (int64_t)(p->pz > 1 ? 2 * p->pz : p->pz) * (2 * p->py) * (2 * p->px);
+    return ((int64_t)(2 * p->pz - 1) * (2 * p->py - 1) * (2 * p->px - 1) - 1) / 2;
+}
+
+int64_t ppp_cons_elems(const ppp_params *p) {
+    if (!p) return -1;
+    const ppp_box &b = p->cons_box;
+    return ppp_cons_planes(p) * (int64_t)(b.z1 - b.z0) * (b.y1 - b.y0) * (b.x1 - b.x0);
+}
+
+int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
+                  float *d_count, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || (!d_cons && !d_count)) return fail(PPP_ERR_INVALID_ARG, "NULL pred / outputs");
+    if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, d_count, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus");
+}
+
+int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
+                     const uint8_t *d_overlap, float *d_score, const ppp_box *score_box,
+                     const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_cons || !d_score) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    ppp_box sb = {0, 0, 0, p->Z, p->Y, p->X};
+    if (score_box) sb = *score_box;
+    if (sb.z0 < 0 || sb.y0 < 0 || sb.x0 < 0 || sb.z1 > p->Z || sb.y1 > p->Y || sb.x1 > p->X)
+        return fail(PPP_ERR_INVALID_ARG, "score_box outside the volume");
+    // the consensus tile must hold every base voxel the scored centres read
+    const ppp_box &cb = p->cons_box;
+    auto lo = [](int a, int r) { return a - r < 0 ? 0 : a - r; };
+    auto hi = [](int a, int r, int n) { return a + r > n ? n : a + r; };
+    if (lo(sb.z0, G.rz) < cb.z0 || lo(sb.y0, G.ry) < cb.y0 || lo(sb.x0, G.rx) < cb.x0 ||
+        hi(sb.z1, G.rz, p->Z) > cb.z1 || hi(sb.y1, G.ry, p->Y) > cb.y1 || hi(sb.x1, G.rx, p->X) > cb.x1)
+        return fail(PPP_ERR_INVALID_ARG, "cons_box does not cover score_box grown by the patch radius");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_rank(d_pred, pred_dtype, d_cons, d_overlap, d_score, sb, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_rank_patches");
+}
+
+int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
+                    const uint32_t *d_pairs, uint64_t n_pairs, float *d_aff,
+                    const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n_pairs == 0) return PPP_OK;
+    if (!d_pred || !d_cons || !d_pairs || !d_aff) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_patch_graph(d_pred, pred_dtype, d_cons, d_pairs, n_pairs, d_aff, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph");
+}
+
+size_t ppp_label_workspace_bytes(const ppp_params *p) {
+    if (!p) return 0;
+    return (size_t)3 * sizeof(uint32_t) * (size_t)p->Z * p->Y * p->X;
+}
+
+int ppp_label_components(const uint32_t *d_pairs, const float *d_aff, uint64_t n_pairs,
+                         uint32_t *d_cc_key, void *d_work, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n_pairs == 0) return PPP_OK;
+    if (n_pairs >= (1ull << 31)) return fail(PPP_ERR_UNSUPPORTED, "more than 2^31-1 pair rows");
+    if (!d_pairs || !d_aff || !d_cc_key || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_label(d_pairs, d_aff, n_pairs, d_cc_key, d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_label_components");
+}
+
+int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_nodes,
+                        const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
+                        const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n_nodes == 0) return PPP_OK;
+    if (!d_pred || !d_nodes || !d_labels || !d_instances) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_paint(d_pred, pred_dtype, d_nodes, d_labels, n_nodes, d_instances, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_paint_instances");
+}
+
+int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
+                          const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (!d_cons_compact || !d_cons_reference) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.BV != G.V) return fail(PPP_ERR_INVALID_ARG, "whole-volume consensus required");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_cons_to_reference(d_cons_compact, d_cons_reference, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cons_to_reference");
+}
+
+int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres, uint64_t n,
+                   double thresh, uint32_t *d_bits, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n == 0) return PPP_OK;
+    if (!d_pred || !d_centres || !d_bits) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_patch_bits(d_pred, pred_dtype, d_centres, n, (float)thresh, d_bits, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_bits");
+}
+
+int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
+                   float hi, float lo, float noise, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_labels || !d_pred) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_synth(d_labels, d_pred, pred_dtype, seed, hi, lo, noise, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred");
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// ppp_aux.hip -- small helpers around the hot path: patch bit masks for the host-side
+// greedy cover, and the procedural synthetic prediction generator used by bench / tests.
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+// ---- patch bits: bit r of centre k = (pred[r][c_k] > thresh) ---------------------------
+// One wave per centre; lane l handles channels l, l+64, ...; a ballot packs 64 bits at a
+// time (two uint32 words), so the only global traffic is the C channel values.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    patch_bits_kernel(const T *__restrict__ pred, const uint32_t *__restrict__ centres, uint64_t n,
+                      float thresh, uint32_t *__restrict__ bits, const Geo G) {
+    const uint64_t k = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int words = (G.C + 31) / 32;
+    const long long lc = vox(G, (int)centres[k * 3], (int)centres[k * 3 + 1], (int)centres[k * 3 + 2]);
+    for (int base = 0; base < G.C; base += 64) {
+        const int r = base + lane;
+        const bool on = r < G.C && ldf(pred, (long long)r * G.V + lc) > thresh;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) {
+            bits[k * words + base / 32] = (uint32_t)m;
+            if (base / 32 + 1 < words) bits[k * words + base / 32 + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
+hipError_t launch_patch_bits(const void *pred, int dtype, const uint32_t *centres, uint64_t n,
+                             float thresh, uint32_t *bits, const Geo &G, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 3) / 4));
+    if (dtype == PPP_F16)
+        patch_bits_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, centres, n, thresh, bits, G);
+    else
+        patch_bits_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)pred, centres, n, thresh, bits, G);
+    return hipGetLastError();
+}
+
+// ---- synthetic prediction (patchperpix_amd/synth.py::pred_from_labels) ------------------
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    synth_kernel(const int32_t *__restrict__ labels, T *__restrict__ pred, uint32_t seed_mix,
+                 float hi, float lo, float noise, const Geo G) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    const int r = blockIdx.y;
+    const int x = (int)(v % G.X);
+    const long long t = v / G.X;
+    const int y = (int)(t % G.Y), z = (int)(t / G.Y);
+    const int nz = z + r / (G.py * G.px) - G.rz;
+    const int ny = y + (r / G.px) % G.py - G.ry;
+    const int nx = x + r % G.px - G.rx;
+    const int lab = labels[v];
+    int nb = -1;
+    if (nz >= 0 && nz < G.Z && ny >= 0 && ny < G.Y && nx >= 0 && nx < G.X) nb = labels[vox(G, nz, ny, nx)];
+    const float base = (nb == lab && lab != 0) ? hi : lo;
+    // counter = lin * C + r + seed_mix   (mod 2^32, like the uint64 NumPy code masked to 32 bit)
+    const uint32_t ctr = (uint32_t)((unsigned long long)v * (unsigned long long)G.C + (unsigned long long)r +
+                                    (unsigned long long)seed_mix);
+    const float u = (float)(hash_u32(ctr) >> 8) * (1.0f / 16777216.0f);
+    const float val = base + noise * (2.0f * u - 1.0f);
+    const __half h = __float2half_rn(val);  // through float16, like the zarr on disk
+    if constexpr (sizeof(T) == 2) pred[(long long)r * G.V + v] = h;
+    else pred[(long long)r * G.V + v] = __half2float(h);
+}
+
+hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
+                        float lo, float noise, const Geo &G, hipStream_t s) {
+    const dim3 grid((unsigned)((G.V + 255) / 256), (unsigned)G.C);
+    const uint32_t seed_mix = (uint32_t)(((unsigned long long)seed * 0x9E3779B1ull) & 0xFFFFFFFFull);
+    if (dtype == PPP_F16)
+        synth_kernel<__half><<<grid, dim3(256), 0, s>>>(labels, (__half *)pred, seed_mix, hi, lo, noise, G);
+    else
+        synth_kernel<float><<<grid, dim3(256), 0, s>>>(labels, (float *)pred, seed_mix, hi, lo, noise, G);
+    return hipGetLastError();
+}
+
+}  // namespace ppp

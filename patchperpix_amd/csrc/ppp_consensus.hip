@@ -1,0 +1,137 @@
+// ppp_consensus.hip -- S1: patch-pair scoring + consensus vote, GATHER form.
+//
+// Reference: cuda/fillConsensusArray.cu:5-218 (scatter with float atomicAdd, run twice
+// for value and count) + cuda/normConsensusArray.cu:5-43.
+//
+// The reference scatters: one thread per patch centre c adds a vote to key
+// (offset d, earlier voxel u) for every ordered pixel pair of its patch.  For a fixed
+// key, a centre contributes AT MOST ONE vote (the key fixes the unordered voxel pair
+// {u, w = u + d}; the pos / neg cases on (pred[r_u][c], pred[r_w][c]) are mutually
+// exclusive).  So
+//
+//     cons[d][u] = sum over centres c with u, w in win(c) of  vote(c, u, w)
+//
+// and this kernel computes it directly: one thread per key, looping over the centres in
+// RASTER ORDER of c -- a legal serialisation of the reference's atomics, no atomics, no
+// zero-fill, count and normalisation fused, bit-reproducible.
+//
+// Centre c = u - k + rad where k in [0,p)^3 is the patch offset of u, and k + d the
+// patch offset of w; raster-ascending c  <=>  lexicographically descending k.
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    consensus_gather_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
+                            float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= G.BV) return;
+    // plane -> offset d (signed mixed radix, see ppp_mi355x.h)
+    const int L = (int)blockIdx.y + 1;
+    const int Ls = L + (G.py - 1) * G.wx + (G.px - 1);
+    const int dx = Ls % G.wx - (G.px - 1);
+    const int q = Ls / G.wx;
+    const int dy = q % G.wy - (G.py - 1);
+    const int dz = q / G.wy;
+    // base voxel u (global coords) and partner w
+    const int ux = G.bx0 + (int)(b % G.bX);
+    const long long t = b / G.bX;
+    const int uy = G.by0 + (int)(t % G.bY);
+    const int uz = G.bz0 + (int)(t / G.bY);
+    const int wz = uz + dz, wy = uy + dy, wx = ux + dx;
+
+    float acc = 0.0f, cnt = 0.0f;
+    const T *mid = pred + (long long)G.mid * G.V;
+    bool ok = wz < G.Z && wy >= 0 && wy < G.Y && wx >= 0 && wx < G.X;
+    long long lu = vox(G, uz, uy, ux), lw = 0;
+    if (ok) {
+        lw = vox(G, wz, wy, wx);
+        ok = ldf(mid, lu) > G.th_gt && ldf(mid, lw) > G.th_gt;
+        if (ok && G.use_overlap) ok = ov[lu] == 0 && ov[lw] == 0;
+    }
+    if (ok) {
+        const int kz_hi = min(G.pz - 1, G.pz - 1 - dz), kz_lo = max(0, -dz);
+        const int ky_hi = min(G.py - 1, G.py - 1 - dy), ky_lo = max(0, -dy);
+        const int kx_hi = min(G.px - 1, G.px - 1 - dx), kx_lo = max(0, -dx);
+        for (int kz = kz_hi; kz >= kz_lo; --kz) {
+            const int cz = uz - kz + G.rz;
+            if (cz < G.rz || cz >= G.Z - G.rz) continue;
+            for (int ky = ky_hi; ky >= ky_lo; --ky) {
+                const int cy = uy - ky + G.ry;
+                if (cy < G.ry || cy >= G.Y - G.ry) continue;
+                for (int kx = kx_hi; kx >= kx_lo; --kx) {
+                    const int cx = ux - kx + G.rx;
+                    if (cx < G.rx || cx >= G.X - G.rx) continue;
+                    const long long lc = vox(G, cz, cy, cx);
+                    if (!(ldf(mid, lc) > G.th_gt)) continue;
+                    const int ru = (kz * G.py + ky) * G.px + kx;
+                    const int rw = ((kz + dz) * G.py + (ky + dy)) * G.px + (kx + dx);
+                    const float a = ldf(pred, (long long)ru * G.V + lc);  // about u
+                    const float bb = ldf(pred, (long long)rw * G.V + lc); // about w
+                    if (a > G.th_gt) {
+                        if (bb > G.th_gt) {
+                            acc = acc + vote_value(G, a * bb);
+                            cnt = cnt + 1.0f;
+                        } else if (bb < G.bg_lt) {
+                            acc = acc + (-vote_value(G, a * (1.0f - bb)));
+                            cnt = cnt + 1.0f;
+                        }
+                    } else if (bb > G.th_gt && a < G.bg_lt) {
+                        acc = acc + (-vote_value(G, bb * (1.0f - a)));
+                        cnt = cnt + 1.0f;
+                    }
+                }
+            }
+        }
+    }
+    const long long o = cons_at(G, dz, dy, dx, uz, uy, ux);
+    if (cons) cons[o] = (G.normalise && cnt != 0.0f) ? acc / cnt : acc;
+    if (cnt_out) cnt_out[o] = cnt;
+}
+
+hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, float *cons,
+                            float *cnt, const Geo &G, hipStream_t s) {
+    const dim3 block(256);
+    const dim3 grid((unsigned)((G.BV + 255) / 256), (unsigned)G.n_planes);
+    if (G.layout == PPP_CONS_REFERENCE) {
+        // planes the reference never writes stay zero
+        const size_t bytes = (size_t)(G.pz > 1 ? 2 * G.pz : 1) * G.nsy * G.nsx * G.V * sizeof(float);
+        hipError_t e;
+        if (cons && (e = hipMemsetAsync(cons, 0, bytes, s)) != hipSuccess) return e;
+        if (cnt && (e = hipMemsetAsync(cnt, 0, bytes, s)) != hipSuccess) return e;
+    }
+    if (dtype == PPP_F16)
+        consensus_gather_kernel<__half><<<grid, block, 0, s>>>((const __half *)pred, ov, cons, cnt, G);
+    else
+        consensus_gather_kernel<float><<<grid, block, 0, s>>>((const float *)pred, ov, cons, cnt, G);
+    return hipGetLastError();
+}
+
+// ---- compact -> reference layout ------------------------------------------------------
+__global__ void cons_expand_kernel(const float *__restrict__ compact, float *__restrict__ ref,
+                                   const Geo G) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    const int L = (int)blockIdx.y + 1;
+    const int Ls = L + (G.py - 1) * G.wx + (G.px - 1);
+    const int dx = Ls % G.wx - (G.px - 1);
+    const int q = Ls / G.wx;
+    const int dy = q % G.wy - (G.py - 1);
+    const int dz = q / G.wy;
+    const long long plane =
+        ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (dx + G.px - 1);
+    ref[plane * G.V + v] = compact[(long long)(L - 1) * G.V + v];
+}
+
+hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo &G,
+                                    hipStream_t s) {
+    const size_t bytes = (size_t)(G.pz > 1 ? 2 * G.pz : 1) * G.nsy * G.nsx * G.V * sizeof(float);
+    hipError_t e = hipMemsetAsync(ref, 0, bytes, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((G.V + 255) / 256), (unsigned)G.n_planes);
+    cons_expand_kernel<<<grid, dim3(256), 0, s>>>(compact, ref, G);
+    return hipGetLastError();
+}
+
+}  // namespace ppp

@@ -23,8 +23,8 @@ NOISE = 0.04
 
 def hash_u32(x):
     """lowbias32-style avalanche hash on uint32 arrays (wraps mod 2**32)."""
-    x = np.asarray(x, dtype=np.uint64)
     m = np.uint64(0xFFFFFFFF)
+    x = np.asarray(x, dtype=np.uint64) & m  # counters wrap mod 2**32 first
     x = (x ^ (x >> np.uint64(16))) & m
     x = (x * np.uint64(0x7FEB352D)) & m
     x = (x ^ (x >> np.uint64(15))) & m

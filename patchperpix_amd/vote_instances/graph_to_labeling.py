@@ -1,0 +1,85 @@
+"""Step 6: patch graph -> instance labels
+(reference: PatchPerPix/vote_instances/graph_to_labeling.py)."""
+import logging
+
+import numpy as np
+
+from .. import backend
+from .aff_patch_graph import AffGraph, loadAffgraph
+from .graph_mws import mws, mws_from_pairs
+
+logger = logging.getLogger(__name__)
+
+
+def affGraphToInstancesT(pred_affs, patchshape, rad, debug_output1, debug_output2, instances,
+                         foreground, affgraph, selected_patch_pairs, **kwargs):
+    affgraph = loadAffgraph(affgraph, selected_patch_pairs)
+    return affGraphToInstances(affgraph, pred_affs, patchshape, rad, debug_output1,
+                               debug_output2, instances, foreground, **kwargs)
+
+
+def component_labels(affinity_graph, shape, device, P, **kwargs):
+    """Node coordinates and their instance ids (component rank + 1).
+
+    ``mws=False``: union-find on the device (ppp_label_components); the component order
+    keys are ranked here (a sort of as many numbers as there are components).
+    ``mws=True``: mutex watershed on the host (graph_mws)."""
+    import torch
+    pairs, aff = affinity_graph.pairs, affinity_graph.aff
+    if kwargs["mws"]:
+        ccs = mws_from_pairs(pairs, aff)
+        nodes = [n for cc in ccs for n in cc]
+        labels = [k + 1 for k, cc in enumerate(ccs) for _ in cc]
+        return (np.array(nodes, dtype=np.int32).reshape(-1, 3),
+                np.array(labels, dtype=np.int64))
+    if len(pairs) == 0:
+        return np.zeros((0, 3), np.int32), np.zeros((0,), np.int64)
+    pairs_dev = torch.from_numpy(pairs.view(np.int32)).to(device)
+    aff_dev = torch.from_numpy(aff).to(device)
+    keys = backend.label_components(pairs_dev, aff_dev, P).cpu().numpy()  # [N, 2]
+    valid = keys != backend.NONE_KEY
+    uniq = np.unique(keys[valid])                       # ascending = networkx's order
+    labels = np.zeros(keys.shape, dtype=np.int64)
+    labels[valid] = np.searchsorted(uniq, keys[valid]) + 1
+    nodes = pairs.reshape(-1, 3).astype(np.int32)
+    labels = labels.reshape(-1)
+    keep = labels > 0
+    # one row per node is enough (all occurrences of a node carry the same label)
+    lin = (nodes[:, 0].astype(np.int64) * shape[1] + nodes[:, 1]) * shape[2] + nodes[:, 2]
+    _, first = np.unique(np.where(keep, lin, -1), return_index=True)
+    first = first[keep[first]]
+    return nodes[first], labels[first]
+
+
+def affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, debug_output1,
+                        debug_output2, instances, foreground, **kwargs):
+    """graph_to_labeling.py:34-155.  ``instances`` gives shape and dtype of the output
+    (uint16 single volume, uint32 when stitching); painting happens on the device with
+    "largest component id wins", which is what the reference's in-order overwrite yields."""
+    import torch
+    for opt in ("one_instance_per_channel", "no_overlap_per_channel", "sparse_labels"):
+        if kwargs.get(opt, False):
+            raise NotImplementedError("%s is not supported" % opt)
+    if not isinstance(affinity_graph, AffGraph):   # a networkx graph from outside
+        rows = [(tuple(a) + tuple(b), w) for a, b, w in affinity_graph.edges.data("aff")]
+        affinity_graph = AffGraph([w for _, w in rows], [r for r, _ in rows])
+    logger.info("compute labeling")
+    P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
+    nodes, labels = component_labels(affinity_graph, instances.shape, pred_affs.device, P,
+                                     **kwargs)
+    out_dtype = instances.dtype
+    if len(labels) and labels.max() > np.iinfo(out_dtype).max:
+        raise OverflowError("%d instances do not fit %s" % (labels.max(), out_dtype))
+    inst_dev = torch.from_numpy(np.ascontiguousarray(instances).astype(np.int32)).to(pred_affs.device)
+    if len(nodes):
+        backend.paint_instances(pred_affs,
+                                torch.from_numpy(np.ascontiguousarray(nodes)).to(pred_affs.device),
+                                torch.from_numpy(labels.astype(np.int32)).to(pred_affs.device),
+                                inst_dev, P)
+    instances = inst_dev.cpu().numpy().astype(out_dtype)
+    logger.info("done compute labeling")
+    if kwargs.get("pad_with_ps", False):
+        sl = tuple(slice(int(rad[i]), instances.shape[i] - int(rad[i])) for i in range(3))
+        instances = instances[sl]
+        foreground = foreground[sl]
+    return instances, foreground.astype(np.uint8)

@@ -1,0 +1,88 @@
+"""Step 2: patch ranking (reference: PatchPerPix/vote_instances/ranked_patches.py)."""
+import logging
+
+import numpy as np
+
+from .. import backend
+from .consensus_array import _device_overlap
+
+logger = logging.getLogger(__name__)
+
+
+class PatchList:
+    """The reference's ``[(coord, score), ...]`` list, held as arrays.  Indexing and
+    iteration yield ``(coord ndarray[3], score)`` tuples like the reference's list does."""
+
+    def __init__(self, coords, scores):
+        self.coords = np.ascontiguousarray(np.asarray(coords).reshape(-1, 3), dtype=np.int32)
+        self.scores = np.ascontiguousarray(np.asarray(scores).reshape(-1), dtype=np.float32)
+        assert len(self.coords) == len(self.scores)
+
+    def __len__(self):
+        return len(self.coords)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice) or isinstance(i, np.ndarray):
+            return PatchList(self.coords[i], self.scores[i])
+        return (self.coords[i], self.scores[i])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield (self.coords[i], self.scores[i])
+
+    def lin(self, shape):
+        c = self.coords.astype(np.int64)
+        return np.ascontiguousarray((c[:, 0] * shape[1] + c[:, 1]) * shape[2] + c[:, 2])
+
+    @staticmethod
+    def from_any(obj):
+        if isinstance(obj, PatchList):
+            return obj
+        obj = list(obj)
+        if len(obj) == 0:
+            return PatchList(np.zeros((0, 3)), np.zeros((0,)))
+        return PatchList(np.array([np.asarray(o[0]) for o in obj]),
+                         np.array([o[1] for o in obj]))
+
+
+def rank_patches_cuda(pred_affs, consensus_vote_array, patchshape, neighshape, overlap_mask,
+                      **kwargs):
+    """ranked_patches.py:33-74: returns the (Z,Y,X) float32 score volume (device tensor)."""
+    P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
+    ov = _device_overlap(overlap_mask, pred_affs) if P.use_overlap else None
+    return backend.rank_patches(pred_affs, consensus_vote_array, ov, P,
+                                score_box=kwargs.get("score_box"))
+
+
+def rank_patches_by_score(all_patches_idx, rank_scores, foreground=None, patchshape=None):
+    """ranked_patches.py:21-30: stable sort, best score first.
+
+    Fast path (``foreground`` given, ``all_patches_idx`` None): the interior foreground
+    voxels are enumerated in raster order and stably sorted natively (ppp_host_rank_order),
+    which is the list the reference builds at vote_instances.py:276,286-287."""
+    scores = rank_scores.detach().cpu().numpy() if hasattr(rank_scores, "detach") \
+        else np.asarray(rank_scores)
+    if all_patches_idx is None:
+        lin = backend.host_rank_order(scores, foreground, patchshape)
+        coords = np.stack(np.unravel_index(lin, scores.shape), axis=1)
+        return PatchList(coords, scores.reshape(-1)[lin])
+    coords = np.asarray(all_patches_idx).reshape(-1, 3)
+    s = scores[tuple(coords.T)]
+    order = np.argsort(-s.astype(np.float64), kind="stable")
+    return PatchList(coords[order], s[order])
+
+
+def loadOrComputePatchRanking(pred_affs=None, consensus_vote_array=None, offsets_bases_ff=None,
+                              offsets_bases_fb=None, overlap_mask=None, all_patches=None,
+                              patchshape=None, neighshape=None, rad=None, **kwargs):
+    """ranked_patches.py:108-213 (device branch)."""
+    if not kwargs["cuda"]:
+        raise RuntimeError("patchperpix_amd only implements the device path (cuda=True)")
+    scores = rank_patches_cuda(pred_affs, consensus_vote_array, patchshape, neighshape,
+                               overlap_mask, **kwargs)
+    scores_array = scores.cpu().numpy()
+    ranked = rank_patches_by_score(all_patches, scores_array,
+                                   foreground=kwargs.get("_foreground"), patchshape=patchshape)
+    if len(ranked):
+        logger.info("best/worst score: %s %s", ranked.scores[0], ranked.scores[-1])
+    return ranked, scores_array

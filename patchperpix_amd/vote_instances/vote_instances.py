@@ -1,0 +1,334 @@
+"""Instance assembly orchestration (reference: PatchPerPix/vote_instances/vote_instances.py).
+
+Same entry points and keyword flags as the reference -- ``main`` (:557), ``do_all`` (:486),
+``do_block`` (:455), ``to_instance_seg`` (:150), ``get_arguments`` (:62) -- driving the
+gfx950 kernels of libppp_mi355x.so instead of pycuda-JITed CUDA.  Only the device path
+(``cuda=True``) exists; asking for the NumPy path raises instead of silently falling back.
+"""
+import argparse
+import glob
+import logging
+import os
+
+import numpy as np
+
+from .. import backend
+from .aff_patch_graph import (computeAndStorePatchPairs, computePatchGraph, loadAffgraph,
+                              setAffgraph)
+from .consensus_array import loadOrComputeConsensus
+from .cuda_code import delete_cuda, init_cuda
+from .foreground_cover import computeForegroundCover, thinOutForegroundCover
+from .graph_to_labeling import affGraphToInstances, affGraphToInstancesT
+from .ranked_patches import PatchList, loadOrComputePatchRanking
+from .utilVoteInstances import getResKey, loadAffinities
+from . import io_hdflike
+
+logger = logging.getLogger(__name__)
+
+
+def replace(array, old_values, new_values):
+    values_map = np.arange(int(array.max() + 1), dtype=new_values.dtype)
+    values_map[old_values] = new_values
+    return values_map[array]
+
+
+def merge_dicts(sink, source):
+    if not isinstance(sink, dict) or not isinstance(source, dict):
+        raise TypeError('Args to merge_dicts should be dicts')
+    for k, v in source.items():
+        if isinstance(source[k], dict) and isinstance(sink.get(k), dict):
+            sink[k] = merge_dicts(sink[k], v)
+        else:
+            sink[k] = v
+    return sink
+
+
+def get_arguments(check_required=True, argv=None):
+    """Command line of the reference (vote_instances.py:62-147), same names and defaults."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--affinities', type=str, required=False)
+    parser.add_argument('--affinities_key', type=str, required=False, default="images/pred_affs")
+    parser.add_argument('--basedir', type=str, required=False)
+    parser.add_argument('--mode', type=str, required=False)
+    parser.add_argument('--result_folder', type=str, required=check_required)
+    parser.add_argument('--checkpoint', type=str, required=False)
+    parser.add_argument("--debug", action="store_true")
+    parser.add_argument('--patch_threshold', type=float, default=0.9)
+    parser.add_argument('--fc_threshold', type=float, default=0.5)
+    parser.add_argument('-p', '--patchshape', type=int, action='append', required=check_required)
+    parser.add_argument('--consensus', type=str)
+    parser.add_argument('--consensus_key', type=str, required=False, default="images/consensus")
+    parser.add_argument('--scores', type=str)
+    parser.add_argument('--ranked_patches', type=str)
+    parser.add_argument('--aff_graph', type=str, required=False)
+    parser.add_argument('--selected_patches', type=str, required=False)
+    parser.add_argument('--selected_patch_pairs', type=str, required=False)
+    for flag in ("select_patches_for_sparse_data", "cuda", "skipLookup", "skipThinCover",
+                 "skipRanking", "skipConsensus", "termAfterThinCover", "graphToInst", "mws",
+                 "includeSinglePatchCCS", "removeIntersection", "isbiHack", "mask_fg_border",
+                 "parallel", "save_no_intermediates"):
+        parser.add_argument("--" + flag, action="store_true")
+    for ax in "xyz":
+        parser.add_argument('--crop_%s_s' % ax, type=int, default=0)
+        parser.add_argument('--crop_%s_e' % ax, type=int, default=None)
+    args, _ = parser.parse_known_args(argv)
+    return args
+
+
+def _pad(a, rad, channels=False):
+    width = [(int(r), int(r)) for r in rad]
+    if channels:
+        width = [(0, 0)] + width
+    return np.pad(a, width, mode='constant')
+
+
+def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, **kwargs):
+    """vote_instances.py:150-452.
+
+    pred_affs     (C,Z,Y,X) float32/float16 ndarray, or an already-resident device tensor
+    foreground    (Z,Y,X) bool       mask_to_cover (Z,Y,X) bool, modified in place (:226)
+    numinst       (Z,Y,X) integer    patchshape    int[3]
+    Returns (instances uint16 (Z,Y,X), foreground uint8) -- or (pairs uint32 [N,6],
+    aff float32 [N]) with ``return_intermediates`` -- with the reference's early-outs.
+    """
+    import torch
+    if not kwargs.get('cuda', False):
+        raise RuntimeError("patchperpix_amd implements the device path only: call with "
+                           "cuda=True (the NumPy path of the reference is not provided and "
+                           "nothing falls back to the CPU)")
+    for opt in ("debug", "isbiHack"):
+        if kwargs.get(opt, False):
+            raise NotImplementedError("%s is not supported" % opt)
+    patchshape = np.array([int(p) for p in patchshape])
+    rad = np.array([p // 2 for p in patchshape])
+
+    if kwargs.get("pad_with_ps", False):
+        assert not kwargs.get('blockwise'), "can only pad whole volumes"
+        if torch.is_tensor(pred_affs):
+            pred_affs = torch.nn.functional.pad(
+                pred_affs, (int(rad[2]),) * 2 + (int(rad[1]),) * 2 + (int(rad[0]),) * 2)
+        else:
+            pred_affs = _pad(pred_affs, rad, channels=True)
+        foreground = _pad(foreground, rad)
+        mask_to_cover = _pad(mask_to_cover, rad)
+        numinst = _pad(numinst, rad)
+
+    pred_affs = backend.to_device_pred(pred_affs)   # host->HBM once; f16 stays f16 (exact)
+    shape = tuple(foreground.shape)
+    radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
+    overlap_mask = 1 * (numinst > 1)
+
+    if not kwargs.get('blockwise', False) and kwargs.get('skeletonize_foreground'):
+        try:
+            from skimage.morphology import skeletonize_3d
+        except ImportError as e:
+            raise RuntimeError("skeletonize_foreground needs scikit-image") from e
+        mask_to_cover = skeletonize_3d(mask_to_cover) > 0
+
+    mask_to_cover[overlap_mask > 0] = 0
+    instances = np.zeros(shape, dtype=np.uint16)
+
+    def unpadded(inst, fg):
+        if kwargs.get("pad_with_ps", False):
+            sl = tuple(slice(int(rad[i]), inst.shape[i] - int(rad[i])) for i in range(3))
+            return inst[sl], fg[sl]
+        return inst, fg
+
+    if np.count_nonzero(mask_to_cover[radslice]) == 0:
+        logger.info("no fg found, returning...")
+        if kwargs.get('return_intermediates', False):
+            return None, None
+        inst, fg = unpadded(instances, foreground)
+        return inst.astype(np.uint16), fg.astype(np.uint8)
+
+    neighshape = patchshape.copy()
+    if neighshape[0] > 1:
+        neighshape *= 2
+    else:
+        neighshape[1:] *= 2
+
+    if kwargs.get('graphToInst'):
+        fn = os.path.splitext(os.path.basename(kwargs['affinities']))[0]
+        kwargs['affgraph'] = os.path.join(kwargs['result_folder'], fn + "_aff_graph.npy")
+        kwargs['selected_patch_pairs'] = os.path.join(kwargs['result_folder'],
+                                                      fn + "_selected_patch_pairs.npy")
+        return affGraphToInstancesT(pred_affs, patchshape, rad, None, None, instances,
+                                    foreground, **kwargs)
+
+    if np.count_nonzero(foreground[radslice]) == 0:
+        logger.info("no patches found, returning...")
+        if kwargs.get('return_intermediates', False):
+            return None, None
+        return instances.astype(np.uint16), foreground.astype(np.uint8)
+
+    # (1) consensus
+    if not kwargs.get('skipConsensus'):
+        consensus_vote_array, _, _ = loadOrComputeConsensus(
+            instances, patchshape, neighshape, None, pred_affs, rad, foreground, None,
+            overlap_mask, **kwargs)
+    else:
+        consensus_vote_array = None
+    if kwargs.get('save_consensus', False):
+        return None, None
+
+    # (2) ranking
+    ranked_patches_list, scores_array = None, None
+    if not kwargs.get('skipRanking'):
+        ranked_patches_list, scores_array = loadOrComputePatchRanking(
+            pred_affs=pred_affs, consensus_vote_array=consensus_vote_array,
+            overlap_mask=overlap_mask, all_patches=None, patchshape=patchshape,
+            neighshape=neighshape, rad=rad, _foreground=foreground, **kwargs)
+        logger.info("num ranked patches %s ", len(ranked_patches_list))
+
+    if kwargs.get('aff_graph') is None:
+        if kwargs.get('selected_patches') is not None:
+            coords = np.array(list(kwargs.get('selected_patches'))).reshape(-1, 3)
+            selected_patches_list = PatchList(coords, np.ones(len(coords), np.float32))
+            num_selected = len(selected_patches_list)
+        elif kwargs.get('skipSelection', False):
+            selected_patches_list = ranked_patches_list
+            num_selected = len(ranked_patches_list)
+        else:
+            # (3) greedy cover
+            selected_patches_list, num_selected = computeForegroundCover(
+                overlap_mask, mask_to_cover, patchshape, ranked_patches_list, radslice,
+                pred_affs, rad, None, scores_array, **kwargs)
+        # (4) thinning
+        if not kwargs.get('skipThinCover') and num_selected > 0:
+            selected_patches_list, num_selected = thinOutForegroundCover(
+                mask_to_cover, selected_patches_list, radslice, pred_affs, rad, patchshape,
+                **kwargs)
+
+        if kwargs.get('selected_patch_pairs') is not None:
+            selected_patch_pairsIDs = np.array(kwargs.get('selected_patch_pairs'),
+                                               dtype=np.uint32).reshape(-1, 6)
+        else:
+            selected_patch_pairsIDs = computeAndStorePatchPairs(selected_patches_list,
+                                                                patchshape, **kwargs)
+        if selected_patch_pairsIDs is None:
+            if kwargs.get('return_intermediates', False):
+                return None, None
+            return instances.astype(np.uint16), foreground.astype(np.uint8)
+        if kwargs.get('termAfterThinCover'):
+            raise SystemExit(0)
+
+        # (5) patch graph
+        affinity_graph = computePatchGraph(
+            selected_patches_list, num_selected, selected_patch_pairsIDs, pred_affs,
+            mask_to_cover, patchshape, neighshape, rad, overlap_mask, None,
+            consensus_vote_array, **kwargs)
+        if kwargs.get('return_intermediates'):
+            return selected_patch_pairsIDs, affinity_graph
+        if kwargs.get('termAfterPatchGraph', False):
+            return None, None
+    else:
+        affinity_graph = loadAffgraph(kwargs['aff_graph'], kwargs['selected_patch_pairs'])
+    del consensus_vote_array
+
+    # (6) labelling
+    return affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, None, None,
+                               instances, foreground, **kwargs)
+
+
+def do_block(block, foreground, mask, numinst, **kwargs):
+    """vote_instances.py:455-483."""
+    patchshape = kwargs['patchshape']
+    del kwargs['patchshape']
+    if type(patchshape) != np.ndarray:
+        patchshape = np.array(patchshape)
+    res = to_instance_seg(block, foreground, mask, numinst, patchshape, **kwargs)
+    if kwargs.get('return_intermediates'):
+        return res
+    instances, _ = res
+    rad = np.array([p // 2 for p in patchshape])
+    slices = tuple(slice(r, d - r) for r, d in zip(rad, instances.shape))
+    return instances[slices]
+
+
+def do_all(aff_file, patchshape=np.array([1, 25, 25]), **kwargs):
+    """vote_instances.py:486-554: load one prediction file, assemble, write the result HDF
+    (datasets ``<res_key>`` and ``vote_foreground``, gzip, attrs offset/resolution)."""
+    logger.info("processing %s into %s", aff_file, kwargs['result_folder'])
+    if type(patchshape) is not np.ndarray:
+        patchshape = np.array(patchshape)
+    res_ext = getResKey(**kwargs) if kwargs.get('add_suffix', False) else ''
+    loaded = loadAffinities(aff_file, res_ext, patchshape=patchshape, **kwargs)
+    if loaded is None:
+        return
+    affinities, numinst, foreground = loaded
+    if foreground.ndim == 4:   # loadFg's leading axis on 3-d data
+        foreground = foreground[0]
+    mask = np.copy(foreground)
+    if numinst is None:
+        numinst = np.copy(foreground)
+    kwargs['aff_file'] = aff_file
+    res = to_instance_seg(affinities, foreground, mask, numinst, patchshape, **kwargs)
+    res_key = kwargs.get('res_key', 'vote_instances')
+    instances, foreground = res
+    if instances is None and foreground is None:
+        return
+    foreground = foreground.astype(np.uint8)
+    if kwargs.get('crop_to_foreground', True):
+        instances[foreground == 0] = 0
+    fn = os.path.splitext(os.path.basename(aff_file))[0]
+    out_fn = os.path.join(kwargs['result_folder'], fn + ".hdf")
+    write_result(out_fn, {res_key + res_ext: instances, 'vote_foreground' + res_ext: foreground})
+
+
+def write_result(out_fn, datasets):
+    """HDF5 via h5py when it is importable (the reference's format, vote_instances.py:542-554),
+    otherwise an ``.npz`` next to it carrying the same dataset names."""
+    try:
+        import h5py
+    except ImportError:
+        np.savez_compressed(os.path.splitext(out_fn)[0] + ".npz", **datasets)
+        logger.warning("h5py not available: wrote %s.npz instead of %s",
+                       os.path.splitext(out_fn)[0], out_fn)
+        return
+    with h5py.File(out_fn, 'w') as f2:
+        for key, data in datasets.items():
+            f2.create_dataset(key, data=data, compression='gzip')
+            f2[key].attrs['offset'] = (0, 0, 0)
+            f2[key].attrs['resolution'] = (1, 1, 1)
+
+
+def main(**kwargs):
+    """vote_instances.py:557-604."""
+    if 'check_required' in kwargs:
+        args = get_arguments(check_required=kwargs['check_required'], argv=[])
+    else:
+        args = get_arguments(argv=None if not kwargs else [])
+    args = vars(args)
+    if len(kwargs) > 0:
+        args = merge_dicts(args, kwargs)
+    if 'check_required' in kwargs:
+        assert type(args['patchshape']) in [np.ndarray, tuple, list], \
+            "Please check type of patchshape {}".format(type(args['patchshape']))
+        assert type(args['result_folder']) == str, \
+            "Please check type of result_folder {}".format(type(args['result_folder']))
+    if args.get('cuda') and not args.get('graphToInst', False):
+        args['context'] = init_cuda()
+    os.makedirs(args['result_folder'], exist_ok=True)
+
+    affinities = args['affinities']
+    aff_files = []
+    if affinities is not None:
+        if affinities.endswith(".zarr") or os.path.isfile(affinities):
+            do_all(affinities, **args)
+            return
+        elif os.path.isdir(affinities):
+            aff_files = glob.glob(os.path.join(affinities, "*.hdf"))
+        else:
+            raise RuntimeError("affinities (%s) should be file or dir" % affinities)
+    elif args['mode'] is not None and args['checkpoint'] is not None:
+        aff_files = glob.glob(os.path.join(args['basedir'], args['mode'], "processed",
+                                           args['checkpoint'], "*.hdf"))
+    if args.get('parallel'):
+        raise NotImplementedError
+    for fl in aff_files:
+        do_all(fl, **args)
+    delete_cuda(args.get('context'))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ppp_mi355x.h declares, the
+compute entry points refuse to run without a GPU (no CPU fallback), and the native HOST
+stages (sort, cover, thinning, pair enumeration, mutex watershed) reproduce the reference's
+golden vectors.  No device compute happens here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from patchperpix_amd import backend
+from patchperpix_amd.vote_instances import graph_mws
+
+HEADER = os.path.join(REPO, "include", "ppp_mi355x.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(backend.library_path())
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), "libppp_mi355x.so does not export %s" % n
+    assert L.ppp_abi_version() == backend.ABI_VERSION
+    # and the Python binding covers exactly the same set
+    assert sorted(backend._SIGNATURES) == names
+
+
+def test_params_struct_matches_header_size():
+    # int32 x7, pad, double x2, int32 x8, box 6 x int32  (natural C alignment)
+    assert ctypes.sizeof(backend.Params) == 8 * 4 + 2 * 8 + 8 * 4 + 6 * 4
+    P = backend.make_params((4, 5, 6), (3, 3, 3), patch_threshold=0.9)
+    assert (P.bg_rule, P.thi) == (backend.BG_INV_TH, 1.0 - 0.9)
+    P = backend.make_params((4, 5, 6), (3, 3, 3), patch_threshold=0.4)
+    assert (P.bg_rule, P.thi) == (backend.BG_LESS_THAN_TH, 0.4)   # silent switch, :391-398
+    with pytest.raises(RuntimeError, match="how is bg defined"):
+        backend.make_params((4, 5, 6), (3, 3, 3), patch_threshold=0.9, vi_bg_use_inv_th=False)
+    assert backend.lib().ppp_cons_planes(ctypes.byref(P)) == (5 * 5 * 5 - 1) // 2
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    if backend.device_count() > 0:
+        pytest.skip("a GPU is present")
+    P = backend.make_params((4, 5, 6), (3, 3, 3), patch_threshold=0.5)
+    buf = np.zeros(8, dtype=np.float32)
+    p = buf.ctypes.data_as(ctypes.c_void_p)
+    rc = backend.lib().ppp_consensus(p, 0, None, p, None, ctypes.byref(P), None)
+    assert rc == -2  # PPP_ERR_NO_DEVICE
+    assert b"no CPU path" in backend.lib().ppp_last_error()
+    with pytest.raises(RuntimeError):
+        backend.check(rc)
+
+
+def test_bad_arguments_are_rejected():
+    P = backend.make_params((4, 5, 6), (3, 3, 3), patch_threshold=0.5)
+    P.px = 4
+    assert backend.lib().ppp_consensus(None, 0, None, None, None, ctypes.byref(P), None) == -1
+    assert b"odd" in backend.lib().ppp_last_error()
+
+
+def _bits(pred, coords, thresh):
+    C = pred.shape[0]
+    words = (C + 31) // 32
+    vals = pred[(slice(None),) + tuple(coords.T)].T > np.float32(thresh)     # [n, C]
+    out = np.zeros((len(coords), words), dtype=np.uint32)
+    for r in range(C):
+        out[:, r // 32] |= vals[:, r].astype(np.uint32) << np.uint32(r % 32)
+    return out
+
+
+def test_host_stages_match_reference(golden):
+    g = golden
+    if int(g["early_out"]) in (1, 2):
+        pytest.skip("early-out case")
+    ps = g.patchshape
+    rad = [p // 2 for p in ps]
+    shape = g.foreground.shape
+    # ranking order (stable sort, score descending)
+    lin = backend.host_rank_order(g["scores"], g.foreground, ps)
+    coords = np.stack(np.unravel_index(lin, shape), axis=1)
+    assert np.array_equal(coords, g["ranked_coords"])
+    # cover
+    mask = g.foreground.copy()
+    mask[g.overlap_mask > 0] = 0
+    running = mask.astype(np.uint8)
+    radslice = tuple(slice(rad[i], shape[i] - rad[i]) for i in range(3))
+    remaining = int(np.count_nonzero(running[radslice]))
+    bits = _bits(g.pred, coords, g.kw["fc_threshold"])
+    selected = np.zeros(len(lin), dtype=np.uint8)
+    if g.kw["select_patches_for_sparse_data"]:
+        pix_ths = [0]
+    else:
+        pix_ths = [t for t in [500, 100, 50, 10, 0] if t < int(np.prod(ps) / 2)]
+    for t in pix_ths:
+        remaining, _ = backend.host_cover_pass(
+            running, (g.overlap_mask > 0).astype(np.uint8), ps, lin,
+            np.ascontiguousarray(g["ranked_scores"]), bits, t, None, selected, remaining)
+        if remaining < 1:
+            break
+    cover = coords[selected.astype(bool)]
+    assert np.array_equal(cover, g["cover_coords"])
+    sel = cover
+    if g.has("thin_coords"):
+        sel_lin = np.ascontiguousarray(lin[selected.astype(bool)])
+        keep = backend.host_thin_cover(mask.astype(np.uint8), ps, sel_lin,
+                                       np.ascontiguousarray(bits[selected.astype(bool)]))
+        sel = cover[keep]
+        assert np.array_equal(sel, g["thin_coords"])
+    # pairs
+    sorted_zyx, pairs = backend.host_patch_pairs(
+        sel, ps, include_single=g.kw["includeSinglePatchCCS"])
+    assert np.array_equal(sorted_zyx, g["selected_sorted"])
+    if int(g["early_out"]) == 3:
+        assert pairs is None
+        return
+    assert np.array_equal(pairs, g["pairs"])
+
+
+def test_mutex_watershed_matches_reference(golden):
+    g = golden
+    if not g.kw.get("mws") or int(g["early_out"]) != 0:
+        pytest.skip("not an mws case")
+    from oracle import ppp_oracle as orc
+    ccs = graph_mws.mws_from_pairs(g["pairs"], g["aff"])
+    inst = orc.paint_instances(ccs, g.pred, g.patchshape, g.foreground.shape,
+                               g.kw["patch_threshold"])
+    assert np.array_equal(inst, g["instances"])

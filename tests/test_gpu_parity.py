@@ -1,0 +1,208 @@
+"""GPU (MI355X): the HIP kernels, called through the C ABI, against
+ (a) the golden vectors produced by the reference itself, and
+ (b) the CPU oracle on fresh seeded inputs,
+bit-exact on every float stage (compared as uint32 bit patterns; tolerance 0 ulp) and on
+every integer stage."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import same_partition
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    from patchperpix_amd import backend
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert backend.device_count() >= 1
+    return torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f16=False):
+    from patchperpix_amd import backend
+    P = backend.make_params(pred_host.shape[1:], patchshape, **kw)
+    pred = _dev(torch, pred_host.astype(np.float16) if f16 else pred_host.astype(np.float32))
+    ov = _dev(torch, (overlap_mask > 0).astype(np.uint8)) if P.use_overlap else None
+    cons = backend.consensus(pred, ov, P)
+    score = backend.rank_patches(pred, cons, ov, P)
+    out = dict(cons=cons.cpu().numpy(), score=score.cpu().numpy(), P=P, pred=pred, cons_dev=cons)
+    if pairs is not None and len(pairs):
+        pd = _dev(torch, np.ascontiguousarray(pairs, dtype=np.uint32).view(np.int32))
+        out["aff"] = backend.patch_graph(pred, cons, pd, P).cpu().numpy()
+    return out
+
+
+def test_kernels_match_reference_goldens(golden, torch_cuda):
+    g = golden
+    if int(g["early_out"]) in (1, 2):
+        pytest.skip("early-out case (covered by the end-to-end test)")
+    pairs = g["pairs"] if g.has("pairs") else None
+    for f16 in (False, True):   # the goldens' inputs are float16-representable
+        o = _stage_outputs(torch_cuda, g.pred, g.overlap_mask, g.patchshape, g.kw, pairs, f16)
+        if g.has("cons_pos"):
+            assert np.array_equal(_bits(o["cons"]), _bits(g["cons_pos"]))
+        else:
+            assert hashlib.sha256(np.ascontiguousarray(o["cons"]).tobytes()).hexdigest() == \
+                str(g["cons_pos_sha256"])
+        assert np.array_equal(_bits(o["score"]), _bits(g["scores"]))
+        if pairs is not None:
+            assert np.array_equal(_bits(o["aff"]), _bits(g["aff"]))
+
+
+def test_end_to_end_matches_reference(golden, torch_cuda):
+    """to_instance_seg through the drop-in entry point: identical instance ids (the pair order
+    is the canonical one the golden was generated with), hence identical partition."""
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    g = golden
+    kw = dict(g.kw, debug=False, isbiHack=False, save_no_intermediates=True, sample=1.0,
+              result_folder="/tmp", affinities="x.zarr")
+    inst, fg = vi.to_instance_seg(g.pred.copy(), g.foreground.copy(), g.foreground.copy(),
+                                  g.numinst.copy(), g.patchshape, **kw)
+    if g.has("instances"):
+        assert inst.dtype == np.uint16
+        assert np.array_equal(inst, g["instances"])
+        assert same_partition(inst, g["instances"])
+        assert np.array_equal(fg, g["foreground_out"])
+    else:
+        assert not inst.any()
+    # return_intermediates hands back (pairs, aff) like the reference
+    res = vi.to_instance_seg(g.pred.copy(), g.foreground.copy(), g.foreground.copy(),
+                             g.numinst.copy(), g.patchshape,
+                             **dict(kw, return_intermediates=True))
+    if g.has("aff"):
+        assert np.array_equal(res[0], g["pairs"])
+        assert np.array_equal(_bits(res[1]), _bits(g["aff"]))
+    else:
+        assert res == (None, None)
+
+
+CASES = [
+    # shape, patchshape, synth kwargs, flag overrides
+    ((20, 22, 24), (5, 5, 5), dict(seed=21, cell=[8, 8, 8], overlap_frac=0.02), {}),
+    ((9, 40, 70), (3, 7, 5), dict(seed=22, cell=[4, 10, 9], noise=0.3),
+     dict(patch_threshold=0.8, vi_bg_use_inv_th=True, vi_bg_use_less_than_th=False)),
+    ((1, 64, 67), (1, 9, 9), dict(seed=23, cell=[1, 14, 14], noise=0.2),
+     dict(patch_threshold=0.6, vi_bg_use_half_th=True, vi_bg_use_less_than_th=False,
+          rank_int_counter=True, overlapping_inst=False)),
+    ((18, 18, 18), (7, 7, 7), dict(seed=24, cell=[9, 9, 9]),
+     dict(consensus_norm_prob_product=False, consensus_prob_product=True)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_kernels_match_oracle_on_fresh_inputs(case, torch_cuda):
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd import synth
+    from tests_flags import FLYLIGHT
+    shape, ps, skw, flags = CASES[case]
+    kw = dict(FLYLIGHT, **flags)
+    c = synth.make_case(shape, ps, **skw)
+    # non-float16 values too: perturb in float32 so products are not exactly representable
+    rng = np.random.default_rng(case)
+    pred = (c["pred"] * rng.uniform(0.97, 1.0, size=c["pred"].shape)).astype(np.float32)
+    ov = 1 * (c["numinst"] > 1)
+    ref = orc.to_instance_seg(pred, c["foreground"], c["foreground"].copy(), c["numinst"], ps, **kw)
+    assert "aff" in ref
+    o = _stage_outputs(torch_cuda, pred, ov, ps, kw, ref["pairs"])
+    assert np.array_equal(_bits(o["cons"]), _bits(orc.positive_planes(ref["cons"], ps)))
+    assert np.array_equal(_bits(o["score"]), _bits(ref["scores"]))
+    assert np.array_equal(_bits(o["aff"]), _bits(ref["aff"]))
+    # full path on the device side
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    inst, _ = vi.to_instance_seg(pred.copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), ps,
+                                 **dict(kw, save_no_intermediates=True, sample=1.0,
+                                        result_folder="/tmp", affinities="x.zarr"))
+    assert np.array_equal(inst, ref["instances"])
+
+
+def test_reference_layout_count_and_tiles(torch_cuda):
+    """PPP_CONS_REFERENCE layout, the separate count output, and a consensus TILE (cons_box)
+    agree with the whole-volume compact result."""
+    import ctypes
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    from oracle import ppp_oracle as orc
+    torch = torch_cuda
+    shape, ps = (12, 14, 16), (3, 3, 3)
+    c = synth.make_case(shape, ps, seed=31, cell=[5, 5, 5], overlap_frac=0.02)
+    kw = dict(FLYLIGHT)
+    ov_h = (c["numinst"] > 1).astype(np.uint8)
+    pred, ov = _dev(torch, c["pred"]), _dev(torch, ov_h)
+    P = backend.make_params(shape, ps, **kw)
+    cons, cnt = backend.consensus(pred, ov, P, want_count=True)
+    ref = orc.consensus(c["pred"], ov_h, ps, **kw)
+    assert np.array_equal(_bits(backend.cons_to_reference(cons, P).cpu().numpy()), _bits(ref))
+    Pr = backend.make_params(shape, ps, cons_layout=backend.CONS_REFERENCE, **kw)
+    assert np.array_equal(_bits(backend.consensus(pred, ov, Pr).cpu().numpy()), _bits(ref))
+    # counts: the reference's -DOUTPUT_CNT pass
+    kw_raw = dict(kw, consensus_norm_aff=False, consensus_interleaved_cnt=False)
+    Praw = backend.make_params(shape, ps, **kw_raw)
+    raw, cnt2 = backend.consensus(pred, ov, Praw, want_count=True)
+    assert np.array_equal(cnt.cpu().numpy(), cnt2.cpu().numpy())
+    with np.errstate(invalid="ignore", divide="ignore"):
+        expect = np.where(cnt2.cpu().numpy() != 0, raw.cpu().numpy() / cnt2.cpu().numpy(),
+                          raw.cpu().numpy())
+    assert np.array_equal(_bits(expect), _bits(cons.cpu().numpy()))
+    # a tile of bases + scores for the centres it supports
+    box = (2, 3, 1, 9, 12, 13)
+    Pt = backend.make_params(shape, ps, cons_box=box, **kw)
+    tile = backend.consensus(pred, ov, Pt).cpu().numpy()
+    assert np.array_equal(_bits(tile), _bits(cons.cpu().numpy()[:, 2:9, 3:12, 1:13]))
+    full_score = backend.rank_patches(pred, cons, ov, P).cpu().numpy()
+    sb = (3, 4, 2, 8, 11, 12)
+    part = backend.rank_patches(pred, _dev(torch, tile), ov, Pt, score_box=sb).cpu().numpy()
+    assert np.array_equal(_bits(part[3:8, 4:11, 2:12]), _bits(full_score[3:8, 4:11, 2:12]))
+    with pytest.raises(RuntimeError, match="does not cover"):
+        backend.rank_patches(pred, _dev(torch, tile), ov, Pt, score_box=(1, 4, 2, 8, 11, 12))
+
+
+def test_union_find_labels_match_oracle(torch_cuda):
+    """ppp_label_components on a random sparse graph with many components, zero and negative
+    edges and self loops: same components, same enumeration order as the oracle (which is
+    pinned to networkx through the goldens)."""
+    from patchperpix_amd import backend
+    from patchperpix_amd.vote_instances.aff_patch_graph import AffGraph
+    from patchperpix_amd.vote_instances.graph_to_labeling import component_labels
+    from oracle import ppp_oracle as orc
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    shape = (24, 24, 24)
+    nodes = rng.integers(3, 21, size=(400, 3))
+    i = rng.integers(0, 400, size=3000)
+    j = rng.integers(0, 400, size=3000)
+    pairs = np.concatenate([nodes[i], nodes[j]], axis=1).astype(np.uint32)
+    aff = rng.choice([0.0, -0.5, 0.25, 0.75], p=[0.3, 0.4, 0.2, 0.1], size=3000).astype(np.float32)
+    aff[::97] = 0.5
+    pairs[::97, 3:] = pairs[::97, :3]          # self loops
+    P = backend.make_params(shape, (3, 3, 3), patch_threshold=0.5)
+    got_nodes, got_labels = component_labels(AffGraph(aff, pairs), shape, "cuda", P, mws=False)
+    want = {}
+    for k, cc in enumerate(orc.connected_components(pairs, aff)):
+        for n in cc:
+            want[n] = k + 1
+    got = {tuple(int(v) for v in n): int(l) for n, l in zip(got_nodes, got_labels)}
+    assert got == want
+
+
+def test_synth_on_device_equals_numpy(torch_cuda):
+    from patchperpix_amd import backend, synth
+    torch = torch_cuda
+    shape, ps = (9, 11, 13), (3, 5, 3)
+    lab = synth.cell_labels(shape, [4, 5, 4], seed=3)
+    want = synth.pred_from_labels(lab, ps, seed=7)
+    P = backend.make_params(shape, ps, patch_threshold=0.5)
+    got = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=7, f16=True)
+    assert np.array_equal(got.float().cpu().numpy(), want)
