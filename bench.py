@@ -114,6 +114,10 @@ def main():
 
     backend.EVENTS = {}
     barrier()
+    host_times = None
+    if os.environ.get("PPP_BENCH_STAGES", "1") == "1":
+        # per-stage wall clock (adds a device sync around every stage)
+        backend.HOST_TIMES = host_times = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         inst = step()
@@ -125,6 +129,7 @@ def main():
         dt = float(t.item())
     ev = backend.event_times_ms()
     backend.EVENTS = None
+    backend.HOST_TIMES = None
 
     V = float(np.prod(shape))
     C = int(np.prod(ps))
@@ -152,7 +157,10 @@ def main():
                        "instances_found": int(len(np.unique(inst)) - 1),
                        "parallelism": "tiles%d" % n_gpus},
             "roofline": roofline,
-            "stage_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
+            "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
+            "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
+                              for k, v in (host_times or {}).items()},
+            "workload_stats": dict(backend.NOTES),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ps, cell, kw)

@@ -120,27 +120,33 @@ int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
 /* --- S5: patch graph (edge emission) --------------------------------------------------
  * replaces computePatchGraph_cuda (aff_patch_graph.py:113-187) + kernel computePatchGraph
  * (cuda/computePatchGraph.cu:3-136).  d_pairs u32[n_pairs][6] = (z,y,x) of patch A and B,
- * d_aff f32[n_pairs] out.  The reference's 512-pairs-per-launch loop with its `offset`
- * argument (aff_patch_graph.py:137-159) is one launch here.                             */
+ * d_aff f32[n_pairs] out (d_aff[i] belongs to row i whatever the processing order).
+ * The reference's 512-pairs-per-launch loop with its `offset` argument
+ * (aff_patch_graph.py:137-159) is one launch here.
+ * d_order (optional, may be NULL): a permutation of 0..n_pairs-1 giving the order in which
+ * rows are assigned to lanes.  Results do not depend on it; speed does: rows with the same
+ * patch offset (B - A) placed next to each other run with wave-uniform control flow.      */
 int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
-                    const uint32_t *d_pairs, uint64_t n_pairs, float *d_aff,
-                    const ppp_params *p, void *stream);
+                    const uint32_t *d_pairs, const uint32_t *d_order, uint64_t n_pairs,
+                    float *d_aff, const ppp_params *p, void *stream);
 
 /* --- S6: labelling -------------------------------------------------------------------
  * replaces setAffgraph (aff_patch_graph.py:31-40) + the connected-components branch of
  * affGraphToInstances (graph_to_labeling.py:50-54,61-86).
  *
  * ppp_label_components: union-find (global atomics) over the rows with aff > 0; nodes are
- * patch centres identified by their linear voxel index.  Outputs, per pair row i:
- *   d_cc_key[2*i+0], d_cc_key[2*i+1] (uint32): the ORDER KEY of the component that the
- *   A / B patch of row i belongs to, or 0xFFFFFFFF if that patch is in no component
- *   (no positive edge).  The key of a component is the smallest position 2*row+side at
- *   which any of its members first appears among the rows with aff != 0 -- sorting the
- *   distinct keys ascending reproduces networkx's component enumeration order.
+ * patch centres identified by their linear voxel index.  Output, for every node k of the
+ * caller's node list d_nodes u32[n_nodes][3] (normally the selected patches):
+ *   d_node_key[k] (uint32): the ORDER KEY of the component node k belongs to, or 0xFFFFFFFF
+ *   if it is in no component (no positive edge).  The key of a component is the smallest
+ *   position 2*row+side at which any of its members first appears among the rows with
+ *   aff != 0 -- sorting the distinct keys ascending reproduces networkx's component
+ *   enumeration order (graph_to_labeling.py:54-61).
  * d_work: workspace of ppp_label_workspace_bytes(p) bytes.                              */
 size_t ppp_label_workspace_bytes(const ppp_params *p);
 int ppp_label_components(const uint32_t *d_pairs, const float *d_aff, uint64_t n_pairs,
-                         uint32_t *d_cc_key, void *d_work, const ppp_params *p, void *stream);
+                         const uint32_t *d_nodes, uint64_t n_nodes, uint32_t *d_node_key,
+                         void *d_work, const ppp_params *p, void *stream);
 
 /* ppp_paint_instances: for every node k (d_nodes u32[n_nodes][3]) with label
  * d_labels[k] > 0, write the label into every voxel of its window whose patch value is
@@ -165,6 +171,22 @@ int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
 int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres,
                    uint64_t n, double thresh, uint32_t *d_bits, const ppp_params *p,
                    void *stream);
+
+/* --- patch pairs on the device ---------------------------------------------------------
+ * replaces computeAndStorePatchPairs (aff_patch_graph.py:43-110).  d_sorted_zyx int32[n][3]
+ * is the selected list stably sorted by x (aff_patch_graph.py:45).  Two calls: count the
+ * partners j > i of every patch i, then -- after an exclusive scan of the counts by the
+ * caller -- write the rows (pts[i], pts[j]) in (i, j) order, followed by the n self pairs
+ * when include_single (includeSinglePatchCCS).  Rows: d_rows u32[n_pair_rows (+ n)][6].   */
+int ppp_patch_pairs_count(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                          int64_t *d_counts, const ppp_params *p, void *stream);
+int ppp_patch_pairs_fill(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                         const int64_t *d_offsets, int64_t n_pair_rows, int32_t include_single,
+                         uint32_t *d_rows, const ppp_params *p, void *stream);
+/* sort keys (int64) that group pair rows by patch offset B - A, then by position of A: an
+ * argsort of them is a good d_order for ppp_patch_graph                                    */
+int ppp_pair_sort_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
+                       const ppp_params *p, void *stream);
 
 /* --- host stages (host pointers; they are host code in the reference as well) ---------
  * ppp_host_rank_order: all_patches + rank_patches_by_score (vote_instances.py:276,286-287,

@@ -69,12 +69,23 @@ _SIGNATURES = {
                                         ctypes.POINTER(Box), ctypes.POINTER(Params),
                                         ctypes.c_void_p]),
     "ppp_patch_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                       ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
-                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                       ctypes.c_void_p, ctypes.POINTER(Params),
+                                       ctypes.c_void_p]),
     "ppp_label_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "ppp_label_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
-                                            ctypes.c_void_p, ctypes.c_void_p,
-                                            ctypes.POINTER(Params), ctypes.c_void_p]),
+                                            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.POINTER(Params),
+                                            ctypes.c_void_p]),
+    "ppp_patch_pairs_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.POINTER(Params),
+                                             ctypes.c_void_p]),
+    "ppp_patch_pairs_fill": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.POINTER(Params),
+                                            ctypes.c_void_p]),
+    "ppp_pair_sort_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_paint_instances": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                            ctypes.POINTER(Params), ctypes.c_void_p]),
@@ -232,6 +243,37 @@ class _timed:
             EVENTS.setdefault(self.name, []).append((self.a, self.b))
 
 
+HOST_TIMES = None   # name -> [seconds, ...] wall time of host stages (bench.py switches on)
+
+
+class host_timer:
+    """Wall-clock timer for a host stage (synchronises the device first when enabled, so a
+    stage is not charged for kernels still running from the previous one)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if HOST_TIMES is not None:
+            import time
+            _torch().cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if HOST_TIMES is not None:
+            import time
+            _torch().cuda.synchronize()
+            HOST_TIMES.setdefault(self.name, []).append(time.perf_counter() - self.t0)
+
+
+NOTES = {}
+
+
+def note(key, value):
+    """Record a workload statistic (number of selected patches, pairs, ...)."""
+    NOTES[key] = int(value)
+
+
 def event_times_ms():
     """name -> list of elapsed ms (call after a synchronize)."""
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in (EVENTS or {}).items()}
@@ -294,35 +336,73 @@ def rank_patches(pred, cons, overlap, P, score_box=None, out=None):
     return out
 
 
-def patch_graph(pred, cons, pairs, P):
-    """S5.  pairs: device uint32-as-int32 [N, 6]; returns float32 [N]."""
+def pair_order(pairs, P):
+    """Processing order for ppp_patch_graph: rows grouped by patch offset d = B - A, and by
+    position of A inside a group.  pairs: device int32 [N, 6]; returns device int32 [N]."""
+    torch = _torch()
+    n = int(pairs.shape[0])
+    keys = torch.empty((n,), dtype=torch.int64, device=pairs.device)
+    check(lib().ppp_pair_sort_keys(_dev_ptr(pairs), n, _dev_ptr(keys), ctypes.byref(P), _stream()))
+    return torch.argsort(keys).to(torch.int32)
+
+
+def device_patch_pairs(sorted_zyx, P, max_ps_dist=2, include_single=True):
+    """Pair rows on the device from the x-sorted selected list (device int32 [n, 3]).
+    Returns device int32 [rows, 6] (uint32 bit patterns) or None when there are no rows."""
+    torch = _torch()
+    n = int(sorted_zyx.shape[0])
+    counts = torch.zeros((max(n, 1),), dtype=torch.int64, device=sorted_zyx.device)
+    with _timed("patch_pairs"):
+        check(lib().ppp_patch_pairs_count(_dev_ptr(sorted_zyx), n, int(max_ps_dist),
+                                          _dev_ptr(counts), ctypes.byref(P), _stream()))
+        ends = torch.cumsum(counts, 0)
+        n_rows = int(ends[n - 1].item()) if n else 0
+        total = n_rows + (n if include_single else 0)
+        if total == 0:
+            return None
+        offsets = (ends - counts).contiguous()
+        rows = torch.empty((total, 6), dtype=torch.int32, device=sorted_zyx.device)
+        check(lib().ppp_patch_pairs_fill(_dev_ptr(sorted_zyx), n, int(max_ps_dist),
+                                         _dev_ptr(offsets), n_rows, 1 if include_single else 0,
+                                         _dev_ptr(rows), ctypes.byref(P), _stream()))
+    return rows
+
+
+def patch_graph(pred, cons, pairs, P, order=None):
+    """S5.  pairs: device uint32-as-int32 [N, 6]; order: optional device int32 permutation
+    (see pair_order); returns float32 [N]."""
     torch = _torch()
     n = int(pairs.shape[0])
     aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
     with _timed("patch_graph"):
         check(lib().ppp_patch_graph(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons),
-                                    _dev_ptr(pairs), n, _dev_ptr(aff), ctypes.byref(P),
-                                    _stream()))
+                                    _dev_ptr(pairs), _dev_ptr(order), n, _dev_ptr(aff),
+                                    ctypes.byref(P), _stream()))
     return aff
 
 
-def label_components(pairs, aff, P):
-    """S6 (components).  Returns int64 [N, 2] order keys (NONE_KEY = not in a component)."""
+def label_components(pairs, aff, nodes, P):
+    """S6 (components).  nodes: device int32 [K, 3]; returns int64 [K] order keys
+    (NONE_KEY = not in a component)."""
     torch = _torch()
-    n = int(pairs.shape[0])
-    keys = torch.empty((n, 2), dtype=torch.int32, device=pairs.device)
+    n = 0 if pairs is None else int(pairs.shape[0])
+    k = int(nodes.shape[0])
+    keys = torch.empty((k,), dtype=torch.int32, device=nodes.device)
     nbytes = int(lib().ppp_label_workspace_bytes(ctypes.byref(P)))
-    work = torch.empty((nbytes,), dtype=torch.uint8, device=pairs.device)
-    check(lib().ppp_label_components(_dev_ptr(pairs), _dev_ptr(aff), n, _dev_ptr(keys),
-                                     _dev_ptr(work), ctypes.byref(P), _stream()))
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=nodes.device)
+    with _timed("label_components"):
+        check(lib().ppp_label_components(_dev_ptr(pairs), _dev_ptr(aff), n, _dev_ptr(nodes), k,
+                                         _dev_ptr(keys), _dev_ptr(work), ctypes.byref(P),
+                                         _stream()))
     return keys.to(torch.int64) & 0xFFFFFFFF
 
 
 def paint_instances(pred, nodes, labels, instances, P):
     """S6 (paint).  nodes int32 [K, 3], labels int32 [K], instances int32 (Z, Y, X) in place."""
-    check(lib().ppp_paint_instances(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(nodes),
-                                    _dev_ptr(labels), int(nodes.shape[0]), _dev_ptr(instances),
-                                    ctypes.byref(P), _stream()))
+    with _timed("paint_instances"):
+        check(lib().ppp_paint_instances(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(nodes),
+                                        _dev_ptr(labels), int(nodes.shape[0]),
+                                        _dev_ptr(instances), ctypes.byref(P), _stream()))
     return instances
 
 

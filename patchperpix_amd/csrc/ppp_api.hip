@@ -176,15 +176,16 @@ int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
 }
 
 int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
-                    const uint32_t *d_pairs, uint64_t n_pairs, float *d_aff,
-                    const ppp_params *p, void *stream) {
+                    const uint32_t *d_pairs, const uint32_t *d_order, uint64_t n_pairs,
+                    float *d_aff, const ppp_params *p, void *stream) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     PPP_TRY(check_dtype(pred_dtype));
     if (n_pairs == 0) return PPP_OK;
+    if (n_pairs >= (1ull << 32)) return fail(PPP_ERR_UNSUPPORTED, "more than 2^32-1 pair rows");
     if (!d_pred || !d_cons || !d_pairs || !d_aff) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
     PPP_TRY(need_device());
-    hipError_t e = ppp::launch_patch_graph(d_pred, pred_dtype, d_cons, d_pairs, n_pairs, d_aff, G, (hipStream_t)stream);
+    hipError_t e = ppp::launch_patch_graph(d_pred, pred_dtype, d_cons, d_pairs, d_order, n_pairs, d_aff, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph");
 }
 
@@ -194,15 +195,62 @@ size_t ppp_label_workspace_bytes(const ppp_params *p) {
 }
 
 int ppp_label_components(const uint32_t *d_pairs, const float *d_aff, uint64_t n_pairs,
-                         uint32_t *d_cc_key, void *d_work, const ppp_params *p, void *stream) {
+                         const uint32_t *d_nodes, uint64_t n_nodes, uint32_t *d_node_key,
+                         void *d_work, const ppp_params *p, void *stream) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
-    if (n_pairs == 0) return PPP_OK;
+    if (n_nodes == 0) return PPP_OK;
     if (n_pairs >= (1ull << 31)) return fail(PPP_ERR_UNSUPPORTED, "more than 2^31-1 pair rows");
-    if (!d_pairs || !d_aff || !d_cc_key || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if ((n_pairs && (!d_pairs || !d_aff)) || !d_nodes || !d_node_key || !d_work)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
     PPP_TRY(need_device());
-    hipError_t e = ppp::launch_label(d_pairs, d_aff, n_pairs, d_cc_key, d_work, G, (hipStream_t)stream);
+    hipError_t e = ppp::launch_label(d_pairs, d_aff, n_pairs, d_nodes, n_nodes, d_node_key, d_work, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_label_components");
+}
+
+static int pair_box(const ppp_params *p, int32_t max_ps_dist, int *box, int *l1max) {
+    if (max_ps_dist < 0) return fail(PPP_ERR_INVALID_ARG, "max_ps_dist < 0");
+    box[0] = max_ps_dist * p->pz; box[1] = max_ps_dist * p->py; box[2] = max_ps_dist * p->px;
+    *l1max = 2 * (p->pz + p->py + p->px);
+    return PPP_OK;
+}
+
+int ppp_patch_pairs_count(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                          int64_t *d_counts, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n == 0) return PPP_OK;
+    if (!d_sorted_zyx || !d_counts) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    int box[3], l1max;
+    PPP_TRY(pair_box(p, max_ps_dist, box, &l1max));
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pairs_count(d_sorted_zyx, n, box, l1max, d_counts, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_pairs_count");
+}
+
+int ppp_patch_pairs_fill(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                         const int64_t *d_offsets, int64_t n_pair_rows, int32_t include_single,
+                         uint32_t *d_rows, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n == 0) return PPP_OK;
+    if (!d_sorted_zyx || !d_offsets || !d_rows) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    int box[3], l1max;
+    PPP_TRY(pair_box(p, max_ps_dist, box, &l1max));
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pairs_fill(d_sorted_zyx, n, box, l1max, d_offsets, n_pair_rows, include_single, d_rows, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_pairs_fill");
+}
+
+int ppp_pair_sort_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
+                       const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n_rows == 0) return PPP_OK;
+    if (!d_rows || !d_keys) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pair_keys(d_rows, n_rows, d_keys, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_pair_sort_keys");
 }
 
 int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_nodes,

@@ -9,10 +9,18 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
 hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uint8_t *ov,
                        float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
-                              const uint32_t *pairs, uint64_t n, float *aff, const Geo &G,
-                              hipStream_t s);
-hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n, uint32_t *cc_key,
-                        void *work, const Geo &G, hipStream_t s);
+                              const uint32_t *pairs, const uint32_t *order, uint64_t n,
+                              float *aff, const Geo &G, hipStream_t s);
+hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n,
+                        const uint32_t *nodes, uint64_t n_nodes, uint32_t *node_key, void *work,
+                        const Geo &G, hipStream_t s);
+hipError_t launch_pairs_count(const int32_t *pts, int64_t n, const int *box, int l1max,
+                              int64_t *counts, hipStream_t s);
+hipError_t launch_pairs_fill(const int32_t *pts, int64_t n, const int *box, int l1max,
+                             const int64_t *offsets, int64_t n_pair_rows, int include_single,
+                             uint32_t *rows, hipStream_t s);
+hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
+                            hipStream_t s);
 hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,
                         const uint32_t *labels, uint64_t n, uint32_t *inst, const Geo &G,
                         hipStream_t s);

@@ -89,28 +89,45 @@ __global__ void label_key_kernel(const uint32_t *__restrict__ pairs,
     atomicMin(&cckey[find_root(parent, v)], firstpos[v]);
 }
 
-__global__ void label_emit_kernel(const uint32_t *__restrict__ pairs, uint64_t n,
+__global__ void label_emit_kernel(const uint32_t *__restrict__ nodes, uint64_t n_nodes,
                                   uint32_t *parent, const uint32_t *__restrict__ cckey,
+                                  const uint32_t *__restrict__ firstpos,
                                   uint32_t *__restrict__ out, const Geo G) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n_nodes) return;
+    const uint32_t x = node_of(G, nodes + i * 3);
     // a node without any positive edge is its own root and its key stayed NONE
-    out[2 * i] = cckey[find_root(parent, node_of(G, pairs + i * 6))];
-    out[2 * i + 1] = cckey[find_root(parent, node_of(G, pairs + i * 6 + 3))];
+    out[i] = cckey[find_root(parent, x)];
 }
 
-hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n, uint32_t *cc_key,
-                        void *work, const Geo &G, hipStream_t s) {
-    if (n == 0) return hipSuccess;
+__global__ void label_init_nodes_kernel(const uint32_t *__restrict__ nodes, uint64_t n_nodes,
+                                        uint32_t *parent, uint32_t *firstpos, uint32_t *cckey,
+                                        const Geo G) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t x = node_of(G, nodes + i * 3);
+    parent[x] = x; firstpos[x] = NONE; cckey[x] = NONE;
+}
+
+hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n,
+                        const uint32_t *nodes, uint64_t n_nodes, uint32_t *node_key, void *work,
+                        const Geo &G, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
     uint32_t *parent = (uint32_t *)work;
     uint32_t *firstpos = parent + G.V;
     uint32_t *cckey = firstpos + G.V;
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    label_init_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, firstpos, cckey, G);
-    label_firstpos_kernel<<<grid, block, 0, s>>>(pairs, aff, n, firstpos, G);
-    label_union_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, G);
-    label_key_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, firstpos, cckey, G);
-    label_emit_kernel<<<grid, block, 0, s>>>(pairs, n, parent, cckey, cc_key, G);
+    const dim3 block(256);
+    const dim3 gn((unsigned)((n_nodes + 255) / 256));
+    // nodes that never occur in a row still need a defined state for the emit pass
+    label_init_nodes_kernel<<<gn, block, 0, s>>>(nodes, n_nodes, parent, firstpos, cckey, G);
+    if (n) {
+        const dim3 grid((unsigned)((n + 255) / 256));
+        label_init_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, firstpos, cckey, G);
+        label_firstpos_kernel<<<grid, block, 0, s>>>(pairs, aff, n, firstpos, G);
+        label_union_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, G);
+        label_key_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, firstpos, cckey, G);
+    }
+    label_emit_kernel<<<gn, block, 0, s>>>(nodes, n_nodes, parent, cckey, firstpos, node_key, G);
     return hipGetLastError();
 }
 

@@ -1,82 +1,177 @@
 // ppp_patch_graph.hip -- S5: affinity of a pair of selected patches from the consensus.
 //
-// Reference: cuda/computePatchGraph.cu:3-136 (one thread per patch pair).  The float sum
-// and the LCG thinning of the patch intersection are order dependent, so each pair is
-// evaluated by one lane in the reference's loop order (bit-identical result).
+// Reference: cuda/computePatchGraph.cu:3-136 -- one thread per patch pair (A, B) walks all
+// p^3 x p^3 pixel pairs (z1 in A, z2 in B); pairs of foreground pixels that are close enough
+// gather consensus[z2 - z1][earlier pixel]; pixel pairs inside the patch intersection are
+// thinned to ~20 % by a per-pair LCG.  The float sum and the LCG are ORDER dependent, so each
+// patch pair is evaluated by ONE lane in exactly the reference's loop order (bit-identical).
+//
+// MI355X mapping.  With one lane per pair, everything that depends only on the patch offset
+// d = cB - cA (which (r1, r2) combinations are in range, which consensus plane and base
+// offset they address, whether they lie in the intersection) is the same for all pairs with
+// the same d.  The caller passes a processing ORDER that groups pairs by d; a wave then runs
+// the loops with scalar (SGPR) control flow and scalar address arithmetic, and the per-lane
+// work shrinks to: two bit tests, the predicated LCG step, one gather at
+// `lane_base + scalar_offset`, one add.  The per-pixel foreground tests of the reference
+// (pred[mid][z] > TH and pred[r][c] > TH, :44-52,60-66) are evaluated once per patch into bit
+// masks held in LDS, instead of p^3 times inside the inner loop.
 #include "ppp_kernels.hpp"
 
 namespace ppp {
 
+static constexpr int PG_WAVES = 4;     // waves per workgroup (independent of each other)
+
+// bit r = (pred[mid][c + r - rad] > TH) && (pred[r][c] > TH)
 template <typename T>
-__global__ void __launch_bounds__(64)
+__device__ __forceinline__ void patch_fg_words(const T *__restrict__ pred, const Geo &G, int cz,
+                                               int cy, int cx, uint32_t *lds_col /* [word*64] */,
+                                               int words) {
+    const T *mid = pred + (long long)G.mid * G.V;
+    const long long lc = vox(G, cz, cy, cx);
+    int r = 0;
+    for (int w = 0; w < words; ++w) {
+        uint32_t bits = 0;
+        for (int b = 0; b < 32 && r < G.C; ++b, ++r) {
+            const int z = cz + r / (G.py * G.px) - G.rz;
+            const int y = cy + (r / G.px) % G.py - G.ry;
+            const int x = cx + r % G.px - G.rx;
+            const bool on = ldf(mid, vox(G, z, y, x)) > G.th_gt &&
+                            ldf(pred, (long long)r * G.V + lc) > G.th_gt;
+            bits |= (on ? 1u : 0u) << b;
+        }
+        lds_col[w * 64] = bits;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64 * PG_WAVES)
     patch_graph_kernel(const T *__restrict__ pred, const float *__restrict__ cons,
-                       const uint32_t *__restrict__ pairs, const uint64_t n,
-                       float *__restrict__ aff, const Geo G) {
-    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n) return;
-    const int az = (int)pairs[id * 6 + 0], ay = (int)pairs[id * 6 + 1], ax = (int)pairs[id * 6 + 2];
-    const int bz = (int)pairs[id * 6 + 3], by = (int)pairs[id * 6 + 4], bx = (int)pairs[id * 6 + 5];
+                       const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ order,
+                       const uint64_t n, float *__restrict__ aff, const Geo G) {
+    extern __shared__ uint32_t lds_raw[];  // [PG_WAVES][2][words][64]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t slot = ((uint64_t)blockIdx.x * PG_WAVES + wave) * 64 + lane;
+    const bool live = slot < n;
+    const uint64_t id = live ? (order ? (uint64_t)order[slot] : slot) : 0;
+    const int words = (G.C + 31) / 32;
+    uint32_t *lds_a = lds_raw + (size_t)(wave * 2 + 0) * words * 64;
+    uint32_t *lds_b = lds_raw + (size_t)(wave * 2 + 1) * words * 64;
+
+    int az = 0, ay = 0, ax = 0, bz = 0, by = 0, bx = 0;
+    if (live) {
+        az = (int)pairs[id * 6 + 0]; ay = (int)pairs[id * 6 + 1]; ax = (int)pairs[id * 6 + 2];
+        bz = (int)pairs[id * 6 + 3]; by = (int)pairs[id * 6 + 4]; bx = (int)pairs[id * 6 + 5];
+        patch_fg_words(pred, G, az, ay, ax, lds_a + lane, words);
+        patch_fg_words(pred, G, bz, by, bx, lds_b + lane, words);
+    }
     uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by * (uint32_t)ax *
                    (uint32_t)bx;
-    const long long ca = vox(G, az, ay, ax), cb = vox(G, bz, by, bx);
-    const T *mid = pred + (long long)G.mid * G.V;
+    // consensus strides of the base voxel (tile or volume) and this lane's base index of cA
+    long long sY, sZ, laneA;
+    if (G.layout == PPP_CONS_REFERENCE) {
+        sY = G.X; sZ = (long long)G.X * G.Y;
+        laneA = vox(G, az, ay, ax);
+    } else {
+        sY = G.bX; sZ = (long long)G.bX * G.bY;
+        laneA = ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0);
+    }
+    const long long plane_stride = G.layout == PPP_CONS_REFERENCE ? G.V : G.BV;
+    const int dzl = bz - az, dyl = by - ay, dxl = bx - ax;
     float acc = 0.0f;
     unsigned fg_cnt = 0;
-    int a = 0;
-    for (int z1o = 0; z1o < G.pz; ++z1o)
-        for (int y1o = 0; y1o < G.py; ++y1o)
-            for (int x1o = 0; x1o < G.px; ++x1o, ++a) {
-                const int z1 = az + z1o - G.rz, y1 = ay + y1o - G.ry, x1 = ax + x1o - G.rx;
-                const long long u1 = vox(G, z1, y1, x1);
-                if (!(ldf(mid, u1) > G.th_gt)) continue;
-                if (!(ldf(pred, (long long)a * G.V + ca) > G.th_gt)) continue;
-                const bool in_b = abs(x1 - bx) <= G.rx && abs(y1 - by) <= G.ry && abs(z1 - bz) <= G.rz;
-                int b = 0;
-                for (int z2o = 0; z2o < G.pz; ++z2o)
-                    for (int y2o = 0; y2o < G.py; ++y2o)
-                        for (int x2o = 0; x2o < G.px; ++x2o, ++b) {
-                            const int z2 = bz + z2o - G.rz, y2 = by + y2o - G.ry,
-                                      x2 = bx + x2o - G.rx;
-                            const long long u2 = vox(G, z2, y2, x2);
-                            if (!(ldf(mid, u2) > G.th_gt)) continue;
-                            if (!(ldf(pred, (long long)b * G.V + cb) > G.th_gt)) continue;
-                            if (in_b && abs(x2 - ax) <= G.rx && abs(y2 - ay) <= G.ry &&
-                                abs(z2 - az) <= G.rz) {
-                                rnd = rnd * 1103515245U;
-                                const float rnd_t = (float)rnd / 4294967296.0f;
-                                if ((double)rnd_t > 0.2) continue;
+
+    // process the distinct patch offsets d present in this wave one after the other
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        // readlane keeps d in SGPRs: all loop bounds / address math below stay scalar
+        const int dz = __builtin_amdgcn_readlane(dzl, first), dy = __builtin_amdgcn_readlane(dyl, first),
+                  dx = __builtin_amdgcn_readlane(dxl, first);
+        const bool mine = live && dzl == dz && dyl == dy && dxl == dx;
+        todo &= ~__ballot(mine);
+
+        int r1 = 0;
+        for (int z1o = 0; z1o < G.pz; ++z1o)
+            for (int y1o = 0; y1o < G.py; ++y1o)
+                for (int x1o = 0; x1o < G.px; ++x1o, ++r1) {
+                    const bool bit_a = mine && ((lds_a[(r1 >> 5) * 64 + lane] >> (r1 & 31)) & 1u);
+                    if (__ballot(bit_a) == 0) continue;
+                    // z1 relative to cA / cB
+                    const int e1z = z1o - G.rz, e1y = y1o - G.ry, e1x = x1o - G.rx;
+                    const bool in_b = abs(e1x - dx) <= G.rx && abs(e1y - dy) <= G.ry &&
+                                      abs(e1z - dz) <= G.rz;
+                    // r2 candidates: |d + r2 - r1| <= p per axis
+                    const int z_lo = max(0, z1o - dz - G.pz), z_hi = min(G.pz - 1, z1o - dz + G.pz);
+                    const int y_lo = max(0, y1o - dy - G.py), y_hi = min(G.py - 1, y1o - dy + G.py);
+                    const int x_lo = max(0, x1o - dx - G.px), x_hi = min(G.px - 1, x1o - dx + G.px);
+                    for (int z2o = z_lo; z2o <= z_hi; ++z2o)
+                        for (int y2o = y_lo; y2o <= y_hi; ++y2o) {
+                            const int r2row = (z2o * G.py + y2o) * G.px;
+                            for (int x2o = x_lo; x2o <= x_hi; ++x2o) {
+                                const int r2 = r2row + x2o;
+                                // z2 - z1
+                                int qz = dz + z2o - z1o, qy = dy + y2o - y1o, qx = dx + x2o - x1o;
+                                const bool fwd = qz > 0 || (qz == 0 && (qy > 0 || (qy == 0 && qx >= 0)));
+                                long long off;  // base voxel relative to cA
+                                if (fwd) {
+                                    off = (long long)e1z * sZ + (long long)e1y * sY + e1x;
+                                } else {
+                                    qz = -qz; qy = -qy; qx = -qx;
+                                    off = (long long)(dz + z2o - G.rz) * sZ +
+                                          (long long)(dy + y2o - G.ry) * sY + (dx + x2o - G.rx);
+                                }
+                                const bool inter = in_b && abs(dx + x2o - G.rx) <= G.rx &&
+                                                   abs(dy + y2o - G.ry) <= G.ry &&
+                                                   abs(dz + z2o - G.rz) <= G.rz;
+                                // reference bound 0 <= q + p - 1 < 2p (checked AFTER the LCG step)
+                                const bool in_range = qz >= -(G.pz - 1) && qz <= G.pz &&
+                                                      qy >= -(G.py - 1) && qy <= G.py &&
+                                                      qx >= -(G.px - 1) && qx <= G.px;
+                                if (!inter && !in_range) continue;
+                                bool valid = bit_a && ((lds_b[(r2 >> 5) * 64 + lane] >> (r2 & 31)) & 1u);
+                                if (inter) {
+                                    const uint32_t nxt = rnd * 1103515245U;
+                                    const float rnd_t = (float)nxt / 4294967296.0f;
+                                    rnd = valid ? nxt : rnd;
+                                    valid = valid && !((double)rnd_t > 0.2);
+                                }
+                                if (!in_range) continue;
+                                // planes with a component == +p and the zero offset are never
+                                // written by S1: they read as 0 but still count
+                                const bool stored = qz < G.pz && qy < G.py && qx < G.px &&
+                                                    (qz | qy | qx) != 0;
+                                if (stored) {
+                                    long long plane;
+                                    if (G.layout == PPP_CONS_REFERENCE)
+                                        plane = ((long long)(qz + G.pz - 1) * G.nsy + (qy + G.py - 1)) * G.nsx +
+                                                (qx + G.px - 1);
+                                    else
+                                        plane = ((long long)qz * G.wy + qy) * G.wx + qx - 1;
+                                    const float *src = cons + plane * plane_stride + off;
+                                    float v = 0.0f;
+                                    if (valid) v = src[laneA];
+                                    acc += v;
+                                }
+                                fg_cnt += valid ? 1u : 0u;
                             }
-                            int dz, dy, dx, ez, ey, ex;  // offset, base voxel
-                            if (u1 <= u2) {
-                                dz = z2 - z1; dy = y2 - y1; dx = x2 - x1; ez = z1; ey = y1; ex = x1;
-                            } else {
-                                dz = z1 - z2; dy = y1 - y2; dx = x1 - x2; ez = z2; ey = y2; ex = x2;
-                            }
-                            // reference bound: 0 <= d + p - 1 < 2p  (allows d = +p)
-                            if (dz < -(G.pz - 1) || dz > G.pz || dy < -(G.py - 1) || dy > G.py ||
-                                dx < -(G.px - 1) || dx > G.px)
-                                continue;
-                            // planes with a component == +p, and the zero offset, are never
-                            // written by S1: they read as 0 but still count
-                            const bool stored = dz < G.pz && dy < G.py && dx < G.px &&
-                                                (dz | dy | dx) != 0;
-                            if (stored) acc += cons[cons_at(G, dz, dy, dx, ez, ey, ex)];
-                            else acc += 0.0f;
-                            fg_cnt += 1;
                         }
-            }
-    aff[id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
+                }
+    }
+    if (live) aff[id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
 }
 
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
-                              const uint32_t *pairs, uint64_t n, float *aff, const Geo &G,
-                              hipStream_t s) {
+                              const uint32_t *pairs, const uint32_t *order, uint64_t n,
+                              float *aff, const Geo &G, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 63) / 64));
+    const size_t lds_bytes = (size_t)PG_WAVES * 2 * ((G.C + 31) / 32) * 64 * sizeof(uint32_t);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const uint64_t per_block = 64ull * PG_WAVES;
+    const dim3 grid((unsigned)((n + per_block - 1) / per_block));
     if (dtype == PPP_F16)
-        patch_graph_kernel<__half><<<grid, dim3(64), 0, s>>>((const __half *)pred, cons, pairs, n, aff, G);
+        patch_graph_kernel<__half><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>((const __half *)pred, cons, pairs, order, n, aff, G);
     else
-        patch_graph_kernel<float><<<grid, dim3(64), 0, s>>>((const float *)pred, cons, pairs, n, aff, G);
+        patch_graph_kernel<float><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>((const float *)pred, cons, pairs, order, n, aff, G);
     return hipGetLastError();
 }
 

@@ -19,36 +19,28 @@ def affGraphToInstancesT(pred_affs, patchshape, rad, debug_output1, debug_output
 
 
 def component_labels(affinity_graph, shape, device, P, **kwargs):
-    """Node coordinates and their instance ids (component rank + 1).
+    """Node coordinates (int32 [K, 3]) and their instance ids (component rank + 1).
 
-    ``mws=False``: union-find on the device (ppp_label_components); the component order
-    keys are ranked here (a sort of as many numbers as there are components).
-    ``mws=True``: mutex watershed on the host (graph_mws)."""
+    ``mws=False``: union-find on the device (ppp_label_components) gives every node the order
+    key of its component; ranking the distinct keys (as many numbers as components) happens
+    here.  ``mws=True``: mutex watershed on the host (graph_mws)."""
     import torch
-    pairs, aff = affinity_graph.pairs, affinity_graph.aff
     if kwargs["mws"]:
-        ccs = mws_from_pairs(pairs, aff)
+        ccs = mws_from_pairs(affinity_graph.pairs, affinity_graph.aff)
         nodes = [n for cc in ccs for n in cc]
         labels = [k + 1 for k, cc in enumerate(ccs) for _ in cc]
         return (np.array(nodes, dtype=np.int32).reshape(-1, 3),
                 np.array(labels, dtype=np.int64))
-    if len(pairs) == 0:
+    nodes = affinity_graph.pairs_obj.nodes
+    if len(nodes) == 0:
         return np.zeros((0, 3), np.int32), np.zeros((0,), np.int64)
-    pairs_dev = torch.from_numpy(pairs.view(np.int32)).to(device)
-    aff_dev = torch.from_numpy(aff).to(device)
-    keys = backend.label_components(pairs_dev, aff_dev, P).cpu().numpy()  # [N, 2]
+    nodes_dev = torch.from_numpy(nodes).to(device)
+    keys = backend.label_components(affinity_graph.pairs_obj.rows_dev, affinity_graph.aff_dev,
+                                    nodes_dev, P).cpu().numpy()
     valid = keys != backend.NONE_KEY
     uniq = np.unique(keys[valid])                       # ascending = networkx's order
-    labels = np.zeros(keys.shape, dtype=np.int64)
-    labels[valid] = np.searchsorted(uniq, keys[valid]) + 1
-    nodes = pairs.reshape(-1, 3).astype(np.int32)
-    labels = labels.reshape(-1)
-    keep = labels > 0
-    # one row per node is enough (all occurrences of a node carry the same label)
-    lin = (nodes[:, 0].astype(np.int64) * shape[1] + nodes[:, 1]) * shape[2] + nodes[:, 2]
-    _, first = np.unique(np.where(keep, lin, -1), return_index=True)
-    first = first[keep[first]]
-    return nodes[first], labels[first]
+    labels = np.searchsorted(uniq, keys[valid]) + 1
+    return nodes[valid], labels.astype(np.int64)
 
 
 def affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, debug_output1,
@@ -62,7 +54,8 @@ def affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, debug_output
             raise NotImplementedError("%s is not supported" % opt)
     if not isinstance(affinity_graph, AffGraph):   # a networkx graph from outside
         rows = [(tuple(a) + tuple(b), w) for a, b, w in affinity_graph.edges.data("aff")]
-        affinity_graph = AffGraph([w for _, w in rows], [r for r, _ in rows])
+        affinity_graph = AffGraph([w for _, w in rows], [r for r, _ in rows],
+                                  device=pred_affs.device)
     logger.info("compute labeling")
     P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
     nodes, labels = component_labels(affinity_graph, instances.shape, pred_affs.device, P,

@@ -13,8 +13,8 @@ import os
 import numpy as np
 
 from .. import backend
-from .aff_patch_graph import (computeAndStorePatchPairs, computePatchGraph, loadAffgraph,
-                              setAffgraph)
+from .aff_patch_graph import (PatchPairs, computeAndStorePatchPairs, computePatchGraph,
+                              loadAffgraph, setAffgraph)
 from .consensus_array import loadOrComputeConsensus
 from .cuda_code import delete_cuda, init_cuda
 from .foreground_cover import computeForegroundCover, thinOutForegroundCover
@@ -163,9 +163,10 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
 
     # (1) consensus
     if not kwargs.get('skipConsensus'):
-        consensus_vote_array, _, _ = loadOrComputeConsensus(
-            instances, patchshape, neighshape, None, pred_affs, rad, foreground, None,
-            overlap_mask, **kwargs)
+        with backend.host_timer("s1_consensus"):
+            consensus_vote_array, _, _ = loadOrComputeConsensus(
+                instances, patchshape, neighshape, None, pred_affs, rad, foreground, None,
+                overlap_mask, **kwargs)
     else:
         consensus_vote_array = None
     if kwargs.get('save_consensus', False):
@@ -174,10 +175,11 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     # (2) ranking
     ranked_patches_list, scores_array = None, None
     if not kwargs.get('skipRanking'):
-        ranked_patches_list, scores_array = loadOrComputePatchRanking(
-            pred_affs=pred_affs, consensus_vote_array=consensus_vote_array,
-            overlap_mask=overlap_mask, all_patches=None, patchshape=patchshape,
-            neighshape=neighshape, rad=rad, _foreground=foreground, **kwargs)
+        with backend.host_timer("s2_rank_and_sort"):
+            ranked_patches_list, scores_array = loadOrComputePatchRanking(
+                pred_affs=pred_affs, consensus_vote_array=consensus_vote_array,
+                overlap_mask=overlap_mask, all_patches=None, patchshape=patchshape,
+                neighshape=neighshape, rad=rad, _foreground=foreground, **kwargs)
         logger.info("num ranked patches %s ", len(ranked_patches_list))
 
     if kwargs.get('aff_graph') is None:
@@ -190,21 +192,28 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
             num_selected = len(ranked_patches_list)
         else:
             # (3) greedy cover
-            selected_patches_list, num_selected = computeForegroundCover(
-                overlap_mask, mask_to_cover, patchshape, ranked_patches_list, radslice,
-                pred_affs, rad, None, scores_array, **kwargs)
+            with backend.host_timer("s3_cover"):
+                selected_patches_list, num_selected = computeForegroundCover(
+                    overlap_mask, mask_to_cover, patchshape, ranked_patches_list, radslice,
+                    pred_affs, rad, None, scores_array, **kwargs)
         # (4) thinning
         if not kwargs.get('skipThinCover') and num_selected > 0:
-            selected_patches_list, num_selected = thinOutForegroundCover(
-                mask_to_cover, selected_patches_list, radslice, pred_affs, rad, patchshape,
-                **kwargs)
+            with backend.host_timer("s4_thin"):
+                selected_patches_list, num_selected = thinOutForegroundCover(
+                    mask_to_cover, selected_patches_list, radslice, pred_affs, rad,
+                    patchshape, **kwargs)
 
         if kwargs.get('selected_patch_pairs') is not None:
-            selected_patch_pairsIDs = np.array(kwargs.get('selected_patch_pairs'),
-                                               dtype=np.uint32).reshape(-1, 6)
+            selected_patch_pairsIDs = PatchPairs.from_host(
+                np.array(kwargs.get('selected_patch_pairs'), dtype=np.uint32).reshape(-1, 6),
+                pred_affs.device)
+            if len(selected_patch_pairsIDs) == 0:
+                selected_patch_pairsIDs = None
         else:
-            selected_patch_pairsIDs = computeAndStorePatchPairs(selected_patches_list,
-                                                                patchshape, **kwargs)
+            with backend.host_timer("pairs"):
+                selected_patch_pairsIDs = computeAndStorePatchPairs(
+                    selected_patches_list, patchshape, _volume_shape=shape,
+                    _device=pred_affs.device, **kwargs)
         if selected_patch_pairsIDs is None:
             if kwargs.get('return_intermediates', False):
                 return None, None
@@ -213,12 +222,15 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
             raise SystemExit(0)
 
         # (5) patch graph
-        affinity_graph = computePatchGraph(
-            selected_patches_list, num_selected, selected_patch_pairsIDs, pred_affs,
-            mask_to_cover, patchshape, neighshape, rad, overlap_mask, None,
-            consensus_vote_array, **kwargs)
+        with backend.host_timer("s5_patch_graph"):
+            affinity_graph = computePatchGraph(
+                selected_patches_list, num_selected, selected_patch_pairsIDs, pred_affs,
+                mask_to_cover, patchshape, neighshape, rad, overlap_mask, None,
+                consensus_vote_array, **kwargs)
+        backend.note("n_selected", num_selected)
+        backend.note("n_pairs", len(selected_patch_pairsIDs))
         if kwargs.get('return_intermediates'):
-            return selected_patch_pairsIDs, affinity_graph
+            return selected_patch_pairsIDs.numpy(), affinity_graph
         if kwargs.get('termAfterPatchGraph', False):
             return None, None
     else:
@@ -226,8 +238,9 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     del consensus_vote_array
 
     # (6) labelling
-    return affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, None, None,
-                               instances, foreground, **kwargs)
+    with backend.host_timer("s6_label_paint"):
+        return affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, None, None,
+                                   instances, foreground, **kwargs)
 
 
 def do_block(block, foreground, mask, numinst, **kwargs):

@@ -40,7 +40,10 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
     out = dict(cons=cons.cpu().numpy(), score=score.cpu().numpy(), P=P, pred=pred, cons_dev=cons)
     if pairs is not None and len(pairs):
         pd = _dev(torch, np.ascontiguousarray(pairs, dtype=np.uint32).view(np.int32))
-        out["aff"] = backend.patch_graph(pred, cons, pd, P).cpu().numpy()
+        out["aff"] = backend.patch_graph(pred, cons, pd, P).cpu().numpy()          # row order
+        order = backend.pair_order(pd, P)                                         # grouped
+        aff2 = backend.patch_graph(pred, cons, pd, P, order=order).cpu().numpy()
+        assert np.array_equal(out["aff"].view(np.uint32), aff2.view(np.uint32))
     return out
 
 
@@ -188,13 +191,30 @@ def test_union_find_labels_match_oracle(torch_cuda):
     aff[::97] = 0.5
     pairs[::97, 3:] = pairs[::97, :3]          # self loops
     P = backend.make_params(shape, (3, 3, 3), patch_threshold=0.5)
-    got_nodes, got_labels = component_labels(AffGraph(aff, pairs), shape, "cuda", P, mws=False)
+    got_nodes, got_labels = component_labels(AffGraph(aff, pairs, device="cuda"), shape, "cuda",
+                                             P, mws=False)
     want = {}
     for k, cc in enumerate(orc.connected_components(pairs, aff)):
         for n in cc:
             want[n] = k + 1
     got = {tuple(int(v) for v in n): int(l) for n, l in zip(got_nodes, got_labels)}
     assert got == want
+
+
+def test_device_pairs_match_reference(golden, torch_cuda):
+    """ppp_patch_pairs_count/_fill against the golden canonical pair list (and therefore, as
+    a set, against the reference's cKDTree + filter output)."""
+    from patchperpix_amd import backend
+    g = golden
+    if not g.has("selected_sorted") or len(g["selected_sorted"]) == 0:
+        pytest.skip("no selected patches")
+    P = backend.make_params(g.foreground.shape, g.patchshape, **g.kw)
+    pts = _dev(torch_cuda, g["selected_sorted"].astype(np.int32))
+    rows = backend.device_patch_pairs(pts, P, include_single=g.kw["includeSinglePatchCCS"])
+    if int(g["early_out"]) == 3:
+        assert rows is None
+        return
+    assert np.array_equal(rows.cpu().numpy().view(np.uint32), g["pairs"])
 
 
 def test_synth_on_device_equals_numpy(torch_cuda):
