@@ -29,6 +29,11 @@
  *                     d = (dz,dy,dx), |d_i| <= p_i-1: plane = L-1 with
  *                     L = (dz*(2py-1) + dy)*(2px-1) + dx  (L > 0 <=> d positive).
  *                     These are exactly the planes the reference ever writes.
+ *  PPP_CONS_VOXEL_MAJOR [bz][by][bx][W] float32, W = (2pz-1)(2py-1)(2px-1): for every base
+ *                     voxel v the consensus between v and v+q for ALL signed offsets q
+ *                     (index Lc + (qz*(2py-1)+qy)*(2px-1)+qx, Lc = (W-1)/2); made from a
+ *                     COMPACT array by ppp_cons_to_voxel_major; the layout ppp_patch_graph
+ *                     is fastest on (every lane sweeps contiguous memory).
  *  PPP_CONS_REFERENCE [NSZ][NSY][NSX][Z][Y][X] float32, index o = d + p - 1,
  *                     NS = 2p (NSZ = 1 when pz == 1): the reference's array
  *                     (consensus_array.py:99-106); cons_box must be the whole volume.
@@ -61,7 +66,7 @@ enum ppp_dtype { PPP_F32 = 0, PPP_F16 = 1 };
 enum ppp_bg_rule { PPP_BG_INV_TH = 0, PPP_BG_HALF_TH = 1, PPP_BG_LESS_THAN_TH = 2 };
 /* vote value: (none = 1) / -DPROB_PRODUCT / -DNORM_PROB_PRODUCT (utilVoteInstances.py:412-427) */
 enum ppp_value_rule { PPP_VAL_COUNT = 0, PPP_VAL_PROB_PRODUCT = 1, PPP_VAL_NORM_PROB_PRODUCT = 2 };
-enum ppp_cons_layout { PPP_CONS_COMPACT = 0, PPP_CONS_REFERENCE = 1 };
+enum ppp_cons_layout { PPP_CONS_COMPACT = 0, PPP_CONS_REFERENCE = 1, PPP_CONS_VOXEL_MAJOR = 2 };
 
 typedef struct ppp_box {
     int32_t z0, y0, x0; /* inclusive */
@@ -162,6 +167,10 @@ int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_no
  * array (what create_consensus_array_cuda returns / save_consensus writes).             */
 int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
                           const ppp_params *p, void *stream);
+
+/* re-layout a COMPACT consensus (p->cons_box, p->cons_layout ignored) as VOXEL_MAJOR       */
+int ppp_cons_to_voxel_major(const float *d_cons_compact, float *d_cons_voxel_major,
+                            const ppp_params *p, void *stream);
 
 /* --- foreground / patch bit helpers used by the host stages --------------------------
  * ppp_patch_bits: for n centres (d_centres u32[n][3]) pack (pred[r][c] > thresh) for

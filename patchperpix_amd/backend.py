@@ -16,7 +16,7 @@ from . import build as _build
 F32, F16 = 0, 1
 BG_INV_TH, BG_HALF_TH, BG_LESS_THAN_TH = 0, 1, 2
 VAL_COUNT, VAL_PROB_PRODUCT, VAL_NORM_PROB_PRODUCT = 0, 1, 2
-CONS_COMPACT, CONS_REFERENCE = 0, 1
+CONS_COMPACT, CONS_REFERENCE, CONS_VOXEL_MAJOR = 0, 1, 2
 ABI_VERSION = 1
 NONE_KEY = 0xFFFFFFFF
 
@@ -91,6 +91,8 @@ _SIGNATURES = {
                                            ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_cons_to_reference": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_cons_to_voxel_major": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_patch_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p,
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
@@ -413,6 +415,22 @@ def cons_to_reference(cons_compact, P):
     check(lib().ppp_cons_to_reference(_dev_ptr(cons_compact), _dev_ptr(ref), ctypes.byref(P),
                                       _stream()))
     return ref
+
+
+def cons_to_voxel_major(cons_compact, P):
+    """Re-layout for ppp_patch_graph.  Returns (tensor [bz, by, bx, W], params with
+    cons_layout = VOXEL_MAJOR)."""
+    torch = _torch()
+    W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
+    vm = torch.empty(P.cons_box.shape() + (W,), dtype=torch.float32, device=cons_compact.device)
+    Pc = P.copy()
+    Pc.cons_layout = CONS_COMPACT
+    with _timed("cons_to_voxel_major"):
+        check(lib().ppp_cons_to_voxel_major(_dev_ptr(cons_compact), _dev_ptr(vm), ctypes.byref(Pc),
+                                            _stream()))
+    Pv = P.copy()
+    Pv.cons_layout = CONS_VOXEL_MAJOR
+    return vm, Pv
 
 
 def patch_bits(pred, centres, thresh, P):

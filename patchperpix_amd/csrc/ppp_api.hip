@@ -82,7 +82,7 @@ int make_geo(const ppp_params *p, ppp::Geo *G) {
     if (g.layout == PPP_CONS_REFERENCE) {
         if (b.z0 || b.y0 || b.x0 || b.z1 != p->Z || b.y1 != p->Y || b.x1 != p->X)
             return fail(PPP_ERR_INVALID_ARG, "reference layout needs cons_box = whole volume");
-    } else if (g.layout != PPP_CONS_COMPACT) {
+    } else if (g.layout != PPP_CONS_COMPACT && g.layout != PPP_CONS_VOXEL_MAJOR) {
         return fail(PPP_ERR_INVALID_ARG, "bad cons_layout %d", p->cons_layout);
     }
     g.bz0 = b.z0; g.by0 = b.y0; g.bx0 = b.x0;
@@ -130,7 +130,8 @@ int64_t ppp_cons_planes(const ppp_params *p) {
     if (!p) return -1;
     if (p->cons_layout == PPP_CONS_REFERENCE)
         return (int64_t)(p->pz > 1 ? 2 * p->pz : p->pz) * (2 * p->py) * (2 * p->px);
-    return ((int64_t)(2 * p->pz - 1) * (2 * p->py - 1) * (2 * p->px - 1) - 1) / 2;
+    const int64_t w = (int64_t)(2 * p->pz - 1) * (2 * p->py - 1) * (2 * p->px - 1);
+    return p->cons_layout == PPP_CONS_VOXEL_MAJOR ? w : (w - 1) / 2;
 }
 
 int64_t ppp_cons_elems(const ppp_params *p) {
@@ -146,6 +147,7 @@ int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, 
     PPP_TRY(check_dtype(pred_dtype));
     if (!d_pred || (!d_cons && !d_count)) return fail(PPP_ERR_INVALID_ARG, "NULL pred / outputs");
     if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    if (G.layout == PPP_CONS_VOXEL_MAJOR) return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus writes COMPACT or REFERENCE layout");
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, d_count, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus");
@@ -159,6 +161,7 @@ int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
     PPP_TRY(check_dtype(pred_dtype));
     if (!d_pred || !d_cons || !d_score) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
     if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    if (G.layout == PPP_CONS_VOXEL_MAJOR) return fail(PPP_ERR_UNSUPPORTED, "ppp_rank_patches reads COMPACT or REFERENCE layout");
     ppp_box sb = {0, 0, 0, p->Z, p->Y, p->X};
     if (score_box) sb = *score_box;
     if (sb.z0 < 0 || sb.y0 < 0 || sb.x0 < 0 || sb.z1 > p->Z || sb.y1 > p->Y || sb.x1 > p->X)
@@ -275,6 +278,17 @@ int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_cons_to_reference(d_cons_compact, d_cons_reference, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cons_to_reference");
+}
+
+int ppp_cons_to_voxel_major(const float *d_cons_compact, float *d_cons_voxel_major,
+                            const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (!d_cons_compact || !d_cons_voxel_major) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.layout == PPP_CONS_REFERENCE) return fail(PPP_ERR_INVALID_ARG, "source must be a COMPACT consensus");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_cons_to_voxel_major(d_cons_compact, d_cons_voxel_major, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cons_to_voxel_major");
 }
 
 int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres, uint64_t n,

@@ -134,4 +134,66 @@ hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo 
     return hipGetLastError();
 }
 
+// ---- compact (plane-major) -> symmetric voxel-major ---------------------------------------
+// S[v][L] for all SIGNED offsets q (|q_i| <= p_i-1), L = Lc + (qz*wy + qy)*wx + qx:
+//     q > 0 :  cons[q][v]          (v is the earlier voxel)
+//     q < 0 :  cons[-q][v + q]     (v is the later voxel)
+//     q = 0 :  0
+// i.e. the consensus between voxel v and voxel v+q.  The patch-graph kernel reads, for a
+// fixed pixel z1, a run of consecutive L -- contiguous in this layout.  64x64 LDS transpose:
+// coalesced reads along the voxel axis, coalesced writes along L.
+__global__ void __launch_bounds__(256)
+    cons_voxel_major_kernel(const float *__restrict__ compact, float *__restrict__ S, const Geo G,
+                            const int W) {
+    __shared__ float tile[64][65];
+    const int Lc = (W - 1) / 2;
+    const long long v0 = (long long)blockIdx.x * 64;
+    const int L0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long v = v0 + lane;
+    int bx = 0, by = 0, bz = 0;
+    if (v < G.BV) {
+        bx = (int)(v % G.bX);
+        const long long t = v / G.bX;
+        by = (int)(t % G.bY);
+        bz = (int)(t / G.bY);
+    }
+    for (int i = wave; i < 64; i += 4) {
+        const int L = L0 + i;
+        float val = 0.0f;
+        if (L < W && v < G.BV && L != Lc) {
+            int Ls = L - Lc;
+            const bool neg = Ls < 0;
+            if (neg) Ls = -Ls;
+            const int t2 = Ls + (G.py - 1) * G.wx + (G.px - 1);
+            const int qx = t2 % G.wx - (G.px - 1);
+            const int q2 = t2 / G.wx;
+            const int qy = q2 % G.wy - (G.py - 1);
+            const int qz = q2 / G.wy;
+            if (!neg) {
+                val = compact[(long long)(Ls - 1) * G.BV + v];
+            } else {
+                const int ez = bz - qz, ey = by - qy, ex = bx - qx;  // earlier voxel v + q
+                if (ez >= 0 && ey >= 0 && ey < G.bY && ex >= 0 && ex < G.bX)
+                    val = compact[(long long)(Ls - 1) * G.BV + ((long long)ez * G.bY + ey) * G.bX + ex];
+            }
+        }
+        tile[i][lane] = val;
+    }
+    __syncthreads();
+    for (int i = wave; i < 64; i += 4) {
+        const long long vv = v0 + i;
+        const int L = L0 + lane;
+        if (vv < G.BV && L < W) S[vv * W + L] = tile[lane][i];
+    }
+}
+
+hipError_t launch_cons_to_voxel_major(const float *compact, float *S, const Geo &G,
+                                      hipStream_t s) {
+    const int W = (2 * G.pz - 1) * G.wy * G.wx;
+    const dim3 grid((unsigned)((G.BV + 63) / 64), (unsigned)((W + 63) / 64));
+    cons_voxel_major_kernel<<<grid, dim3(256), 0, s>>>(compact, S, G, W);
+    return hipGetLastError();
+}
+
 }  // namespace ppp

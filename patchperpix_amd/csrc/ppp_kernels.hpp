@@ -24,6 +24,8 @@ hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, con
 hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,
                         const uint32_t *labels, uint64_t n, uint32_t *inst, const Geo &G,
                         hipStream_t s);
+hipError_t launch_cons_to_voxel_major(const float *compact, float *S, const Geo &G,
+                                      hipStream_t s);
 hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo &G,
                                     hipStream_t s);
 hipError_t launch_patch_bits(const void *pred, int dtype, const uint32_t *centres, uint64_t n,

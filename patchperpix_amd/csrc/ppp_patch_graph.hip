@@ -160,6 +160,109 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
     if (live) aff[id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
 }
 
+// ---- fast path: symmetric voxel-major consensus (see cons_voxel_major_kernel) -------------
+// S[v][L(q)] = consensus between voxel v and v + q for every signed offset q.  For a fixed
+// pixel z1 = cA + e1 the inner loops over r2 walk q = d + r2 - r1 in raster order, i.e. L
+// ascending: every lane sweeps one contiguous row segment of S, so each cache line it pulls
+// is used completely (the plane-major layout costs one 64-byte line per 4-byte gather).
+template <typename T>
+__global__ void __launch_bounds__(64 * PG_WAVES)
+    patch_graph_vm_kernel(const T *__restrict__ pred, const float *__restrict__ S,
+                          const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ order,
+                          const uint64_t n, float *__restrict__ aff, const Geo G) {
+    extern __shared__ uint32_t lds_raw[];  // [PG_WAVES][2][words][64]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t slot = ((uint64_t)blockIdx.x * PG_WAVES + wave) * 64 + lane;
+    const bool live = slot < n;
+    const uint64_t id = live ? (order ? (uint64_t)order[slot] : slot) : 0;
+    const int words = (G.C + 31) / 32;
+    uint32_t *lds_a = lds_raw + (size_t)(wave * 2 + 0) * words * 64;
+    uint32_t *lds_b = lds_raw + (size_t)(wave * 2 + 1) * words * 64;
+
+    int az = 0, ay = 0, ax = 0, bz = 0, by = 0, bx = 0;
+    if (live) {
+        az = (int)pairs[id * 6 + 0]; ay = (int)pairs[id * 6 + 1]; ax = (int)pairs[id * 6 + 2];
+        bz = (int)pairs[id * 6 + 3]; by = (int)pairs[id * 6 + 4]; bx = (int)pairs[id * 6 + 5];
+        patch_fg_words(pred, G, az, ay, ax, lds_a + lane, words);
+        patch_fg_words(pred, G, bz, by, bx, lds_b + lane, words);
+    }
+    uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by * (uint32_t)ax *
+                   (uint32_t)bx;
+    const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
+    const long long laneA = ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0);
+    const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
+    const int dzl = bz - az, dyl = by - ay, dxl = bx - ax;
+    float acc = 0.0f;
+    unsigned fg_cnt = 0;
+
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const int dz = __builtin_amdgcn_readlane(dzl, first), dy = __builtin_amdgcn_readlane(dyl, first),
+                  dx = __builtin_amdgcn_readlane(dxl, first);
+        const bool mine = live && dzl == dz && dyl == dy && dxl == dx;
+        todo &= ~__ballot(mine);
+
+        int r1 = 0;
+        for (int z1o = 0; z1o < G.pz; ++z1o)
+            for (int y1o = 0; y1o < G.py; ++y1o)
+                for (int x1o = 0; x1o < G.px; ++x1o, ++r1) {
+                    const bool bit_a = mine && ((lds_a[(r1 >> 5) * 64 + lane] >> (r1 & 31)) & 1u);
+                    if (__ballot(bit_a) == 0) continue;
+                    const int e1z = z1o - G.rz, e1y = y1o - G.ry, e1x = x1o - G.rx;
+                    const bool in_b = abs(e1x - dx) <= G.rx && abs(e1y - dy) <= G.ry &&
+                                      abs(e1z - dz) <= G.rz;
+                    // this lane's row of S for pixel z1
+                    const float *row = S + (laneA + (long long)e1z * sZ + (long long)e1y * sY + e1x) * W + Lc;
+                    const int z_lo = max(0, z1o - dz - G.pz), z_hi = min(G.pz - 1, z1o - dz + G.pz);
+                    const int y_lo = max(0, y1o - dy - G.py), y_hi = min(G.py - 1, y1o - dy + G.py);
+                    const int x_lo = max(0, x1o - dx - G.px), x_hi = min(G.px - 1, x1o - dx + G.px);
+                    for (int z2o = z_lo; z2o <= z_hi; ++z2o) {
+                        const int qz = dz + z2o - z1o;
+                        const bool iz = in_b && abs(dz + z2o - G.rz) <= G.rz;
+                        for (int y2o = y_lo; y2o <= y_hi; ++y2o) {
+                            const int qy = dy + y2o - y1o;
+                            const bool izy = iz && abs(dy + y2o - G.ry) <= G.ry;
+                            const int r2row = (z2o * G.py + y2o) * G.px;
+                            const int Lrow = (qz * G.wy + qy) * G.wx;
+                            for (int x2o = x_lo; x2o <= x_hi; ++x2o) {
+                                const int r2 = r2row + x2o;
+                                const int qx = dx + x2o - x1o;
+                                // z1 <= z2 (raster)  <=>  q >= 0 lexicographically
+                                const bool fwd = qz > 0 || (qz == 0 && (qy > 0 || (qy == 0 && qx >= 0)));
+                                // reference bound on the ORIENTED offset o = +-q: -(p-1) <= o <= p
+                                const int lo_z = fwd ? -(G.pz - 1) : -G.pz, hi_z = fwd ? G.pz : G.pz - 1;
+                                const int lo_y = fwd ? -(G.py - 1) : -G.py, hi_y = fwd ? G.py : G.py - 1;
+                                const int lo_x = fwd ? -(G.px - 1) : -G.px, hi_x = fwd ? G.px : G.px - 1;
+                                const bool in_range = qz >= lo_z && qz <= hi_z && qy >= lo_y &&
+                                                      qy <= hi_y && qx >= lo_x && qx <= hi_x;
+                                const bool inter = izy && abs(dx + x2o - G.rx) <= G.rx;
+                                if (!inter && !in_range) continue;
+                                bool valid = bit_a && ((lds_b[(r2 >> 5) * 64 + lane] >> (r2 & 31)) & 1u);
+                                if (inter) {
+                                    const uint32_t nxt = rnd * 1103515245U;
+                                    const float rnd_t = (float)nxt / 4294967296.0f;
+                                    rnd = valid ? nxt : rnd;
+                                    valid = valid && !((double)rnd_t > 0.2);
+                                }
+                                if (!in_range) continue;
+                                // |q_i| == p and q == 0 are never written by S1: 0, but counted
+                                const bool stored = abs(qz) < G.pz && abs(qy) < G.py && abs(qx) < G.px &&
+                                                    (qz | qy | qx) != 0;
+                                if (stored) {
+                                    float v = 0.0f;
+                                    if (valid) v = row[Lrow + qx];
+                                    acc += v;
+                                }
+                                fg_cnt += valid ? 1u : 0u;
+                            }
+                        }
+                    }
+                }
+    }
+    if (live) aff[id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
+}
+
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
                               const uint32_t *pairs, const uint32_t *order, uint64_t n,
                               float *aff, const Geo &G, hipStream_t s) {
@@ -168,6 +271,13 @@ hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const uint64_t per_block = 64ull * PG_WAVES;
     const dim3 grid((unsigned)((n + per_block - 1) / per_block));
+    if (G.layout == PPP_CONS_VOXEL_MAJOR) {
+        if (dtype == PPP_F16)
+            patch_graph_vm_kernel<__half><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>((const __half *)pred, cons, pairs, order, n, aff, G);
+        else
+            patch_graph_vm_kernel<float><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>((const float *)pred, cons, pairs, order, n, aff, G);
+        return hipGetLastError();
+    }
     if (dtype == PPP_F16)
         patch_graph_kernel<__half><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>((const __half *)pred, cons, pairs, order, n, aff, G);
     else

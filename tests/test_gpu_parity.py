@@ -44,6 +44,9 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
         order = backend.pair_order(pd, P)                                         # grouped
         aff2 = backend.patch_graph(pred, cons, pd, P, order=order).cpu().numpy()
         assert np.array_equal(out["aff"].view(np.uint32), aff2.view(np.uint32))
+        vm, Pv = backend.cons_to_voxel_major(cons, P)                             # re-layout
+        aff3 = backend.patch_graph(pred, vm, pd, Pv, order=order).cpu().numpy()
+        assert np.array_equal(out["aff"].view(np.uint32), aff3.view(np.uint32))
     return out
 
 
