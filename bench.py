@@ -141,7 +141,7 @@ def main():
     roofline = None
     if s1_ms:
         achieved = alg_bytes / (s1_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "consensus_gather_kernel", "achieved": achieved,
+        roofline = {"bound": "hbm", "kernel": "consensus_v2_kernel", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "algorithmic_bytes": alg_bytes, "avg_ms": s1_ms}
 

@@ -34,7 +34,7 @@ def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + os.environ.get("PPP_EXTRA_FLAGS", "").split() + sources() + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

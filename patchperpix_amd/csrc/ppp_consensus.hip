@@ -17,6 +17,8 @@
 //
 // Centre c = u - k + rad where k in [0,p)^3 is the patch offset of u, and k + d the
 // patch offset of w; raster-ascending c  <=>  lexicographically descending k.
+#include <cstdlib>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -100,6 +102,12 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
         hipError_t e;
         if (cons && (e = hipMemsetAsync(cons, 0, bytes, s)) != hipSuccess) return e;
         if (cnt && (e = hipMemsetAsync(cnt, 0, bytes, s)) != hipSuccess) return e;
+    }
+    // specialised kernel for px in {3,5,7,9}; PPP_CONSENSUS_GENERIC=1 forces the generic one
+    static const bool force_generic = getenv("PPP_CONSENSUS_GENERIC") != nullptr;
+    if (!force_generic) {
+        const hipError_t e2 = launch_consensus_v2(pred, dtype, ov, cons, cnt, G, s);
+        if (e2 != hipErrorNotSupported) return e2;
     }
     if (dtype == PPP_F16)
         consensus_gather_kernel<__half><<<grid, block, 0, s>>>((const __half *)pred, ov, cons, cnt, G);

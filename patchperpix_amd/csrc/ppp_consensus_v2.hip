@@ -1,0 +1,315 @@
+// ppp_consensus_v2.hip -- S1, second generation (px in {3,5,7,9}; other shapes use the generic
+// kernel in ppp_consensus.hip).  Same arithmetic, same summation order, bit-identical output.
+//
+//   cons[d][u] = sum over centres c (raster order) of vote(pred[k][c], pred[k+d][c]),
+//   c = u - k + rad, k = patch offset of u, k + d = patch offset of w = u + d.
+//
+// Work decomposition
+//   wave  = 64 consecutive base voxels u along x  x  one offset row (dz, dy);
+//   lane  = one u, holding the 2*PX-1 accumulators (+ integer counts) of all dx in registers;
+//   loops = kz, ky (descending, scalar), kx and the partner column j = kx + dx fully unrolled.
+//   Summing k in descending order == raster order of the centre, per key.
+//
+// Operands.  For one (kz, ky) the wave needs two rows of PX channels, (kz, ky, *) "about u" and
+// (kz+dz, ky+dy, *) "about w", at the 64+PX-1 centres of its x-run.  They are CLASSIFIED while
+// being staged into a wave-private LDS image:
+//       t = +v        if v > TH        (and the pixel it talks about is valid foreground)
+//       t = -(1 - v)  if v < BG        (same condition)
+//       t = 0         otherwise
+// ("about u" entries also fold in the centre's own foreground / interior test).  A pair then
+// votes iff x = ta*tb != 0 and not both negative; |x| is exactly the float product the
+// reference forms (v1*v2 or v1*(1-v2)), its sign is the sign of the vote.
+//
+// Normalised votes.  The reference evaluates (float)(((double)x - TH*TH) / (1.0 - TH*TH)).  The
+// kernel computes (|x| - TH^2) in double exactly like that, multiplies by the rounded reciprocal
+// instead of dividing (<= 2.5 double ulp away from the correctly rounded quotient) and rounds to
+// float.  The float result can differ from the reference only if a float rounding boundary lies
+// within those few double ulps, which is visible in the low 29 mantissa bits of the product; in
+// that (~2^-26 probability) case the lane redoes the vote with the true double division.  The
+// result is therefore bit-identical, at one double multiply instead of a double division.
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+static constexpr int V2_WAVES = 4;
+
+template <int PX>
+struct V2 {
+    static constexpr int RX = PX / 2;
+    static constexpr int NC = 64 + PX - 1;       // centres per x-run
+    static constexpr int NT = 64 + 2 * (PX - 1); // target pixels per x-run
+    static constexpr int NACC = 2 * PX - 1;
+    static constexpr int IMG = 2 * PX * NC;      // floats of LDS image per wave
+};
+
+// one vote; VAL, EXACT compile-time so that the unrolled tile is straight-line code.
+// amb_min tracks (VALU only, no lane masks) how close any fast-path double result came to a
+// float rounding midpoint.
+template <int VAL, bool EXACT>
+__device__ __forceinline__ void vote(const double th2, const double den, const double inv_den,
+                                     float ta, float tb, float &acc, unsigned &cnt,
+                                     unsigned &amb_min) {
+    const float x = ta * tb;
+    // a vote needs two classified operands that are not both "background" (negative)
+    const bool valid = (x != 0.0f) && ((__float_as_int(ta) & __float_as_int(tb)) >= 0);
+    float y;
+    if constexpr (VAL == PPP_VAL_NORM_PROB_PRODUCT) {
+        // sign(x) * fl32(fl64(fl64(|x| - TH^2) / den)); rounding is sign-symmetric, so the
+        // sign is carried through the double arithmetic
+        const double xd = (double)x;
+        const double r = xd - __builtin_copysign(th2, xd);
+        if constexpr (EXACT) {
+            y = (float)(r / den);
+        } else {
+            const double yd = r * inv_den;
+            y = (float)yd;
+            // distance of the 29 discarded mantissa bits from the midpoint pattern (window
+            // [mid-4, mid+4] maps to [0, 8]); invalid lanes may raise a harmless false alarm
+            const unsigned lo = (unsigned)__double2loint(yd) & 0x1FFFFFFFu;
+            amb_min = min(amb_min, lo - (0x10000000u - 4u));
+        }
+    } else if constexpr (VAL == PPP_VAL_PROB_PRODUCT) {
+        y = x;
+    } else {
+        y = copysignf(1.0f, x);
+    }
+    acc = acc + (valid ? y : 0.0f);
+    cnt += valid ? 1u : 0u;
+}
+
+// all votes of one (kz, ky): kx descending (raster order of the centre), every partner column.
+// ROW0: offset row (dz, dy) == (0, 0), where only dx > 0 exists.  Returns "some fast-path
+// result was ambiguous" (never when EXACT).
+template <int PX, int VAL, bool ROW0, bool EXACT>
+__device__ __forceinline__ bool tile_votes(const float *ia, const float *ib, const bool u_ok,
+                                           const double th2, const double den,
+                                           const double inv_den, float (&acc)[2 * PX - 1],
+                                           unsigned (&cnt)[2 * PX - 1]) {
+    constexpr int NC = 64 + PX - 1;
+    unsigned amb_min = 0xFFFFFFFFu;
+#pragma unroll
+    for (int kx = PX - 1; kx >= 0; --kx) {
+        const float ta = u_ok ? ia[kx * NC - kx] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            if (ROW0 && j <= kx) continue;   // offsets must be lexicographically positive
+            vote<VAL, EXACT>(th2, den, inv_den, ta, ib[j * NC - kx], acc[j - kx + PX - 1],
+                             cnt[j - kx + PX - 1], amb_min);
+        }
+#ifndef PPP_V2_NOSCHED
+        // keep the scheduler from interleaving all PX*PX votes (lane-mask register pressure)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    return amb_min <= 8u;
+}
+
+template <typename T, int PX, int VAL>
+__global__ void __launch_bounds__(64 * V2_WAVES)
+    consensus_v2_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
+                        float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
+                        const int n_rows, const int runs_per_line, const long long n_waves) {
+    using K = V2<PX>;
+    constexpr int NE = (K::IMG + 63) / 64;           // staged elements per lane and tile
+    constexpr int NEA = (PX * K::NC + 63) / 64;      // ... of which may belong to the "about u" rows
+    __shared__ float lds[V2_WAVES][K::IMG];
+    __shared__ uint8_t lds_valid[V2_WAVES][2][K::NT + 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // XCD-aware order: blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
+    // range of (x-run, row) work so that the rows of one x-run meet in one L2
+    long long bid = blockIdx.x;
+    {
+        const long long nb = gridDim.x, per = nb / 8, main = per * 8;
+        if (bid < main) bid = (bid % 8) * per + bid / 8;
+    }
+    const long long wid = bid * V2_WAVES + wave;
+    if (wid >= n_waves) return;
+    const int row = (int)(wid % n_rows);
+    long long run = wid / n_rows;
+    // offset row (dz, dy): row 0..py-1 -> dz = 0, dy = 0..py-1; then dz >= 1, dy = -(py-1)..py-1
+    int dz, dy;
+    if (row < G.py) { dz = 0; dy = row; }
+    else { const int t = row - G.py; dz = 1 + t / G.wy; dy = t % G.wy - (G.py - 1); }
+    // x-run -> base voxels (box coordinates -> global)
+    const int xr = (int)(run % runs_per_line);
+    run /= runs_per_line;
+    const int uy = G.by0 + (int)(run % G.bY);
+    const int uz = G.bz0 + (int)(run / G.bY);
+    const int ux0 = G.bx0 + xr * 64;
+    const int ux = ux0 + lane;
+    const bool lane_ok = ux < G.bx0 + G.bX;
+    const int wz = uz + dz, wy = uy + dy;
+    const bool w_row_ok = wz < G.Z && wy >= 0 && wy < G.Y;
+    const bool row0 = dz == 0 && dy == 0;
+
+    float acc[K::NACC];
+    unsigned cnt[K::NACC];
+#pragma unroll
+    for (int i = 0; i < K::NACC; ++i) { acc[i] = 0.0f; cnt[i] = 0u; }
+
+    const T *mid = pred + (long long)G.mid * G.V;
+    float *img = lds[wave];
+    uint8_t *uval = lds_valid[wave][0], *wval = lds_valid[wave][1];
+    // validity (foreground && !overlap) of the target pixels on the u row and on the w row,
+    // x in [ux0 - (PX-1), ux0 + 63 + (PX-1)]
+    for (int i = lane; i < K::NT; i += 64) {
+        const int x = ux0 - (PX - 1) + i;
+        bool vu = false, vw = false;
+        if (x >= 0 && x < G.X) {
+            const long long lu = vox(G, uz, uy, x);
+            vu = ldf(mid, lu) > G.th_gt && (!G.use_overlap || ov[lu] == 0);
+            if (w_row_ok) {
+                const long long lw = vox(G, wz, wy, x);
+                vw = ldf(mid, lw) > G.th_gt && (!G.use_overlap || ov[lw] == 0);
+            }
+        }
+        uval[i] = vu; wval[i] = vw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool u_ok = lane_ok && uval[lane + PX - 1];
+    const double inv_den = 1.0 / G.den;
+
+    // Per-lane description of the NE image elements this lane stages for every tile
+    // (element e = it*64 + lane  ->  row half, column j, centre i): constant over the tiles.
+    //   ok_bits  bit it : the pixel the value talks about is valid and the centre is inside
+    //                     the x-interior (centre foreground is tile dependent, tested later)
+    //   el_off[it]      : j * V + clamped centre x  (added to the tile's row base)
+    unsigned ok_bits = 0;
+    long long el_off[NE];
+    int el_cx[NE];
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+        const int e = it * 64 + lane;
+        const int i = e % K::NC;
+        const int j = (e / K::NC) % PX;
+        const bool is_b = e >= PX * K::NC;
+        const int cx = ux0 - (PX - 1) + K::RX + i;
+        bool ok = e < K::IMG && cx >= K::RX && cx < G.X - K::RX;
+        if (ok) {
+            const int ti = cx + j - K::RX - (ux0 - (PX - 1));
+            ok = is_b ? wval[ti] : uval[ti];
+        }
+        ok_bits |= (ok ? 1u : 0u) << it;
+        const int cxc = min(max(cx, 0), G.X - 1);
+        el_cx[it] = cxc;
+        el_off[it] = (long long)j * G.V + cxc;
+    }
+
+    if (w_row_ok) {
+        const int kz_hi = min(G.pz - 1, G.pz - 1 - dz), kz_lo = max(0, -dz);
+        const int ky_hi = min(G.py - 1, G.py - 1 - dy), ky_lo = max(0, -dy);
+        // tiles (kz, ky) in descending order, skipping centre rows outside the interior
+        int kz = kz_hi, ky = ky_hi + 1;
+        auto next_tile = [&](int &z, int &y) -> bool {
+            while (true) {
+                if (--y < ky_lo) { y = ky_hi; --z; }
+                if (z < kz_lo) return false;
+                const int cz = uz - z + G.rz, cy = uy - y + G.ry;
+                if (cz >= G.rz && cz < G.Z - G.rz && cy >= G.ry && cy < G.Y - G.ry) return true;
+            }
+        };
+        float raw[NE], cmid[NEA];
+        // issue the (independent, unconditional) loads of one tile into registers
+        auto load_tile = [&](int z, int y) {
+            const long long crow = vox(G, uz - z + G.rz, uy - y + G.ry, 0);
+            const long long ra0 = (long long)((z * G.py + y) * PX) * G.V + crow;
+            const long long rb0 = (long long)(((z + dz) * G.py + (y + dy)) * PX) * G.V + crow;
+#pragma unroll
+            for (int it = 0; it < NE; ++it) {
+                const bool is_b = it * 64 + lane >= PX * K::NC;
+                raw[it] = ldf(pred, (is_b ? rb0 : ra0) + el_off[it]);
+                if (it < NEA) cmid[it] = ldf(mid, crow + el_cx[it]);
+            }
+        };
+        bool have = next_tile(kz, ky);
+        if (have) load_tile(kz, ky);
+        while (have) {
+            // ---- classify the loaded tile into the wave-private LDS image
+#pragma unroll
+            for (int it = 0; it < NE; ++it) {
+                const int e = it * 64 + lane;
+                bool ok = (ok_bits >> it) & 1u;
+                if (it < NEA) ok = ok && (e >= PX * K::NC || cmid[it] > G.th_gt);  // centre fg
+                const float v = raw[it];
+                const float t = v > G.th_gt ? v : (v < G.bg_lt ? -(1.0f - v) : 0.0f);
+                if (e < K::IMG) img[e] = ok ? t : 0.0f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- prefetch the next tile; its latency hides behind this tile's votes
+            have = next_tile(kz, ky);
+            if (have) load_tile(kz, ky);
+            // ---- votes (fast path; redo the tile with true divisions if any lane saw an
+            //      ambiguous rounding -- probability ~2^-26 per vote)
+            const float *ia = img + lane + (PX - 1);
+            const float *ib = img + PX * K::NC + lane + (PX - 1);
+            float acc0[K::NACC];
+            unsigned cnt0[K::NACC];
+#pragma unroll
+            for (int i = 0; i < K::NACC; ++i) { acc0[i] = acc[i]; cnt0[i] = cnt[i]; }
+            const bool amb = row0 ? tile_votes<PX, VAL, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt)
+                                  : tile_votes<PX, VAL, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+            if (VAL == PPP_VAL_NORM_PROB_PRODUCT && __ballot(amb) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < K::NACC; ++i) { acc[i] = acc0[i]; cnt[i] = cnt0[i]; }
+                if (row0) tile_votes<PX, VAL, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                else tile_votes<PX, VAL, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!lane_ok) return;
+#pragma unroll
+    for (int i = 0; i < K::NACC; ++i) {
+        const int dx = i - (PX - 1);
+        if (dz == 0 && dy == 0 && dx <= 0) continue;
+        const long long o = cons_at(G, dz, dy, dx, uz, uy, ux);
+        const float c = (float)cnt[i];
+        if (cons) cons[o] = (G.normalise && cnt[i] != 0u) ? acc[i] / c : acc[i];
+        if (cnt_out) cnt_out[o] = c;
+    }
+}
+
+template <typename T, int PX>
+static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                            const Geo &G, hipStream_t s) {
+    const int n_rows = (G.pz - 1) * G.wy + G.py;
+    const int runs_per_line = (G.bX + 63) / 64;
+    const long long n_waves = (long long)runs_per_line * G.bY * G.bZ * n_rows;
+    const long long n_blocks = (n_waves + V2_WAVES - 1) / V2_WAVES;
+    if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)n_blocks), block(64 * V2_WAVES);
+    if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT)
+        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT><<<grid, block, 0, s>>>(
+            pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    else if (G.value_rule == PPP_VAL_PROB_PRODUCT)
+        consensus_v2_kernel<T, PX, PPP_VAL_PROB_PRODUCT><<<grid, block, 0, s>>>(
+            pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    else
+        consensus_v2_kernel<T, PX, PPP_VAL_COUNT><<<grid, block, 0, s>>>(
+            pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    return hipGetLastError();
+}
+
+// returns hipErrorNotSupported when the shape has no specialised kernel
+hipError_t launch_consensus_v2(const void *pred, int dtype, const uint8_t *ov, float *cons,
+                               float *cnt, const Geo &G, hipStream_t s) {
+#define PPP_V2_CASE(P)                                                                          \
+    case P:                                                                                     \
+        return dtype == PPP_F16                                                                 \
+                   ? launch_v2<__half, P>((const __half *)pred, ov, cons, cnt, G, s)            \
+                   : launch_v2<float, P>((const float *)pred, ov, cons, cnt, G, s);
+    switch (G.px) {
+        PPP_V2_CASE(3)
+        PPP_V2_CASE(5)
+        PPP_V2_CASE(7)
+        PPP_V2_CASE(9)
+    default:
+        return hipErrorNotSupported;
+    }
+#undef PPP_V2_CASE
+}
+
+}  // namespace ppp

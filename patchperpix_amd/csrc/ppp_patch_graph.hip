@@ -15,6 +15,8 @@
 // `lane_base + scalar_offset`, one add.  The per-pixel foreground tests of the reference
 // (pred[mid][z] > TH and pred[r][c] > TH, :44-52,60-66) are evaluated once per patch into bit
 // masks held in LDS, instead of p^3 times inside the inner loop.
+#include <cstdlib>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -263,6 +265,147 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
     if (live) aff[id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
 }
 
+// ---- voxel-major fast path, px-specialised: the x-run of one (r1, z2o, y2o) row is fetched
+// with (up to) two 16-byte loads per lane and consumed from registers -- 2 gather
+// instructions instead of up to PX (each gather instruction costs the texture-address unit 64
+// distinct cache lines, which is what bounds this kernel).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename T, int PX>
+__global__ void __launch_bounds__(64 * PG_WAVES)
+    patch_graph_vm2_kernel(const T *__restrict__ pred, const float *__restrict__ S,
+                           const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ order,
+                           const uint64_t n, float *__restrict__ aff, const Geo G) {
+    extern __shared__ uint32_t lds_raw[];  // [PG_WAVES][2][words][64]
+    constexpr int RX = PX / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t slot = ((uint64_t)blockIdx.x * PG_WAVES + wave) * 64 + lane;
+    const bool live = slot < n;
+    const uint64_t id = live ? (order ? (uint64_t)order[slot] : slot) : 0;
+    const int words = (G.C + 31) / 32;
+    uint32_t *lds_a = lds_raw + (size_t)(wave * 2 + 0) * words * 64;
+    uint32_t *lds_b = lds_raw + (size_t)(wave * 2 + 1) * words * 64;
+
+    int az = 0, ay = 0, ax = 0, bz = 0, by = 0, bx = 0;
+    if (live) {
+        az = (int)pairs[id * 6 + 0]; ay = (int)pairs[id * 6 + 1]; ax = (int)pairs[id * 6 + 2];
+        bz = (int)pairs[id * 6 + 3]; by = (int)pairs[id * 6 + 4]; bx = (int)pairs[id * 6 + 5];
+        patch_fg_words(pred, G, az, ay, ax, lds_a + lane, words);
+        patch_fg_words(pred, G, bz, by, bx, lds_b + lane, words);
+    }
+    uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by * (uint32_t)ax *
+                   (uint32_t)bx;
+    const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
+    const long long laneA = live ? ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0) : 0;
+    const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
+    const long long n_elems = G.BV * (long long)W;
+    const int dzl = bz - az, dyl = by - ay, dxl = bx - ax;
+    float acc = 0.0f;
+    unsigned fg_cnt = 0;
+
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const int dz = __builtin_amdgcn_readlane(dzl, first), dy = __builtin_amdgcn_readlane(dyl, first),
+                  dx = __builtin_amdgcn_readlane(dxl, first);
+        const bool mine = live && dzl == dz && dyl == dy && dxl == dx;
+        todo &= ~__ballot(mine);
+
+        int r1 = 0;
+        for (int z1o = 0; z1o < G.pz; ++z1o)
+            for (int y1o = 0; y1o < G.py; ++y1o)
+                for (int x1o = 0; x1o < PX; ++x1o, ++r1) {
+                    const bool bit_a = mine && ((lds_a[(r1 >> 5) * 64 + lane] >> (r1 & 31)) & 1u);
+                    if (__ballot(bit_a) == 0) continue;
+                    const int e1z = z1o - G.rz, e1y = y1o - G.ry, e1x = x1o - RX;
+                    const bool in_b = abs(e1x - dx) <= RX && abs(e1y - dy) <= G.ry &&
+                                      abs(e1z - dz) <= G.rz;
+                    // index of this lane's S row for pixel z1 (clamped for idle lanes)
+                    const long long rowi = (laneA + (long long)e1z * sZ + (long long)e1y * sY + e1x) * W + Lc;
+                    const int z_lo = max(0, z1o - dz - G.pz), z_hi = min(G.pz - 1, z1o - dz + G.pz);
+                    const int y_lo = max(0, y1o - dy - G.py), y_hi = min(G.py - 1, y1o - dy + G.py);
+                    const int x_lo = max(0, x1o - dx - PX), x_hi = min(PX - 1, x1o - dx + PX);
+                    if (x_lo > x_hi) continue;
+                    for (int z2o = z_lo; z2o <= z_hi; ++z2o) {
+                        const int qz = dz + z2o - z1o;
+                        const bool iz = in_b && abs(dz + z2o - G.rz) <= G.rz;
+                        for (int y2o = y_lo; y2o <= y_hi; ++y2o) {
+                            const int qy = dy + y2o - y1o;
+                            const bool izy = iz && abs(dy + y2o - G.ry) <= G.ry;
+                            const int r2row = (z2o * G.py + y2o) * PX;
+                            // stored offsets on this row: |qz|, |qy| < p, and qx clipped to
+                            // [-(PX-1), PX-1]; fetch [qx_first, qx_first + 8) in two loads
+                            const bool row_stored = abs(qz) < G.pz && abs(qy) < G.py;
+                            const int qx_first = max(dx + x_lo - x1o, -(PX - 1));
+                            float v[8];
+                            {
+                                long long i0 = rowi + (long long)(qz * G.wy + qy) * G.wx + qx_first;
+                                // keep both 16-byte loads inside the buffer (values outside the
+                                // row are never used)
+                                i0 = max(0ll, min(i0, n_elems - 8));
+                                f4u lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+                                if (row_stored && bit_a) {
+                                    lo4 = *reinterpret_cast<const f4u *>(S + i0);
+                                    // second load only when the run is longer than 4 pixels (uniform)
+                                    if (PX > 4 && x_hi - x_lo >= 4) hi4 = *reinterpret_cast<const f4u *>(S + i0 + 4);
+                                }
+                                v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
+                                v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+                                // if the clamp moved the window, re-centre the register window
+                                const int shift = (int)(rowi + (long long)(qz * G.wy + qy) * G.wx + qx_first - i0);
+                                if (__builtin_expect(__ballot(shift != 0 && bit_a) != 0ull, 0)) {
+                                    float t[8];
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) {
+                                        float val = 0.f;
+#pragma unroll
+                                        for (int m = 0; m < 8; ++m) val = (m == k + shift) ? v[m] : val;
+                                        t[k] = val;
+                                    }
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) v[k] = shift != 0 ? t[k] : v[k];
+                                }
+                            }
+#pragma unroll
+                            for (int t = 0; t < PX; ++t) {
+                                const int x2o = x_lo + t;
+                                if (x2o > x_hi) break;
+                                const int r2 = r2row + x2o;
+                                const int qx = dx + x2o - x1o;
+                                const bool fwd = qz > 0 || (qz == 0 && (qy > 0 || (qy == 0 && qx >= 0)));
+                                const int lo_z = fwd ? -(G.pz - 1) : -G.pz, hi_z = fwd ? G.pz : G.pz - 1;
+                                const int lo_y = fwd ? -(G.py - 1) : -G.py, hi_y = fwd ? G.py : G.py - 1;
+                                const int lo_x = fwd ? -(PX - 1) : -PX, hi_x = fwd ? PX : PX - 1;
+                                const bool in_range = qz >= lo_z && qz <= hi_z && qy >= lo_y &&
+                                                      qy <= hi_y && qx >= lo_x && qx <= hi_x;
+                                const bool inter = izy && abs(dx + x2o - RX) <= RX;
+                                if (!inter && !in_range) continue;
+                                bool valid = bit_a && ((lds_b[(r2 >> 5) * 64 + lane] >> (r2 & 31)) & 1u);
+                                if (inter) {
+                                    const uint32_t nxt = rnd * 1103515245U;
+                                    const float rnd_t = (float)nxt / 4294967296.0f;
+                                    rnd = valid ? nxt : rnd;
+                                    valid = valid && !((double)rnd_t > 0.2);
+                                }
+                                if (!in_range) continue;
+                                const bool stored = row_stored && abs(qx) < PX && (qz | qy | qx) != 0;
+                                if (stored) {
+                                    // register slot of offset qx inside the fetched window
+                                    const int k = qx - qx_first;
+                                    float val = 0.0f;
+#pragma unroll
+                                    for (int m = 0; m < 8; ++m) val = (m == k) ? v[m] : val;
+                                    acc += valid ? val : 0.0f;
+                                }
+                                fg_cnt += valid ? 1u : 0u;
+                            }
+                        }
+                    }
+                }
+    }
+    if (live) aff[id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
+}
+
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
                               const uint32_t *pairs, const uint32_t *order, uint64_t n,
                               float *aff, const Geo &G, hipStream_t s) {
@@ -271,6 +414,25 @@ hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const uint64_t per_block = 64ull * PG_WAVES;
     const dim3 grid((unsigned)((n + per_block - 1) / per_block));
+    static const bool vm_generic = getenv("PPP_PATCH_GRAPH_GENERIC") != nullptr;
+    if (G.layout == PPP_CONS_VOXEL_MAJOR && !vm_generic && G.px <= 7 &&
+        (G.px == 3 || G.px == 5 || G.px == 7)) {
+#define PPP_PG_CASE(P)                                                                                          \
+    case P:                                                                                                     \
+        if (dtype == PPP_F16)                                                                                   \
+            patch_graph_vm2_kernel<__half, P><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>(                     \
+                (const __half *)pred, cons, pairs, order, n, aff, G);                                           \
+        else                                                                                                    \
+            patch_graph_vm2_kernel<float, P><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>(                      \
+                (const float *)pred, cons, pairs, order, n, aff, G);                                            \
+        return hipGetLastError();
+        switch (G.px) {
+            PPP_PG_CASE(3)
+            PPP_PG_CASE(5)
+            PPP_PG_CASE(7)
+        }
+#undef PPP_PG_CASE
+    }
     if (G.layout == PPP_CONS_VOXEL_MAJOR) {
         if (dtype == PPP_F16)
             patch_graph_vm_kernel<__half><<<grid, dim3(64 * PG_WAVES), lds_bytes, s>>>((const __half *)pred, cons, pairs, order, n, aff, G);

@@ -4,6 +4,8 @@
 // accumulation runs in the reference's loop order (r1 raster, r2 raster), so the score is
 // bit-identical given the same consensus.  Lanes of a wave are consecutive centres along
 // x, so every consensus gather (same plane, consecutive base voxels) is coalesced.
+#include <cstdlib>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -77,6 +79,12 @@ hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uin
                        float *score, const ppp_box &sb, const Geo &G, hipStream_t s) {
     const long long n = (long long)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
     if (n <= 0) return hipSuccess;
+    // specialised kernel for px in {3,5,7,9}; PPP_RANK_GENERIC=1 forces the generic one
+    static const bool force_generic = getenv("PPP_RANK_GENERIC") != nullptr;
+    if (!force_generic) {
+        const hipError_t e2 = launch_rank_v2(pred, dtype, cons, ov, score, sb, G, s);
+        if (e2 != hipErrorNotSupported) return e2;
+    }
     const dim3 grid((unsigned)((n + 255) / 256));
     if (dtype == PPP_F16)
         rank_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, cons, ov, score, sb, G);

@@ -1,0 +1,186 @@
+// ppp_rank_v2.hip -- S2, second generation (px in {3,5,7,9}; other shapes use ppp_rank.hip).
+// Same sequential float accumulation order as the reference (cuda/rankPatches.cu:28-147), hence
+// bit-identical scores given the same consensus.
+//
+// One lane = one patch centre c, a wave = 64 consecutive centres along x.  What the reference
+// re-derives inside its p^3 x p^3 loop from global memory is hoisted into three per-centre bit
+// masks over the patch pixels r (kept in LDS, word-major so a wave reads them conflict-free):
+//     V[r]  pixel z = c + r - rad is valid        (pred[mid][z] > TH  and, if OVERLAP, not overlap)
+//     P[r]  V[r] and pred[r][c] > TH              ("foreground" pixel of the patch)
+//     N[r]  V[r] and pred[r][c] < BG              ("background" pixel of the patch)
+// For a in P (first pixel) the reference walks every b != a with V[b]:
+//     b in P, b > a : acc += cons[b-a][z_a]                         (:88-101)
+//     b in N        : acc -= cons[key], key = (b-a, z_a) if b > a else (a-b, z_b)   (:102-138)
+//     fgCnt += 1 unless (b in P and b < a)                           (:139)
+// so fgCnt = |P|*(|V|-1) - |P|*(|P|-1)/2 in closed form, and only the (a, b) combinations above
+// touch memory.  Loops over a and (bz, by) are wave-uniform (scalar); the innermost PX pixels
+// are unrolled: PX independent coalesced gathers (lane = consecutive base voxels) are issued
+// together, then added in order.  Groups no lane needs are skipped with one ballot.
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+static constexpr int R2_WAVES = 4;
+
+template <typename T, int PX, bool COUNT_POS_NEG>
+__global__ void __launch_bounds__(64 * R2_WAVES)
+    rank_v2_kernel(const T *__restrict__ pred, const float *__restrict__ cons,
+                   const uint8_t *__restrict__ ov, float *__restrict__ score, const ppp_box sb,
+                   const Geo G, const int runs_per_line, const long long n_waves) {
+    extern __shared__ uint32_t lds_raw[];  // [R2_WAVES][3][words][64]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (wid >= n_waves) return;
+    const int words = (G.C + 31) / 32;
+    uint32_t *Pw = lds_raw + (size_t)(wave * 3 + 0) * words * 64 + lane;
+    uint32_t *Nw = lds_raw + (size_t)(wave * 3 + 1) * words * 64 + lane;
+    uint32_t *Vw = lds_raw + (size_t)(wave * 3 + 2) * words * 64 + lane;
+
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0;
+    const int xr = (int)(wid % runs_per_line);
+    const long long t0 = wid / runs_per_line;
+    const int cy = sb.y0 + (int)(t0 % sY);
+    const int cz = sb.z0 + (int)(t0 / sY);
+    const int cx = sb.x0 + xr * 64 + lane;
+    const bool in_box = cx < sb.x0 + sX;
+    const long long lc = vox(G, cz, cy, min(cx, G.X - 1));
+    const T *mid = pred + (long long)G.mid * G.V;
+    const bool inter = in_box && interior(G, cz, cy, cx);
+    const bool fg = inter && ldf(mid, lc) > G.th_gt;
+    if (in_box && !inter) score[lc] = G.norm_rank ? -1.0f : -9999999.0f;
+    if (in_box && inter && !fg) score[lc] = 0.0f;   // the reference leaves the allocation's zero
+    if (__ballot(fg) == 0) return;
+
+    // ---- per-centre bit masks
+    unsigned nP = 0, nV = 0;
+    {
+        int r = 0;
+        for (int w = 0; w < words; ++w) {
+            uint32_t p = 0, n = 0, v = 0;
+            for (int b = 0; b < 32 && r < G.C; ++b, ++r) {
+                if (fg) {
+                    const int z = cz + r / (G.py * PX) - G.rz;
+                    const int y = cy + (r / PX) % G.py - G.ry;
+                    const int x = cx + r % PX - PX / 2;
+                    const long long lz = vox(G, z, y, x);
+                    const bool valid = ldf(mid, lz) > G.th_gt && (!G.use_overlap || ov[lz] == 0);
+                    const float val = ldf(pred, (long long)r * G.V + lc);
+                    const uint32_t bit = 1u << b;
+                    if (valid) v |= bit;
+                    if (valid && val > G.th_gt) p |= bit;
+                    if (valid && val < G.bg_lt) n |= bit;
+                }
+            }
+            Pw[w * 64] = p; Nw[w * 64] = n; Vw[w * 64] = v;
+            nP += __popc(p); nV += __popc(v);
+        }
+    }
+    // this lane's base index of c inside the consensus buffer, and the strides of a base voxel
+    long long sYc, sZc, laneC, plane_stride;
+    if (G.layout == PPP_CONS_REFERENCE) {
+        sYc = G.X; sZc = (long long)G.X * G.Y; plane_stride = G.V;
+        laneC = lc;
+    } else {
+        sYc = G.bX; sZc = (long long)G.bX * G.bY; plane_stride = G.BV;
+        laneC = ((long long)(cz - G.bz0) * G.bY + (cy - G.by0)) * G.bX + (min(cx, G.X - 1) - G.bx0);
+    }
+    if (!fg) laneC = 0;   // inactive lanes read a harmless in-bounds element
+
+    float acc = 0.0f;
+    for (int az = 0, a = 0; az < G.pz; ++az)
+        for (int ay = 0; ay < G.py; ++ay)
+            for (int ax = 0; ax < PX; ++ax, ++a) {
+                const bool pa = fg && ((Pw[(a >> 5) * 64] >> (a & 31)) & 1u);
+                if (__ballot(pa) == 0) continue;
+                const long long off_a = (long long)(az - G.rz) * sZc + (long long)(ay - G.ry) * sYc + (ax - PX / 2);
+                for (int bz = 0; bz < G.pz; ++bz)
+                    for (int by = 0; by < G.py; ++by) {
+                        const int b0 = (bz * G.py + by) * PX;
+                        // PX-bit fields of P and N starting at bit b0 (may straddle two words)
+                        const int w0 = b0 >> 5, sh = b0 & 31;
+                        uint64_t p64 = Pw[w0 * 64], n64 = Nw[w0 * 64];
+                        if (sh + PX > 32) {
+                            p64 |= (uint64_t)Pw[(w0 + 1) * 64] << 32;
+                            n64 |= (uint64_t)Nw[(w0 + 1) * 64] << 32;
+                        }
+                        uint32_t pf = (uint32_t)(p64 >> sh) & ((1u << PX) - 1u);
+                        uint32_t nf = (uint32_t)(n64 >> sh) & ((1u << PX) - 1u);
+                        // pos votes only for b > a
+                        const int row_cmp = b0 - (a - ax);   // (<0: row before a's, 0: same row, >0: after)
+                        if (row_cmp < 0) pf = 0;
+                        else if (row_cmp == 0) pf &= ~((2u << ax) - 1u);   // keep bits j > ax
+                        uint32_t need = pa ? (pf | nf) : 0u;
+                        if (row_cmp == 0) need &= ~(1u << ax);             // b == a never votes
+                        if (__ballot(need != 0) == 0) continue;
+                        const long long off_b0 = (long long)(bz - G.rz) * sZc + (long long)(by - G.ry) * sYc - PX / 2;
+                        float v[PX];
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const int b = b0 + j;
+                            // forward (b > a): key (b - a, z_a); backward (b < a): key (a - b, z_b)
+                            int dz = bz - az, dy = by - ay, dx = j - ax;
+                            long long off = off_a;
+                            if (b < a) { dz = -dz; dy = -dy; dx = -dx; off = off_b0 + j; }
+                            long long plane;
+                            if (G.layout == PPP_CONS_REFERENCE)
+                                plane = ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (dx + PX - 1);
+                            else
+                                plane = ((long long)dz * G.wy + dy) * G.wx + dx - 1;
+                            if (b == a) plane = 0, off = 0;   // unused slot, keep the address valid
+                            v[j] = fg ? cons[plane * plane_stride + off + laneC] : 0.0f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const bool is_p = (pf >> j) & 1u, is_n = (nf >> j) & 1u;
+                            const bool use = pa && (is_p || is_n) && !(row_cmp == 0 && j == ax);
+                            float c = v[j];
+                            if (COUNT_POS_NEG) c = (c != 0.0f) ? copysignf(1.0f, c) : (is_p ? -1.0f : 1.0f);
+                            // acc += c for a foreground partner, acc -= c for a background partner
+                            const float term = is_p ? c : -c;
+                            acc = acc + (use ? term : 0.0f);
+                        }
+                    }
+            }
+    if (fg) {
+        const unsigned fg_cnt = nP * (nV - 1u) - nP * (nP - 1u) / 2u;
+        score[lc] = G.norm_rank ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
+    }
+}
+
+template <typename T, int PX>
+static hipError_t launch_r2(const T *pred, const float *cons, const uint8_t *ov, float *score,
+                            const ppp_box &sb, const Geo &G, hipStream_t s) {
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const int runs_per_line = (sX + 63) / 64;
+    const long long n_waves = (long long)runs_per_line * sY * sZ;
+    const size_t per_wave = (size_t)3 * ((G.C + 31) / 32) * 64 * sizeof(uint32_t);
+    int waves = R2_WAVES;
+    while (waves > 1 && waves * per_wave > 40 * 1024) waves >>= 1;   // keep >= 4 blocks per CU
+    if (waves * per_wave > 64 * 1024) return hipErrorNotSupported;
+    const size_t lds = waves * per_wave;
+    const dim3 grid((unsigned)((n_waves + waves - 1) / waves)), block(64 * waves);
+    if (G.count_pos_neg)
+        rank_v2_kernel<T, PX, true><<<grid, block, lds, s>>>(pred, cons, ov, score, sb, G, runs_per_line, n_waves);
+    else
+        rank_v2_kernel<T, PX, false><<<grid, block, lds, s>>>(pred, cons, ov, score, sb, G, runs_per_line, n_waves);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_v2(const void *pred, int dtype, const float *cons, const uint8_t *ov,
+                          float *score, const ppp_box &sb, const Geo &G, hipStream_t s) {
+#define PPP_R2_CASE(P)                                                                          \
+    case P:                                                                                     \
+        return dtype == PPP_F16 ? launch_r2<__half, P>((const __half *)pred, cons, ov, score, sb, G, s) \
+                                : launch_r2<float, P>((const float *)pred, cons, ov, score, sb, G, s);
+    switch (G.px) {
+        PPP_R2_CASE(3)
+        PPP_R2_CASE(5)
+        PPP_R2_CASE(7)
+        PPP_R2_CASE(9)
+    default:
+        return hipErrorNotSupported;
+    }
+#undef PPP_R2_CASE
+}
+
+}  // namespace ppp
