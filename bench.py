@@ -7,9 +7,10 @@ HBM when the timed region starts.  Prints ONE JSON line ("Measure
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: every rank assembles its own
-z-slab tile of an N-times larger volume (weak scaling, no collective on the data path in
-this round -- see DESIGN.md "Multi-GPU").
+N > 1 is launched by torch.distributed.run, one rank per GPU: ONE volume, N times taller than
+the 1-GPU workload (weak scaling), is split into z-slabs with patch-radius halos
+(patchperpix_amd/tiling.py); the ranks meet in four RCCL all-reduces and every rank ends with
+the complete instance map -- see DESIGN.md "Multi-GPU".
 """
 import argparse
 import json
@@ -92,17 +93,40 @@ def main():
 
     shape, ps, cell = WORKLOADS[args.workload]
     kw = dict(FLYLIGHT)
-    P = backend.make_params(shape, ps, **kw)
-    # every rank: its own z-slab of an N-times taller volume (distinct instances per rank)
-    labels = device_labels(torch, shape, cell, seed=0, z_offset=rank * shape[0])
-    pred = backend.synth_pred(labels, P, seed=rank, f16=True)       # resident in HBM
-    fg_host = (labels != 0).cpu().numpy()
-    numinst = fg_host.astype(np.uint8)
-    torch.cuda.synchronize()
+    from patchperpix_amd import tiling
+    if world == 1:
+        P = backend.make_params(shape, ps, **kw)
+        labels = device_labels(torch, shape, cell, seed=0)
+        pred = backend.synth_pred(labels, P, seed=0, f16=True)       # resident in HBM
+        fg_host = (labels != 0).cpu().numpy()
+        numinst = fg_host.astype(np.uint8)
+        gshape = shape
 
-    def step():
-        inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps, **kw)
-        return inst
+        def step():
+            inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps, **kw)
+            return inst
+    else:
+        # ONE volume, `world` times taller than the 1-GPU workload (weak scaling), split into
+        # z-slabs: rank r holds the prediction of its slab + halo only; the ranks meet in four
+        # RCCL all-reduces (scores, cover bits, pair affinities, painted slabs)
+        gshape = (shape[0] * world, shape[1], shape[2])
+        slabs = tiling.plan_slabs(gshape[0], world)
+        mine = tiling.slabs_of_rank(slabs, rank, world)
+        lo, hi = tiling.local_range(mine, gshape[0], ps)
+        lshape = (hi - lo, shape[1], shape[2])
+        Pl = backend.make_params(lshape, ps, **kw)
+        labels_l = device_labels(torch, lshape, cell, seed=0, z_offset=lo)
+        pred = backend.synth_pred(labels_l, Pl, seed=0, f16=True,
+                                  voxel_offset=lo * shape[1] * shape[2])
+        fg_host = (device_labels(torch, gshape, cell, seed=0) != 0).cpu().numpy()
+        numinst = fg_host.astype(np.uint8)
+        comm = tiling.TorchDistComm()
+
+        def step():
+            inst, _ = tiling.assemble(pred, lo, gshape, fg_host.copy(), fg_host.copy(), numinst,
+                                      ps, mine, comm=comm, **kw)
+            return inst
+    torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         inst = step()
@@ -133,7 +157,7 @@ def main():
 
     V = float(np.prod(shape))
     C = int(np.prod(ps))
-    value = n_gpus * V * args.steps / dt / 1e6
+    value = float(np.prod(gshape)) * args.steps / dt / 1e6
     # roofline of the dominant kernel (S1 consensus): algorithmic bytes = prediction block
     # read once (f16 resident: 2*C*V) + overlap mask (V); outputs excluded
     s1_ms = float(np.mean(ev["consensus"])) if ev.get("consensus") else None
@@ -155,7 +179,7 @@ def main():
                        "pred_dtype": "f16 resident, widened to f32 in registers",
                        "flags": "flylight default.toml [vote_instances]",
                        "instances_found": int(len(np.unique(inst)) - 1),
-                       "parallelism": "tiles%d" % n_gpus},
+                       "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus},
             "roofline": roofline,
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
             "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)

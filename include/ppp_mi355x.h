@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PPP_ABI_VERSION 1
+#define PPP_ABI_VERSION 2
 
 enum ppp_error {
     PPP_OK = 0,
@@ -88,6 +88,10 @@ typedef struct ppp_params {
     int32_t norm_aff;      /* -DNORM_PATCH_AFFINITY                                      */
     int32_t cons_layout;   /* enum ppp_cons_layout                                       */
     ppp_box cons_box;      /* base voxels held by the consensus buffer (tile)            */
+    int32_t origin_z, origin_y, origin_x; /* global coordinate of local voxel (0,0,0) when the
+                              buffers hold a sub-volume (slab of a larger volume); only the
+                              per-pair LCG seed of ppp_patch_graph depends on absolute
+                              coordinates (computePatchGraph.cu:24-27)                          */
 } ppp_params;
 
 /* --- library / device ------------------------------------------------------------- */
@@ -224,9 +228,11 @@ int64_t ppp_host_patch_pairs(const int32_t *sel_zyx, int64_t n, const int32_t *p
                              uint32_t *pairs);
 
 /* --- synthetic input (bench / tests only; same hash as patchperpix_amd/synth.py) ------
- * fills d_pred (C,Z,Y,X) from a label volume d_labels int32 (Z,Y,X).                    */
+ * fills d_pred (C,Z,Y,X) from a label volume d_labels int32 (Z,Y,X).  voxel_offset is the
+ * linear index of local voxel 0 in the global volume (0 unless the buffers are a slab).    */
 int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
-                   float hi, float lo, float noise, const ppp_params *p, void *stream);
+                   float hi, float lo, float noise, uint64_t voxel_offset, const ppp_params *p,
+                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ typedef struct {
     int32_t norm_rank;     /* -DNORM_PATCH_RANK                                    */
     int32_t count_pos_neg; /* -DCOUNT_POS_NEG                                      */
     int32_t norm_aff;      /* -DNORM_PATCH_AFFINITY                                */
+    int32_t oz, oy, ox;    /* global coordinate of local voxel (0,0,0): the reference's LCG
+                              seed uses absolute coordinates (tests of slab decompositions) */
 } ppp_oracle_params;
 
 /* ---- small helpers ---------------------------------------------------------- */
@@ -253,8 +255,8 @@ void ppp_oracle_patch_graph(const float *pred, const float *cons, const uint32_t
                   ax = (int)pairs[id * 6 + 2];
         const int bz = (int)pairs[id * 6 + 3], by = (int)pairs[id * 6 + 4],
                   bx = (int)pairs[id * 6 + 5];
-        uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by *
-                       (uint32_t)ax * (uint32_t)bx;
+        uint32_t rnd = (uint32_t)(az + P->oz) * (uint32_t)(bz + P->oz) * (uint32_t)(ay + P->oy) *
+                       (uint32_t)(by + P->oy) * (uint32_t)(ax + P->ox) * (uint32_t)(bx + P->ox);
         const size_t ca = vox(&g, az, ay, ax), cb = vox(&g, bz, by, bx);
         float acc = 0.0f;
         unsigned fg_cnt = 0;

@@ -38,7 +38,7 @@ class Params(ctypes.Structure):
                [("th", ctypes.c_double), ("thi", ctypes.c_double)] + \
                [(n, ctypes.c_int32) for n in
                 ("bg_rule", "value_rule", "use_overlap", "norm_rank",
-                 "count_pos_neg", "norm_aff")]
+                 "count_pos_neg", "norm_aff", "oz", "oy", "ox")]
 
 
 def build(force=False):
@@ -102,6 +102,7 @@ def make_params(shape_zyx, patchshape, **kw):
     P.norm_rank = 1 if kw.get("rank_norm_patch_score", True) else 0
     P.count_pos_neg = 1 if kw.get("rank_int_counter", False) else 0
     P.norm_aff = 1 if kw.get("patch_graph_norm_aff", True) else 0
+    P.oz, P.oy, P.ox = [int(v) for v in kw.get("origin", (0, 0, 0))]
     return P
 
 

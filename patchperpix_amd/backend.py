@@ -17,7 +17,7 @@ F32, F16 = 0, 1
 BG_INV_TH, BG_HALF_TH, BG_LESS_THAN_TH = 0, 1, 2
 VAL_COUNT, VAL_PROB_PRODUCT, VAL_NORM_PROB_PRODUCT = 0, 1, 2
 CONS_COMPACT, CONS_REFERENCE, CONS_VOXEL_MAJOR = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 NONE_KEY = 0xFFFFFFFF
 
 
@@ -37,7 +37,9 @@ class Params(ctypes.Structure):
                 ("use_overlap", ctypes.c_int32), ("normalise", ctypes.c_int32),
                 ("norm_rank", ctypes.c_int32), ("count_pos_neg", ctypes.c_int32),
                 ("norm_aff", ctypes.c_int32), ("cons_layout", ctypes.c_int32),
-                ("cons_box", Box)]
+                ("cons_box", Box),
+                ("origin_z", ctypes.c_int32), ("origin_y", ctypes.c_int32),
+                ("origin_x", ctypes.c_int32)]
 
     @property
     def shape(self):
@@ -98,7 +100,8 @@ _SIGNATURES = {
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_synth_pred": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
-                                      ctypes.c_float, ctypes.POINTER(Params), ctypes.c_void_p]),
+                                      ctypes.c_float, ctypes.c_uint64, ctypes.POINTER(Params),
+                                      ctypes.c_void_p]),
     "ppp_host_rank_order": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p]),
     "ppp_host_cover_pass": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -153,7 +156,8 @@ def device_count():
 # ----------------------------------------------------------------------------------------
 # parameters from the reference's kwargs (utilVoteInstances.py:340-449)
 # ----------------------------------------------------------------------------------------
-def make_params(shape_zyx, patchshape, cons_box=None, cons_layout=CONS_COMPACT, **kw):
+def make_params(shape_zyx, patchshape, cons_box=None, cons_layout=CONS_COMPACT,
+                origin=(0, 0, 0), **kw):
     """Translate the reference's keyword flags into ppp_params.
 
     Mirrors loadKernelFromFile's TH/THI substitution and setKernelBuildOptions' -D flags,
@@ -193,15 +197,17 @@ def make_params(shape_zyx, patchshape, cons_box=None, cons_layout=CONS_COMPACT, 
     if cons_box is None:
         cons_box = (0, 0, 0, P.Z, P.Y, P.X)
     P.cons_box = Box(*[int(v) for v in cons_box])
+    P.origin_z, P.origin_y, P.origin_x = [int(v) for v in origin]
     return P
 
 
 def params_from_kwargs(shape_zyx, patchshape, kwargs):
     """make_params for a reference-style kwargs dict (which may carry this package's own
     ``cons_box`` / ``cons_layout`` entries next to the reference's flags)."""
-    kw = {k: v for k, v in kwargs.items() if k not in ("cons_box", "cons_layout")}
+    kw = {k: v for k, v in kwargs.items() if k not in ("cons_box", "cons_layout", "origin")}
     return make_params(shape_zyx, patchshape, cons_box=kwargs.get("cons_box"),
-                       cons_layout=kwargs.get("cons_layout", CONS_COMPACT), **kw)
+                       cons_layout=kwargs.get("cons_layout", CONS_COMPACT),
+                       origin=kwargs.get("origin", (0, 0, 0)), **kw)
 
 
 # ----------------------------------------------------------------------------------------
@@ -445,14 +451,16 @@ def patch_bits(pred, centres, thresh, P):
     return bits
 
 
-def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True):
-    """Procedural prediction volume on the device (bench / tests)."""
+def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True, voxel_offset=0):
+    """Procedural prediction volume on the device (bench / tests).  voxel_offset: linear index
+    of local voxel 0 in the global volume when `labels` is a z-slab of a larger volume."""
     torch = _torch()
     C = P.pz * P.py * P.px
     pred = torch.empty((C,) + P.shape, dtype=torch.float16 if f16 else torch.float32,
                        device=labels.device)
     check(lib().ppp_synth_pred(_dev_ptr(labels), _dev_ptr(pred), F16 if f16 else F32,
-                               int(seed) & 0xFFFFFFFF, hi, lo, noise, ctypes.byref(P), _stream()))
+                               int(seed) & 0xFFFFFFFF, hi, lo, noise, int(voxel_offset),
+                               ctypes.byref(P), _stream()))
     return pred
 
 

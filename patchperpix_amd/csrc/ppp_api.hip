@@ -91,6 +91,7 @@ int make_geo(const ppp_params *p, ppp::Geo *G) {
     g.nsy = 2 * p->py; g.nsx = 2 * p->px;
     g.wy = 2 * p->py - 1; g.wx = 2 * p->px - 1;
     g.n_planes = ((2 * p->pz - 1) * g.wy * g.wx - 1) / 2;
+    g.oz = p->origin_z; g.oy = p->origin_y; g.ox = p->origin_x;
     *G = g;
     return PPP_OK;
 }
@@ -304,13 +305,14 @@ int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres
 }
 
 int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
-                   float hi, float lo, float noise, const ppp_params *p, void *stream) {
+                   float hi, float lo, float noise, uint64_t voxel_offset, const ppp_params *p,
+                   void *stream) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     PPP_TRY(check_dtype(pred_dtype));
     if (!d_labels || !d_pred) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
     PPP_TRY(need_device());
-    hipError_t e = ppp::launch_synth(d_labels, d_pred, pred_dtype, seed, hi, lo, noise, G, (hipStream_t)stream);
+    hipError_t e = ppp::launch_synth(d_labels, d_pred, pred_dtype, seed, hi, lo, noise, voxel_offset, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred");
 }
 

@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 template <typename T>
 __global__ void __launch_bounds__(256)
     synth_kernel(const int32_t *__restrict__ labels, T *__restrict__ pred, uint32_t seed_mix,
-                 float hi, float lo, float noise, const Geo G) {
+                 float hi, float lo, float noise, unsigned long long voxel_offset, const Geo G) {
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= G.V) return;
     const int r = blockIdx.y;
@@ -62,8 +62,9 @@ __global__ void __launch_bounds__(256)
     if (nz >= 0 && nz < G.Z && ny >= 0 && ny < G.Y && nx >= 0 && nx < G.X) nb = labels[vox(G, nz, ny, nx)];
     const float base = (nb == lab && lab != 0) ? hi : lo;
     // counter = lin * C + r + seed_mix   (mod 2^32, like the uint64 NumPy code masked to 32 bit)
-    const uint32_t ctr = (uint32_t)((unsigned long long)v * (unsigned long long)G.C + (unsigned long long)r +
-                                    (unsigned long long)seed_mix);
+    // counter of the GLOBAL voxel, so a slab of a larger volume gets the same values
+    const uint32_t ctr = (uint32_t)(((unsigned long long)v + voxel_offset) * (unsigned long long)G.C +
+                                    (unsigned long long)r + (unsigned long long)seed_mix);
     const float u = (float)(hash_u32(ctr) >> 8) * (1.0f / 16777216.0f);
     const float val = base + noise * (2.0f * u - 1.0f);
     const __half h = __float2half_rn(val);  // through float16, like the zarr on disk
@@ -72,13 +73,14 @@ __global__ void __launch_bounds__(256)
 }
 
 hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
-                        float lo, float noise, const Geo &G, hipStream_t s) {
+                        float lo, float noise, unsigned long long voxel_offset, const Geo &G,
+                        hipStream_t s) {
     const dim3 grid((unsigned)((G.V + 255) / 256), (unsigned)G.C);
     const uint32_t seed_mix = (uint32_t)(((unsigned long long)seed * 0x9E3779B1ull) & 0xFFFFFFFFull);
     if (dtype == PPP_F16)
-        synth_kernel<__half><<<grid, dim3(256), 0, s>>>(labels, (__half *)pred, seed_mix, hi, lo, noise, G);
+        synth_kernel<__half><<<grid, dim3(256), 0, s>>>(labels, (__half *)pred, seed_mix, hi, lo, noise, voxel_offset, G);
     else
-        synth_kernel<float><<<grid, dim3(256), 0, s>>>(labels, (float *)pred, seed_mix, hi, lo, noise, G);
+        synth_kernel<float><<<grid, dim3(256), 0, s>>>(labels, (float *)pred, seed_mix, hi, lo, noise, voxel_offset, G);
     return hipGetLastError();
 }
 

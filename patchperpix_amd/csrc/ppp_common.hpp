@@ -33,6 +33,7 @@ struct Geo {
     int nsy, nsx;       // reference layout plane grid
     int wy, wx;         // 2py-1, 2px-1 (compact plane grid)
     int n_planes;       // compact: ((2pz-1)(2py-1)(2px-1)-1)/2
+    int oz, oy, ox;     // global coordinate of local voxel (0,0,0)
 };
 
 template <typename T>

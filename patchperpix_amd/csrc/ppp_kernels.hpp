@@ -35,6 +35,7 @@ hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo 
 hipError_t launch_patch_bits(const void *pred, int dtype, const uint32_t *centres, uint64_t n,
                              float thresh, uint32_t *bits, const Geo &G, hipStream_t s);
 hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
-                        float lo, float noise, const Geo &G, hipStream_t s);
+                        float lo, float noise, unsigned long long voxel_offset, const Geo &G,
+                        hipStream_t s);
 
 }  // namespace ppp

@@ -66,8 +66,9 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
         patch_fg_words(pred, G, az, ay, ax, lds_a + lane, words);
         patch_fg_words(pred, G, bz, by, bx, lds_b + lane, words);
     }
-    uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by * (uint32_t)ax *
-                   (uint32_t)bx;
+    // the LCG seed is the product of the GLOBAL coordinates (computePatchGraph.cu:24-27)
+    uint32_t rnd = (uint32_t)(az + G.oz) * (uint32_t)(bz + G.oz) * (uint32_t)(ay + G.oy) *
+                   (uint32_t)(by + G.oy) * (uint32_t)(ax + G.ox) * (uint32_t)(bx + G.ox);
     // consensus strides of the base voxel (tile or volume) and this lane's base index of cA
     long long sY, sZ, laneA;
     if (G.layout == PPP_CONS_REFERENCE) {
@@ -188,8 +189,9 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
         patch_fg_words(pred, G, az, ay, ax, lds_a + lane, words);
         patch_fg_words(pred, G, bz, by, bx, lds_b + lane, words);
     }
-    uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by * (uint32_t)ax *
-                   (uint32_t)bx;
+    // the LCG seed is the product of the GLOBAL coordinates (computePatchGraph.cu:24-27)
+    uint32_t rnd = (uint32_t)(az + G.oz) * (uint32_t)(bz + G.oz) * (uint32_t)(ay + G.oy) *
+                   (uint32_t)(by + G.oy) * (uint32_t)(ax + G.ox) * (uint32_t)(bx + G.ox);
     const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
     const long long laneA = ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0);
     const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
@@ -293,8 +295,9 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
         patch_fg_words(pred, G, az, ay, ax, lds_a + lane, words);
         patch_fg_words(pred, G, bz, by, bx, lds_b + lane, words);
     }
-    uint32_t rnd = (uint32_t)az * (uint32_t)bz * (uint32_t)ay * (uint32_t)by * (uint32_t)ax *
-                   (uint32_t)bx;
+    // the LCG seed is the product of the GLOBAL coordinates (computePatchGraph.cu:24-27)
+    uint32_t rnd = (uint32_t)(az + G.oz) * (uint32_t)(bz + G.oz) * (uint32_t)(ay + G.oy) *
+                   (uint32_t)(by + G.oy) * (uint32_t)(ax + G.ox) * (uint32_t)(bx + G.ox);
     const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
     const long long laneA = live ? ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0) : 0;
     const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
@@ -342,12 +345,12 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
                                 long long i0 = rowi + (long long)(qz * G.wy + qy) * G.wx + qx_first;
                                 // keep both 16-byte loads inside the buffer (values outside the
                                 // row are never used)
-                                i0 = max(0ll, min(i0, n_elems - 8));
+                                const bool two = PX > 4 && x_hi - x_lo >= 4;   // run longer than 4 pixels (uniform)
+                                i0 = max(0ll, min(i0, n_elems - (two ? 8 : 4)));
                                 f4u lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
                                 if (row_stored && bit_a) {
                                     lo4 = *reinterpret_cast<const f4u *>(S + i0);
-                                    // second load only when the run is longer than 4 pixels (uniform)
-                                    if (PX > 4 && x_hi - x_lo >= 4) hi4 = *reinterpret_cast<const f4u *>(S + i0 + 4);
+                                    if (two) hi4 = *reinterpret_cast<const f4u *>(S + i0 + 4);
                                 }
                                 v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
                                 v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;

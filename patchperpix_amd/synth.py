@@ -9,7 +9,7 @@ rounded through float16 (the on-disk dtype of ``volumes/pred_affs``, reference
 ``experiments/flylight/setups/setup01/predict_no_gp.py:243-257``) and widened to
 float32.  Noise is a counter-based integer hash of ``(seed, r, v)`` so the very same
 values can be produced tile by tile on the device (``ppp_synth_pred`` in
-``csrc/ppp_synth.hip`` uses the identical hash).
+``csrc/ppp_aux.hip`` uses the identical hash).
 
 Used by the tests, the golden-vector generator and ``bench.py``; it is not part of
 the hot path.

@@ -1,0 +1,394 @@
+"""Spatial tiling of the vote_instances path: z-slabs with patch-radius halos.
+
+One mechanism serves two purposes
+
+* **multi-GPU** (one process per GPU, ``torch.distributed`` / RCCL): every rank owns a
+  contiguous range of z-slabs of ONE volume, holds the prediction for its range grown by the
+  halo, and the ranks meet in four collectives (scores, patch bits of the cover candidates,
+  pair affinities, painted instance slabs);
+* **single-GPU tiling** of volumes whose consensus array does not fit: the slabs of one rank
+  are processed one after the other, the consensus living only for one slab at a time.
+
+It replaces the reference's scale-out mechanism -- ``stitch_patch_graph.py``: blocks of
+``chunksize`` + margin, a patch graph per block, inter-block edges recomputed on face overlaps,
+one global labelling (:110-399, :553-669) -- but, unlike it, reproduces the WHOLE-VOLUME result
+exactly: the order-defined global stages (ranking, greedy cover, thinning, component order) run
+on globally gathered data, identically on every rank; only the voxel-local stages (S1 consensus,
+S2 scores, S5 pair affinities, painting) are sharded.
+
+Halos along z (rz = pz // 2; y and x are not split):
+  scores of centres   [z0, z1)            need consensus bases [z0 - rz, z1 + rz)
+  pairs with A in     [z0, z1)            need consensus bases [z0 - rz - (pz-1), z1 + rz)
+  consensus of bases  [b0, b1)            needs the prediction on [b0 - 2 rz, b1 + 2 rz)
+  foreground bits of partner patches B    need the prediction on [z0 - 2 pz - rz, z1 + 2 pz + rz)
+so a rank holds its slabs grown by H = 2 pz + rz slices (clipped to the volume).  Local buffers
+use local coordinates; ``ppp_params.origin_z`` carries the global offset (the per-pair LCG seed
+of the patch-graph kernel is the only thing that depends on absolute coordinates).
+"""
+import logging
+
+import numpy as np
+
+from . import backend
+
+logger = logging.getLogger(__name__)
+
+
+def halo(patchshape):
+    pz = int(patchshape[0])
+    return 2 * pz + pz // 2
+
+
+def plan_slabs(Z, n_slabs):
+    """n_slabs contiguous z-ranges covering [0, Z)."""
+    n_slabs = max(1, min(int(n_slabs), int(Z)))
+    edges = np.linspace(0, Z, n_slabs + 1).round().astype(int)
+    return [(int(edges[i]), int(edges[i + 1])) for i in range(n_slabs) if edges[i + 1] > edges[i]]
+
+
+def slabs_of_rank(slabs, rank, world):
+    """Contiguous block of slabs owned by `rank`."""
+    per = [len(slabs) * r // world for r in range(world + 1)]
+    return slabs[per[rank]:per[rank + 1]]
+
+
+def local_range(my_slabs, Z, patchshape):
+    """Global z-range [lo, hi) of the prediction a rank must hold for its slabs."""
+    H = halo(patchshape)
+    return max(0, my_slabs[0][0] - H), min(Z, my_slabs[-1][1] + H)
+
+
+# ------------------------------------------------------------------------------------------
+# communication
+# ------------------------------------------------------------------------------------------
+class LocalComm:
+    """Single process."""
+    rank, world = 0, 1
+
+    def all_reduce_sum(self, t):
+        return t
+
+
+class TorchDistComm:
+    """torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce_sum(self, t):
+        """In-place sum over ranks.  Every element is non-zero on at most one rank (each voxel,
+        candidate or pair row has one owner), so the sum is an exact gather."""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+# ------------------------------------------------------------------------------------------
+# device operations (the C ABI); tests substitute an oracle-backed object with the same API
+# ------------------------------------------------------------------------------------------
+class DeviceOps:
+    def __init__(self, device="cuda"):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+
+    def consensus(self, pred, ov, P):
+        return backend.consensus(pred, ov if P.use_overlap else None, P)
+
+    def rank_patches(self, pred, cons, ov, P, score_box):
+        return backend.rank_patches(pred, cons, ov if P.use_overlap else None, P,
+                                    score_box=score_box)
+
+    def patch_bits(self, pred, centres, thresh, P):
+        return backend.patch_bits(pred, centres, thresh, P)
+
+    def patch_pairs(self, sorted_zyx, P, max_ps_dist, include_single):
+        return backend.device_patch_pairs(sorted_zyx, P, max_ps_dist=max_ps_dist,
+                                          include_single=include_single)
+
+    def patch_graph(self, pred, cons, rows, P):
+        order = backend.pair_order(rows, P)
+        vm, Pv = backend.cons_to_voxel_major(cons, P)
+        return backend.patch_graph(pred, vm, rows, Pv, order=order)
+
+    def label_components(self, rows, aff, nodes, P):
+        return backend.label_components(rows, aff, nodes, P)
+
+    def paint(self, pred, nodes, labels, inst, P):
+        return backend.paint_instances(pred, nodes, labels, inst, P)
+
+
+# ------------------------------------------------------------------------------------------
+# the slab pipeline
+# ------------------------------------------------------------------------------------------
+def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchshape, my_slabs,
+             comm=None, ops=None, **kw):
+    """vote_instances on a z-slab decomposition.
+
+    pred_local  (C, hi-lo, Y, X) tensor on ops.device: the prediction for global z in [lo, hi)
+    shape       global (Z, Y, X);  foreground / mask_to_cover / numinst: GLOBAL host arrays
+    my_slabs    [(z0, z1), ...] owned by this rank (contiguous, inside [lo, hi) minus halo)
+    Returns (instances uint16 (Z,Y,X) -- complete on every rank --, foreground uint8), or
+    (pairs, aff) with return_intermediates, with the reference's early-outs.
+    """
+    import torch
+    comm = comm or LocalComm()
+    ops = ops or DeviceOps()
+    dev = ops.device
+    Z, Y, X = [int(s) for s in shape]
+    ps = [int(p) for p in patchshape]
+    rz = ps[0] // 2
+    rad = np.array([p // 2 for p in ps])
+    Zl = int(pred_local.shape[1])
+    hi = lo + Zl
+    radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
+    overlap_mask = 1 * (numinst > 1)
+    mask_to_cover[overlap_mask > 0] = 0
+    instances0 = np.zeros(shape, dtype=np.uint16)
+    want_inter = kw.get("return_intermediates", False)
+
+    def early():
+        return (None, None) if want_inter else (instances0, foreground.astype(np.uint8))
+
+    if np.count_nonzero(mask_to_cover[radslice]) == 0 or \
+            np.count_nonzero(foreground[radslice]) == 0:
+        return early()
+
+    flags = {k: v for k, v in kw.items() if k not in ("cons_box", "cons_layout", "origin")}
+    local_shape = (Zl, Y, X)
+
+    def params(box_z=None):
+        box = None if box_z is None else (box_z[0] - lo, 0, 0, box_z[1] - lo, Y, X)
+        return backend.make_params(local_shape, ps, cons_box=box, origin=(lo, 0, 0), **flags)
+
+    Pg = backend.make_params(shape, ps, **flags)          # global geometry (pairs, labels)
+    ov_local = torch.from_numpy(
+        np.ascontiguousarray((overlap_mask[lo:hi] > 0).astype(np.uint8))).to(dev)
+    keep_cons = len(my_slabs) == 1 and kw.get("_keep_cons", True)
+    kept = {}
+
+    def bases_for_pairs(z0, z1):
+        return max(0, z0 - rz - (ps[0] - 1)), min(Z, z1 + rz)
+
+    # ---- stage A: consensus + scores per slab --------------------------------------------
+    score_dev = torch.zeros(shape, dtype=torch.float32, device=dev)
+    for (z0, z1) in my_slabs:
+        bz = bases_for_pairs(z0, z1) if keep_cons else (max(0, z0 - rz), min(Z, z1 + rz))
+        P = params(bz)
+        with backend.host_timer("s1_consensus"):
+            cons = ops.consensus(pred_local, ov_local, P)
+        with backend.host_timer("s2_rank"):
+            sc = ops.rank_patches(pred_local, cons, ov_local, P,
+                                  (z0 - lo, 0, 0, z1 - lo, Y, X))
+        score_dev[z0:z1] = sc[z0 - lo:z1 - lo]
+        if keep_cons:
+            kept[(z0, z1)] = (cons, P)
+        del cons, sc
+    comm.all_reduce_sum(score_dev)
+    scores = score_dev.cpu().numpy()
+    del score_dev
+
+    # ---- stage B: ranking, greedy cover, thinning (global; identical on every rank) -------
+    def owned(z):
+        m = np.zeros(len(z), dtype=bool)
+        for (z0, z1) in my_slabs:
+            m |= (z >= z0) & (z < z1)
+        return m
+
+    def gathered_bits(coords, thresh):
+        """Patch bits of `coords` (global): each rank packs those centred in its own slabs,
+        the sum over ranks is the full table."""
+        words = (int(np.prod(ps)) + 31) // 32
+        bits = torch.zeros((len(coords), words), dtype=torch.int32, device=dev)
+        mine = np.flatnonzero(owned(coords[:, 0]))
+        if len(mine):
+            loc = coords[mine].astype(np.int32).copy()
+            loc[:, 0] -= lo
+            b = ops.patch_bits(pred_local, torch.from_numpy(np.ascontiguousarray(loc)).to(dev),
+                               kw["fc_threshold"], params())
+            bits[torch.from_numpy(mine).to(dev)] = b
+        comm.all_reduce_sum(bits)
+        return bits.cpu().numpy().view(np.uint32)
+
+    with backend.host_timer("sort"):
+        lin = backend.host_rank_order(scores, foreground, ps)
+    coords = np.stack(np.unravel_index(lin, shape), axis=1).astype(np.int32)
+    rscores = np.ascontiguousarray(scores.reshape(-1)[lin])
+    if kw.get("selected_patches") is not None:
+        sel_coords = np.array(list(kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
+    elif kw.get("skipSelection", False):
+        sel_coords = coords
+    else:
+        with backend.host_timer("s3_cover"):
+            running = np.ascontiguousarray(mask_to_cover).astype(np.uint8)
+            ov_host = np.ascontiguousarray(overlap_mask > 0).astype(np.uint8)
+            selected = np.zeros(len(lin), dtype=np.uint8)
+            pix_ths = [0] if kw["select_patches_for_sparse_data"] else \
+                [t for t in [500, 100, 50, 10, 0] if t < int(np.prod(ps) / 2)]
+            thr = kw.get("score_threshold", False)
+            thr = thr if isinstance(thr, float) else None
+            remaining = int(np.count_nonzero(running[radslice]))
+            chunk = int(kw.get("_cover_chunk", 1 << 20))
+            for pix_th in pix_ths:
+                for s in range(0, len(lin), chunk):
+                    if remaining <= 0:
+                        break
+                    e = min(len(lin), s + chunk)
+                    bits = gathered_bits(coords[s:e], kw["fc_threshold"])
+                    remaining, stopped = backend.host_cover_pass(
+                        running, ov_host, ps, lin[s:e], rscores[s:e], bits, pix_th, thr,
+                        selected[s:e], remaining)
+                    if stopped:
+                        break
+                if remaining < 1:
+                    break
+            sel_coords = coords[selected.astype(bool)]
+    if not kw.get("skipThinCover") and len(sel_coords) > 0:
+        with backend.host_timer("s4_thin"):
+            bits = gathered_bits(sel_coords, kw["fc_threshold"])
+            sel_lin = (sel_coords[:, 0].astype(np.int64) * Y + sel_coords[:, 1]) * X + sel_coords[:, 2]
+            keep = backend.host_thin_cover(np.ascontiguousarray(mask_to_cover).astype(np.uint8),
+                                           ps, np.ascontiguousarray(sel_lin), bits)
+            sel_coords = sel_coords[keep]
+
+    # ---- pairs (global coordinates; replicated, it is cheap) -------------------------------
+    order = np.argsort(sel_coords[:, 2], kind="stable")
+    nodes = np.ascontiguousarray(sel_coords[order].astype(np.int32))
+    nodes_dev = torch.from_numpy(nodes).to(dev)
+    if kw.get("selected_patch_pairs") is not None:
+        rows_host = np.ascontiguousarray(
+            np.array(kw["selected_patch_pairs"], dtype=np.uint32).reshape(-1, 6))
+        rows = torch.from_numpy(rows_host.view(np.int32)).to(dev) if len(rows_host) else None
+    else:
+        with backend.host_timer("pairs"):
+            rows = ops.patch_pairs(nodes_dev, Pg,
+                                   kw.get("max_total_patch_distance_in_ps_multiples", 2),
+                                   kw["includeSinglePatchCCS"])
+    if rows is None:
+        return early()
+    n_rows = int(rows.shape[0])
+    backend.note("n_selected", len(nodes))
+    backend.note("n_pairs", n_rows)
+
+    # ---- stage C: pair affinities, each pair on the rank / slab that owns patch A ----------
+    aff = torch.zeros((n_rows,), dtype=torch.float32, device=dev)
+    shift = torch.tensor([lo, 0, 0, lo, 0, 0], dtype=torch.int32, device=dev)
+    with backend.host_timer("s5_patch_graph"):
+        for (z0, z1) in my_slabs:
+            idx = torch.nonzero((rows[:, 0] >= z0) & (rows[:, 0] < z1)).reshape(-1)
+            if idx.numel() == 0:
+                continue
+            if keep_cons:
+                cons, P = kept.pop((z0, z1))
+            else:
+                P = params(bases_for_pairs(z0, z1))
+                cons = ops.consensus(pred_local, ov_local, P)
+            rows_l = (rows[idx] - shift).contiguous()
+            aff[idx] = ops.patch_graph(pred_local, cons, rows_l, P)
+            del cons
+    kept.clear()
+    comm.all_reduce_sum(aff)
+    if want_inter:
+        return rows.cpu().numpy().view(np.uint32), aff.cpu().numpy()
+
+    # ---- stage D: components (replicated) and painting of the own slabs ---------------------
+    with backend.host_timer("s6_label_paint"):
+        if kw.get("mws"):
+            from .vote_instances.graph_mws import mws_from_pairs
+            ccs = mws_from_pairs(rows.cpu().numpy().view(np.uint32), aff.cpu().numpy())
+            lab_nodes = np.array([n for cc in ccs for n in cc], dtype=np.int32).reshape(-1, 3)
+            labels = np.array([k + 1 for k, cc in enumerate(ccs) for _ in cc], dtype=np.int64)
+        else:
+            keys = ops.label_components(rows, aff, nodes_dev, Pg).cpu().numpy()
+            valid = keys != backend.NONE_KEY
+            uniq = np.unique(keys[valid])
+            lab_nodes = nodes[valid]
+            labels = (np.searchsorted(uniq, keys[valid]) + 1).astype(np.int64)
+        if len(labels) and labels.max() > np.iinfo(np.uint16).max:
+            raise OverflowError("%d instances do not fit uint16" % labels.max())
+        inst_dev = torch.zeros(shape, dtype=torch.int32, device=dev)
+        Pl = params()
+        for (z0, z1) in my_slabs:
+            near = (lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)
+            if not near.any():
+                continue
+            loc = lab_nodes[near].copy()
+            loc[:, 0] -= lo
+            inst_l = torch.zeros(local_shape, dtype=torch.int32, device=dev)
+            ops.paint(pred_local, torch.from_numpy(np.ascontiguousarray(loc)).to(dev),
+                      torch.from_numpy(labels[near].astype(np.int32)).to(dev), inst_l, Pl)
+            inst_dev[z0:z1] = inst_l[z0 - lo:z1 - lo]
+            del inst_l
+        comm.all_reduce_sum(inst_dev)
+        instances = inst_dev.cpu().numpy().astype(np.uint16)
+    return instances, foreground.astype(np.uint8)
+
+
+def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,
+                          **kw):
+    """Single-process tiling: the whole prediction is resident, the consensus lives for one
+    z-slab at a time."""
+    pred = backend.to_device_pred(pred_affs)
+    shape = tuple(int(s) for s in pred.shape[1:])
+    slabs = plan_slabs(shape[0], n_slabs)
+    return assemble(pred, 0, shape, foreground, mask_to_cover, numinst, patchshape, slabs, **kw)
+
+
+def stitch_main(pred_file, result_folder=".", **kwargs):
+    """Entry point behind ``vote_instances.stitch_patch_graph.main`` (reference
+    stitch_patch_graph.py:672-894): bounding box of the cleaned foreground, assembly of the
+    boxed volume (tiled when ``chunksize`` asks for it), result file with ``vote_instances``,
+    ``vote_foreground`` and ``vote_instances_masked``."""
+    import os
+    from scipy import ndimage
+    from .vote_instances import utilVoteInstances as util
+    from .vote_instances.stitch_patch_graph import clean_mask
+    from .vote_instances.vote_instances import write_result
+    patchshape = np.array(kwargs["patchshape"])
+    kw = dict(kwargs)
+    kw.pop("patchshape")
+    loaded = util.loadAffinities(pred_file, "", patchshape=patchshape, **kw)
+    if loaded is None:
+        return
+    affinities, numinst, foreground = loaded
+    foreground = np.squeeze(foreground)
+    if foreground.ndim == 2:
+        foreground = foreground[None]
+    if numinst is None:
+        numinst = foreground.astype(np.uint8)
+    numinst = np.squeeze(numinst).reshape(foreground.shape)
+    shape = foreground.shape
+    # bounding box of the cleaned mask (stitch_patch_graph.py:745-767)
+    mask = foreground
+    if kw.get("ignore_small_comps", 0) > 0:
+        mask = clean_mask(foreground, ndimage.generate_binary_structure(3, 1),
+                          kw["ignore_small_comps"])
+    if kw.get("only_bb", False) and mask.any():
+        nz = np.nonzero(mask)
+        rad = patchshape // 2
+        bb = tuple(slice(max(0, int(nz[i].min()) - int(rad[i])),
+                         min(shape[i], int(nz[i].max()) + 1 + int(rad[i]))) for i in range(3))
+    else:
+        bb = tuple(slice(0, s) for s in shape)
+    sub = (slice(None),) + bb
+    n_slabs = 1
+    if kw.get("chunksize") is not None and kw.get("blockwise", False):
+        n_slabs = max(1, int(np.ceil((bb[0].stop - bb[0].start) / kw["chunksize"][0])))
+    kw["blockwise"] = False
+    fg_bb = np.ascontiguousarray(foreground[bb])
+    inst_bb, _ = to_instance_seg_tiled(
+        np.ascontiguousarray(affinities[sub]), fg_bb, fg_bb.copy(),
+        np.ascontiguousarray(numinst[bb]), patchshape, n_slabs, **kw)
+    instances = np.zeros(shape, dtype=np.uint16)
+    instances[bb] = inst_bb
+    masked = instances.copy()
+    masked[foreground == 0] = 0
+    os.makedirs(result_folder, exist_ok=True)
+    fn = os.path.splitext(os.path.basename(pred_file.rstrip("/")))[0]
+    res_key = kw.get("res_key", "vote_instances")
+    write_result(os.path.join(result_folder, fn + ".hdf"),
+                 {res_key: instances, "vote_foreground": foreground.astype(np.uint8),
+                  res_key + "_masked": masked})
+    return instances

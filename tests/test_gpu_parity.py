@@ -229,3 +229,18 @@ def test_synth_on_device_equals_numpy(torch_cuda):
     P = backend.make_params(shape, ps, patch_threshold=0.5)
     got = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=7, f16=True)
     assert np.array_equal(got.float().cpu().numpy(), want)
+
+
+def test_synth_slab_equals_global_slice(torch_cuda):
+    """A z-slab generated with voxel_offset carries the same values as the global volume."""
+    from patchperpix_amd import backend, synth
+    torch = torch_cuda
+    shape, ps = (12, 9, 10), (3, 3, 3)
+    lab = synth.cell_labels(shape, [4, 4, 4], seed=5)
+    want = synth.pred_from_labels(lab, ps, seed=3)
+    lo, hi = 4, 11
+    Pl = backend.make_params((hi - lo, 9, 10), ps, patch_threshold=0.5)
+    got = backend.synth_pred(_dev(torch, lab[lo:hi].astype(np.int32)), Pl, seed=3, f16=False,
+                             voxel_offset=lo * 9 * 10).cpu().numpy()
+    # interior slices only: at the slab's z-edges the neighbour labels are outside the slab
+    assert np.array_equal(got[:, 1:-1], want[:, lo + 1:hi - 1])

@@ -1,0 +1,108 @@
+"""The z-slab decomposition (patchperpix_amd.tiling) reproduces the whole-volume result.
+
+CPU: the slab / halo / ownership / collective logic is run with the oracle standing in for the
+HIP kernels (tests/oracle_ops.py) -- in one process with several slabs, and in TWO processes
+over torch.distributed (gloo) -- and compared with the oracle's whole-volume result.
+GPU (-m gpu): the same comparison with the real kernels, slabs processed sequentially."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from patchperpix_amd import synth, tiling
+from patchperpix_amd.flags import FLYLIGHT
+
+
+def make_case(seed=61, shape=(44, 12, 13), ps=(3, 3, 3)):
+    c = synth.make_case(shape, ps, seed=seed, cell=[5, 5, 5], overlap_frac=0.02)
+    return c, list(ps), dict(FLYLIGHT)
+
+
+def whole_volume(c, ps, kw):
+    from oracle import ppp_oracle as orc
+    return orc.to_instance_seg(c["pred"], c["foreground"], c["foreground"].copy(), c["numinst"],
+                               ps, **kw)
+
+
+def test_plan_and_halo():
+    slabs = tiling.plan_slabs(44, 4)
+    assert slabs[0][0] == 0 and slabs[-1][1] == 44
+    assert all(a[1] == b[0] for a, b in zip(slabs, slabs[1:]))
+    assert tiling.slabs_of_rank(slabs, 0, 2) + tiling.slabs_of_rank(slabs, 1, 2) == slabs
+    assert tiling.halo((7, 7, 7)) == 17
+    assert tiling.local_range(slabs[1:2], 44, (3, 3, 3)) == (max(0, slabs[1][0] - 7), min(44, slabs[1][1] + 7))
+
+
+@pytest.mark.parametrize("n_slabs,thin", [(1, False), (3, False), (4, True)])
+def test_sequential_slabs_equal_whole_volume_cpu(n_slabs, thin):
+    import torch
+    from oracle_ops import OracleOps
+    c, ps, kw = make_case()
+    kw["skipThinCover"] = not thin
+    ref = whole_volume(c, ps, kw)
+    ops = OracleOps(**kw)
+    slabs = tiling.plan_slabs(c["pred"].shape[1], n_slabs)
+    inst, fg = tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                               c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                               slabs, ops=ops, _cover_chunk=500, **kw)
+    assert np.array_equal(inst, ref["instances"])
+    pairs, aff = tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                                 c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                                 slabs, ops=ops, return_intermediates=True, **kw)
+    assert np.array_equal(pairs, ref["pairs"])
+    assert np.array_equal(aff.view(np.uint32), ref["aff"].view(np.uint32))
+
+
+WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+from patchperpix_amd import tiling
+from test_tiling import make_case
+from oracle_ops import OracleOps
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+c, ps, kw = make_case()
+Z = c["pred"].shape[1]
+slabs = tiling.plan_slabs(Z, 4)
+mine = tiling.slabs_of_rank(slabs, rank, world)
+lo, hi = tiling.local_range(mine, Z, ps)
+pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi]))   # halo'd slab only
+inst, fg = tiling.assemble(pred_local, lo, c["foreground"].shape, c["foreground"].copy(),
+                           c["foreground"].copy(), c["numinst"], ps, mine,
+                           comm=tiling.TorchDistComm(), ops=OracleOps(**kw), _cover_chunk=700, **kw)
+np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_gloo_equal_whole_volume(tmp_path):
+    c, ps, kw = make_case()
+    ref = whole_volume(c, ps, kw)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(repo=REPO, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                           "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29591", str(script)], env=env, timeout=900)
+    for r in range(2):
+        inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
+        assert np.array_equal(inst, ref["instances"]), "rank %d differs" % r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_slabs", [1, 3])
+def test_sequential_slabs_equal_whole_volume_gpu(n_slabs):
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    c = synth.make_case((48, 20, 22), (5, 5, 5), seed=62, cell=[8, 8, 8], overlap_frac=0.02)
+    ps, kw = [5, 5, 5], dict(FLYLIGHT)
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), ps, **kw)
+    got, _ = tiling.to_instance_seg_tiled(c["pred"].copy(), c["foreground"].copy(),
+                                          c["foreground"].copy(), c["numinst"].copy(), ps,
+                                          n_slabs, **kw)
+    assert np.array_equal(got, want)
+    assert got.any()
