@@ -113,11 +113,16 @@ def main():
         slabs = tiling.plan_slabs(gshape[0], world)
         mine = tiling.slabs_of_rank(slabs, rank, world)
         lo, hi = tiling.local_range(mine, gshape[0], ps)
-        lshape = (hi - lo, shape[1], shape[2])
-        Pl = backend.make_params(lshape, ps, **kw)
-        labels_l = device_labels(torch, lshape, cell, seed=0, z_offset=lo)
-        pred = backend.synth_pred(labels_l, Pl, seed=0, f16=True,
-                                  voxel_offset=lo * shape[1] * shape[2])
+        # generate rz extra slices on both sides so that every channel of the kept range sees
+        # its true neighbours, then keep [lo, hi)
+        glo, ghi = max(0, lo - ps[0] // 2), min(gshape[0], hi + ps[0] // 2)
+        eshape = (ghi - glo, shape[1], shape[2])
+        Pe = backend.make_params(eshape, ps, **kw)
+        labels_e = device_labels(torch, eshape, cell, seed=0, z_offset=glo)
+        pred = backend.synth_pred(labels_e, Pe, seed=0, f16=True,
+                                  voxel_offset=glo * shape[1] * shape[2])
+        pred = pred[:, lo - glo:hi - glo].contiguous()
+        del labels_e
         fg_host = (device_labels(torch, gshape, cell, seed=0) != 0).cpu().numpy()
         numinst = fg_host.astype(np.uint8)
         comm = tiling.TorchDistComm()

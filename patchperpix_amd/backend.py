@@ -485,6 +485,32 @@ def host_rank_order(score, foreground, patchshape):
     return out[:n].copy()
 
 
+def padded_mask(mask):
+    """uint8 0/1 copy of a (Z,Y,X) mask whose buffer has 8 spare bytes at the end, as the native
+    cover functions require; returns (volume view, owner)."""
+    flat = np.zeros(mask.size + 8, dtype=np.uint8)
+    flat[:mask.size] = (np.asarray(mask).reshape(-1) != 0)
+    return flat[:mask.size].reshape(mask.shape), flat
+
+
+def rank_order_device(score, foreground, patchshape):
+    """all_patches + rank_patches_by_score on the device: interior foreground voxels in raster
+    order, stably sorted by score descending (vote_instances.py:276,286-287,
+    ranked_patches.py:21-30).  score: device float32 (Z,Y,X); foreground: host bool.
+    Returns (lin int64 host, scores float32 host)."""
+    torch = _torch()
+    ps = [int(p) for p in patchshape]
+    Z, Y, X = score.shape
+    m = np.zeros((Z, Y, X), dtype=bool)
+    r = [p // 2 for p in ps]
+    m[r[0]:Z - r[0], r[1]:Y - r[1], r[2]:X - r[2]] = True
+    m &= np.asarray(foreground) != 0
+    idx = torch.nonzero(torch.from_numpy(m).to(score.device).reshape(-1)).reshape(-1)  # raster
+    s = score.reshape(-1)[idx]
+    s_sorted, order = torch.sort(s, descending=True, stable=True)
+    return idx[order].cpu().numpy(), s_sorted.cpu().numpy()
+
+
 def host_cover_pass(mask_running, overlap, patchshape, ranked_lin, ranked_score, bits, pix_th,
                     score_threshold, selected, remaining):
     """In place on mask_running (uint8) and selected (uint8); returns (new `remaining`,

@@ -31,24 +31,44 @@ struct Dims {
 
 inline bool bit(const uint32_t *b, int r) { return (b[r >> 5] >> (r & 31)) & 1u; }
 
-// number of window voxels that are set in `mask` and in the patch bits; optionally clears
-// them (returns how many of the cleared voxels were interior through *cleared_interior)
+// bits [r, r + n) of a packed bit table (n <= 32)
+inline uint32_t bit_field(const uint32_t *b, int r, int n) {
+    const int w = r >> 5, sh = r & 31;
+    uint64_t v = b[w];
+    if (sh + n > 32) v |= (uint64_t)b[w + 1] << 32;
+    return (uint32_t)(v >> sh) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
+}
+
+// 8 mask bytes (each 0 or 1) -> 8 bits, byte k -> bit k
+inline uint32_t pack8(const uint8_t *p) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    return (uint32_t)((w * 0x0102040810204080ull) >> 56);
+}
+
+// number of window voxels that are set in `mask` (bytes 0/1) and in the patch bits; optionally
+// clears them (returns how many of the cleared voxels were interior through *cleared_interior).
+// Rows are tested 8 voxels at a time: pack the mask bytes to bits, AND with the patch bits of
+// that row, popcount.  `mask` must have 8 readable bytes past the last voxel (callers pad).
 template <bool CLEAR>
 inline int window_hits(const Dims &D, uint8_t *mask, const uint32_t *bits, int cz, int cy,
                        int cx, int64_t *cleared_interior) {
     int hits = 0, r = 0;
     for (int dz = 0; dz < D.pz; ++dz)
-        for (int dy = 0; dy < D.py; ++dy) {
+        for (int dy = 0; dy < D.py; ++dy, r += D.px) {
             const int z = cz + dz - D.rz, y = cy + dy - D.ry;
             uint8_t *row = mask + D.lin(z, y, cx - D.rx);
-            for (int dx = 0; dx < D.px; ++dx, ++r) {
-                if (row[dx] && bit(bits, r)) {
-                    ++hits;
-                    if (CLEAR) {
-                        row[dx] = 0;
-                        if (D.interior(z, y, cx + dx - D.rx)) ++*cleared_interior;
+            for (int x0 = 0; x0 < D.px; x0 += 8) {
+                const int n = D.px - x0 < 8 ? D.px - x0 : 8;
+                uint32_t m = pack8(row + x0) & bit_field(bits, r + x0, n);
+                hits += __builtin_popcount(m);
+                if (CLEAR)
+                    while (m) {
+                        const int k = __builtin_ctz(m);
+                        m &= m - 1;
+                        row[x0 + k] = 0;
+                        if (D.interior(z, y, cx + x0 + k - D.rx)) ++*cleared_interior;
                     }
-                }
             }
         }
     return hits;
@@ -76,7 +96,8 @@ int64_t ppp_host_rank_order(const float *h_score, const uint8_t *h_foreground, c
 }
 
 // One pass of computeForegroundCoverLoop over the ranked list (foreground_cover.py:111-180).
-//   h_mask_running : uint8 (Z,Y,X), updated in place
+//   h_mask_running : uint8 (Z,Y,X) with values 0/1, updated in place; the buffer must have 8
+//                    readable bytes after the last voxel (rows are tested 8 voxels at a time)
 //   h_overlap      : uint8 (Z,Y,X) or NULL
 //   ranked_lin     : linear voxel index of every ranked patch centre (all interior)
 //   bits           : [n][words] patch bits (pred[:,c] > fc_threshold), see ppp_patch_bits
@@ -92,6 +113,25 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
     const Dims D(vol, patchshape);
     int64_t picked = 0;
     if (stopped) *stopped = 0;
+    // Coarse occupancy grid (8^3 blocks) of the running mask: once most of the foreground is
+    // covered, almost every remaining candidate has an empty window and is rejected by looking
+    // at <= 8 block counters instead of its p^3 window.
+    constexpr int B = 8;
+    const int GZ = (D.Z + B - 1) / B, GY = (D.Y + B - 1) / B, GX = (D.X + B - 1) / B;
+    std::vector<int32_t> occ((size_t)GZ * GY * GX, 0);
+    for (int z = 0; z < D.Z; ++z)
+        for (int y = 0; y < D.Y; ++y) {
+            const uint8_t *row = h_mask_running + D.lin(z, y, 0);
+            int32_t *orow = occ.data() + ((size_t)(z / B) * GY + y / B) * GX;
+            for (int x = 0; x < D.X; ++x) orow[x / B] += row[x] != 0;
+        }
+    auto window_empty = [&](int cz, int cy, int cx) {
+        for (int gz = (cz - D.rz) / B; gz <= (cz + D.rz) / B; ++gz)
+            for (int gy = (cy - D.ry) / B; gy <= (cy + D.ry) / B; ++gy)
+                for (int gx = (cx - D.rx) / B; gx <= (cx + D.rx) / B; ++gx)
+                    if (occ[((size_t)gz * GY + gy) * GX + gx]) return false;
+        return true;
+    };
     for (int64_t i = 0; i < n && *remaining > 0; ++i) {
         if (selected[i]) continue;
         if (!std::isnan(score_threshold) && (double)ranked_score[i] < score_threshold) {
@@ -101,12 +141,25 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
         const int64_t c = ranked_lin[i];
         if (h_overlap && h_overlap[c] > 0) continue;
         const int cx = (int)(c % D.X), cy = (int)((c / D.X) % D.Y), cz = (int)(c / ((int64_t)D.X * D.Y));
+        if (pix_th >= 0 && window_empty(cz, cy, cx)) continue;   // count 0 is never > pix_th
         const uint32_t *b = bits + i * D.words;
         if (window_hits<false>(D, h_mask_running, b, cz, cy, cx, nullptr) > pix_th) {
             selected[i] = 1;
             ++picked;
+            // clear, keeping the occupancy grid in step
             int64_t cleared = 0;
-            window_hits<true>(D, h_mask_running, b, cz, cy, cx, &cleared);
+            int r = 0;
+            for (int dz = 0; dz < D.pz; ++dz)
+                for (int dy = 0; dy < D.py; ++dy)
+                    for (int dx = 0; dx < D.px; ++dx, ++r) {
+                        const int z = cz + dz - D.rz, y = cy + dy - D.ry, x = cx + dx - D.rx;
+                        uint8_t &m = h_mask_running[D.lin(z, y, x)];
+                        if (m && bit(b, r)) {
+                            m = 0;
+                            --occ[((size_t)(z / B) * GY + y / B) * GX + x / B];
+                            if (D.interior(z, y, x)) ++cleared;
+                        }
+                    }
             *remaining -= cleared;
         }
     }
@@ -121,7 +174,8 @@ int64_t ppp_host_thin_cover(const uint8_t *h_mask, const int32_t *vol, const int
                             uint8_t *keep) {
     const Dims D(vol, patchshape);
     const int64_t V = (int64_t)D.Z * D.Y * D.X;
-    std::vector<uint8_t> running(h_mask, h_mask + V);
+    std::vector<uint8_t> running(V + 8, 0);   // + 8 readable bytes for the 8-at-a-time row test
+    memcpy(running.data(), h_mask, (size_t)V);
     memset(keep, 0, (size_t)n);
     if (n == 0) return 0;
     int64_t remaining = 0;

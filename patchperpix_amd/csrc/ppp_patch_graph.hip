@@ -329,77 +329,93 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
                     const int y_lo = max(0, y1o - dy - G.py), y_hi = min(G.py - 1, y1o - dy + G.py);
                     const int x_lo = max(0, x1o - dx - PX), x_hi = min(PX - 1, x1o - dx + PX);
                     if (x_lo > x_hi) continue;
+                    const int n_x = x_hi - x_lo + 1;          // candidates on a row (<= PX)
+                    const int qx0 = dx + x_lo - x1o;          // offset of candidate t = 0
+                    // bit t set <=> lo <= qx0 + t <= hi  (t in [0, n_x))
+                    auto tmask = [&](int lo_q, int hi_q) -> uint32_t {
+                        const int a = max(lo_q - qx0, 0), b = min(hi_q - qx0, n_x - 1);
+                        return a > b ? 0u : (((2u << b) - 1u) & ~((1u << a) - 1u));
+                    };
+                    // x parts (the same for every row of this r1)
+                    const uint32_t mx_fwd = tmask(-(PX - 1), PX), mx_back = tmask(-PX, PX - 1);
+                    const uint32_t mx_nonneg = tmask(0, 2 * PX), mx_stored = tmask(-(PX - 1), PX - 1);
+                    // |dx + x2o - RX| <= RX with x2o = x_lo + t
+                    uint32_t mx_inter = 0;
+                    if (in_b) {
+                        const int a = max(-dx - x_lo, 0), b = min(2 * RX - dx - x_lo, n_x - 1);
+                        mx_inter = a > b ? 0u : (((2u << b) - 1u) & ~((1u << a) - 1u));
+                    }
                     for (int z2o = z_lo; z2o <= z_hi; ++z2o) {
                         const int qz = dz + z2o - z1o;
-                        const bool iz = in_b && abs(dz + z2o - G.rz) <= G.rz;
+                        const bool iz = abs(dz + z2o - G.rz) <= G.rz;
                         for (int y2o = y_lo; y2o <= y_hi; ++y2o) {
                             const int qy = dy + y2o - y1o;
                             const bool izy = iz && abs(dy + y2o - G.ry) <= G.ry;
                             const int r2row = (z2o * G.py + y2o) * PX;
-                            // stored offsets on this row: |qz|, |qy| < p, and qx clipped to
-                            // [-(PX-1), PX-1]; fetch [qx_first, qx_first + 8) in two loads
+                            // orientation of the pixel pair: z1 before z2 (raster) <=> q >= 0
+                            const int sgn = qz != 0 ? qz : qy;      // sign of (qz, qy)
+                            const bool zy_f = qz >= -(G.pz - 1) && qz <= G.pz && qy >= -(G.py - 1) && qy <= G.py;
+                            const bool zy_b = qz >= -G.pz && qz <= G.pz - 1 && qy >= -G.py && qy <= G.py - 1;
                             const bool row_stored = abs(qz) < G.pz && abs(qy) < G.py;
-                            const int qx_first = max(dx + x_lo - x1o, -(PX - 1));
+                            // per-candidate masks of this row (all scalar)
+                            const uint32_t m_fwd = sgn > 0 ? ~0u : (sgn < 0 ? 0u : mx_nonneg);
+                            const uint32_t m_range = (zy_f ? (mx_fwd & m_fwd) : 0u) | (zy_b ? (mx_back & ~m_fwd) : 0u);
+                            const uint32_t m_inter = izy ? mx_inter : 0u;
+                            uint32_t m_stored = row_stored ? (mx_stored & m_range) : 0u;
+                            if (sgn == 0 && qx0 <= 0 && -qx0 < n_x) m_stored &= ~(1u << (-qx0));   // q == 0
+                            if ((m_range | m_inter) == 0u) continue;
+                            // foreground bits of patch B for the candidates of this row
+                            const int b0 = r2row + x_lo, w0 = b0 >> 5, sh = b0 & 31;
+                            uint64_t f64 = lds_b[w0 * 64 + lane];
+                            if (sh + n_x > 32) f64 |= (uint64_t)lds_b[(w0 + 1) * 64 + lane] << 32;
+                            const uint32_t fb = bit_a ? (uint32_t)(f64 >> sh) : 0u;
+                            // consensus values: window [qx0, qx0 + 8) of this lane's row
                             float v[8];
-                            {
-                                long long i0 = rowi + (long long)(qz * G.wy + qy) * G.wx + qx_first;
-                                // keep both 16-byte loads inside the buffer (values outside the
-                                // row are never used)
-                                const bool two = PX > 4 && x_hi - x_lo >= 4;   // run longer than 4 pixels (uniform)
+                            if (m_stored != 0u) {
+                                const bool two = PX > 4 && n_x > 4;
+                                long long i0 = rowi + (long long)(qz * G.wy + qy) * G.wx + qx0;
+                                const long long want = i0;
                                 i0 = max(0ll, min(i0, n_elems - (two ? 8 : 4)));
                                 f4u lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
-                                if (row_stored && bit_a) {
+                                if (fb != 0u) {
                                     lo4 = *reinterpret_cast<const f4u *>(S + i0);
                                     if (two) hi4 = *reinterpret_cast<const f4u *>(S + i0 + 4);
                                 }
                                 v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
                                 v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-                                // if the clamp moved the window, re-centre the register window
-                                const int shift = (int)(rowi + (long long)(qz * G.wy + qy) * G.wx + qx_first - i0);
-                                if (__builtin_expect(__ballot(shift != 0 && bit_a) != 0ull, 0)) {
-                                    float t[8];
+                                // the clamp only moves the window at the two ends of the buffer
+                                const int shift = (int)(want - i0);
+                                if (__builtin_expect(__ballot(shift != 0 && fb != 0u) != 0ull, 0)) {
+                                    float tt[8];
 #pragma unroll
                                     for (int k = 0; k < 8; ++k) {
                                         float val = 0.f;
 #pragma unroll
                                         for (int m = 0; m < 8; ++m) val = (m == k + shift) ? v[m] : val;
-                                        t[k] = val;
+                                        tt[k] = val;
                                     }
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) v[k] = shift != 0 ? t[k] : v[k];
+                                    for (int k = 0; k < 8; ++k) v[k] = shift != 0 ? tt[k] : v[k];
                                 }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) v[k] = 0.0f;
                             }
 #pragma unroll
                             for (int t = 0; t < PX; ++t) {
-                                const int x2o = x_lo + t;
-                                if (x2o > x_hi) break;
-                                const int r2 = r2row + x2o;
-                                const int qx = dx + x2o - x1o;
-                                const bool fwd = qz > 0 || (qz == 0 && (qy > 0 || (qy == 0 && qx >= 0)));
-                                const int lo_z = fwd ? -(G.pz - 1) : -G.pz, hi_z = fwd ? G.pz : G.pz - 1;
-                                const int lo_y = fwd ? -(G.py - 1) : -G.py, hi_y = fwd ? G.py : G.py - 1;
-                                const int lo_x = fwd ? -(PX - 1) : -PX, hi_x = fwd ? PX : PX - 1;
-                                const bool in_range = qz >= lo_z && qz <= hi_z && qy >= lo_y &&
-                                                      qy <= hi_y && qx >= lo_x && qx <= hi_x;
-                                const bool inter = izy && abs(dx + x2o - RX) <= RX;
+                                if (t >= n_x) break;
+                                const bool inter = (m_inter >> t) & 1u, in_range = (m_range >> t) & 1u;
                                 if (!inter && !in_range) continue;
-                                bool valid = bit_a && ((lds_b[(r2 >> 5) * 64 + lane] >> (r2 & 31)) & 1u);
+                                bool valid = (fb >> t) & 1u;
                                 if (inter) {
                                     const uint32_t nxt = rnd * 1103515245U;
                                     const float rnd_t = (float)nxt / 4294967296.0f;
                                     rnd = valid ? nxt : rnd;
-                                    valid = valid && !((double)rnd_t > 0.2);
+                                    // rnd_t > 0.2 (double)  <=>  rnd_t > largest float <= 0.2
+                                    valid = valid && !(rnd_t > 0.19999998807907104f);
                                 }
                                 if (!in_range) continue;
-                                const bool stored = row_stored && abs(qx) < PX && (qz | qy | qx) != 0;
-                                if (stored) {
-                                    // register slot of offset qx inside the fetched window
-                                    const int k = qx - qx_first;
-                                    float val = 0.0f;
-#pragma unroll
-                                    for (int m = 0; m < 8; ++m) val = (m == k) ? v[m] : val;
-                                    acc += valid ? val : 0.0f;
-                                }
+                                if ((m_stored >> t) & 1u) acc += valid ? v[t] : 0.0f;
                                 fg_cnt += valid ? 1u : 0u;
                             }
                         }

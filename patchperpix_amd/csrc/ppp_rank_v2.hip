@@ -112,22 +112,32 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                         uint32_t need = pa ? (pf | nf) : 0u;
                         if (row_cmp == 0) need &= ~(1u << ax);             // b == a never votes
                         if (__ballot(need != 0) == 0) continue;
-                        const long long off_b0 = (long long)(bz - G.rz) * sZc + (long long)(by - G.ry) * sYc - PX / 2;
+                        // Addresses.  forward (b > a): key (b - a, z_a) -> plane rises by one per j;
+                        // backward (b < a): key (a - b, z_b) -> plane falls by one, base moves by +1.
+                        // Two scalar base pointers per group, one scalar 64-bit add per element
+                        // (this loop is bound by the scalar ALU, not by the vector one).
+                        const int dz = bz - az, dy = by - ay;
+                        long long plane_f, plane_b;   // planes of j = 0
+                        if (G.layout == PPP_CONS_REFERENCE) {
+                            plane_f = ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (-ax + PX - 1);
+                            plane_b = ((long long)(-dz + G.pz - 1) * G.nsy + (-dy + G.py - 1)) * G.nsx + (ax + PX - 1);
+                        } else {
+                            plane_f = ((long long)dz * G.wy + dy) * G.wx - ax - 1;
+                            plane_b = ((long long)(-dz) * G.wy - dy) * G.wx + ax - 1;
+                        }
+                        const float *pf_ptr = cons + plane_f * plane_stride + off_a;
+                        const float *pb_ptr = cons + plane_b * plane_stride +
+                                              ((long long)(bz - G.rz) * sZc + (long long)(by - G.ry) * sYc - PX / 2);
                         float v[PX];
 #pragma unroll
                         for (int j = 0; j < PX; ++j) {
-                            const int b = b0 + j;
-                            // forward (b > a): key (b - a, z_a); backward (b < a): key (a - b, z_b)
-                            int dz = bz - az, dy = by - ay, dx = j - ax;
-                            long long off = off_a;
-                            if (b < a) { dz = -dz; dy = -dy; dx = -dx; off = off_b0 + j; }
-                            long long plane;
-                            if (G.layout == PPP_CONS_REFERENCE)
-                                plane = ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (dx + PX - 1);
-                            else
-                                plane = ((long long)dz * G.wy + dy) * G.wx + dx - 1;
-                            if (b == a) plane = 0, off = 0;   // unused slot, keep the address valid
-                            v[j] = fg ? cons[plane * plane_stride + off + laneC] : 0.0f;
+                            // same row: j < ax backward, j > ax forward, j == ax unused
+                            const bool back = row_cmp < 0 || (row_cmp == 0 && j < ax);
+                            const bool skip = row_cmp == 0 && j == ax;
+                            const float *src = back ? pb_ptr : pf_ptr;
+                            v[j] = (fg && !skip) ? src[laneC] : 0.0f;
+                            pf_ptr += plane_stride;
+                            pb_ptr += 1 - plane_stride;
                         }
 #pragma unroll
                         for (int j = 0; j < PX; ++j) {

@@ -113,6 +113,9 @@ class DeviceOps:
         vm, Pv = backend.cons_to_voxel_major(cons, P)
         return backend.patch_graph(pred, vm, rows, Pv, order=order)
 
+    def rank_order(self, score_dev, score_host, foreground, ps):
+        return backend.rank_order_device(score_dev, foreground, ps)
+
     def label_components(self, rows, aff, nodes, P):
         return backend.label_components(rows, aff, nodes, P)
 
@@ -188,7 +191,6 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         del cons, sc
     comm.all_reduce_sum(score_dev)
     scores = score_dev.cpu().numpy()
-    del score_dev
 
     # ---- stage B: ranking, greedy cover, thinning (global; identical on every rank) -------
     def owned(z):
@@ -213,16 +215,16 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         return bits.cpu().numpy().view(np.uint32)
 
     with backend.host_timer("sort"):
-        lin = backend.host_rank_order(scores, foreground, ps)
+        lin, rscores = ops.rank_order(score_dev, scores, foreground, ps)
+    del score_dev
     coords = np.stack(np.unravel_index(lin, shape), axis=1).astype(np.int32)
-    rscores = np.ascontiguousarray(scores.reshape(-1)[lin])
     if kw.get("selected_patches") is not None:
         sel_coords = np.array(list(kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
     elif kw.get("skipSelection", False):
         sel_coords = coords
     else:
         with backend.host_timer("s3_cover"):
-            running = np.ascontiguousarray(mask_to_cover).astype(np.uint8)
+            running, _owner = backend.padded_mask(mask_to_cover)
             ov_host = np.ascontiguousarray(overlap_mask > 0).astype(np.uint8)
             selected = np.zeros(len(lin), dtype=np.uint8)
             pix_ths = [0] if kw["select_patches_for_sparse_data"] else \

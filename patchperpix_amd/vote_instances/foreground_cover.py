@@ -33,7 +33,7 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
             raise NotImplementedError("%s is not supported" % opt)
     ranked = PatchList.from_any(ranked_patches_list)
     P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
-    running = np.ascontiguousarray(mask_to_cover).astype(np.uint8)
+    running, _owner = backend.padded_mask(mask_to_cover)
     overlap = np.ascontiguousarray(np.asarray(overlap_mask) > 0).astype(np.uint8)
     selected = np.zeros(len(ranked), dtype=np.uint8)
     if kwargs["select_patches_for_sparse_data"]:

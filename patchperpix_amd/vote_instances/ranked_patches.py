@@ -81,8 +81,14 @@ def loadOrComputePatchRanking(pred_affs=None, consensus_vote_array=None, offsets
     scores = rank_patches_cuda(pred_affs, consensus_vote_array, patchshape, neighshape,
                                overlap_mask, **kwargs)
     scores_array = scores.cpu().numpy()
-    ranked = rank_patches_by_score(all_patches, scores_array,
-                                   foreground=kwargs.get("_foreground"), patchshape=patchshape)
+    if all_patches is None and kwargs.get("_foreground") is not None:
+        # stable descending sort on the device (same order as Python's sorted(..., reverse=True))
+        lin, s = backend.rank_order_device(scores, kwargs["_foreground"], patchshape)
+        ranked = PatchList(np.stack(np.unravel_index(lin, scores_array.shape), axis=1), s)
+    else:
+        ranked = rank_patches_by_score(all_patches, scores_array,
+                                       foreground=kwargs.get("_foreground"),
+                                       patchshape=patchshape)
     if len(ranked):
         logger.info("best/worst score: %s %s", ranked.scores[0], ranked.scores[-1])
     return ranked, scores_array

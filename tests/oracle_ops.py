@@ -73,6 +73,10 @@ class OracleOps:
                               rows.numpy().view(np.uint32), self._ps(P), **kw)
         return torch.from_numpy(aff)
 
+    def rank_order(self, score_dev, score_host, foreground, ps):
+        lin = backend.host_rank_order(score_host, foreground, ps)
+        return lin, np.ascontiguousarray(score_host.reshape(-1)[lin])
+
     def label_components(self, rows, aff, nodes, P):
         ccs = orc.connected_components(rows.numpy().view(np.uint32), aff.numpy())
         key = {}

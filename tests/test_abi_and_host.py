@@ -89,7 +89,7 @@ def test_host_stages_match_reference(golden):
     # cover
     mask = g.foreground.copy()
     mask[g.overlap_mask > 0] = 0
-    running = mask.astype(np.uint8)
+    running, _owner = backend.padded_mask(mask)
     radslice = tuple(slice(rad[i], shape[i] - rad[i]) for i in range(3))
     remaining = int(np.count_nonzero(running[radslice]))
     bits = _bits(g.pred, coords, g.kw["fc_threshold"])
