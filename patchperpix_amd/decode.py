@@ -1,0 +1,148 @@
+"""ppp+dec: decode a per-voxel code into the patch prediction before voting
+(reference: experiments/flylight/setups/setup01/decode.py:16-130 and the decoder half of
+``Autoencoder``, setup01/torch_model.py:452-544).
+
+The decoder is the only dense-contraction piece next to the hot path; it runs as plain
+torch-ROCm convolutions (MIOpen / rocBLAS), everything around it -- gathering the codes at the
+foreground voxels, scattering the decoded patches into the (C, Z, Y, X) prediction block -- is
+done on the device in whole batches instead of the reference's per-voxel Python loop
+(decode.py:43-65), and the result can be handed to ``to_instance_seg`` without leaving HBM.
+
+PARITY UNPINNED for the decoder arithmetic: the reference builds it from
+``funlib.learn.torch`` (``ConvPass``, ``Upsample``; git dependency, branch ``ppp``, not vendored
+and not importable here) and ships no checkpoint.  ``PatchDecoder`` restates the published
+structure of those blocks (conv stack with "same" padding and an activation after every conv;
+``resize_conv`` = nearest-neighbour upsampling followed by one conv pass); the gather / scatter
+semantics are tested against a literal restatement of the reference loop.
+"""
+import logging
+import os
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _conv_pass(nd, c_in, c_out, kernel_sizes, activation):
+    torch = _torch()
+    conv = {2: torch.nn.Conv2d, 3: torch.nn.Conv3d}[nd]
+    layers = []
+    for ks in kernel_sizes:
+        layers.append(conv(c_in, c_out, ks, padding=tuple(k // 2 for k in ks)))
+        if activation is not None:
+            layers.append(getattr(torch.nn, activation)())
+        c_in = c_out
+    return torch.nn.Sequential(*layers)
+
+
+class PatchDecoder(_torch().nn.Module):
+    """Decoder half of the reference's Autoencoder (torch_model.py:497-544): reshape the code to
+    (code_fmaps, s, .., s), 1x1 conv ``from_code``, then per stage [upsample -> conv pass]; the
+    last conv pass has no activation (logits); centre crop to the patch shape."""
+
+    def __init__(self, config):
+        super().__init__()
+        torch = _torch()
+        act = {"relu": "ReLU", "sigmoid": "Sigmoid"}.get(config["activation"], config["activation"])
+        self.patchshape = tuple(int(p) for p in config["input_shape_squeezed"])
+        nd = self.nd = len(self.patchshape)
+        ks = [[int(config["kernel_size"])] * nd] * int(config["num_repetitions"])
+        self.code_fmaps = int(config["code_fmaps"])
+        self.code_units = int(config["code_units"])
+        s = round((self.code_units / self.code_fmaps) ** (1.0 / nd))
+        assert s ** nd * self.code_fmaps == self.code_units, \
+            "size of spatially reshaped code has to add up to code units"
+        self.code_shape = (-1, self.code_fmaps) + (s,) * nd
+        nf_prev = int(config["num_fmaps"][-1])
+        self.from_code = _conv_pass(nd, self.code_fmaps, nf_prev, [[1] * nd], act)
+        ups, convs = [], []
+        stages = list(reversed(config["num_fmaps"]))[1:] + [1]
+        for idx, nf in enumerate(stages):
+            factor = tuple(int(f) for f in config["downsample_factors"][-idx])
+            if config.get("upsampling", "resize_conv") != "resize_conv":
+                raise NotImplementedError("only resize_conv upsampling is restated")
+            ups.append(torch.nn.Sequential(
+                torch.nn.Upsample(scale_factor=factor, mode="nearest"),
+                _conv_pass(nd, nf_prev, nf, [[int(config["kernel_size"])] * nd], act)))
+            convs.append(_conv_pass(nd, nf, nf, ks, None if nf == 1 else act))
+            nf_prev = nf
+        self.up = torch.nn.ModuleList(ups)
+        self.up_conv = torch.nn.ModuleList(convs)
+
+    def forward(self, code):
+        torch = _torch()
+        out = torch.reshape(code, self.code_shape)
+        out = self.from_code(out)
+        for up, conv in zip(self.up, self.up_conv):
+            out = conv(up(out))
+        # centre crop (PatchPerPix/util: crop) to the patch shape
+        sl = [slice(None), slice(None)]
+        for have, want in zip(out.shape[2:], self.patchshape):
+            o = (have - want) // 2
+            sl.append(slice(o, o + want))
+        return out[tuple(sl)]
+
+
+def foreground_from_numinst(pred_numinstfg, fg_thresh):
+    """decode.py:33-37: numinst probabilities [0, 1, 2] -> fg where P(0) < 0.1, else threshold."""
+    if pred_numinstfg.shape[0] > 1:
+        return np.array(pred_numinstfg[0] < 0.1).astype(np.uint8)
+    return np.squeeze((pred_numinstfg >= fg_thresh).astype(np.uint8))
+
+
+def decode_volume(decoder, pred_code, pred_fg, batch_size=1024, device="cuda", out_dtype=None):
+    """decode_sample (decode.py:16-66) on the device: returns the (C, *spatial) prediction
+    tensor (float32 unless out_dtype), zero outside the foreground."""
+    torch = _torch()
+    out_dtype = out_dtype or torch.float32
+    code = torch.as_tensor(np.asarray(pred_code), device=device).float()
+    fg = torch.as_tensor(np.asarray(pred_fg) != 0, device=device)
+    units = code.shape[0]
+    C = int(np.prod(decoder.patchshape))
+    flat_code = code.reshape(units, -1)
+    idx = torch.nonzero(fg.reshape(-1)).reshape(-1)
+    out = torch.zeros((C, flat_code.shape[1]), dtype=out_dtype, device=device)
+    decoder = decoder.to(device).eval()
+    with torch.no_grad():
+        for s in range(0, int(idx.numel()), int(batch_size)):
+            sel = idx[s:s + batch_size]
+            patches = decoder(flat_code[:, sel].t().contiguous())       # (B, 1, *patch)
+            out[:, sel] = patches.reshape(len(sel), C).t().to(out_dtype)
+    return out.reshape((C,) + tuple(fg.shape))
+
+
+def decode(**config):
+    """decode(**cfg) of the reference (decode.py:69-130): load the decoder weights, decode every
+    sample, write ``aff_key`` as float16."""
+    torch = _torch()
+    from .vote_instances import io_hdflike
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    ae = dict(config.get("autoencoder") or config.get("included_ae_config") or {})
+    ae.setdefault("code_units", config["code_units"])
+    ae.setdefault("input_shape_squeezed",
+                  tuple(int(p) for p in config["patchshape"] if int(p) > 1))
+    decoder = PatchDecoder(ae)
+    ckpt = torch.load(config["checkpoint_file"], map_location=device)
+    state = ckpt["swa_model_state_dict" if config.get("use_swa") else "model_state_dict"]
+    dec_state = {k.split("decoder.", 1)[1]: v for k, v in state.items() if "decoder." in k}
+    decoder.load_state_dict(dec_state, strict=False)
+    for sample in config["samples"]:
+        with io_hdflike.open_container(sample, "r") as f:
+            code = np.array(f[config["code_key"]])
+            numinstfg = np.array(f[config.get("numinst_key", config.get("fg_key"))])
+        fg = foreground_from_numinst(numinstfg, config.get("fg_thresh", 0.5))
+        pred = decode_volume(decoder, code, fg, config.get("decode_batch_size", 1024), device)
+        name = os.path.basename(sample).split(".")[0]
+        outfn = os.path.join(config["output_folder"], name + "." + config["output_format"])
+        with io_hdflike.open_container(outfn, "a" if os.path.exists(outfn) else "w") as f:
+            data = pred.cpu().numpy().astype(np.float16)
+            if config["output_format"] == "zarr":
+                f.create(config["aff_key"], shape=data.shape, dtype=np.float16)
+                f[config["aff_key"]][:] = data
+            else:
+                f.create_dataset(config["aff_key"], data=data, compression="gzip")

@@ -351,10 +351,20 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
     patchshape = np.array(kwargs["patchshape"])
     kw = dict(kwargs)
     kw.pop("patchshape")
-    loaded = util.loadAffinities(pred_file, "", patchshape=patchshape, **kw)
-    if loaded is None:
-        return
-    affinities, numinst, foreground = loaded
+    if pred_file.endswith(".npy"):
+        # (C, Z, Y, X) array; foreground from the centre channel (utilVoteInstances.py:233-242,
+        # whose own .npy branch only handles 2-d data)
+        affinities = np.load(pred_file)
+        if affinities.ndim == 3:
+            affinities = affinities[:, None]
+        mid = int(np.prod(patchshape)) // 2
+        foreground = np.array(affinities[mid]) > util.getFgThreshold(**kw)
+        numinst = 1 * foreground
+    else:
+        loaded = util.loadAffinities(pred_file, "", patchshape=patchshape, **kw)
+        if loaded is None:
+            return
+        affinities, numinst, foreground = loaded
     foreground = np.squeeze(foreground)
     if foreground.ndim == 2:
         foreground = foreground[None]
