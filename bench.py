@@ -30,10 +30,14 @@ WORKLOADS = {
     # reduced variants for quick checks
     "synth64_p5": ((64, 64, 64), (5, 5, 5), (12, 12, 12)),
     "synth96_p7": ((96, 96, 96), (7, 7, 7), (18, 18, 18)),
+    # large volumes: the consensus no longer fits, the path tiles itself into z-slabs
+    "synth256_p7": ((256, 256, 256), (7, 7, 7), (18, 18, 18)),
+    "synth256_p9": ((256, 256, 256), (9, 9, 9), (24, 24, 24)),
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
 }
 CPU_SAMPLE = {"flylight140_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
+              "synth256_p7": (28, 28, 28), "synth256_p9": (26, 26, 26),
               "synth64_p5": (24, 24, 24), "synth512_p9": (26, 26, 26)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -73,6 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="flylight140_p7", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slabs", type=int, default=None,
+                    help="force the number of z-slabs of the single-GPU tiled path")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +107,9 @@ def main():
         fg_host = (labels != 0).cpu().numpy()
         numinst = fg_host.astype(np.uint8)
         gshape = shape
+
+        if args.slabs:
+            kw["_n_slabs"] = args.slabs
 
         def step():
             inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps, **kw)
@@ -142,6 +151,7 @@ def main():
         torch.cuda.synchronize()
 
     backend.EVENTS = {}
+    backend.NOTES.clear()
     barrier()
     host_times = None
     if os.environ.get("PPP_BENCH_STAGES", "1") == "1":
@@ -163,17 +173,28 @@ def main():
     V = float(np.prod(shape))
     C = int(np.prod(ps))
     value = float(np.prod(gshape)) * args.steps / dt / 1e6
-    # roofline of the dominant kernel (S1 consensus): algorithmic bytes = prediction block
-    # read once (f16 resident: 2*C*V) + overlap mask (V); outputs excluded
-    s1_ms = float(np.mean(ev["consensus"])) if ev.get("consensus") else None
-    alg_bytes = 2.0 * C * V + V
+    # Roofline of the scoring kernel (S1 consensus).  Algorithmic bytes per base voxel: the
+    # prediction block read once (f16 resident: 2*C) + the overlap mask (1); outputs excluded
+    # (SURVEY 8d).  A launch processes the base voxels of its consensus box (the whole volume
+    # when untiled; the tiled path launches S1 per slab, twice where it recomputes the
+    # consensus for the patch-graph stage).
+    s1_total_ms = float(np.sum(ev["consensus"])) if ev.get("consensus") else None
+    s1_voxels = backend.NOTES.get("s1_base_voxels", 0)
     roofline = None
-    if s1_ms:
-        achieved = alg_bytes / (s1_ms * 1e-3) / 1e9
+    if s1_total_ms:
+        alg_bytes = (2.0 * C + 1.0) * s1_voxels
+        achieved = alg_bytes / (s1_total_ms * 1e-3) / 1e9
+        votes = float(C) * (C - 1) / 2.0 * s1_voxels   # upper bound: every voxel foreground
         roofline = {"bound": "hbm", "kernel": "consensus_v2_kernel", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes": alg_bytes, "avg_ms": s1_ms}
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / len(ev["consensus"]),
+                    "launches": len(ev["consensus"]),
+                    "avg_ms": s1_total_ms / len(ev["consensus"]),
+                    "note": "VALU-bound (PMC: profiles/): C(C-1)/2 pair votes per voxel",
+                    "pair_votes_per_s_upper": votes / (s1_total_ms * 1e-3)}
 
+    if rank == 0 and roofline is not None:
+        roofline.update(pmc_traffic("consensus_v2_kernel"))
     if rank == 0:
         out = {
             "metric": "Mvoxels/sec assembled (vote_instances)", "value": value,
@@ -196,6 +217,29 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM traffic of `kernel` per launch from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE, separate passes, in KiB).
+    Raw counter values; on gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by
+    2x and is uncalibrated for the narrow loads of this kernel (MI355X_MICROARCH.md, HBM)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write.txt")))
+    if not files:
+        return {"traffic": None}
+    vals = {}
+    for ln in open(files[-1]):
+        if kernel in ln:
+            parts = ln.split()
+            for name in ("FETCH_SIZE", "WRITE_SIZE"):
+                if name in parts:
+                    vals[name] = float(parts[parts.index(name) + 1]) * 1024.0
+    if len(vals) < 2:
+        return {"traffic": None}
+    return {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "traffic_read": vals["FETCH_SIZE"],
+            "traffic_write": vals["WRITE_SIZE"],
+            "traffic_source": os.path.relpath(files[-1], ROOT) + " (flylight140_p7, raw counters)"}
 
 
 def cpu_baseline(workload, ps, cell, kw):

@@ -282,6 +282,10 @@ def note(key, value):
     NOTES[key] = int(value)
 
 
+def note_add(key, value):
+    NOTES[key] = NOTES.get(key, 0) + int(value)
+
+
 def event_times_ms():
     """name -> list of elapsed ms (call after a synchronize)."""
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in (EVENTS or {}).items()}
@@ -325,6 +329,7 @@ def consensus(pred, overlap, P, want_count=False):
         shape = (int(L.ppp_cons_planes(ctypes.byref(P))),) + P.cons_box.shape()
     cons = torch.empty(shape, dtype=torch.float32, device=pred.device)
     cnt = torch.empty(shape, dtype=torch.float32, device=pred.device) if want_count else None
+    note_add("s1_base_voxels", int(np.prod(P.cons_box.shape())))
     with _timed("consensus"):
         check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
                               _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))

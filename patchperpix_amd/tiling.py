@@ -328,6 +328,23 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     return instances, foreground.astype(np.uint8)
 
 
+def slabs_needed(shape, patchshape, free_bytes, safety=0.7):
+    """Smallest number of z-slabs whose consensus working set (compact planes + the voxel-major
+    copy the patch-graph kernel reads = 3x the compact size, on a box of own thickness + 4*rz
+    slices) fits into `free_bytes` of device memory."""
+    pz, py, px = [int(p) for p in patchshape]
+    planes = ((2 * pz - 1) * (2 * py - 1) * (2 * px - 1) - 1) // 2
+    per_slice = 3.0 * planes * 4 * int(shape[1]) * int(shape[2])
+    extra = 4 * (pz // 2)
+    budget = safety * free_bytes
+    Z = int(shape[0])
+    for n in range(1, Z + 1):
+        own = -(-Z // n)
+        if (min(Z, own + extra)) * per_slice <= budget:
+            return n
+    return Z
+
+
 def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,
                           **kw):
     """Single-process tiling: the whole prediction is resident, the consensus lives for one

@@ -115,6 +115,19 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
 
     pred_affs = backend.to_device_pred(pred_affs)   # host->HBM once; f16 stays f16 (exact)
     shape = tuple(foreground.shape)
+    # Volumes whose consensus does not fit in HBM are assembled slab by slab (identical result,
+    # patchperpix_amd/tiling.py); `_n_slabs` forces a slab count.
+    n_slabs = kwargs.get("_n_slabs")
+    if n_slabs is None and not kwargs.get("save_consensus", False):
+        from .. import tiling
+        n_slabs = tiling.slabs_needed(shape, patchshape, torch.cuda.mem_get_info()[0])
+    if n_slabs and n_slabs > 1 and not kwargs.get("graphToInst") \
+            and kwargs.get("aff_graph") is None and not kwargs.get("pad_with_ps", False):
+        from .. import tiling
+        logger.info("assembling in %d z-slabs", n_slabs)
+        kw = {k: v for k, v in kwargs.items() if k != "_n_slabs"}
+        return tiling.assemble(pred_affs, 0, shape, foreground, mask_to_cover, numinst,
+                               patchshape, tiling.plan_slabs(shape[0], n_slabs), **kw)
     radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
     overlap_mask = 1 * (numinst > 1)
 
