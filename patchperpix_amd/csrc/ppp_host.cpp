@@ -146,20 +146,28 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
         if (window_hits<false>(D, h_mask_running, b, cz, cy, cx, nullptr) > pix_th) {
             selected[i] = 1;
             ++picked;
-            // clear, keeping the occupancy grid in step
+            // clear row by row (8 voxels at a time), keeping the occupancy grid in step
             int64_t cleared = 0;
             int r = 0;
             for (int dz = 0; dz < D.pz; ++dz)
-                for (int dy = 0; dy < D.py; ++dy)
-                    for (int dx = 0; dx < D.px; ++dx, ++r) {
-                        const int z = cz + dz - D.rz, y = cy + dy - D.ry, x = cx + dx - D.rx;
-                        uint8_t &m = h_mask_running[D.lin(z, y, x)];
-                        if (m && bit(b, r)) {
-                            m = 0;
-                            --occ[((size_t)(z / B) * GY + y / B) * GX + x / B];
-                            if (D.interior(z, y, x)) ++cleared;
+                for (int dy = 0; dy < D.py; ++dy, r += D.px) {
+                    const int z = cz + dz - D.rz, y = cy + dy - D.ry;
+                    const bool zy_int = z >= D.rz && z < D.Z - D.rz && y >= D.ry && y < D.Y - D.ry;
+                    uint8_t *row = h_mask_running + D.lin(z, y, cx - D.rx);
+                    int32_t *orow = occ.data() + ((size_t)(z / B) * GY + y / B) * GX;
+                    for (int x0 = 0; x0 < D.px; x0 += 8) {
+                        const int nb = D.px - x0 < 8 ? D.px - x0 : 8;
+                        uint32_t m = pack8(row + x0) & bit_field(b, r + x0, nb);
+                        while (m) {
+                            const int k = __builtin_ctz(m);
+                            m &= m - 1;
+                            const int x = cx - D.rx + x0 + k;
+                            row[x0 + k] = 0;
+                            --orow[x / B];
+                            cleared += zy_int && x >= D.rx && x < D.X - D.rx;
                         }
                     }
+                }
             *remaining -= cleared;
         }
     }
