@@ -193,7 +193,8 @@ def main():
                     "note": "VALU-bound (PMC: profiles/): C(C-1)/2 pair votes per voxel",
                     "pair_votes_per_s_upper": votes / (s1_total_ms * 1e-3)}
 
-    if rank == 0 and roofline is not None:
+    if rank == 0 and roofline is not None and args.workload == "flylight140_p7" and world == 1 \
+            and not args.slabs:
         roofline.update(pmc_traffic("consensus_v2_kernel"))
     if rank == 0:
         out = {

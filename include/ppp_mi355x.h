@@ -139,6 +139,20 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
                     const uint32_t *d_pairs, const uint32_t *d_order, uint64_t n_pairs,
                     float *d_aff, const ppp_params *p, void *stream);
 
+/* Same result, different work decomposition: one workgroup per patch A stages the consensus
+ * row of every pixel of A once in LDS and serves all pairs (A, *) from it (VOXEL_MAJOR layout
+ * only; px in {3,5,7,9}, otherwise PPP_ERR_UNSUPPORTED).  The caller groups the rows by patch A:
+ *   d_order            row ids, rows of one patch A contiguous (any order inside a group; rows
+ *                      with similar B - A next to each other diverge least)
+ *   d_group_start      int64 [n_groups + 1], positions in d_order where the groups start
+ *   d_chunk_offsets    int64 [n_groups + 1], exclusive scan of ceil(group size / 256);
+ *                      n_blocks = d_chunk_offsets[n_groups]                                  */
+int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                             const uint32_t *d_pairs, const uint32_t *d_order,
+                             const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                             int32_t n_groups, int64_t n_blocks, float *d_aff,
+                             const ppp_params *p, void *stream);
+
 /* --- S6: labelling -------------------------------------------------------------------
  * replaces setAffgraph (aff_patch_graph.py:31-40) + the connected-components branch of
  * affGraphToInstances (graph_to_labeling.py:50-54,61-86).

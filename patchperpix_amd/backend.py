@@ -74,6 +74,11 @@ _SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.c_void_p, ctypes.POINTER(Params),
                                        ctypes.c_void_p]),
+    "ppp_patch_graph_by_patch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                ctypes.c_void_p, ctypes.POINTER(Params),
+                                                ctypes.c_void_p]),
     "ppp_label_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "ppp_label_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
@@ -327,6 +332,8 @@ def consensus(pred, overlap, P, want_count=False):
         shape = (2 * P.pz if P.pz > 1 else 1, 2 * P.py, 2 * P.px, P.Z, P.Y, P.X)
     else:
         shape = (int(L.ppp_cons_planes(ctypes.byref(P))),) + P.cons_box.shape()
+    if int(np.prod(shape)) * 4 > torch.cuda.mem_get_info()[0]:
+        torch.cuda.empty_cache()
     cons = torch.empty(shape, dtype=torch.float32, device=pred.device)
     cnt = torch.empty(shape, dtype=torch.float32, device=pred.device) if want_count else None
     note_add("s1_base_voxels", int(np.prod(P.cons_box.shape())))
@@ -357,6 +364,53 @@ def pair_order(pairs, P):
     keys = torch.empty((n,), dtype=torch.int64, device=pairs.device)
     check(lib().ppp_pair_sort_keys(_dev_ptr(pairs), n, _dev_ptr(keys), ctypes.byref(P), _stream()))
     return torch.argsort(keys).to(torch.int32)
+
+
+def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
+    """S5 with one workgroup per patch A (ppp_patch_graph_by_patch): groups the rows by A
+    (inside a group by patch offset, so neighbouring lanes do similar work), then launches."""
+    torch = _torch()
+    n = int(pairs.shape[0])
+    aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
+    if n == 0:
+        return aff
+    r = pairs.to(torch.int64)
+    lin = (r[:, 0] * Pv.Y + r[:, 1]) * Pv.X + r[:, 2]
+    dkey = ((r[:, 3] - r[:, 0] + 2 * Pv.pz) * (4 * Pv.py + 1) + (r[:, 4] - r[:, 1] + 2 * Pv.py)) \
+        * (4 * Pv.px + 1) + (r[:, 5] - r[:, 2] + 2 * Pv.px)
+    del r
+    key = lin * (1 << 17) + dkey
+    del dkey
+    order = torch.argsort(key)
+    del key
+    _, counts = torch.unique_consecutive(lin[order], return_counts=True)
+    del lin
+    zero = torch.zeros((1,), dtype=torch.int64, device=pred.device)
+    group_start = torch.cat([zero, torch.cumsum(counts, 0)])
+    chunk_offsets = torch.cat([zero, torch.cumsum((counts + 255) // 256, 0)])
+    n_groups = int(counts.shape[0])
+    n_blocks = int(chunk_offsets[-1].item())
+    order32 = order.to(torch.int32)
+    del order
+    with _timed("patch_graph"):
+        check(lib().ppp_patch_graph_by_patch(
+            _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
+            _dev_ptr(order32), _dev_ptr(group_start.contiguous()),
+            _dev_ptr(chunk_offsets.contiguous()), n_groups, n_blocks, _dev_ptr(aff),
+            ctypes.byref(Pv), _stream()))
+    return aff
+
+
+def patch_graph_auto(pred, cons_compact, pairs, P):
+    """S5 from a COMPACT consensus: re-layout to voxel-major, then the pair-per-lane kernel with
+    offset-grouped lanes.  PPP_PATCH_GRAPH=patch selects the workgroup-per-patch kernel instead
+    (same bits; measured slower on dense volumes: it trades the HBM traffic of the gathers --
+    5.4 TB -> 0.3 TB on the 140^3 benchmark -- for divergent per-lane control flow, 26 % lane
+    utilisation, 2.1 s vs 1.6 s)."""
+    vm, Pv = cons_to_voxel_major(cons_compact, P)
+    if os.environ.get("PPP_PATCH_GRAPH", "pairs") == "patch" and P.px in (3, 5, 7, 9):
+        return patch_graph_by_patch(pred, vm, pairs, Pv)
+    return patch_graph(pred, vm, pairs, Pv, order=pair_order(pairs, P))
 
 
 def device_patch_pairs(sorted_zyx, P, max_ps_dist=2, include_single=True):
@@ -433,6 +487,9 @@ def cons_to_voxel_major(cons_compact, P):
     cons_layout = VOXEL_MAJOR)."""
     torch = _torch()
     W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
+    need = int(np.prod(P.cons_box.shape())) * W * 4
+    if need > torch.cuda.mem_get_info()[0]:
+        torch.cuda.empty_cache()   # hand cached-but-free blocks back before the big allocation
     vm = torch.empty(P.cons_box.shape() + (W,), dtype=torch.float32, device=cons_compact.device)
     Pc = P.copy()
     Pc.cons_layout = CONS_COMPACT

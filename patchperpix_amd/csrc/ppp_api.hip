@@ -193,6 +193,29 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph");
 }
 
+int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                             const uint32_t *d_pairs, const uint32_t *d_order,
+                             const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                             int32_t n_groups, int64_t n_blocks, float *d_aff,
+                             const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n_groups == 0) return PPP_OK;
+    if (!d_pred || !d_cons_vm || !d_pairs || !d_order || !d_group_start || !d_chunk_offsets || !d_aff)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.layout != PPP_CONS_VOXEL_MAJOR)
+        return fail(PPP_ERR_INVALID_ARG, "ppp_patch_graph_by_patch reads the VOXEL_MAJOR layout");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_patch_graph_pa(d_pred, pred_dtype, d_cons_vm, d_pairs, d_order,
+                                              (const long long *)d_group_start,
+                                              (const long long *)d_chunk_offsets, n_groups, n_blocks,
+                                              d_aff, G, (hipStream_t)stream);
+    if (e == hipErrorNotSupported)
+        return fail(PPP_ERR_UNSUPPORTED, "no per-patch kernel for this patch shape");
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph_by_patch");
+}
+
 size_t ppp_label_workspace_bytes(const ppp_params *p) {
     if (!p) return 0;
     return (size_t)3 * sizeof(uint32_t) * (size_t)p->Z * p->Y * p->X;

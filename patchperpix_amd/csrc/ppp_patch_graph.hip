@@ -280,6 +280,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
                            const uint64_t n, float *__restrict__ aff, const Geo G) {
     extern __shared__ uint32_t lds_raw[];  // [PG_WAVES][2][words][64]
     constexpr int RX = PX / 2;
+    constexpr int NV = ((PX + 3) / 4) * 4;   // floats of the per-row register window
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint64_t slot = ((uint64_t)blockIdx.x * PG_WAVES + wave) * 64 + lane;
     const bool live = slot < n;
@@ -369,37 +370,39 @@ __global__ void __launch_bounds__(64 * PG_WAVES)
                             uint64_t f64 = lds_b[w0 * 64 + lane];
                             if (sh + n_x > 32) f64 |= (uint64_t)lds_b[(w0 + 1) * 64 + lane] << 32;
                             const uint32_t fb = bit_a ? (uint32_t)(f64 >> sh) : 0u;
-                            // consensus values: window [qx0, qx0 + 8) of this lane's row
-                            float v[8];
+                            // consensus values: window [qx0, qx0 + NV) of this lane's row, fetched
+                            // with as many 16-byte loads as the run needs (uniform count)
+                            float v[NV];
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) v[k] = 0.0f;
                             if (m_stored != 0u) {
-                                const bool two = PX > 4 && n_x > 4;
+                                const int n_ld = (n_x + 3) >> 2;          // 1 .. NV/4
                                 long long i0 = rowi + (long long)(qz * G.wy + qy) * G.wx + qx0;
                                 const long long want = i0;
-                                i0 = max(0ll, min(i0, n_elems - (two ? 8 : 4)));
-                                f4u lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+                                i0 = max(0ll, min(i0, n_elems - 4 * n_ld));
                                 if (fb != 0u) {
-                                    lo4 = *reinterpret_cast<const f4u *>(S + i0);
-                                    if (two) hi4 = *reinterpret_cast<const f4u *>(S + i0 + 4);
+#pragma unroll
+                                    for (int q4 = 0; q4 < NV / 4; ++q4)
+                                        if (q4 < n_ld) {
+                                            const f4u t4 = *reinterpret_cast<const f4u *>(S + i0 + 4 * q4);
+                                            v[4 * q4 + 0] = t4.x; v[4 * q4 + 1] = t4.y;
+                                            v[4 * q4 + 2] = t4.z; v[4 * q4 + 3] = t4.w;
+                                        }
                                 }
-                                v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
-                                v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
                                 // the clamp only moves the window at the two ends of the buffer
                                 const int shift = (int)(want - i0);
                                 if (__builtin_expect(__ballot(shift != 0 && fb != 0u) != 0ull, 0)) {
-                                    float tt[8];
+                                    float tt[NV];
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) {
+                                    for (int k = 0; k < NV; ++k) {
                                         float val = 0.f;
 #pragma unroll
-                                        for (int m = 0; m < 8; ++m) val = (m == k + shift) ? v[m] : val;
+                                        for (int m = 0; m < NV; ++m) val = (m == k + shift) ? v[m] : val;
                                         tt[k] = val;
                                     }
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) v[k] = shift != 0 ? tt[k] : v[k];
+                                    for (int k = 0; k < NV; ++k) v[k] = shift != 0 ? tt[k] : v[k];
                                 }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) v[k] = 0.0f;
                             }
 #pragma unroll
                             for (int t = 0; t < PX; ++t) {
@@ -434,8 +437,8 @@ hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
     const uint64_t per_block = 64ull * PG_WAVES;
     const dim3 grid((unsigned)((n + per_block - 1) / per_block));
     static const bool vm_generic = getenv("PPP_PATCH_GRAPH_GENERIC") != nullptr;
-    if (G.layout == PPP_CONS_VOXEL_MAJOR && !vm_generic && G.px <= 7 &&
-        (G.px == 3 || G.px == 5 || G.px == 7)) {
+    if (G.layout == PPP_CONS_VOXEL_MAJOR && !vm_generic &&
+        (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9)) {
 #define PPP_PG_CASE(P)                                                                                          \
     case P:                                                                                                     \
         if (dtype == PPP_F16)                                                                                   \
@@ -449,6 +452,7 @@ hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
             PPP_PG_CASE(3)
             PPP_PG_CASE(5)
             PPP_PG_CASE(7)
+            PPP_PG_CASE(9)
         }
 #undef PPP_PG_CASE
     }

@@ -109,9 +109,7 @@ class DeviceOps:
                                           include_single=include_single)
 
     def patch_graph(self, pred, cons, rows, P):
-        order = backend.pair_order(rows, P)
-        vm, Pv = backend.cons_to_voxel_major(cons, P)
-        return backend.patch_graph(pred, vm, rows, Pv, order=order)
+        return backend.patch_graph_auto(pred, cons, rows, P)
 
     def rank_order(self, score_dev, score_host, foreground, ps):
         return backend.rank_order_device(score_dev, foreground, ps)
@@ -289,7 +287,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 cons = ops.consensus(pred_local, ov_local, P)
             rows_l = (rows[idx] - shift).contiguous()
             aff[idx] = ops.patch_graph(pred_local, cons, rows_l, P)
-            del cons
+            del cons, rows_l, idx
     kept.clear()
     comm.all_reduce_sum(aff)
     if want_inter:
@@ -328,7 +326,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     return instances, foreground.astype(np.uint8)
 
 
-def slabs_needed(shape, patchshape, free_bytes, safety=0.7):
+def slabs_needed(shape, patchshape, free_bytes, safety=0.6):
     """Smallest number of z-slabs whose consensus working set (compact planes + the voxel-major
     copy the patch-graph kernel reads = 3x the compact size, on a box of own thickness + 4*rz
     slices) fits into `free_bytes` of device memory."""

@@ -139,14 +139,13 @@ def computePatchGraph_cuda(pred_affs, consensus_vote_array, selected_patch_pairs
     pairs = selected_patch_pairsIDs
     if not isinstance(pairs, PatchPairs):
         pairs = PatchPairs.from_host(pairs, pred_affs.device)
-    order = backend.pair_order(pairs.rows_dev, P)
-    cons = consensus_vote_array
-    if P.cons_layout == backend.CONS_COMPACT and kwargs.get("_voxel_major", True):
-        # one streaming re-layout, after which every lane of the patch-graph kernel sweeps
-        # contiguous memory (3x fewer HBM bytes than gathering from the plane-major array)
-        cons, P = backend.cons_to_voxel_major(cons, P)
-    aff = backend.patch_graph(pred_affs, cons, pairs.rows_dev, P, order=order)
-    del cons
+    if P.cons_layout == backend.CONS_COMPACT:
+        # one streaming re-layout to voxel-major, then one workgroup per patch A serving all its
+        # pairs from LDS-staged consensus rows (or pair-per-lane kernels for other patch shapes)
+        aff = backend.patch_graph_auto(pred_affs, consensus_vote_array, pairs.rows_dev, P)
+    else:
+        aff = backend.patch_graph(pred_affs, consensus_vote_array, pairs.rows_dev, P,
+                                  order=backend.pair_order(pairs.rows_dev, P))
     if kwargs.get("save_patch_graph", False) or kwargs.get("termAfterPatchGraph", False):
         fn = os.path.splitext(os.path.basename(kwargs["affinities"]))[0]
         np.save(os.path.join(kwargs["result_folder"], fn + "_selected_patch_pairs.npy"),

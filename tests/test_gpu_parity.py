@@ -47,6 +47,9 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
         vm, Pv = backend.cons_to_voxel_major(cons, P)                             # re-layout
         aff3 = backend.patch_graph(pred, vm, pd, Pv, order=order).cpu().numpy()
         assert np.array_equal(out["aff"].view(np.uint32), aff3.view(np.uint32))
+        if P.px in (3, 5, 7, 9):                                                  # per-patch kernel
+            aff4 = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
+            assert np.array_equal(out["aff"].view(np.uint32), aff4.view(np.uint32))
     return out
 
 
@@ -104,6 +107,10 @@ CASES = [
           rank_int_counter=True, overlapping_inst=False)),
     ((18, 18, 18), (7, 7, 7), dict(seed=24, cell=[9, 9, 9]),
      dict(consensus_norm_prob_product=False, consensus_prob_product=True)),
+    ((13, 14, 17), (9, 9, 9), dict(seed=25, cell=[12, 12, 12], overlap_frac=0.01), {}),
+    ((1, 70, 75), (1, 25, 25), dict(seed=26, cell=[1, 30, 30]),
+     dict(patch_threshold=0.9, vi_bg_use_inv_th=True, vi_bg_use_less_than_th=False,
+          overlapping_inst=False)),     # wormbodies-like 2-d shape: the generic kernels
 ]
 
 
