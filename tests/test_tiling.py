@@ -67,7 +67,7 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 c, ps, kw = make_case()
 Z = c["pred"].shape[1]
-slabs = tiling.plan_slabs(Z, 4)
+slabs = tiling.plan_slabs(Z, int(os.environ.get("PPP_TEST_SLABS", "4")))
 mine = tiling.slabs_of_rank(slabs, rank, world)
 lo, hi = tiling.local_range(mine, Z, ps)
 pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi]))   # halo'd slab only
@@ -79,12 +79,14 @@ dist.destroy_process_group()
 """
 
 
-def test_two_ranks_gloo_equal_whole_volume(tmp_path):
+@pytest.mark.parametrize("n_slabs", [4, 2])   # 2 slabs per rank / one slab per rank (kept consensus)
+def test_two_ranks_gloo_equal_whole_volume(tmp_path, n_slabs):
     c, ps, kw = make_case()
     ref = whole_volume(c, ps, kw)
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(repo=REPO, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", OMP_NUM_THREADS="1",
+               PPP_TEST_SLABS=str(n_slabs))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                            "--master-port", "29591", str(script)], env=env, timeout=900)
