@@ -16,6 +16,8 @@
 // touch memory.  Loops over a and (bz, by) are wave-uniform (scalar); the innermost PX pixels
 // are unrolled: PX independent coalesced gathers (lane = consecutive base voxels) are issued
 // together, then added in order.  Groups no lane needs are skipped with one ballot.
+#include <type_traits>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -117,38 +119,48 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                         // Two scalar base pointers per group, one scalar 64-bit add per element
                         // (this loop is bound by the scalar ALU, not by the vector one).
                         const int dz = bz - az, dy = by - ay;
-                        long long plane_f, plane_b;   // planes of j = 0
-                        if (G.layout == PPP_CONS_REFERENCE) {
-                            plane_f = ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (-ax + PX - 1);
-                            plane_b = ((long long)(-dz + G.pz - 1) * G.nsy + (-dy + G.py - 1)) * G.nsx + (ax + PX - 1);
-                        } else {
-                            plane_f = ((long long)dz * G.wy + dy) * G.wx - ax - 1;
-                            plane_b = ((long long)(-dz) * G.wy - dy) * G.wx + ax - 1;
-                        }
-                        const float *pf_ptr = cons + plane_f * plane_stride + off_a;
-                        const float *pb_ptr = cons + plane_b * plane_stride +
-                                              ((long long)(bz - G.rz) * sZc + (long long)(by - G.ry) * sYc - PX / 2);
-                        float v[PX];
+                        // Gathers + ordered accumulation of one group.  MODE is the position of
+                        // the partner row relative to a's row: -1 before (all b < a, backward
+                        // keys), +1 after (all b > a, forward keys), 0 the same row (mixed).
+                        // Keeping it a compile-time constant removes the per-element scalar
+                        // selects (this loop is bound by the scalar ALU).
+                        auto run_group = [&](auto mode_tag) {
+                            constexpr int MODE = decltype(mode_tag)::value;
+                            long long plane_f = 0, plane_b = 0;   // planes of j = 0
+                            if (G.layout == PPP_CONS_REFERENCE) {
+                                if (MODE >= 0) plane_f = ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (-ax + PX - 1);
+                                if (MODE <= 0) plane_b = ((long long)(-dz + G.pz - 1) * G.nsy + (-dy + G.py - 1)) * G.nsx + (ax + PX - 1);
+                            } else {
+                                if (MODE >= 0) plane_f = ((long long)dz * G.wy + dy) * G.wx - ax - 1;
+                                if (MODE <= 0) plane_b = ((long long)(-dz) * G.wy - dy) * G.wx + ax - 1;
+                            }
+                            const float *pf_ptr = cons + plane_f * plane_stride + off_a;
+                            const float *pb_ptr = cons + plane_b * plane_stride +
+                                                  ((long long)(bz - G.rz) * sZc + (long long)(by - G.ry) * sYc - PX / 2);
+                            float v[PX];
 #pragma unroll
-                        for (int j = 0; j < PX; ++j) {
-                            // same row: j < ax backward, j > ax forward, j == ax unused
-                            const bool back = row_cmp < 0 || (row_cmp == 0 && j < ax);
-                            const bool skip = row_cmp == 0 && j == ax;
-                            const float *src = back ? pb_ptr : pf_ptr;
-                            v[j] = (fg && !skip) ? src[laneC] : 0.0f;
-                            pf_ptr += plane_stride;
-                            pb_ptr += 1 - plane_stride;
-                        }
+                            for (int j = 0; j < PX; ++j) {
+                                const bool back = MODE < 0 || (MODE == 0 && j < ax);
+                                const bool skip = MODE == 0 && j == ax;
+                                const float *src = MODE < 0 ? pb_ptr : (MODE > 0 ? pf_ptr : (back ? pb_ptr : pf_ptr));
+                                v[j] = (fg && !skip) ? src[laneC] : 0.0f;
+                                if (MODE >= 0) pf_ptr += plane_stride;
+                                if (MODE <= 0) pb_ptr += 1 - plane_stride;
+                            }
 #pragma unroll
-                        for (int j = 0; j < PX; ++j) {
-                            const bool is_p = (pf >> j) & 1u, is_n = (nf >> j) & 1u;
-                            const bool use = pa && (is_p || is_n) && !(row_cmp == 0 && j == ax);
-                            float c = v[j];
-                            if (COUNT_POS_NEG) c = (c != 0.0f) ? copysignf(1.0f, c) : (is_p ? -1.0f : 1.0f);
-                            // acc += c for a foreground partner, acc -= c for a background partner
-                            const float term = is_p ? c : -c;
-                            acc = acc + (use ? term : 0.0f);
-                        }
+                            for (int j = 0; j < PX; ++j) {
+                                const bool is_p = (pf >> j) & 1u, is_n = (nf >> j) & 1u;
+                                const bool use = pa && (is_p || is_n) && !(MODE == 0 && j == ax);
+                                float c = v[j];
+                                if (COUNT_POS_NEG) c = (c != 0.0f) ? copysignf(1.0f, c) : (is_p ? -1.0f : 1.0f);
+                                // acc += c for a foreground partner, acc -= c for a background one
+                                const float term = is_p ? c : -c;
+                                acc = acc + (use ? term : 0.0f);
+                            }
+                        };
+                        if (row_cmp < 0) run_group(std::integral_constant<int, -1>{});
+                        else if (row_cmp > 0) run_group(std::integral_constant<int, 1>{});
+                        else run_group(std::integral_constant<int, 0>{});
                     }
             }
     if (fg) {
