@@ -87,6 +87,8 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
         laneC = ((long long)(cz - G.bz0) * G.bY + (cy - G.by0)) * G.bX + (min(cx, G.X - 1) - G.bx0);
     }
     if (!fg) laneC = 0;   // inactive lanes read a harmless in-bounds element
+    const long long step_y = (long long)(G.layout == PPP_CONS_REFERENCE ? G.nsx : G.wx) * plane_stride;
+    const long long step_z = (long long)(G.layout == PPP_CONS_REFERENCE ? G.nsy * G.nsx : G.wy * G.wx) * plane_stride;
 
     float acc = 0.0f;
     for (int az = 0, a = 0; az < G.pz; ++az)
@@ -95,8 +97,22 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                 const bool pa = fg && ((Pw[(a >> 5) * 64] >> (a & 31)) & 1u);
                 if (__ballot(pa) == 0) continue;
                 const long long off_a = (long long)(az - G.rz) * sZc + (long long)(ay - G.ry) * sYc + (ax - PX / 2);
-                for (int bz = 0; bz < G.pz; ++bz)
-                    for (int by = 0; by < G.py; ++by) {
+                // Running base pointers of the partner row (bz, by), j = 0: forward keys
+                // (b - a, z_a) and backward keys (a - b, z_b).  One scalar 64-bit add per row
+                // step instead of re-deriving plane * stride (the loop is scalar-ALU bound).
+                const float *pf_z, *pb_z;
+                if (G.layout == PPP_CONS_REFERENCE) {
+                    pf_z = cons + (((long long)(-az + G.pz - 1) * G.nsy + (-ay + G.py - 1)) * G.nsx + (-ax + PX - 1)) * plane_stride + off_a;
+                    pb_z = cons + (((long long)(az + G.pz - 1) * G.nsy + (ay + G.py - 1)) * G.nsx + (ax + PX - 1)) * plane_stride +
+                           ((long long)(-G.rz) * sZc + (long long)(-G.ry) * sYc - PX / 2);
+                } else {
+                    pf_z = cons + (((long long)(-az) * G.wy - ay) * G.wx - ax - 1) * plane_stride + off_a;
+                    pb_z = cons + (((long long)az * G.wy + ay) * G.wx + ax - 1) * plane_stride +
+                           ((long long)(-G.rz) * sZc + (long long)(-G.ry) * sYc - PX / 2);
+                }
+                for (int bz = 0; bz < G.pz; ++bz, pf_z += step_z, pb_z += sZc - step_z) {
+                    const float *pf_y = pf_z, *pb_y = pb_z;
+                    for (int by = 0; by < G.py; ++by, pf_y += step_y, pb_y += sYc - step_y) {
                         const int b0 = (bz * G.py + by) * PX;
                         // PX-bit fields of P and N starting at bit b0 (may straddle two words)
                         const int w0 = b0 >> 5, sh = b0 & 31;
@@ -118,7 +134,6 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                         // backward (b < a): key (a - b, z_b) -> plane falls by one, base moves by +1.
                         // Two scalar base pointers per group, one scalar 64-bit add per element
                         // (this loop is bound by the scalar ALU, not by the vector one).
-                        const int dz = bz - az, dy = by - ay;
                         // Gathers + ordered accumulation of one group.  MODE is the position of
                         // the partner row relative to a's row: -1 before (all b < a, backward
                         // keys), +1 after (all b > a, forward keys), 0 the same row (mixed).
@@ -126,17 +141,7 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                         // selects (this loop is bound by the scalar ALU).
                         auto run_group = [&](auto mode_tag) {
                             constexpr int MODE = decltype(mode_tag)::value;
-                            long long plane_f = 0, plane_b = 0;   // planes of j = 0
-                            if (G.layout == PPP_CONS_REFERENCE) {
-                                if (MODE >= 0) plane_f = ((long long)(dz + G.pz - 1) * G.nsy + (dy + G.py - 1)) * G.nsx + (-ax + PX - 1);
-                                if (MODE <= 0) plane_b = ((long long)(-dz + G.pz - 1) * G.nsy + (-dy + G.py - 1)) * G.nsx + (ax + PX - 1);
-                            } else {
-                                if (MODE >= 0) plane_f = ((long long)dz * G.wy + dy) * G.wx - ax - 1;
-                                if (MODE <= 0) plane_b = ((long long)(-dz) * G.wy - dy) * G.wx + ax - 1;
-                            }
-                            const float *pf_ptr = cons + plane_f * plane_stride + off_a;
-                            const float *pb_ptr = cons + plane_b * plane_stride +
-                                                  ((long long)(bz - G.rz) * sZc + (long long)(by - G.ry) * sYc - PX / 2);
+                            const float *pf_ptr = pf_y, *pb_ptr = pb_y;
                             float v[PX];
 #pragma unroll
                             for (int j = 0; j < PX; ++j) {
@@ -162,6 +167,7 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                         else if (row_cmp > 0) run_group(std::integral_constant<int, 1>{});
                         else run_group(std::integral_constant<int, 0>{});
                     }
+                }
             }
     if (fg) {
         const unsigned fg_cnt = nP * (nV - 1u) - nP * (nP - 1u) / 2u;

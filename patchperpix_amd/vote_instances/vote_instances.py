@@ -120,8 +120,10 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     n_slabs = kwargs.get("_n_slabs")
     if n_slabs is None and not kwargs.get("save_consensus", False):
         from .. import tiling
-        torch.cuda.empty_cache()
-        n_slabs = tiling.slabs_needed(shape, patchshape, torch.cuda.mem_get_info()[0])
+        # free HBM + what the caching allocator holds but has not handed out
+        avail = torch.cuda.mem_get_info()[0] + \
+            (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+        n_slabs = tiling.slabs_needed(shape, patchshape, avail)
     if n_slabs and n_slabs > 1 and not kwargs.get("graphToInst") \
             and kwargs.get("aff_graph") is None and not kwargs.get("pad_with_ps", False):
         from .. import tiling
