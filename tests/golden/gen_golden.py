@@ -387,6 +387,23 @@ CASES = {
 }
 # cases whose consensus array is too big to commit: keep a SHA-256 of the float bits
 HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells"}
+# cases that are ALSO run through the reference's NumPy path (cuda=False; int16 +-1 votes,
+# SURVEY 8c "recipe A").  Different arithmetic from the kernels: only the final instance map
+# is stored, to document that both semantics agree on well separated instances.
+CPU_PATH_CASES = {"c2d_p5_blobs", "c3d_p3_blobs"}
+
+
+def run_reference_cpu_path(case, flags):
+    import vote_instances as vi
+    kw = dict(FLYLIGHT)
+    kw.update(FIXED)
+    kw.update(flags)
+    kw.update(cuda=False, skipLookup=False, mutex=threading.Lock())
+    patchshape = np.array(case["patchshape"])
+    fg = case["foreground"].copy()
+    inst, _ = vi.to_instance_seg(case["pred"].astype(np.float32), fg, fg.copy(),
+                                 case["numinst"].copy(), patchshape, **kw)
+    return np.asarray(inst)
 
 
 def main(argv):
@@ -410,6 +427,8 @@ def main(argv):
             c = np.ascontiguousarray(out.pop("cons_pos"))
             out["cons_pos_sha256"] = np.array(hashlib.sha256(c.tobytes()).hexdigest())
             out["cons_pos_sum"] = np.array(c.astype(np.float64).sum())
+        if name in CPU_PATH_CASES:
+            out["instances_cpu_path"] = run_reference_cpu_path(case, flags)
         kw = dict(FLYLIGHT)
         kw.update(flags)
         np.savez_compressed(

@@ -132,3 +132,12 @@ def test_mutex_watershed_matches_reference(golden):
     inst = orc.paint_instances(ccs, g.pred, g.patchshape, g.foreground.shape,
                                g.kw["patch_threshold"])
     assert np.array_equal(inst, g["instances"])
+
+
+def test_size_limits_are_reported():
+    """Volumes of 2^31 voxels or more and > 160 KB of patch bits are refused with a message,
+    not mis-addressed."""
+    P = backend.make_params((2048, 1024, 1024), (3, 3, 3), patch_threshold=0.5)
+    rc = backend.lib().ppp_cons_to_reference(ctypes.c_void_p(8), ctypes.c_void_p(8),
+                                             ctypes.byref(P), None)
+    assert rc == -4 and b"2^31" in backend.lib().ppp_last_error()

@@ -251,3 +251,38 @@ def test_synth_slab_equals_global_slice(torch_cuda):
                              voxel_offset=lo * 9 * 10).cpu().numpy()
     # interior slices only: at the slab's z-edges the neighbour labels are outside the slab
     assert np.array_equal(got[:, 1:-1], want[:, lo + 1:hi - 1])
+
+
+def test_large_volume_consistency(torch_cuda):
+    """96^3 / 7^3 (about 12 M pairs, every patch offset populated): the pair-per-lane and the
+    workgroup-per-patch patch-graph kernels agree bit for bit, and the 3-slab tiled assembly
+    equals the untiled one."""
+    from patchperpix_amd import backend, synth, tiling
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    shape, ps = (96, 96, 96), (7, 7, 7)
+    kw = dict(FLYLIGHT)
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, [18, 18, 18], seed=0)
+    labels = _dev(torch, lab.astype(np.int32))
+    pred = backend.synth_pred(labels, P, seed=0, f16=True)
+    fg = lab != 0
+    res = vi.to_instance_seg(pred, fg.copy(), fg.copy(), fg.astype(np.uint8), ps,
+                             **dict(kw, return_intermediates=True, _n_slabs=1))
+    pairs, aff = res
+    assert len(pairs) > 5_000_000
+    ov = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    cons = backend.consensus(pred, ov, P)
+    vm, Pv = backend.cons_to_voxel_major(cons, P)
+    del cons
+    pd = _dev(torch, pairs.view(np.int32))
+    aff_pa = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
+    assert np.array_equal(aff_pa.view(np.uint32), aff.view(np.uint32))
+    del vm, pd
+    whole, _ = vi.to_instance_seg(pred, fg.copy(), fg.copy(), fg.astype(np.uint8), ps,
+                                  **dict(kw, _n_slabs=1))
+    tiled, _ = vi.to_instance_seg(pred, fg.copy(), fg.copy(), fg.astype(np.uint8), ps,
+                                  **dict(kw, _n_slabs=3))
+    assert whole.max() > 50
+    assert np.array_equal(whole, tiled)

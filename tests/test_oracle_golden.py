@@ -90,3 +90,18 @@ def _cons_ref_layout(g):
                 cons[dz + pz - 1, dy + py - 1, dx + px - 1] = g["cons_pos"][k]
                 k += 1
     return cons
+
+
+@pytest.mark.parametrize("name", ["c2d_p5_blobs", "c3d_p3_blobs"])
+def test_reference_numpy_path_agrees_on_separated_instances(name):
+    """The reference's NumPy path (cuda=False: int16 +-1 votes, integer ranks -- different
+    arithmetic from the kernels) and the kernel semantics give the same
+    partition of two well separated instances wherever both label a voxel.  This is the
+    'plumbing' relation of BASELINE config [0]; it is not a bit-parity claim."""
+    from conftest import Golden
+    g = Golden(name)
+    a, b = g["instances_cpu_path"], g["instances"]
+    both = (a > 0) & (b > 0)
+    assert both.sum() > 0.9 * max((a > 0).sum(), (b > 0).sum())
+    assert len(np.unique(a[a > 0])) == len(np.unique(b[b > 0])) == 2
+    assert same_partition(np.where(both, a, 0), np.where(both, b, 0))
