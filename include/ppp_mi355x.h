@@ -199,6 +199,26 @@ int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres
                    uint64_t n, double thresh, uint32_t *d_bits, const ppp_params *p,
                    void *stream);
 
+/* --- greedy foreground cover on the device ---------------------------------------------
+ * ppp_cover_pass: one pass of computeForegroundCoverLoop (foreground_cover.py:111-180) as an
+ * exact priority-parallel algorithm (csrc/ppp_cover.hip): every patch whose state is 0 takes
+ * part; it ends up 1 (selected: more than pix_th voxels of the running mask were inside its
+ * window where its prediction is > fc_threshold when its turn came) or 2 (not selected).
+ *   d_mask    u8  [Z][Y][X]         running mask, cleared in place like mask_running
+ *   d_bits    u32 [n][ceil(C/32)]   ppp_patch_bits(fc_threshold) of the ranked patches
+ *   d_lin     i64 [n]               linear centre index of ranked patch k (interior centres)
+ *   d_state   i32 [n]               in/out, see above (1 / 2 on entry: does not take part)
+ *   d_cleared i32 [n]               out: interior voxels patch k cleared (0 if not selected)
+ *   d_work    ppp_cover_workspace_bytes(n, p) bytes
+ * The loop's stop rule ("interior of the mask is empty", checked before every patch) is not
+ * applied here: the caller cuts the selected list, in rank order, after the patch at which
+ * the running sum of d_cleared reaches the number of set interior voxels.  *rounds (may be
+ * NULL) returns the number of parallel rounds.  Synchronises the stream.                   */
+int64_t ppp_cover_workspace_bytes(int64_t n, const ppp_params *p);
+int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
+                   int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
+                   const ppp_params *p, void *stream, int32_t *rounds);
+
 /* --- patch pairs on the device ---------------------------------------------------------
  * replaces computeAndStorePatchPairs (aff_patch_graph.py:43-110).  d_sorted_zyx int32[n][3]
  * is the selected list stably sorted by x (aff_patch_graph.py:45).  Two calls: count the

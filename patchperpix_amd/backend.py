@@ -103,6 +103,11 @@ _SIGNATURES = {
     "ppp_patch_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p,
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_cover_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.POINTER(Params)]),
+    "ppp_cover_pass": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
+                                      ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "ppp_synth_pred": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_uint64, ctypes.POINTER(Params),
@@ -511,6 +516,25 @@ def patch_bits(pred, centres, thresh, P):
     check(lib().ppp_patch_bits(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(centres), n,
                                float(thresh), _dev_ptr(bits), ctypes.byref(P), _stream()))
     return bits
+
+
+def cover_pass_device(mask, bits, lin, state, pix_th, P):
+    """One pass of the greedy cover on the device (foreground_cover.py:111-180 without the stop
+    rule, see ppp_cover_pass).  mask uint8 (Z,Y,X) is cleared in place; state int32 [n]
+    (0 = takes part; ends 1 selected / 2 not) is updated in place.
+    Returns (cleared int32 [n], rounds)."""
+    torch = _torch()
+    n = int(state.numel())
+    cleared = torch.empty(n, dtype=torch.int32, device=mask.device)
+    nbytes = int(lib().ppp_cover_workspace_bytes(n, ctypes.byref(P)))
+    check(min(nbytes, 0))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=mask.device)
+    rounds = ctypes.c_int32(0)
+    with _timed("cover"):
+        check(lib().ppp_cover_pass(_dev_ptr(mask), _dev_ptr(bits), _dev_ptr(lin), n, int(pix_th),
+                                   _dev_ptr(state), _dev_ptr(cleared), _dev_ptr(work),
+                                   ctypes.byref(P), _stream(), ctypes.byref(rounds)))
+    return cleared, int(rounds.value)
 
 
 def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True, voxel_offset=0):

@@ -339,4 +339,29 @@ int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred");
 }
 
+int64_t ppp_cover_workspace_bytes(int64_t n, const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return (int64_t)ppp::cover_workspace_bytes(n < 0 ? 0 : n, G);
+}
+
+int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
+                   int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
+                   const ppp_params *p, void *stream, int32_t *rounds) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (rounds) *rounds = 0;
+    if (n <= 0) return PPP_OK;
+    if (n > 0x7F000000LL) return fail(PPP_ERR_INVALID_ARG, "too many ranked patches for one cover pass");
+    if (G.px > 32) return fail(PPP_ERR_UNSUPPORTED, "ppp_cover_pass needs patch rows of at most 32 voxels");
+    if (!d_mask || !d_bits || !d_lin || !d_state || !d_cleared || !d_work)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    int r = 0;
+    hipError_t e = ppp::run_cover_pass(d_mask, d_bits, (const long long *)d_lin, n, pix_th, d_state,
+                                       d_cleared, d_work, G, (hipStream_t)stream, &r);
+    if (rounds) *rounds = r;
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_pass");
+}
+
 }  // extern "C"

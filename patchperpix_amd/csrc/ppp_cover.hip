@@ -1,0 +1,276 @@
+// ppp_cover.hip -- S3, the greedy foreground cover, as an EXACT priority-parallel algorithm.
+//
+// Reference: foreground_cover.py:111-180 (computeForegroundCoverLoop) walks the ranked patch
+// list sequentially: a patch is selected iff more than pixTh voxels of the still uncovered mask
+// lie inside its window where its prediction is > fc_threshold; those voxels are then cleared.
+//
+// The outcome for patch i only depends on the selected patches of HIGHER rank whose windows
+// overlap win(i) (centres within p-1 per axis).  Hence rounds of
+//   count   : h_i = |mask & win_i & bits_i| for every undecided patch; h_i <= pixTh can never
+//             recover (the mask only shrinks) -> decided "not selected" at once;
+//   ready   : an undecided patch is ready when no undecided patch of higher rank lies within
+//             p-1 of it (3-d min filter over the volume of undecided ranks);
+//   select  : every ready patch is selected and clears its voxels.  Ready patches never
+//             overlap each other, and when i is decided every higher-ranked overlapping patch
+//             is decided and no lower-ranked overlapping one has touched the mask, so win(i)
+//             is exactly what the sequential loop would see at i's turn.
+// reproduce the sequential result.  The loop's stop rule (it ends as soon as the interior of
+// the mask is empty) is applied afterwards from the per-patch "cleared interior voxels"
+// counts, in rank order (host side, foreground_cover.py driver).
+//
+// The undecided patches live in a volume (rank k at the patch centre), and every kernel of a
+// round is a coalesced sweep over that volume: no lists, no compaction, no atomics on the data
+// path.  A patch is only recounted when a patch selected in the previous round overlaps it
+// (the selecting wave marks the (2p-1)^3 box of centres it can affect in a byte volume), the
+// recount stops at the first window row that settles "more than pixTh", and the host only
+// synchronises once per batch of rounds.
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+static constexpr int32_t RANK_NONE = 0x7F7F7F7F;
+static constexpr int COVER_BATCH = 8;   // rounds per host synchronisation
+
+struct CoverWork {
+    int32_t *rank_vol, *nbr_min, *tmp;   // [V] each
+    uint8_t *dirty;                      // [V]
+    uint32_t *mbits;                     // [Z*Y][XW] running mask, one bit per voxel
+    int32_t *counters;                   // [COVER_BATCH]
+};
+
+// words per row of the bit mask: one spare word so a window may be read as two words
+__host__ __device__ __forceinline__ int row_words(const Geo &G) { return (G.X + 31) / 32 + 1; }
+
+__device__ __forceinline__ void centre_of(const Geo &G, long long c, int &cz, int &cy, int &cx) {
+    cx = (int)(c % G.X);
+    cy = (int)((c / G.X) % G.Y);
+    cz = (int)(c / ((long long)G.X * G.Y));
+}
+
+// n (<= 32) bits starting at bit `start` of a little-endian bit string held in 32-bit words;
+// `limit` = number of readable words
+__device__ __forceinline__ uint32_t bit_window(const uint32_t *w, int start, int n, int limit) {
+    const int i = start >> 5, sh = start & 31;
+    const uint32_t lo = w[i];
+    const uint32_t hi = (i + 1 < limit) ? w[i + 1] : 0u;
+    const uint32_t v = (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh);
+    return n >= 32 ? v : (v & ((1u << n) - 1u));
+}
+
+// byte mask -> bit mask (thread per word) and back (thread per voxel)
+__global__ void __launch_bounds__(256)
+    cover_pack_kernel(const uint8_t *__restrict__ mask, uint32_t *__restrict__ mbits, const Geo G) {
+    const int XW = row_words(G);
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (t >= (long long)G.Z * G.Y * XW) return;
+    const int w = (int)(t % XW);
+    const long long row = t / XW;
+    uint32_t v = 0;
+    for (int i = 0; i < 32; ++i) {
+        const int x = w * 32 + i;
+        if (x < G.X && mask[row * G.X + x] != 0) v |= 1u << i;
+    }
+    mbits[t] = v;
+}
+__global__ void __launch_bounds__(256)
+    cover_unpack_kernel(const uint32_t *__restrict__ mbits, uint8_t *__restrict__ mask, const Geo G) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    const int x = (int)(v % G.X);
+    const long long row = v / G.X;
+    // keep the caller's byte values where the bit survived
+    if (!((mbits[row * row_words(G) + (x >> 5)] >> (x & 31)) & 1u)) mask[v] = 0;
+}
+
+// state[k] == 0: undecided.  Enter every undecided patch into the rank volume.
+__global__ void __launch_bounds__(256)
+    cover_init_kernel(const long long *__restrict__ lin, const int32_t *__restrict__ state, int n,
+                      int32_t *__restrict__ rank_vol) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && state[k] == 0) rank_vol[lin[k]] = k;
+}
+
+// Thread per voxel: an undecided patch centred here whose neighbourhood changed is recounted
+// (per row of the window: mask bits AND patch bits, popcount) and rejected when it can cover
+// <= pix_th voxels.  Consumes the dirty marks; flags whether any patch is still undecided.
+__global__ void __launch_bounds__(256)
+    cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
+                       uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
+                       int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive, const Geo G) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool in = v < G.V;
+    const int k = in ? rank_vol[v] : RANK_NONE;
+    bool alive = k != RANK_NONE;
+    const bool marked = in && dirty[v] != 0;
+    if (marked) dirty[v] = 0;
+    if (alive && marked) {
+        const int words = (G.C + 31) / 32, XW = row_words(G);
+        int cz, cy, cx;
+        centre_of(G, v, cz, cy, cx);
+        const uint32_t *b = bits + (long long)k * words;
+        const int start = cx - G.rx, wi = start >> 5, sh = start & 31;
+        const bool two = sh + G.px > 32;
+        const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
+        // sliding 64-bit window over the patch's bit string
+        unsigned long long win = b[0] | ((unsigned long long)(words > 1 ? b[1] : 0u) << 32);
+        int have = 64, next = 2, hits = 0;
+        // only "more than pix_th" matters: stop at the first plane of rows that settles it
+        // (with pix_th = 0 a surviving patch is usually done after the first plane)
+        for (int dz = 0; dz < G.pz && hits <= pix_th; ++dz) {
+            const uint32_t *row = mbits + ((long long)(cz + dz - G.rz) * G.Y + (cy - G.ry)) * XW + wi;
+            for (int dy = 0; dy < G.py; ++dy, row += XW) {
+                unsigned long long mw = row[0];
+                if (two) mw |= (unsigned long long)row[1] << 32;
+                hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                win >>= G.px;
+                have -= G.px;
+                if (have <= 32) {
+                    win |= (unsigned long long)(next < words ? b[next] : 0u) << have;
+                    ++next;
+                    have += 32;
+                }
+            }
+        }
+        if (hits <= pix_th) {
+            alive = false;
+            state[k] = 2;
+            rank_vol[v] = RANK_NONE;
+        }
+    }
+    // "is any patch still undecided": a plain store of the same value from every wave that
+    // has one (same-address atomics from ~V/64 waves would dominate the kernel)
+    if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+}
+
+// 1-d running minimum of width 2*radius+1 along one axis (stride in elements, n along axis)
+__global__ void __launch_bounds__(256)
+    cover_minfilter_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                           const long long V, const int n, const long long stride, const int radius) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int pos = (int)((v / stride) % n);
+    int32_t m = RANK_NONE;
+    for (int d = -radius; d <= radius; ++d) {
+        const int q = pos + d;
+        if (q >= 0 && q < n) m = min(m, in[v + (long long)d * stride]);
+    }
+    out[v] = m;
+}
+
+// Thread per voxel: the best ranked undecided patch of its neighbourhood selects itself; its
+// wave clears the voxels (lane per window row) and marks the centres whose counts may have
+// changed.  Selected patches never share a voxel, but they may share a mask word.
+__global__ void __launch_bounds__(256)
+    cover_select_kernel(uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
+                        const int32_t *__restrict__ nbr_min, int32_t *__restrict__ state,
+                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
+                        uint8_t *__restrict__ dirty, const Geo G) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = v < G.V ? rank_vol[v] : RANK_NONE;
+    unsigned long long todo = __ballot(k != RANK_NONE && nbr_min[v] == k);
+    const int words = (G.C + 31) / 32, XW = row_words(G);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int kk = __shfl(k, src);
+        const long long cc = v - lane + src;
+        int cz, cy, cx;
+        centre_of(G, cc, cz, cy, cx);
+        const uint32_t *b = bits + (long long)kk * words;
+        const int start = cx - G.rx, sh = start & 31;
+        // window bits whose voxel is an interior x position
+        uint32_t xin = 0;
+        for (int i = 0; i < G.px; ++i)
+            if (start + i >= G.rx && start + i < G.X - G.rx) xin |= 1u << i;
+        int cleared = 0;
+        for (int r = lane; r < G.pz * G.py; r += 64) {
+            const int z = cz + r / G.py - G.rz, y = cy + r % G.py - G.ry;
+            uint32_t *row = mbits + ((long long)z * G.Y + y) * XW;
+            const uint32_t cl = bit_window(row, start, G.px, XW) & bit_window(b, r * G.px, G.px, words);
+            if (cl) {
+                atomicAnd(row + (start >> 5), ~(cl << sh));
+                if (sh && (cl >> (32 - sh))) atomicAnd(row + (start >> 5) + 1, ~(cl >> (32 - sh)));
+                if (z >= G.rz && z < G.Z - G.rz && y >= G.ry && y < G.Y - G.ry) cleared += __popc(cl & xin);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) cleared += __shfl_xor(cleared, o);
+        // every centre within p-1 of this one has a window that overlaps the cleared voxels
+        const int z0 = max(cz - (G.pz - 1), 0), z1 = min(cz + G.pz - 1, G.Z - 1);
+        const int y0 = max(cy - (G.py - 1), 0), y1 = min(cy + G.py - 1, G.Y - 1);
+        const int x0 = max(cx - (G.px - 1), 0), x1 = min(cx + G.px - 1, G.X - 1);
+        const int ny = y1 - y0 + 1, nx = x1 - x0 + 1;
+        const int rows = (z1 - z0 + 1) * ny;
+        for (int row = lane; row < rows; row += 64) {
+            uint8_t *d = dirty + vox(G, z0 + row / ny, y0 + row % ny, x0);
+            for (int x = 0; x < nx; ++x) d[x] = 1;
+        }
+        if (lane == src) {
+            state[kk] = 1;
+            rank_vol[cc] = RANK_NONE;
+            cleared_interior[kk] = cleared;
+        }
+    }
+}
+
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+size_t cover_workspace_bytes(long long n, const Geo &G) {
+    (void)n;
+    return 3 * up256((size_t)G.V * 4) + up256((size_t)G.V) +
+           up256((size_t)G.Z * G.Y * row_words(G) * 4) + 256;
+}
+
+static CoverWork carve(void *work, const Geo &G) {
+    CoverWork W;
+    char *p = (char *)work;
+    W.rank_vol = (int32_t *)p; p += up256((size_t)G.V * 4);
+    W.nbr_min = (int32_t *)p;  p += up256((size_t)G.V * 4);
+    W.tmp = (int32_t *)p;      p += up256((size_t)G.V * 4);
+    W.dirty = (uint8_t *)p;    p += up256((size_t)G.V);
+    W.mbits = (uint32_t *)p;   p += up256((size_t)G.Z * G.Y * row_words(G) * 4);
+    W.counters = (int32_t *)p;
+    return W;
+}
+
+// One pass of the cover loop without the stop rule.  Returns the number of rounds in *rounds.
+hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
+                          int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
+                          hipStream_t s, int *rounds) {
+    *rounds = 0;
+    if (n <= 0) return hipSuccess;
+    CoverWork W = carve(work, G);
+    hipError_t e;
+    if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;   // count everything once
+    if ((e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
+    const long long n_words = (long long)G.Z * G.Y * row_words(G);
+    cover_pack_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(mask, W.mbits, G);
+    cover_init_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(lin, state, (int)n, W.rank_vol);
+    int32_t n_alive = 1;
+    while (n_alive > 0) {
+        if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
+        for (int r = 0; r < COVER_BATCH; ++r) {
+            cover_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
+                                                       W.counters + r, G);
+            // x, then y, then z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
+            cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.rank_vol, W.nbr_min, G.V, G.X, 1, G.px - 1);
+            cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.nbr_min, W.tmp, G.V, G.Y, G.X, G.py - 1);
+            cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.tmp, W.nbr_min, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+            cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
+                                                        W.dirty, G);
+        }
+        *rounds += COVER_BATCH;
+        // "any patch undecided" at the start of the batch's last round; if none, that round
+        // was a no-op and nothing is left
+        if ((e = hipMemcpyAsync(&n_alive, W.counters + COVER_BATCH - 1, 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
+            return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    cover_unpack_kernel<<<vgrid, block, 0, s>>>(W.mbits, mask, G);
+    return hipGetLastError();
+}
+
+}  // namespace ppp

@@ -42,4 +42,9 @@ hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t s
                         float lo, float noise, unsigned long long voxel_offset, const Geo &G,
                         hipStream_t s);
 
+size_t cover_workspace_bytes(long long n, const Geo &G);
+hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
+                          int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
+                          hipStream_t s, int *rounds);
+
 }  // namespace ppp

@@ -1,12 +1,14 @@
 """Steps 3 and 4: greedy foreground cover and set-cover thinning
 (reference: PatchPerPix/vote_instances/foreground_cover.py).
 
-Host stages, as in the reference, but the per-patch work runs natively
-(ppp_host_cover_pass / ppp_host_thin_cover) on bit masks ``pred[:, c] > fc_threshold`` that
-the device packs (ppp_patch_bits), chunk by chunk, so the (C,Z,Y,X) prediction never leaves
-the GPU.
+The greedy cover runs on the device as an exact priority-parallel algorithm
+(ppp_cover_count / _ready / _select, see csrc/ppp_cover.hip); ``PPP_COVER=host`` selects the
+sequential native host loop (ppp_host_cover_pass) instead, which is also what the thinning
+step uses.  Both work on bit masks ``pred[:, c] > fc_threshold`` that the device packs
+(ppp_patch_bits), so the (C,Z,Y,X) prediction never leaves the GPU.
 """
 import logging
+import os
 
 import numpy as np
 
@@ -33,6 +35,11 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
             raise NotImplementedError("%s is not supported" % opt)
     ranked = PatchList.from_any(ranked_patches_list)
     P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
+    # the device form packs a window row into one 32-bit word; wider patches (none of the
+    # reference's configurations) take the sequential native loop
+    if os.environ.get("PPP_COVER", "device") != "host" and int(patchshape[2]) <= 32:
+        return _cover_on_device(overlap_mask, mask_to_cover, patchshape, ranked, radslice,
+                                pred_affs, P, silent, **kwargs)
     running, _owner = backend.padded_mask(mask_to_cover)
     overlap = np.ascontiguousarray(np.asarray(overlap_mask) > 0).astype(np.uint8)
     selected = np.zeros(len(ranked), dtype=np.uint8)
@@ -62,6 +69,71 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
         if remaining < 1:
             break
     sel = ranked[np.flatnonzero(selected)]
+    if len(sel) and not silent:
+        logger.info("num patches to cover foreground: %s best score: %s, worst score: %s, "
+                    "uncovered: %s", len(sel), sel.scores[0], sel.scores[-1], remaining)
+    return sel, len(sel)
+
+
+def _pix_thresholds(patchshape, kwargs):
+    if kwargs["select_patches_for_sparse_data"]:
+        return [0]
+    mid = int(np.prod(patchshape) / 2)
+    return [t for t in [500, 100, 50, 10, 0] if t < mid]
+
+
+def _cover_on_device(overlap_mask, mask_to_cover, patchshape, ranked, radslice, pred_affs, P,
+                     silent, **kwargs):
+    """Same result as the sequential loop (see csrc/ppp_cover.hip for the argument)."""
+    import torch
+    dev = pred_affs.device
+    n = len(ranked)
+    if n == 0:
+        return ranked, 0
+    mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
+                            .astype(np.uint8)).to(dev)
+    lin_h = ranked.lin(mask.shape)
+    lin = torch.from_numpy(lin_h).to(dev)
+    coords = torch.from_numpy(ranked.coords).to(dev)
+    bits = backend.patch_bits(pred_affs, coords, kwargs["fc_threshold"], P)
+    # patches that never take part: centre on an overlap voxel (foreground_cover.py:140-141),
+    # and everything from the first score below score_threshold on (the pass breaks there)
+    never = torch.zeros(n, dtype=torch.bool, device=dev)
+    ov = np.asarray(overlap_mask)
+    if ov.any():
+        never |= torch.from_numpy(np.ascontiguousarray(ov.reshape(-1)[lin_h] > 0)).to(dev)
+    thr = kwargs.get("score_threshold", False)
+    if isinstance(thr, float):
+        below = np.flatnonzero(ranked.scores.astype(np.float64) < thr)
+        if len(below):
+            never[int(below[0]):] = True
+    interior = tuple(radslice)
+    remaining = int(torch.count_nonzero(mask[interior]).item())
+    selected = torch.zeros(n, dtype=torch.bool, device=dev)
+    total_rounds = 0
+    for pix_th in _pix_thresholds(patchshape, kwargs):
+        if remaining <= 0:
+            break
+        if not silent:
+            logger.info("compute foreground cover, threshold %s", pix_th)
+        state = torch.where(selected, 1, torch.where(never, 2, 0)).to(torch.int32)
+        cleared, rounds = backend.cover_pass_device(mask, bits, lin, state, pix_th, P)
+        total_rounds += rounds
+        new = (state == 1) & ~selected
+        idx = torch.nonzero(new).flatten()                 # rank order
+        left = remaining - torch.cumsum(cleared[idx].long(), 0)
+        done = torch.nonzero(left <= 0).flatten()
+        if done.numel():
+            # the sequential loop ends right after the patch that empties the interior
+            idx = idx[:int(done[0].item()) + 1]
+            remaining = 0
+        else:
+            remaining = int(left[-1].item()) if idx.numel() else remaining
+        selected[idx] = True
+        if remaining < 1:
+            break
+    backend.note("cover_rounds", total_rounds)
+    sel = ranked[np.flatnonzero(selected.cpu().numpy())]
     if len(sel) and not silent:
         logger.info("num patches to cover foreground: %s best score: %s, worst score: %s, "
                     "uncovered: %s", len(sel), sel.scores[0], sel.scores[-1], remaining)

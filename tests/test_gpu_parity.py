@@ -286,3 +286,65 @@ def test_large_volume_consistency(torch_cuda):
                                   **dict(kw, _n_slabs=3))
     assert whole.max() > 50
     assert np.array_equal(whole, tiled)
+
+
+def _cover_inputs(torch, pred_host, foreground, numinst, ps, kw):
+    """ranked list + mask exactly as to_instance_seg builds them."""
+    from patchperpix_amd import backend
+    from patchperpix_amd.vote_instances import ranked_patches as rp
+    P = backend.make_params(pred_host.shape[1:], ps, **kw)
+    pred = _dev(torch, pred_host.astype(np.float32))
+    overlap = 1 * (numinst > 1)
+    ov = _dev(torch, (overlap > 0).astype(np.uint8)) if P.use_overlap else None
+    cons = backend.consensus(pred, ov, P)
+    score = backend.rank_patches(pred, cons, ov, P)
+    rad = [p // 2 for p in ps]
+    radslice = tuple(slice(r, s - r) for r, s in zip(rad, pred_host.shape[1:]))
+    fg = foreground.astype(bool)
+    ranked = rp.rank_patches_by_score(None, score, foreground=fg, patchshape=ps)
+    mask = fg.copy()
+    mask[overlap > 0] = 0
+    return pred, overlap, mask, ranked, radslice, rad
+
+
+def test_device_cover_matches_reference_goldens(golden, torch_cuda, monkeypatch):
+    from patchperpix_amd.vote_instances import foreground_cover as fc
+    g = golden
+    if not g.has("cover_coords"):
+        pytest.skip("early-out case")
+    pred, overlap, mask, ranked, radslice, rad = _cover_inputs(
+        torch_cuda, g.pred, g.foreground, g.numinst, g.patchshape, g.kw)
+    assert np.array_equal(ranked.coords, g["ranked_coords"])
+    for mode in ("device", "host"):
+        monkeypatch.setenv("PPP_COVER", mode)
+        sel, n = fc.computeForegroundCover(overlap, mask.copy(), g.patchshape, ranked, radslice,
+                                           pred, rad, None, None, silent=True, **g.kw)
+        assert np.array_equal(sel.coords, g["cover_coords"]), mode
+
+
+@pytest.mark.parametrize("variant", ["sparse", "passes", "score_threshold", "p7"])
+def test_device_cover_matches_sequential_loop(variant, torch_cuda, monkeypatch):
+    """Larger volumes and every rule of the loop: several pixel-threshold passes, overlap
+    centres, the score threshold break and the stop rule."""
+    from patchperpix_amd import synth
+    from patchperpix_amd.vote_instances import foreground_cover as fc
+    from tests_flags import FLYLIGHT
+    kw = dict(FLYLIGHT)
+    shape, ps, skw = (40, 48, 56), (5, 5, 5), dict(seed=61, cell=[9, 10, 11], overlap_frac=0.02)
+    if variant == "passes":
+        kw["select_patches_for_sparse_data"] = False
+    elif variant == "score_threshold":
+        kw["score_threshold"] = 0.55
+    elif variant == "p7":
+        shape, ps, skw = (30, 44, 52), (7, 7, 7), dict(seed=62, cell=[12, 12, 12], noise=0.25)
+    c = synth.make_case(shape, ps, **skw)
+    pred, overlap, mask, ranked, radslice, rad = _cover_inputs(
+        torch_cuda, c["pred"], c["foreground"], c["numinst"], ps, kw)
+    out = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("PPP_COVER", mode)
+        sel, n = fc.computeForegroundCover(overlap, mask.copy(), ps, ranked, radslice,
+                                           pred, rad, None, None, silent=True, **kw)
+        out[mode] = sel.coords
+    assert len(out["host"]) > 20
+    assert np.array_equal(out["device"], out["host"])
