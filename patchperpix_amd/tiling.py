@@ -114,6 +114,18 @@ class DeviceOps:
     def rank_order(self, score_dev, score_host, foreground, ps):
         return backend.rank_order_device(score_dev, foreground, ps)
 
+    def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw):
+        """Greedy cover of the global mask (replicated: every rank runs the same rounds on
+        its own device).  Returns a bool array over the ranked list."""
+        from .vote_instances import foreground_cover as fc
+        torch = self.torch
+        mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
+                                .astype(np.uint8)).to(self.device)
+        sel, _ = fc.greedy_cover_device(mask, bits, torch.from_numpy(lin).to(self.device),
+                                        torch.from_numpy(never).to(self.device), pix_ths,
+                                        radslice, P)
+        return sel.cpu().numpy()
+
     def label_components(self, rows, aff, nodes, P):
         return backend.label_components(rows, aff, nodes, P)
 
@@ -210,7 +222,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                                kw["fc_threshold"], params())
             bits[torch.from_numpy(mine).to(dev)] = b
         comm.all_reduce_sum(bits)
-        return bits.cpu().numpy().view(np.uint32)
+        return bits
 
     with backend.host_timer("sort"):
         lin, rscores = ops.rank_order(score_dev, scores, foreground, ps)
@@ -222,32 +234,16 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         sel_coords = coords
     else:
         with backend.host_timer("s3_cover"):
-            running, _owner = backend.padded_mask(mask_to_cover)
-            ov_host = np.ascontiguousarray(overlap_mask > 0).astype(np.uint8)
-            selected = np.zeros(len(lin), dtype=np.uint8)
-            pix_ths = [0] if kw["select_patches_for_sparse_data"] else \
-                [t for t in [500, 100, 50, 10, 0] if t < int(np.prod(ps) / 2)]
-            thr = kw.get("score_threshold", False)
-            thr = thr if isinstance(thr, float) else None
-            remaining = int(np.count_nonzero(running[radslice]))
-            chunk = int(kw.get("_cover_chunk", 1 << 20))
-            for pix_th in pix_ths:
-                for s in range(0, len(lin), chunk):
-                    if remaining <= 0:
-                        break
-                    e = min(len(lin), s + chunk)
-                    bits = gathered_bits(coords[s:e], kw["fc_threshold"])
-                    remaining, stopped = backend.host_cover_pass(
-                        running, ov_host, ps, lin[s:e], rscores[s:e], bits, pix_th, thr,
-                        selected[s:e], remaining)
-                    if stopped:
-                        break
-                if remaining < 1:
-                    break
-            sel_coords = coords[selected.astype(bool)]
+            from .vote_instances import foreground_cover as fc
+            bits = gathered_bits(coords, kw["fc_threshold"])
+            never = fc.never_selected(overlap_mask, lin, rscores, kw.get("score_threshold", False))
+            selected = ops.greedy_cover(mask_to_cover, bits, lin, rscores, never,
+                                        fc._pix_thresholds(ps, kw), radslice, Pg, kw)
+            del bits
+            sel_coords = coords[selected]
     if not kw.get("skipThinCover") and len(sel_coords) > 0:
         with backend.host_timer("s4_thin"):
-            bits = gathered_bits(sel_coords, kw["fc_threshold"])
+            bits = gathered_bits(sel_coords, kw["fc_threshold"]).cpu().numpy().view(np.uint32)
             sel_lin = (sel_coords[:, 0].astype(np.int64) * Y + sel_coords[:, 1]) * X + sel_coords[:, 2]
             keep = backend.host_thin_cover(np.ascontiguousarray(mask_to_cover).astype(np.uint8),
                                            ps, np.ascontiguousarray(sel_lin), bits)

@@ -82,57 +82,71 @@ def _pix_thresholds(patchshape, kwargs):
     return [t for t in [500, 100, 50, 10, 0] if t < mid]
 
 
-def _cover_on_device(overlap_mask, mask_to_cover, patchshape, ranked, radslice, pred_affs, P,
-                     silent, **kwargs):
-    """Same result as the sequential loop (see csrc/ppp_cover.hip for the argument)."""
+def greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P, silent=True):
+    """All passes of the cover on the device.  mask uint8 (Z,Y,X) device tensor (cleared in
+    place), bits int32 [n, words] patch bits in rank order, lin int64 [n] centres, never bool
+    [n] patches that do not take part.  Returns (selected bool [n] device, uncovered)."""
     import torch
-    dev = pred_affs.device
-    n = len(ranked)
-    if n == 0:
-        return ranked, 0
-    mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
-                            .astype(np.uint8)).to(dev)
-    lin_h = ranked.lin(mask.shape)
-    lin = torch.from_numpy(lin_h).to(dev)
-    coords = torch.from_numpy(ranked.coords).to(dev)
-    bits = backend.patch_bits(pred_affs, coords, kwargs["fc_threshold"], P)
-    # patches that never take part: centre on an overlap voxel (foreground_cover.py:140-141),
-    # and everything from the first score below score_threshold on (the pass breaks there)
-    never = torch.zeros(n, dtype=torch.bool, device=dev)
-    ov = np.asarray(overlap_mask)
-    if ov.any():
-        never |= torch.from_numpy(np.ascontiguousarray(ov.reshape(-1)[lin_h] > 0)).to(dev)
-    thr = kwargs.get("score_threshold", False)
-    if isinstance(thr, float):
-        below = np.flatnonzero(ranked.scores.astype(np.float64) < thr)
-        if len(below):
-            never[int(below[0]):] = True
-    interior = tuple(radslice)
-    remaining = int(torch.count_nonzero(mask[interior]).item())
-    selected = torch.zeros(n, dtype=torch.bool, device=dev)
+    n = int(lin.numel())
+    remaining = int(torch.count_nonzero(mask[tuple(radslice)]).item())
+    selected = torch.zeros(n, dtype=torch.bool, device=mask.device)
     total_rounds = 0
-    for pix_th in _pix_thresholds(patchshape, kwargs):
+    for pix_th in pix_ths:
         if remaining <= 0:
             break
         if not silent:
             logger.info("compute foreground cover, threshold %s", pix_th)
+        # every pass restarts at rank 0 (the reference passes rpidx by value)
         state = torch.where(selected, 1, torch.where(never, 2, 0)).to(torch.int32)
         cleared, rounds = backend.cover_pass_device(mask, bits, lin, state, pix_th, P)
         total_rounds += rounds
-        new = (state == 1) & ~selected
-        idx = torch.nonzero(new).flatten()                 # rank order
+        idx = torch.nonzero((state == 1) & ~selected).flatten()       # rank order
         left = remaining - torch.cumsum(cleared[idx].long(), 0)
         done = torch.nonzero(left <= 0).flatten()
         if done.numel():
             # the sequential loop ends right after the patch that empties the interior
             idx = idx[:int(done[0].item()) + 1]
             remaining = 0
-        else:
-            remaining = int(left[-1].item()) if idx.numel() else remaining
+        elif idx.numel():
+            remaining = int(left[-1].item())
         selected[idx] = True
         if remaining < 1:
             break
     backend.note("cover_rounds", total_rounds)
+    return selected, remaining
+
+
+def never_selected(overlap_mask, lin_h, scores, score_threshold):
+    """Ranked patches the loop never looks at: centre on an overlap voxel
+    (foreground_cover.py:140-141), and everything from the first score below score_threshold
+    on (the pass breaks there, foreground_cover.py:136-138)."""
+    never = np.zeros(len(lin_h), dtype=bool)
+    ov = np.asarray(overlap_mask)
+    if ov.any():
+        never |= ov.reshape(-1)[lin_h] > 0
+    if isinstance(score_threshold, float):
+        below = np.flatnonzero(np.asarray(scores, dtype=np.float64) < score_threshold)
+        if len(below):
+            never[int(below[0]):] = True
+    return never
+
+
+def _cover_on_device(overlap_mask, mask_to_cover, patchshape, ranked, radslice, pred_affs, P,
+                     silent, **kwargs):
+    """Same result as the sequential loop (see csrc/ppp_cover.hip for the argument)."""
+    import torch
+    dev = pred_affs.device
+    if len(ranked) == 0:
+        return ranked, 0
+    mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
+                            .astype(np.uint8)).to(dev)
+    lin_h = ranked.lin(mask.shape)
+    bits = backend.patch_bits(pred_affs, torch.from_numpy(ranked.coords).to(dev),
+                              kwargs["fc_threshold"], P)
+    never = never_selected(overlap_mask, lin_h, ranked.scores, kwargs.get("score_threshold", False))
+    selected, remaining = greedy_cover_device(
+        mask, bits, torch.from_numpy(lin_h).to(dev), torch.from_numpy(never).to(dev),
+        _pix_thresholds(patchshape, kwargs), radslice, P, silent)
     sel = ranked[np.flatnonzero(selected.cpu().numpy())]
     if len(sel) and not silent:
         logger.info("num patches to cover foreground: %s best score: %s, worst score: %s, "

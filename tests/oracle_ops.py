@@ -100,3 +100,30 @@ class OracleOps:
                 if 0 <= z < a.shape[0] and 0 <= y < a.shape[1] and 0 <= x < a.shape[2]:
                     a[z, y, x] = max(a[z, y, x], lab)
         return inst
+
+    def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw):
+        """The sequential loop (native host code of the library, pinned to the reference's
+        goldens by tests/test_abi_and_host.py)."""
+        running, _owner = backend.padded_mask(mask_to_cover)
+        selected = np.zeros(len(lin), dtype=np.uint8)
+        b = bits.numpy().view(np.uint32)
+        # `never` as the loop sees it: overlap centres are skipped, the score threshold breaks
+        ov = np.zeros(running.size, dtype=np.uint8)
+        thr = kw.get("score_threshold", False)
+        thr = thr if isinstance(thr, float) else None
+        cut = len(lin)
+        if thr is not None:
+            below = np.flatnonzero(np.asarray(scores, dtype=np.float64) < thr)
+            cut = int(below[0]) if len(below) else cut
+        ov[lin[never[:cut].nonzero()[0]]] = 1
+        remaining = int(np.count_nonzero(running[radslice]))
+        for pix_th in pix_ths:
+            if remaining <= 0:
+                break
+            remaining, stopped = backend.host_cover_pass(
+                running, ov.reshape(running.shape), [P.pz, P.py, P.px], lin, scores, b, pix_th,
+                thr, selected, remaining)
+            if remaining < 1:
+                break
+        return selected.astype(bool)
+
