@@ -145,8 +145,10 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
  *   d_order            row ids, rows of one patch A contiguous (any order inside a group; rows
  *                      with similar B - A next to each other diverge least)
  *   d_group_start      int64 [n_groups + 1], positions in d_order where the groups start
- *   d_chunk_offsets    int64 [n_groups + 1], exclusive scan of ceil(group size / 256);
- *                      n_blocks = d_chunk_offsets[n_groups]                                  */
+ *   d_chunk_offsets    int64 [n_groups + 1], exclusive scan of ceil(group size / chunk) with
+ *                      chunk = ppp_patch_graph_by_patch_chunk(p) (rows per workgroup, 0 if
+ *                      the patch shape is unsupported); n_blocks = d_chunk_offsets[n_groups] */
+int32_t ppp_patch_graph_by_patch_chunk(const ppp_params *p);
 int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
                              const uint32_t *d_pairs, const uint32_t *d_order,
                              const int64_t *d_group_start, const int64_t *d_chunk_offsets,

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "ppp_patch_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p,
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_graph_by_patch_chunk": (ctypes.c_int32, [ctypes.POINTER(Params)]),
     "ppp_cover_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.POINTER(Params)]),
     "ppp_cover_pass": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
@@ -392,7 +393,10 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     del lin
     zero = torch.zeros((1,), dtype=torch.int64, device=pred.device)
     group_start = torch.cat([zero, torch.cumsum(counts, 0)])
-    chunk_offsets = torch.cat([zero, torch.cumsum((counts + 255) // 256, 0)])
+    chunk = int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv)))
+    if chunk <= 0:
+        raise RuntimeError("libppp_mi355x: no per-patch kernel for this patch shape")
+    chunk_offsets = torch.cat([zero, torch.cumsum((counts + chunk - 1) // chunk, 0)])
     n_groups = int(counts.shape[0])
     n_blocks = int(chunk_offsets[-1].item())
     order32 = order.to(torch.int32)
@@ -407,13 +411,15 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
 
 
 def patch_graph_auto(pred, cons_compact, pairs, P):
-    """S5 from a COMPACT consensus: re-layout to voxel-major, then the pair-per-lane kernel with
-    offset-grouped lanes.  PPP_PATCH_GRAPH=patch selects the workgroup-per-patch kernel instead
-    (same bits; measured slower on dense volumes: it trades the HBM traffic of the gathers --
-    5.4 TB -> 0.3 TB on the 140^3 benchmark -- for divergent per-lane control flow, 26 % lane
-    utilisation, 2.1 s vs 1.6 s)."""
+    """S5 from a COMPACT consensus: re-layout to voxel-major, then the workgroup-per-patch
+    kernel (consensus rows staged once per patch in LDS; 0.3 TB instead of 5.4 TB of HBM reads
+    on the 140^3 benchmark).  PPP_PATCH_GRAPH=pairs selects the pair-per-lane gather kernel
+    with offset-grouped lanes (same bits), which is also what patch shapes without a per-patch
+    specialisation use."""
     vm, Pv = cons_to_voxel_major(cons_compact, P)
-    if os.environ.get("PPP_PATCH_GRAPH", "pairs") == "patch" and P.px in (3, 5, 7, 9):
+    if os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and \
+            int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv))) > 0 and \
+            max(P.pz, P.py) <= P.px:
         return patch_graph_by_patch(pred, vm, pairs, Pv)
     return patch_graph(pred, vm, pairs, Pv, order=pair_order(pairs, P))
 

@@ -193,6 +193,12 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph");
 }
 
+int32_t ppp_patch_graph_by_patch_chunk(const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return ppp::patch_graph_pa_chunk(G);
+}
+
 int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
                              const uint32_t *d_pairs, const uint32_t *d_order,
                              const int64_t *d_group_start, const int64_t *d_chunk_offsets,

@@ -15,6 +15,7 @@ hipError_t launch_rank_v2(const void *pred, int dtype, const float *cons, const 
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
                               const uint32_t *pairs, const uint32_t *order, uint64_t n,
                               float *aff, const Geo &G, hipStream_t s);
+int patch_graph_pa_chunk(const Geo &G);
 hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, const uint32_t *rows,
                                  const uint32_t *order, const long long *group_start,
                                  const long long *chunk_offsets, int n_groups, long long n_blocks,
