@@ -26,9 +26,19 @@
 
 namespace ppp {
 
+#ifdef PA_STATS
+__device__ unsigned long long pa_stats[8];   // steps, planes, rows, useful slots, lcg rows, live lanes*steps
+#define PA_STAT(i, v) st_##i += (v)
+#else
+#define PA_STAT(i, v)
+#endif
+
 // threads (= pair rows) per workgroup: the [words][threads] foreground bits of the B patches and
 // two row buffers must fit 64 KB of LDS
-template <int PX> struct PaCfg { static constexpr int THREADS = PX <= 7 ? 512 : 256; };
+template <int PX> struct PaCfg {
+    static constexpr int THREADS = 256;
+    static constexpr int MIN_WAVES = PX <= 7 ? 6 : 2;   // waves per SIMD the register budget must allow
+};
 static constexpr int PA_PAD = 16;      // floats of slack either side of the staged row
 
 // bits b in [0, n) with lo <= b <= hi
@@ -63,7 +73,7 @@ __device__ __forceinline__ AxisMasks axis_masks(int dd, int a, int p) {
 }
 
 template <typename T, int PX>
-__global__ void __launch_bounds__(PaCfg<PX>::THREADS)
+__global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     patch_graph_pa_kernel(const T *__restrict__ pred, const float *__restrict__ S,
                           const uint32_t *__restrict__ rows, const uint32_t *__restrict__ order,
                           const long long *__restrict__ group_start,
@@ -175,6 +185,9 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS)
     };
     float acc = 0.0f;
     unsigned fg_cnt = 0;
+#ifdef PA_STATS
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0;
+#endif
 
     // ---- stage the first row
     float st[NST];
@@ -188,8 +201,30 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS)
     }
     __syncthreads();
 
+    // ---- The range / intersection / stored conditions of a whole (y2o, x2o) candidate plane
+    // are evaluated at once as bit masks, bit (y2o - y_first) * PX + x2o, for chunks of RPC rows
+    // (one chunk unless PX = 9).  Per-axis masks are expanded once per pixel row / pixel: EY*
+    // repeat a y bit over the PX bits of its row, RX repeats the x mask in every row.
+    typedef unsigned long long u64;
+    constexpr uint32_t RM = (1u << PX) - 1u;
+    constexpr int RPC = 64 / PX;                         // candidate rows per 64-bit chunk
+    constexpr int NCH = (PX + RPC - 1) / RPC;            // chunks (the launcher checks py <= NCH * RPC)
+    auto expand_y = [&](uint32_t m, int c) -> u64 {
+        u64 e = 0;
+        for (int j = 0; j < RPC; ++j) e |= ((m >> (c * RPC + j)) & 1u) ? ((u64)RM << (PX * j)) : 0ull;
+        return e;
+    };
+    auto repeat_x = [&](uint32_t m) -> u64 {
+        u64 e = 0;
+#pragma unroll
+        for (int j = 0; j < RPC; ++j) e |= (u64)m << (PX * j);
+        return e;
+    };
     int prev_z1o = -1, prev_y1o = -1;
     AxisMasks mz = axis_masks(dz, 0, G.pz), my = axis_masks(dy, 0, G.py);
+    u64 EYf[NCH], EYbk[NCH], EYpos[NCH], EYzero[NCH], EYst[NCH], EYin[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) EYf[c] = EYbk[c] = EYpos[c] = EYzero[c] = EYst[c] = EYin[c] = 0ull;
     for (int k = 0; k < n_u; ++k) {
         const int r1 = ulist[k];
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
@@ -205,65 +240,103 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS)
             }
         }
         if (wave_live) {
-            if (z1o != prev_z1o) { mz = axis_masks(dz, z1o, G.pz); prev_z1o = z1o; prev_y1o = -1; }
-            if (y1o != prev_y1o) { my = axis_masks(dy, y1o, G.py); prev_y1o = y1o; }
+            PA_STAT(0, lane == 0 ? 1 : 0);
+            PA_STAT(5, live ? 1 : 0);
+            if (z1o != prev_z1o) { mz = axis_masks(dz, z1o, G.pz); prev_z1o = z1o; }
+            if (y1o != prev_y1o) {
+                my = axis_masks(dy, y1o, G.py);   // (bits >= py are clear: the masks stop at py)
+                prev_y1o = y1o;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    EYf[c] = expand_y(my.f, c); EYbk[c] = expand_y(my.bk, c); EYpos[c] = expand_y(my.pos, c);
+                    EYzero[c] = expand_y(my.zero, c); EYst[c] = expand_y(my.st, c); EYin[c] = expand_y(my.in, c);
+                }
+            }
             const AxisMasks mx = axis_masks(dx, x1o, PX);
             const bool in_b = abs(x1o - PX / 2 - dx) <= PX / 2 && abs(y1o - G.ry - dy) <= G.ry &&
                               abs(z1o - G.rz - dz) <= G.rz;
-            const uint32_t mx_nonneg = mx.pos | mx.zero;
+            const u64 RXf = repeat_x(mx.f), RXbk = repeat_x(mx.bk), RXst = repeat_x(mx.st),
+                      RXin = in_b ? repeat_x(mx.in) : 0ull, RXnn = repeat_x(mx.pos | mx.zero),
+                      RXzero = repeat_x(mx.zero);
             // union of the lanes' candidate ranges: -p <= d + b - a <= p
             const int z_lo = max(0, z1o - dz_hi - G.pz), z_hi = min(G.pz - 1, z1o - dz_lo + G.pz);
             const int y_lo = max(0, y1o - dy_hi - G.py), y_hi = min(G.py - 1, y1o - dy_lo + G.py);
             for (int z2o = z_lo; z2o <= z_hi; ++z2o) {
                 const uint32_t zb = 1u << z2o;
-                const int qz = mz.q0 + z2o;
                 const bool z_f = mz.f & zb, z_bk = mz.bk & zb, z_pos = mz.pos & zb, z_zero = mz.zero & zb,
                            z_st = mz.st & zb, z_in = mz.in & zb;
-                if (__ballot(z_f || z_bk) == 0ull) continue;
-                for (int y2o = y_lo; y2o <= y_hi; ++y2o) {
-                    const uint32_t yb = 1u << y2o;
-                    const int qy = my.q0 + y2o;
-                    // orientation: z1 before z2 in raster order <=> q >= 0 lexicographically
-                    const bool fwd_all = z_pos || (z_zero && (my.pos & yb));
-                    const bool fwd_x = z_zero && (my.zero & yb);
-                    const uint32_t m_fwd = fwd_all ? ~0u : (fwd_x ? mx_nonneg : 0u);
-                    const bool zy_f = z_f && (my.f & yb), zy_b = z_bk && (my.bk & yb);
-                    const uint32_t m_range = (zy_f ? (mx.f & m_fwd) : 0u) | (zy_b ? (mx.bk & ~m_fwd) : 0u);
-                    const uint32_t m_inter = (in_b && z_in && (my.in & yb)) ? mx.in : 0u;
-                    const bool row_st = z_st && (my.st & yb);
-                    uint32_t m_stored = row_st ? (mx.st & m_range) : 0u;
-                    if (fwd_x) m_stored &= ~mx.zero;                 // q == 0 is never stored
-                    if (__ballot((m_range | m_inter) != 0u) == 0ull) continue;
-                    // foreground bits of patch B on this candidate row
-                    const int b0 = (z2o * G.py + y2o) * PX, w0 = b0 >> 5, sh = b0 & 31;
-                    uint64_t f64 = fbw[w0 * PA_THREADS + tid];
-                    if (sh + PX > 32 && w0 + 1 < words) f64 |= (uint64_t)fbw[(w0 + 1) * PA_THREADS + tid] << 32;
-                    const uint32_t fb = (uint32_t)(f64 >> sh) & ((1u << PX) - 1u);
-                    // the PX consensus values of the row (lanes without a stored row read slot 0)
-                    // (mx.st != 0 bounds q0, so the PX reads stay inside the padded buffer)
-                    const float *rowq = cur + ((row_st && mx.st != 0u) ? Lc + (qz * G.wy + qy) * G.wx + mx.q0 : 0);
-                    float v[PX];
+                if (__ballot(z_f || z_bk || z_in) == 0ull) continue;
+                const int qz = mz.q0 + z2o;
 #pragma unroll
-                    for (int t = 0; t < PX; ++t) v[t] = rowq[t];
-                    uint32_t valid = fb;
-                    if (__ballot(m_inter != 0u) != 0ull) {
+                for (int c = 0; c < NCH; ++c) {
+                    const int c_first = c * RPC;                       // first row of the chunk
+                    const int c_rows = min(RPC, G.py - c_first);
+                    if (NCH > 1 && c_rows <= 0) break;
+                    const int ya = max(y_lo, c_first), yb = min(y_hi, c_first + c_rows - 1);
+                    if (ya > yb) continue;
+                    // forward orientation (pixel z1 before z2 in raster order <=> q >= 0
+                    // lexicographically) and the position of q == 0 (never stored)
+                    const u64 fwd = z_pos ? ~0ull : (z_zero ? (EYpos[c] | (EYzero[c] & RXnn)) : 0ull);
+                    const u64 range = (z_f ? (EYf[c] & RXf & fwd) : 0ull) | (z_bk ? (EYbk[c] & RXbk & ~fwd) : 0ull);
+                    const u64 inter = z_in ? (EYin[c] & RXin) : 0ull;
+                    u64 stored = z_st ? (EYst[c] & RXst & range) : 0ull;
+                    if (z_zero) stored &= ~(EYzero[c] & RXzero);
+                    if (__ballot((range | inter) != 0ull) == 0ull) continue;
+                    PA_STAT(1, lane == 0 ? 1 : 0);
+                    // foreground bits of patch B on these candidate rows
+                    u64 valid;
+                    {
+                        const int nb = c_rows * PX;
+                        const int o = (z2o * G.py + c_first) * PX, w0 = o >> 5, sh = o & 31;
+                        const uint32_t lo = fbw[w0 * PA_THREADS + tid];
+                        const uint32_t mi = w0 + 1 < words ? fbw[(w0 + 1) * PA_THREADS + tid] : 0u;
+                        const uint32_t hi = w0 + 2 < words ? fbw[(w0 + 2) * PA_THREADS + tid] : 0u;
+                        valid = ((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull);
+                        valid &= nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+                    }
+                    if (__ballot(inter != 0ull) != 0ull) {
                         // thinning inside the patch intersection: the LCG advances on every
-                        // foreground candidate, in candidate order
+                        // foreground candidate of the intersection, in candidate order
+                        for (int y2o = ya; y2o <= yb; ++y2o) {
+                            const int bp = PX * (y2o - c_first);
+                            const uint32_t hit_row = (uint32_t)((inter & valid) >> bp) & RM;
+                            if (__ballot(hit_row != 0u) == 0ull) continue;
+                            PA_STAT(4, lane == 0 ? 1 : 0);
+                            uint32_t drop = 0;
 #pragma unroll
-                        for (int t = 0; t < PX; ++t) {
-                            const uint32_t xb = 1u << t;
-                            const uint32_t nxt = rnd * 1103515245U;
-                            const float rnd_t = (float)nxt / 4294967296.0f;
-                            const bool hit = (m_inter & fb & xb) != 0u;
-                            rnd = hit ? nxt : rnd;
-                            // rnd_t > 0.2 (double)  <=>  rnd_t > largest float <= 0.2
-                            if (hit && rnd_t > 0.19999998807907104f) valid &= ~xb;
+                            for (int t = 0; t < PX; ++t) {
+                                const uint32_t xb = 1u << t;
+                                const uint32_t nxt = rnd * 1103515245U;
+                                const bool hit = (hit_row & xb) != 0u;
+                                rnd = hit ? nxt : rnd;
+                                // (float)nxt / 2^32 > 0.2 (compared in double)  <=>  nxt >= 858993441:
+                                // the conversion is monotone and 858993440 is the tie that rounds
+                                // down to 0.2f's predecessor * 2^32 (checked exhaustively around it)
+                                if (hit && nxt >= 858993441u) drop |= xb;
+                            }
+                            valid &= ~((u64)drop << bp);
                         }
                     }
-                    const uint32_t add = m_stored & valid;
+                    fg_cnt += __popcll(range & valid);
+                    const u64 add = stored & valid;
+                    if (__ballot(add != 0ull) == 0ull) continue;
+                    // this lane's offset into the staged row for candidate (y2o = 0, x2o = 0)
+                    const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + mx.q0;
+                    for (int y2o = ya; y2o <= yb; ++y2o) {
+                        const uint32_t rb = (uint32_t)(add >> (PX * (y2o - c_first))) & RM;
+                        if (__ballot(rb != 0u) == 0ull) continue;
+                        PA_STAT(2, lane == 0 ? 1 : 0);
+                        PA_STAT(3, __popc(rb));
+                        // lanes with nothing to add on this row may point anywhere: they read
+                        // slot 0 (one broadcast address; what they read is masked to zero)
+                        const float *rowq = cur + (rb != 0u ? idx0 + y2o * G.wx : 0);
 #pragma unroll
-                    for (int t = 0; t < PX; ++t) acc += ((add >> t) & 1u) ? v[t] : 0.0f;
-                    fg_cnt += __popc(m_range & valid);
+                        for (int t = 0; t < PX; ++t) {
+                            // acc += bit t of rb ? rowq[t] : 0.0f
+                            const int sel = ((int)(rb << (31 - t))) >> 31;
+                            acc += __int_as_float(__float_as_int(rowq[t]) & sel);
+                        }
+                    }
                 }
             }
         }
@@ -278,8 +351,19 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS)
         }
         __syncthreads();
     }
+#ifdef PA_STATS
+    atomicAdd(&pa_stats[0], st_0); atomicAdd(&pa_stats[1], st_1); atomicAdd(&pa_stats[2], st_2);
+    atomicAdd(&pa_stats[3], st_3); atomicAdd(&pa_stats[4], st_4); atomicAdd(&pa_stats[5], st_5);
+#endif
     if (live) aff[row_id] = G.norm_aff ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
 }
+
+#ifdef PA_STATS
+extern "C" void ppp_pa_stats(unsigned long long *out) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_stats), sizeof(pa_stats));
+}
+#endif
 
 int patch_graph_pa_chunk(const Geo &G) {
     switch (G.px) {
@@ -304,6 +388,8 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     // the per-thread staging registers are sized for a (2px-1)^3 row
     const int cube = (2 * G.px - 1) * (2 * G.px - 1) * (2 * G.px - 1);
     if (W > (cube + threads - 1) / threads * threads) return hipErrorNotSupported;
+    // candidate planes are handled as ceil(px / (64 / px)) 64-bit chunks of 64 / px rows
+    if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;
     const size_t lds = (size_t)(2 * WB + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3) + words * threads) * 4;
     if (lds > 64 * 1024 || n_blocks >= (1ll << 31)) return hipErrorNotSupported;
 #define PPP_PA_CASE(P)                                                                             \
