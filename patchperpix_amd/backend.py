@@ -382,10 +382,13 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
         return aff
     r = pairs.to(torch.int64)
     lin = (r[:, 0] * Pv.Y + r[:, 1]) * Pv.X + r[:, 2]
-    dkey = ((r[:, 3] - r[:, 0] + 2 * Pv.pz) * (4 * Pv.py + 1) + (r[:, 4] - r[:, 1] + 2 * Pv.py)) \
-        * (4 * Pv.px + 1) + (r[:, 5] - r[:, 2] + 2 * Pv.px)
-    del r
-    key = lin * (1 << 17) + dkey
+    dz, dy, dx = r[:, 3] - r[:, 0], r[:, 4] - r[:, 1], r[:, 5] - r[:, 2]
+    dkey = ((dz + 2 * Pv.pz) * (4 * Pv.py + 1) + (dy + 2 * Pv.py)) * (4 * Pv.px + 1) + (dx + 2 * Pv.px)
+    # rows whose two windows intersect (they alone run the LCG thinning) are kept together
+    apart = ((dz.abs() >= Pv.pz) | (dy.abs() >= Pv.py) | (dx.abs() >= Pv.px)).to(torch.int64)
+    del r, dz, dy, dx
+    key = lin * (1 << 18) + apart * (1 << 17) + dkey
+    del apart
     del dkey
     order = torch.argsort(key)
     del key

@@ -37,7 +37,7 @@ __device__ unsigned long long pa_stats[8];   // steps, planes, rows, useful slot
 // two row buffers must fit 64 KB of LDS
 template <int PX> struct PaCfg {
     static constexpr int THREADS = 256;
-    static constexpr int MIN_WAVES = PX <= 7 ? 6 : 2;   // waves per SIMD the register budget must allow
+    static constexpr int MIN_WAVES = PX <= 7 ? 5 : 2;   // waves per SIMD the register budget must allow
 };
 static constexpr int PA_PAD = 16;      // floats of slack either side of the staged row
 
