@@ -214,10 +214,12 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
         for (int j = 0; j < RPC; ++j) e |= ((m >> (c * RPC + j)) & 1u) ? ((u64)RM << (PX * j)) : 0ull;
         return e;
     };
+    // x mask repeated in every row, by doubling (rows beyond the chunk are harmless: every use
+    // is ANDed with an EY mask, which is clear there)
     auto repeat_x = [&](uint32_t m) -> u64 {
-        u64 e = 0;
+        u64 e = m;
 #pragma unroll
-        for (int j = 0; j < RPC; ++j) e |= (u64)m << (PX * j);
+        for (int n = 1; n < RPC; n *= 2) e |= e << (PX * n);
         return e;
     };
     int prev_z1o = -1, prev_y1o = -1;
