@@ -236,6 +236,10 @@ int ppp_patch_pairs_fill(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_
  * argsort of them is a good d_order for ppp_patch_graph                                    */
 int ppp_pair_sort_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
                        const ppp_params *p, void *stream);
+/* sort keys (int64) for ppp_patch_graph_by_patch: key >> 18 is the linear index of patch A (the
+ * group), the low bits order a group's rows (intersecting windows first, then by B - A)    */
+int ppp_pair_group_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
+                        const ppp_params *p, void *stream);
 
 /* --- host stages (host pointers; they are host code in the reference as well) ---------
  * ppp_host_rank_order: all_patches + rank_patches_by_score (vote_instances.py:276,286-287,

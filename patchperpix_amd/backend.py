@@ -103,6 +103,8 @@ _SIGNATURES = {
     "ppp_patch_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p,
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_pair_group_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                           ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_patch_graph_by_patch_chunk": (ctypes.c_int32, [ctypes.POINTER(Params)]),
     "ppp_cover_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.POINTER(Params)]),
     "ppp_cover_pass": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -338,15 +340,25 @@ def consensus(pred, overlap, P, want_count=False):
         shape = (2 * P.pz if P.pz > 1 else 1, 2 * P.py, 2 * P.px, P.Z, P.Y, P.X)
     else:
         shape = (int(L.ppp_cons_planes(ctypes.byref(P))),) + P.cons_box.shape()
-    if int(np.prod(shape)) * 4 > torch.cuda.mem_get_info()[0]:
-        torch.cuda.empty_cache()
-    cons = torch.empty(shape, dtype=torch.float32, device=pred.device)
+    cons = _big_empty(shape, pred.device)
     cnt = torch.empty(shape, dtype=torch.float32, device=pred.device) if want_count else None
     note_add("s1_base_voxels", int(np.prod(P.cons_box.shape())))
     with _timed("consensus"):
         check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
                               _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
     return (cons, cnt) if want_count else cons
+
+
+def _big_empty(shape, device):
+    """float32 device buffer of tens of GB.  A block of the right size is normally waiting in
+    torch's cache from the previous slab / step (a fresh hipMalloc costs ~25 ms per GB); only
+    when the allocator really runs dry are the cached blocks handed back first."""
+    torch = _torch()
+    try:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    except torch.OutOfMemoryError:
+        torch.cuda.empty_cache()
+        return torch.empty(shape, dtype=torch.float32, device=device)
 
 
 def rank_patches(pred, cons, overlap, P, score_box=None, out=None):
@@ -380,20 +392,13 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
     if n == 0:
         return aff
-    r = pairs.to(torch.int64)
-    lin = (r[:, 0] * Pv.Y + r[:, 1]) * Pv.X + r[:, 2]
-    dz, dy, dx = r[:, 3] - r[:, 0], r[:, 4] - r[:, 1], r[:, 5] - r[:, 2]
-    dkey = ((dz + 2 * Pv.pz) * (4 * Pv.py + 1) + (dy + 2 * Pv.py)) * (4 * Pv.px + 1) + (dx + 2 * Pv.px)
-    # rows whose two windows intersect (they alone run the LCG thinning) are kept together
-    apart = ((dz.abs() >= Pv.pz) | (dy.abs() >= Pv.py) | (dx.abs() >= Pv.px)).to(torch.int64)
-    del r, dz, dy, dx
-    key = lin * (1 << 18) + apart * (1 << 17) + dkey
-    del apart
-    del dkey
-    order = torch.argsort(key)
-    del key
-    _, counts = torch.unique_consecutive(lin[order], return_counts=True)
-    del lin
+    with host_timer("s5e_group_sort"):
+        keys = torch.empty((n,), dtype=torch.int64, device=pairs.device)
+        check(lib().ppp_pair_group_keys(_dev_ptr(pairs), n, _dev_ptr(keys), ctypes.byref(Pv), _stream()))
+        keys, order = torch.sort(keys)
+    keys >>= 18                                   # linear index of patch A
+    _, counts = torch.unique_consecutive(keys, return_counts=True)
+    del keys
     zero = torch.zeros((1,), dtype=torch.int64, device=pred.device)
     group_start = torch.cat([zero, torch.cumsum(counts, 0)])
     chunk = int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv)))
@@ -501,10 +506,7 @@ def cons_to_voxel_major(cons_compact, P):
     cons_layout = VOXEL_MAJOR)."""
     torch = _torch()
     W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
-    need = int(np.prod(P.cons_box.shape())) * W * 4
-    if need > torch.cuda.mem_get_info()[0]:
-        torch.cuda.empty_cache()   # hand cached-but-free blocks back before the big allocation
-    vm = torch.empty(P.cons_box.shape() + (W,), dtype=torch.float32, device=cons_compact.device)
+    vm = _big_empty(P.cons_box.shape() + (W,), cons_compact.device)
     Pc = P.copy()
     Pc.cons_layout = CONS_COMPACT
     with _timed("cons_to_voxel_major"):

@@ -286,6 +286,19 @@ int ppp_pair_sort_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_pair_sort_keys");
 }
 
+int ppp_pair_group_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
+                        const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n_rows == 0) return PPP_OK;
+    if (!d_rows || !d_keys) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if ((int64_t)(4 * G.pz + 1) * (4 * G.py + 1) * (4 * G.px + 1) > (1 << 17))
+        return fail(PPP_ERR_UNSUPPORTED, "patch shape too large for ppp_pair_group_keys");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pair_group_keys(d_rows, n_rows, d_keys, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_pair_group_keys");
+}
+
 int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_nodes,
                         const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
                         const ppp_params *p, void *stream) {

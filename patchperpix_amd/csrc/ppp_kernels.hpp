@@ -28,6 +28,8 @@ hipError_t launch_pairs_count(const int32_t *pts, int64_t n, const int *box, int
 hipError_t launch_pairs_fill(const int32_t *pts, int64_t n, const int *box, int l1max,
                              const int64_t *offsets, int64_t n_pair_rows, int include_single,
                              uint32_t *rows, hipStream_t s);
+hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
+                                  hipStream_t s);
 hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
                             hipStream_t s);
 hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,

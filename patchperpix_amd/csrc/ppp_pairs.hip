@@ -91,6 +91,28 @@ __global__ void pair_keys_kernel(const uint32_t *__restrict__ rows, const uint64
     keys[i] = key * G.V + (((int64_t)r[0] * G.Y + r[1]) * G.X + r[2]);
 }
 
+// key for ppp_patch_graph_by_patch: rows of one patch A together; inside a group first the
+// rows whose two windows intersect (they alone run the LCG thinning), then by patch offset
+__global__ void pair_group_keys_kernel(const uint32_t *__restrict__ rows, const uint64_t n,
+                                       int64_t *__restrict__ keys, const Geo G) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *r = rows + i * 6;
+    const int dz = (int)r[3] - (int)r[0], dy = (int)r[4] - (int)r[1], dx = (int)r[5] - (int)r[2];
+    const int64_t dkey = ((int64_t)(dz + 2 * G.pz) * (4 * G.py + 1) + (dy + 2 * G.py)) * (4 * G.px + 1) +
+                         (dx + 2 * G.px);
+    const int64_t apart = (abs(dz) >= G.pz || abs(dy) >= G.py || abs(dx) >= G.px) ? 1 : 0;
+    const int64_t lin = ((int64_t)r[0] * G.Y + r[1]) * G.X + r[2];
+    keys[i] = (lin << 18) | (apart << 17) | (dkey & 0x1FFFF);
+}
+
+hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
+                                  hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    pair_group_keys_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(rows, n, keys, G);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
                             hipStream_t s) {
     if (n == 0) return hipSuccess;

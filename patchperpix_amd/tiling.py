@@ -273,17 +273,22 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     shift = torch.tensor([lo, 0, 0, lo, 0, 0], dtype=torch.int32, device=dev)
     with backend.host_timer("s5_patch_graph"):
         for (z0, z1) in my_slabs:
-            idx = torch.nonzero((rows[:, 0] >= z0) & (rows[:, 0] < z1)).reshape(-1)
-            if idx.numel() == 0:
-                continue
-            if keep_cons:
-                cons, P = kept.pop((z0, z1))
-            else:
-                P = params(bases_for_pairs(z0, z1))
-                cons = ops.consensus(pred_local, ov_local, P)
-            rows_l = (rows[idx] - shift).contiguous()
-            aff[idx] = ops.patch_graph(pred_local, cons, rows_l, P)
-            del cons, rows_l, idx
+            with backend.host_timer("s5a_select_rows"):
+                idx = torch.nonzero((rows[:, 0] >= z0) & (rows[:, 0] < z1)).reshape(-1)
+                if idx.numel() == 0:
+                    continue
+                rows_l = (rows[idx] - shift).contiguous()
+            with backend.host_timer("s5b_consensus"):
+                if keep_cons:
+                    cons, P = kept.pop((z0, z1))
+                else:
+                    P = params(bases_for_pairs(z0, z1))
+                    cons = ops.consensus(pred_local, ov_local, P)
+            with backend.host_timer("s5c_patch_graph"):
+                a = ops.patch_graph(pred_local, cons, rows_l, P)
+            with backend.host_timer("s5d_scatter"):
+                aff[idx] = a
+            del cons, rows_l, idx, a
     kept.clear()
     comm.all_reduce_sum(aff)
     if want_inter:
