@@ -590,22 +590,23 @@ def padded_mask(mask):
     return flat[:mask.size].reshape(mask.shape), flat
 
 
-def rank_order_device(score, foreground, patchshape):
+def rank_order_device(score, foreground, patchshape, to_host=True):
     """all_patches + rank_patches_by_score on the device: interior foreground voxels in raster
     order, stably sorted by score descending (vote_instances.py:276,286-287,
     ranked_patches.py:21-30).  score: device float32 (Z,Y,X); foreground: host bool.
-    Returns (lin int64 host, scores float32 host)."""
+    Returns (lin int64, scores float32), NumPy arrays or (to_host=False) device tensors."""
     torch = _torch()
-    ps = [int(p) for p in patchshape]
+    r = [int(p) // 2 for p in patchshape]
     Z, Y, X = score.shape
-    m = np.zeros((Z, Y, X), dtype=bool)
-    r = [p // 2 for p in ps]
-    m[r[0]:Z - r[0], r[1]:Y - r[1], r[2]:X - r[2]] = True
-    m &= np.asarray(foreground) != 0
-    idx = torch.nonzero(torch.from_numpy(m).to(score.device).reshape(-1)).reshape(-1)  # raster
-    s = score.reshape(-1)[idx]
-    s_sorted, order = torch.sort(s, descending=True, stable=True)
-    return idx[order].cpu().numpy(), s_sorted.cpu().numpy()
+    fg = torch.from_numpy(np.ascontiguousarray(np.asarray(foreground) != 0)).to(score.device)
+    m = torch.zeros((Z, Y, X), dtype=torch.bool, device=score.device)
+    m[r[0]:Z - r[0], r[1]:Y - r[1], r[2]:X - r[2]] = fg[r[0]:Z - r[0], r[1]:Y - r[1], r[2]:X - r[2]]
+    idx = torch.nonzero(m.reshape(-1)).reshape(-1)                                    # raster
+    s_sorted, order = torch.sort(score.reshape(-1)[idx], descending=True, stable=True)
+    lin = idx[order]
+    if to_host:
+        return lin.cpu().numpy(), s_sorted.cpu().numpy()
+    return lin, s_sorted
 
 
 def host_cover_pass(mask_running, overlap, patchshape, ranked_lin, ranked_score, bits, pix_th,

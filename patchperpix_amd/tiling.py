@@ -111,20 +111,18 @@ class DeviceOps:
     def patch_graph(self, pred, cons, rows, P):
         return backend.patch_graph_auto(pred, cons, rows, P)
 
-    def rank_order(self, score_dev, score_host, foreground, ps):
-        return backend.rank_order_device(score_dev, foreground, ps)
+    def rank_order(self, score_dev, foreground, ps):
+        """(lin int64, scores float32) of the ranked list, device tensors."""
+        return backend.rank_order_device(score_dev, foreground, ps, to_host=False)
 
     def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw):
         """Greedy cover of the global mask (replicated: every rank runs the same rounds on
-        its own device).  Returns a bool array over the ranked list."""
+        its own device).  Returns a bool tensor over the ranked list."""
         from .vote_instances import foreground_cover as fc
-        torch = self.torch
-        mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
-                                .astype(np.uint8)).to(self.device)
-        sel, _ = fc.greedy_cover_device(mask, bits, torch.from_numpy(lin).to(self.device),
-                                        torch.from_numpy(never).to(self.device), pix_ths,
-                                        radslice, P)
-        return sel.cpu().numpy()
+        mask = self.torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
+                                     .astype(np.uint8)).to(self.device)
+        sel, _ = fc.greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P)
+        return sel
 
     def label_components(self, rows, aff, nodes, P):
         return backend.label_components(rows, aff, nodes, P)
@@ -200,54 +198,66 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             kept[(z0, z1)] = (cons, P)
         del cons, sc
     comm.all_reduce_sum(score_dev)
-    scores = score_dev.cpu().numpy()
 
     # ---- stage B: ranking, greedy cover, thinning (global; identical on every rank) -------
+    # The ranked list stays on the device (it has one entry per foreground voxel of the GLOBAL
+    # volume); only the selected patches come back to the host.
     def owned(z):
-        m = np.zeros(len(z), dtype=bool)
+        m = torch.zeros_like(z, dtype=torch.bool)
         for (z0, z1) in my_slabs:
             m |= (z >= z0) & (z < z1)
         return m
 
-    def gathered_bits(coords, thresh):
-        """Patch bits of `coords` (global): each rank packs those centred in its own slabs,
-        the sum over ranks is the full table."""
+    def gathered_bits(coords_t, thresh):
+        """Patch bits of `coords_t` (global, int32 [n, 3] on the device): each rank packs those
+        centred in its own slabs, the sum over ranks is the full table."""
         words = (int(np.prod(ps)) + 31) // 32
-        bits = torch.zeros((len(coords), words), dtype=torch.int32, device=dev)
-        mine = np.flatnonzero(owned(coords[:, 0]))
-        if len(mine):
-            loc = coords[mine].astype(np.int32).copy()
+        bits = torch.zeros((int(coords_t.shape[0]), words), dtype=torch.int32, device=dev)
+        mine = torch.nonzero(owned(coords_t[:, 0])).reshape(-1)
+        if mine.numel():
+            loc = coords_t[mine].clone()
             loc[:, 0] -= lo
-            b = ops.patch_bits(pred_local, torch.from_numpy(np.ascontiguousarray(loc)).to(dev),
-                               kw["fc_threshold"], params())
-            bits[torch.from_numpy(mine).to(dev)] = b
+            bits[mine] = ops.patch_bits(pred_local, loc.contiguous(), thresh, params())
         comm.all_reduce_sum(bits)
         return bits
 
     with backend.host_timer("sort"):
-        lin, rscores = ops.rank_order(score_dev, scores, foreground, ps)
+        lin_t, rscores_t = ops.rank_order(score_dev, foreground, ps)
     del score_dev
-    coords = np.stack(np.unravel_index(lin, shape), axis=1).astype(np.int32)
+    coords_t = torch.stack([lin_t // (Y * X), (lin_t // X) % Y, lin_t % X], dim=1).to(torch.int32)
     if kw.get("selected_patches") is not None:
         sel_coords = np.array(list(kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
     elif kw.get("skipSelection", False):
-        sel_coords = coords
+        sel_coords = coords_t.cpu().numpy()
     else:
         with backend.host_timer("s3_cover"):
             from .vote_instances import foreground_cover as fc
-            bits = gathered_bits(coords, kw["fc_threshold"])
-            never = fc.never_selected(overlap_mask, lin, rscores, kw.get("score_threshold", False))
-            selected = ops.greedy_cover(mask_to_cover, bits, lin, rscores, never,
+            bits = gathered_bits(coords_t, kw["fc_threshold"])
+            # patches the loop never looks at (foreground_cover.py:136-141): centre on an
+            # overlap voxel; everything from the first score below score_threshold on
+            never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
+            if overlap_mask.any():
+                ov_g = torch.from_numpy(np.ascontiguousarray(overlap_mask.reshape(-1) > 0)).to(dev)
+                never |= ov_g[lin_t]
+                del ov_g
+            thr = kw.get("score_threshold", False)
+            if isinstance(thr, float):
+                below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
+                if below.numel():
+                    never[int(below[0].item()):] = True
+            selected = ops.greedy_cover(mask_to_cover, bits, lin_t, rscores_t, never,
                                         fc._pix_thresholds(ps, kw), radslice, Pg, kw)
-            del bits
-            sel_coords = coords[selected]
+            del bits, never
+            sel_coords = coords_t[selected].cpu().numpy()
     if not kw.get("skipThinCover") and len(sel_coords) > 0:
         with backend.host_timer("s4_thin"):
-            bits = gathered_bits(sel_coords, kw["fc_threshold"]).cpu().numpy().view(np.uint32)
+            bits = gathered_bits(torch.from_numpy(np.ascontiguousarray(sel_coords)).to(dev),
+                                 kw["fc_threshold"]).cpu().numpy().view(np.uint32)
             sel_lin = (sel_coords[:, 0].astype(np.int64) * Y + sel_coords[:, 1]) * X + sel_coords[:, 2]
             keep = backend.host_thin_cover(np.ascontiguousarray(mask_to_cover).astype(np.uint8),
                                            ps, np.ascontiguousarray(sel_lin), bits)
             sel_coords = sel_coords[keep]
+    del lin_t, rscores_t, coords_t
 
     # ---- pairs (global coordinates; replicated, it is cheap) -------------------------------
     order = np.argsort(sel_coords[:, 2], kind="stable")
@@ -302,28 +312,35 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             lab_nodes = np.array([n for cc in ccs for n in cc], dtype=np.int32).reshape(-1, 3)
             labels = np.array([k + 1 for k, cc in enumerate(ccs) for _ in cc], dtype=np.int64)
         else:
-            keys = ops.label_components(rows, aff, nodes_dev, Pg).cpu().numpy()
+            keys = ops.label_components(rows, aff, nodes_dev, Pg)
             valid = keys != backend.NONE_KEY
-            uniq = np.unique(keys[valid])
-            lab_nodes = nodes[valid]
-            labels = (np.searchsorted(uniq, keys[valid]) + 1).astype(np.int64)
-        if len(labels) and labels.max() > np.iinfo(np.uint16).max:
-            raise OverflowError("%d instances do not fit uint16" % labels.max())
+            # component ids in the order of their keys (= networkx's component order)
+            uniq, inverse = torch.unique(keys[valid], sorted=True, return_inverse=True)
+            lab_nodes = nodes_dev[valid]
+            labels = (inverse + 1).to(torch.int32)
+            n_labels = int(uniq.numel())
+            del keys, valid, uniq, inverse
+        if kw.get("mws"):
+            n_labels = int(labels.max()) if len(labels) else 0
+            lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(dev)
+            labels = torch.from_numpy(labels.astype(np.int32)).to(dev)
+        if n_labels > np.iinfo(np.uint16).max:
+            raise OverflowError("%d instances do not fit uint16" % n_labels)
         inst_dev = torch.zeros(shape, dtype=torch.int32, device=dev)
         Pl = params()
         for (z0, z1) in my_slabs:
-            near = (lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)
-            if not near.any():
+            near = torch.nonzero((lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)).reshape(-1)
+            if near.numel() == 0:
                 continue
-            loc = lab_nodes[near].copy()
+            loc = lab_nodes[near].clone()
             loc[:, 0] -= lo
             inst_l = torch.zeros(local_shape, dtype=torch.int32, device=dev)
-            ops.paint(pred_local, torch.from_numpy(np.ascontiguousarray(loc)).to(dev),
-                      torch.from_numpy(labels[near].astype(np.int32)).to(dev), inst_l, Pl)
+            ops.paint(pred_local, loc.contiguous(), labels[near].contiguous(), inst_l, Pl)
             inst_dev[z0:z1] = inst_l[z0 - lo:z1 - lo]
             del inst_l
         comm.all_reduce_sum(inst_dev)
-        instances = inst_dev.cpu().numpy().astype(np.uint16)
+        # ids fit 16 bits (checked above): ship half the bytes to the host
+        instances = inst_dev.to(torch.int16).cpu().numpy().view(np.uint16)
     return instances, foreground.astype(np.uint8)
 
 

@@ -124,7 +124,15 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         avail = torch.cuda.mem_get_info()[0] + \
             (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
         n_slabs = tiling.slabs_needed(shape, patchshape, avail)
-    if n_slabs and n_slabs > 1 and not kwargs.get("graphToInst") \
+    # With nothing to store or load between the stages, the single-slab case takes the same
+    # code path: it keeps the ranked patch list on the device instead of materialising the
+    # reference's host lists between the stage functions (PPP_PIPELINE=stages keeps them).
+    plain = kwargs.get("save_no_intermediates", False) and not kwargs.get("debug", False) \
+        and not any(kwargs.get(k) for k in ("skeletonize_foreground", "skipConsensus", "skipRanking",
+                                            "termAfterThinCover", "termAfterPatchGraph",
+                                            "save_consensus", "blockwise")) \
+        and os.environ.get("PPP_PIPELINE", "fused") != "stages"
+    if n_slabs and (n_slabs > 1 or plain) and not kwargs.get("graphToInst") \
             and kwargs.get("aff_graph") is None and not kwargs.get("pad_with_ps", False):
         from .. import tiling
         logger.info("assembling in %d z-slabs", n_slabs)

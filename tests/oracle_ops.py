@@ -73,9 +73,10 @@ class OracleOps:
                               rows.numpy().view(np.uint32), self._ps(P), **kw)
         return torch.from_numpy(aff)
 
-    def rank_order(self, score_dev, score_host, foreground, ps):
+    def rank_order(self, score_dev, foreground, ps):
+        score_host = score_dev.numpy()
         lin = backend.host_rank_order(score_host, foreground, ps)
-        return lin, np.ascontiguousarray(score_host.reshape(-1)[lin])
+        return torch.from_numpy(lin), torch.from_numpy(np.ascontiguousarray(score_host.reshape(-1)[lin]))
 
     def label_components(self, rows, aff, nodes, P):
         ccs = orc.connected_components(rows.numpy().view(np.uint32), aff.numpy())
@@ -104,6 +105,7 @@ class OracleOps:
     def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw):
         """The sequential loop (native host code of the library, pinned to the reference's
         goldens by tests/test_abi_and_host.py)."""
+        lin, scores, never = lin.numpy(), scores.numpy(), never.numpy()
         running, _owner = backend.padded_mask(mask_to_cover)
         selected = np.zeros(len(lin), dtype=np.uint8)
         b = bits.numpy().view(np.uint32)
@@ -125,5 +127,4 @@ class OracleOps:
                 thr, selected, remaining)
             if remaining < 1:
                 break
-        return selected.astype(bool)
-
+        return torch.from_numpy(selected.astype(bool))

@@ -70,10 +70,13 @@ def test_kernels_match_reference_goldens(golden, torch_cuda):
             assert np.array_equal(_bits(o["aff"]), _bits(g["aff"]))
 
 
-def test_end_to_end_matches_reference(golden, torch_cuda):
+@pytest.mark.parametrize("pipeline", ["fused", "stages"])
+def test_end_to_end_matches_reference(golden, torch_cuda, monkeypatch, pipeline):
     """to_instance_seg through the drop-in entry point: identical instance ids (the pair order
-    is the canonical one the golden was generated with), hence identical partition."""
+    is the canonical one the golden was generated with), hence identical partition.  Both the
+    device-resident pipeline and the one that goes through the reference's stage functions."""
     from patchperpix_amd.vote_instances import vote_instances as vi
+    monkeypatch.setenv("PPP_PIPELINE", pipeline)
     g = golden
     kw = dict(g.kw, debug=False, isbiHack=False, save_no_intermediates=True, sample=1.0,
               result_folder="/tmp", affinities="x.zarr")
