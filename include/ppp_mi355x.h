@@ -267,6 +267,16 @@ int64_t ppp_host_patch_pairs(const int32_t *sel_zyx, int64_t n, const int32_t *p
                              int32_t max_ps_dist, int32_t include_single, int32_t *sorted_zyx,
                              uint32_t *pairs);
 
+/* ppp_host_mws: mutex watershed on the patch graph (graph_mws.py:7-85 on the graph of
+ *   setAffgraph, aff_patch_graph.py:31-40), host code like the reference.  pairs u32 [n][6],
+ *   aff f32 [n]; vol = (Z,Y,X).  Writes every node of the graph (rows with aff != 0, first
+ *   appearance order) to out_nodes int32 [cap][3] with its instance label in out_labels
+ *   (1 + position of its component in the reference's output list; 0 = in no component).
+ *   *n_labels = length of that list (emptied components included).  Returns the number of
+ *   nodes, or -1 when cap is too small.                                                     */
+int64_t ppp_host_mws(const uint32_t *pairs, const float *aff, int64_t n_rows, const int32_t *vol,
+                     int32_t *out_nodes, int32_t *out_labels, int64_t cap, int64_t *n_labels);
+
 /* --- synthetic input (bench / tests only; same hash as patchperpix_amd/synth.py) ------
  * fills d_pred (C,Z,Y,X) from a label volume d_labels int32 (Z,Y,X).  voxel_offset is the
  * linear index of local voxel 0 in the global volume (0 unless the buffers are a slab).    */

@@ -115,6 +115,9 @@ _SIGNATURES = {
                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_uint64, ctypes.POINTER(Params),
                                       ctypes.c_void_p]),
+    "ppp_host_mws": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "ppp_host_rank_order": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p]),
     "ppp_host_cover_pass": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -570,6 +573,26 @@ def _np_ptr(a):
 
 def _i32(seq):
     return np.ascontiguousarray(np.array(seq, dtype=np.int32))
+
+
+def host_mws(pairs, aff, shape):
+    """Mutex watershed on the patch graph (ppp_host_mws).  pairs uint32 [n, 6], aff float32 [n]
+    (host arrays).  Returns (nodes int32 [k, 3], labels int64 [k], n_labels): the nodes that
+    ended up in a component and their instance ids; n_labels = number of ids issued."""
+    pairs = np.ascontiguousarray(np.asarray(pairs).reshape(-1, 6), dtype=np.uint32)
+    aff = np.ascontiguousarray(aff, dtype=np.float32)
+    n = len(aff)
+    cap = min(2 * n, int(np.prod(shape))) + 1
+    nodes = np.empty((cap, 3), dtype=np.int32)
+    labels = np.empty((cap,), dtype=np.int32)
+    n_labels = ctypes.c_int64(0)
+    k = int(lib().ppp_host_mws(_np_ptr(pairs), _np_ptr(aff), n, _np_ptr(_i32(shape)), _np_ptr(nodes),
+                               _np_ptr(labels), cap, ctypes.byref(n_labels)))
+    if k < 0:
+        raise RuntimeError("libppp_mi355x: ppp_host_mws: %s" %
+                           ("node capacity too small" if k == -1 else "coordinate outside the volume"))
+    keep = labels[:k] > 0
+    return nodes[:k][keep], labels[:k][keep].astype(np.int64), int(n_labels.value)
 
 
 def host_rank_order(score, foreground, patchshape):

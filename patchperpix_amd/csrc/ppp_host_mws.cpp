@@ -1,0 +1,232 @@
+// ppp_host_mws.cpp -- mutex watershed on the patch graph, host side like the reference
+// (PatchPerPix/vote_instances/graph_mws.py:7-85 on the graph built by setAffgraph,
+// aff_patch_graph.py:31-40).
+//
+// Same decisions as the reference, without its O(E * |mutex|) scans:
+//   * nodes are numbered by first appearance among the rows with aff != 0, edges are visited in
+//     networkx's order (node-major in insertion order, neighbours in insertion order, each edge
+//     once at its first-visited endpoint; a repeated row overwrites the value of its edge) and
+//     stably sorted by |aff| descending (graph_mws.py:23-29);
+//   * component membership lives in a union-find whose roots carry the reference's component id;
+//     a new component gets max(ids in use) + 1, a merge keeps the smaller id (:37-38, :66-72);
+//   * "is there a mutex edge between these components" (:46-48, :59-62) is answered from, per
+//     component, the set of nodes that have a mutex edge into it, merged small-to-large;
+//   * the output order is the creation order of the ids -- a re-issued id keeps its first
+//     position and a component emptied by a merge stays in the list (:79-82) -- so the instance
+//     label of a node is 1 + position of its component's id in that order.
+#include <stdint.h>
+
+#include <algorithm>
+#include <set>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/ppp_mi355x.h"
+
+namespace {
+
+struct Edge {
+    int32_t a, b;
+    float w;        // |aff|
+    int8_t attractive;
+};
+
+struct Dsu {
+    std::vector<int32_t> parent;
+    int32_t find(int32_t x) {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// pairs u32 [n_rows][6] (A zyx, B zyx), aff f32 [n_rows], vol = volume shape (for node keys).
+// out_nodes int32 [cap][3] / out_labels int32 [cap]: every node of the graph (first-appearance
+// order) with its label, 0 for nodes the watershed left unassigned.  *n_labels = number of
+// labels issued (including emptied components).  Returns the number of nodes, -1 if cap is
+// too small, -2 for a coordinate outside vol.
+int64_t ppp_host_mws(const uint32_t *pairs, const float *aff, int64_t n_rows, const int32_t *vol,
+                     int32_t *out_nodes, int32_t *out_labels, int64_t cap, int64_t *n_labels) {
+    const int64_t Y = vol[1], X = vol[2];
+    auto lin = [&](const uint32_t *c) { return ((int64_t)c[0] * Y + c[1]) * X + c[2]; };
+
+    // ---- nodes and (deduplicated) edges in insertion order --------------------------------
+    // voxel -> node id: a direct table for volumes up to 2^28 voxels, a hash map beyond
+    const int64_t V = (int64_t)vol[0] * Y * X;
+    const bool direct = V <= (1ll << 28);
+    std::vector<int32_t> table(direct ? (size_t)V : 0, -1);
+    std::unordered_map<int64_t, int32_t> node_id;
+    std::vector<int64_t> node_key;
+    struct Row { int32_t u, v; float a; };
+    std::vector<Row> rows;
+    rows.reserve((size_t)n_rows);
+    for (int64_t i = 0; i < n_rows; ++i) {
+        if (aff[i] == 0.0f) continue;          // setAffgraph skips exact zeros (NaN is kept)
+        int32_t id[2];
+        for (int s = 0; s < 2; ++s) {
+            const int64_t k = lin(pairs + i * 6 + 3 * s);
+            if (direct) {
+                if (k < 0 || k >= V) return -2;
+                if (table[k] < 0) {
+                    table[k] = (int32_t)node_key.size();
+                    node_key.push_back(k);
+                }
+                id[s] = table[k];
+            } else {
+                auto it = node_id.find(k);
+                if (it == node_id.end()) {
+                    it = node_id.emplace(k, (int32_t)node_key.size()).first;
+                    node_key.push_back(k);
+                }
+                id[s] = it->second;
+            }
+        }
+        rows.push_back({id[0], id[1], aff[i]});
+    }
+    std::vector<int32_t>().swap(table);
+    const int32_t N = (int32_t)node_key.size();
+    if (N > cap) return -1;
+    // a repeated (unordered) node pair keeps its first position and takes the last value
+    {
+        std::vector<uint64_t> key(rows.size());
+        for (size_t i = 0; i < rows.size(); ++i) {
+            const uint32_t lo = (uint32_t)std::min(rows[i].u, rows[i].v), hi = (uint32_t)std::max(rows[i].u, rows[i].v);
+            key[i] = ((uint64_t)lo << 32) | hi;
+        }
+        std::vector<uint64_t> sorted(key);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+            std::unordered_map<uint64_t, size_t> first;
+            std::vector<Row> uniq;
+            for (size_t i = 0; i < rows.size(); ++i) {
+                auto it = first.find(key[i]);
+                if (it == first.end()) {
+                    first.emplace(key[i], uniq.size());
+                    uniq.push_back(rows[i]);
+                } else {
+                    uniq[it->second].a = rows[i].a;
+                }
+            }
+            rows.swap(uniq);
+        }
+    }
+    // adjacency in insertion order (CSR), then networkx's edge order
+    std::vector<int64_t> start((size_t)N + 1, 0);
+    for (const Row &r : rows) {
+        ++start[r.u + 1];
+        if (r.u != r.v) ++start[r.v + 1];
+    }
+    for (int32_t n = 0; n < N; ++n) start[n + 1] += start[n];
+    std::vector<int32_t> nbr((size_t)start[N]);
+    std::vector<float> nbr_a((size_t)start[N]);
+    {
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (const Row &r : rows) {
+            nbr[fill[r.u]] = r.v; nbr_a[fill[r.u]++] = r.a;
+            if (r.u != r.v) { nbr[fill[r.v]] = r.u; nbr_a[fill[r.v]++] = r.a; }
+        }
+    }
+    std::vector<Edge> edges;
+    edges.reserve(rows.size());
+    for (int32_t n = 0; n < N; ++n)
+        for (int64_t j = start[n]; j < start[n + 1]; ++j)
+            if (nbr[j] >= n) {
+                const float a = nbr_a[j];
+                // graph_mws.py:17-21: a > 0 attractive, everything else (incl. NaN) repulsive
+                edges.push_back(a > 0 ? Edge{n, nbr[j], a, 1} : Edge{n, nbr[j], -a, -1});
+            }
+    std::vector<int32_t>().swap(nbr);
+    std::vector<float>().swap(nbr_a);
+    std::vector<Row>().swap(rows);
+    std::stable_sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.w > y.w; });
+
+    // ---- the watershed ---------------------------------------------------------------------
+    Dsu dsu;
+    dsu.parent.resize((size_t)N);
+    for (int32_t i = 0; i < N; ++i) dsu.parent[i] = i;
+    std::vector<int32_t> cc_of_root((size_t)N, 0);      // component id carried by a root (0: none)
+    std::vector<std::vector<int32_t>> node_mutex((size_t)N);
+    std::unordered_map<int32_t, std::unordered_set<int32_t>> cc_mutex;   // id -> nodes with a mutex edge into it
+    std::unordered_map<int32_t, int32_t> root_of_cc;    // id -> root
+    std::set<int32_t> in_use;                           // ids currently held by some node
+    std::vector<int32_t> created;                       // ids in creation order (first issue)
+    std::unordered_set<int32_t> ever;
+    auto cc = [&](int32_t n) { return cc_of_root[dsu.find(n)]; };
+
+    for (const Edge &e : edges) {
+        if (e.attractive == 1) {
+            const int32_t r0 = dsu.find(e.a), r1 = dsu.find(e.b);
+            const int32_t c0 = cc_of_root[r0], c1 = cc_of_root[r1];
+            if (c0 == 0 && c1 == 0) {
+                const int32_t id = (in_use.empty() ? 0 : *in_use.rbegin()) + 1;
+                if (r0 != r1) dsu.parent[r1] = r0;
+                cc_of_root[r0] = id;
+                root_of_cc[id] = r0;
+                in_use.insert(id);
+                if (ever.insert(id).second) created.push_back(id);
+                auto &m = cc_mutex[id];
+                m.clear();
+                m.insert(node_mutex[e.a].begin(), node_mutex[e.a].end());
+                m.insert(node_mutex[e.b].begin(), node_mutex[e.b].end());
+            } else if (c0 == 0 || c1 == 0) {
+                const int32_t id = std::max(c0, c1);
+                const int32_t ena = c0 == 0 ? e.a : e.b, r_ena = c0 == 0 ? r0 : r1, r_cc = c0 == 0 ? r1 : r0;
+                auto &m = cc_mutex[id];
+                if (m.find(ena) == m.end()) {
+                    dsu.parent[r_ena] = r_cc;
+                    m.insert(node_mutex[ena].begin(), node_mutex[ena].end());
+                }
+            } else if (c0 != c1) {
+                auto &m0 = cc_mutex[c0], &m1 = cc_mutex[c1];
+                const bool first_small = m0.size() <= m1.size();
+                auto &small = first_small ? m0 : m1;
+                const int32_t big_id = first_small ? c1 : c0;
+                bool has_mutex = false;
+                for (int32_t x : small)
+                    if (cc(x) == big_id) { has_mutex = true; break; }
+                if (!has_mutex) {
+                    const int32_t keep = std::min(c0, c1), drop = std::max(c0, c1);
+                    dsu.parent[r1] = r0;
+                    cc_of_root[r0] = keep;
+                    root_of_cc[keep] = r0;
+                    root_of_cc.erase(drop);
+                    in_use.erase(drop);
+                    // union of the two mutex sets under `keep`, moving the smaller one
+                    auto &big = first_small ? m1 : m0;
+                    big.insert(small.begin(), small.end());
+                    if (&big != &cc_mutex[keep]) cc_mutex[keep].swap(big);
+                    cc_mutex[drop].clear();
+                }
+            }
+        } else {
+            node_mutex[e.a].push_back(e.b);
+            node_mutex[e.b].push_back(e.a);
+            const int32_t ca = cc(e.a), cb = cc(e.b);
+            if (ca != 0) cc_mutex[ca].insert(e.b);
+            if (cb != 0) cc_mutex[cb].insert(e.a);
+        }
+    }
+
+    // ---- labels ------------------------------------------------------------------------------
+    std::unordered_map<int32_t, int32_t> label_of_id;
+    for (size_t i = 0; i < created.size(); ++i) label_of_id[created[i]] = (int32_t)i + 1;
+    for (int32_t n = 0; n < N; ++n) {
+        const int64_t k = node_key[n];
+        out_nodes[3 * (int64_t)n + 0] = (int32_t)(k / (Y * X));
+        out_nodes[3 * (int64_t)n + 1] = (int32_t)((k / X) % Y);
+        out_nodes[3 * (int64_t)n + 2] = (int32_t)(k % X);
+        const int32_t id = cc(n);
+        out_labels[n] = id == 0 ? 0 : label_of_id[id];
+    }
+    if (n_labels) *n_labels = (int64_t)created.size();
+    return N;
+}
+
+}  // extern "C"

@@ -307,10 +307,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     # ---- stage D: components (replicated) and painting of the own slabs ---------------------
     with backend.host_timer("s6_label_paint"):
         if kw.get("mws"):
-            from .vote_instances.graph_mws import mws_from_pairs
-            ccs = mws_from_pairs(rows.cpu().numpy().view(np.uint32), aff.cpu().numpy())
-            lab_nodes = np.array([n for cc in ccs for n in cc], dtype=np.int32).reshape(-1, 3)
-            labels = np.array([k + 1 for k, cc in enumerate(ccs) for _ in cc], dtype=np.int64)
+            lab_nodes, labels, n_labels = backend.host_mws(rows.cpu().numpy().view(np.uint32),
+                                                           aff.cpu().numpy(), shape)
+            lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(dev)
+            labels = torch.from_numpy(labels.astype(np.int32)).to(dev)
         else:
             keys = ops.label_components(rows, aff, nodes_dev, Pg)
             valid = keys != backend.NONE_KEY
@@ -320,10 +320,6 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             labels = (inverse + 1).to(torch.int32)
             n_labels = int(uniq.numel())
             del keys, valid, uniq, inverse
-        if kw.get("mws"):
-            n_labels = int(labels.max()) if len(labels) else 0
-            lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(dev)
-            labels = torch.from_numpy(labels.astype(np.int32)).to(dev)
         if n_labels > np.iinfo(np.uint16).max:
             raise OverflowError("%d instances do not fit uint16" % n_labels)
         inst_dev = torch.zeros(shape, dtype=torch.int32, device=dev)

@@ -23,14 +23,12 @@ def component_labels(affinity_graph, shape, device, P, **kwargs):
 
     ``mws=False``: union-find on the device (ppp_label_components) gives every node the order
     key of its component; ranking the distinct keys (as many numbers as components) happens
-    here.  ``mws=True``: mutex watershed on the host (graph_mws)."""
+    here.  ``mws=True``: mutex watershed on the host (ppp_host_mws)."""
     import torch
     if kwargs["mws"]:
-        ccs = mws_from_pairs(affinity_graph.pairs, affinity_graph.aff)
-        nodes = [n for cc in ccs for n in cc]
-        labels = [k + 1 for k, cc in enumerate(ccs) for _ in cc]
-        return (np.array(nodes, dtype=np.int32).reshape(-1, 3),
-                np.array(labels, dtype=np.int64))
+        # native (csrc/ppp_host_mws.cpp); graph_mws.mws_from_pairs is the same in Python
+        nodes, labels, _ = backend.host_mws(affinity_graph.pairs, affinity_graph.aff, shape)
+        return nodes, labels
     nodes = affinity_graph.pairs_obj.nodes
     if len(nodes) == 0:
         return np.zeros((0, 3), np.int32), np.zeros((0,), np.int64)

@@ -141,3 +141,51 @@ def test_size_limits_are_reported():
     rc = backend.lib().ppp_cons_to_reference(ctypes.c_void_p(8), ctypes.c_void_p(8),
                                              ctypes.byref(P), None)
     assert rc == -4 and b"2^31" in backend.lib().ppp_last_error()
+
+
+def _labels_from_ccs(ccs):
+    """node -> label exactly as graph_to_labeling paints the reference's ccs list."""
+    out = {}
+    for k, cc in enumerate(ccs):
+        for n in cc:
+            out[tuple(int(v) for v in n)] = k + 1
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_native_mws_equals_python_restatement(seed):
+    """ppp_host_mws against graph_mws.mws_from_pairs (itself pinned to the reference's golden,
+    tests/test_oracle_golden.py): same label for every node, same number of issued labels, on
+    random graphs with tied weights, self loops, zero and repeated rows."""
+    from patchperpix_amd import backend
+    from patchperpix_amd.vote_instances.graph_mws import mws_from_pairs
+    rng = np.random.default_rng(seed)
+    shape = (6, 7, 8)
+    n_nodes = int(rng.integers(5, 60))
+    lin = rng.choice(int(np.prod(shape)), size=n_nodes, replace=False)
+    coords = np.stack(np.unravel_index(lin, shape), axis=1).astype(np.uint32)
+    n_rows = int(rng.integers(n_nodes, 6 * n_nodes))
+    a = rng.integers(0, n_nodes, size=n_rows)
+    b = rng.integers(0, n_nodes, size=n_rows)
+    if seed % 3 == 0:
+        b[: n_rows // 8] = a[: n_rows // 8]          # self loops
+    pairs = np.concatenate([coords[a], coords[b]], axis=1)
+    # few distinct magnitudes -> many ties; some exact zeros; both signs
+    aff = (rng.integers(-6, 7, size=n_rows) / 8.0).astype(np.float32)
+    if seed % 2:
+        aff = (aff * rng.uniform(0.5, 1.0, size=n_rows)).astype(np.float32)
+    ref = _labels_from_ccs(mws_from_pairs(pairs, aff))
+    n_ref = len(mws_from_pairs(pairs, aff))
+    nodes, labels, n_labels = backend.host_mws(pairs, aff, shape)
+    got = {tuple(int(v) for v in n): int(l) for n, l in zip(nodes, labels)}
+    assert got == ref
+    assert n_labels == n_ref
+
+
+def test_native_mws_empty_and_all_repulsive():
+    from patchperpix_amd import backend
+    nodes, labels, n = backend.host_mws(np.zeros((0, 6), np.uint32), np.zeros((0,), np.float32), (4, 4, 4))
+    assert len(nodes) == 0 and n == 0
+    pairs = np.array([[0, 0, 0, 0, 0, 1], [0, 0, 1, 0, 0, 2]], dtype=np.uint32)
+    nodes, labels, n = backend.host_mws(pairs, np.array([-0.5, -0.25], np.float32), (4, 4, 4))
+    assert len(nodes) == 0 and n == 0
