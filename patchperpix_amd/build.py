@@ -8,7 +8,8 @@ import os
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB = os.path.join(CSRC, "libppp_mi355x.so")
+# PPP_LIB: load / build an alternative library file (kernel experiments side by side)
+LIB = os.environ.get("PPP_LIB") or os.path.join(CSRC, "libppp_mi355x.so")
 ARCH = "gfx950"
 # -ffp-contract=off: the float arithmetic must round exactly like the reference's
 # (no fused multiply-add across the statements being restated).

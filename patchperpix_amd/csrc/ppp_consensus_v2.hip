@@ -27,11 +27,16 @@
 // within those few double ulps, which is visible in the low 29 mantissa bits of the product; in
 // that (~2^-26 probability) case the lane redoes the vote with the true double division.  The
 // result is therefore bit-identical, at one double multiply instead of a double division.
+#include <stdlib.h>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
 
 static constexpr int V2_WAVES = 4;
+#ifndef PPP_S1_MINWAVES
+#define PPP_S1_MINWAVES(PX) ((PX) <= 7 ? 3 : 2)   // waves per SIMD the register budget must allow
+#endif
 
 template <int PX>
 struct V2 {
@@ -45,15 +50,31 @@ struct V2 {
 // one vote; VAL, EXACT compile-time so that the unrolled tile is straight-line code.
 // amb_min tracks (VALU only, no lane masks) how close any fast-path double result came to a
 // float rounding midpoint.
-template <int VAL, bool EXACT>
+template <int VAL, bool EXACT, bool TH05>
 __device__ __forceinline__ void vote(const double th2, const double den, const double inv_den,
-                                     float ta, float tb, float &acc, unsigned &cnt,
+                                     float ta, int lim, float tb, float &acc, unsigned &cnt,
                                      unsigned &amb_min) {
-    const float x = ta * tb;
-    // a vote needs two classified operands that are not both "background" (negative)
-    const bool valid = (x != 0.0f) && ((__float_as_int(ta) & __float_as_int(tb)) >= 0);
+    // a vote needs two classified operands that are not both "background" (negative): the
+    // caller passes lim = 0 when ta is negative (a negative tb then becomes +0 in the integer
+    // max) and INT_MIN otherwise, so that validity is just "product != 0"
+    const float x = ta * __int_as_float(max(__float_as_int(tb), lim));
+    const bool valid = x != 0.0f;
     float y;
-    if constexpr (VAL == PPP_VAL_NORM_PROB_PRODUCT) {
+    if constexpr (VAL == PPP_VAL_NORM_PROB_PRODUCT && TH05 && !EXACT) {
+        // TH = 0.5: (float)(((double)|x| - 0.25) / 0.75) in float arithmetic only.  |x| >= 0.25
+        // for every classified pair, so d = |x| - 0.25 is exact in float; q0 = d * fl(4/3) is
+        // within an ulp of the quotient, r = d - 0.75 * q0 is exact (fma) and fma(r, fl(4/3), q0)
+        // is the correctly rounded d / 0.75.  The double division of the reference never lands
+        // within half a double ulp of a float midpoint (4d/3 has the bit pattern 0101.. / 1010..
+        // past the quotient), so its double rounding is harmless.  Checked EXHAUSTIVELY for all
+        // 2.0e8 floats x in [0.25, 2^22] (tests/test_abi_and_host.py::test_th05_quotient).  All
+        // operations are odd-symmetric, so the sign of x rides along.
+        const float d = x - copysignf(0.25f, x);
+        const float c43 = 0x1.555556p+0f;
+        const float q0 = d * c43;
+        const float r = __fmaf_rn(-0.75f, q0, d);
+        y = __fmaf_rn(r, c43, q0);
+    } else if constexpr (VAL == PPP_VAL_NORM_PROB_PRODUCT) {
         // sign(x) * fl32(fl64(fl64(|x| - TH^2) / den)); rounding is sign-symmetric, so the
         // sign is carried through the double arithmetic
         const double xd = (double)x;
@@ -80,7 +101,7 @@ __device__ __forceinline__ void vote(const double th2, const double den, const d
 // all votes of one (kz, ky): kx descending (raster order of the centre), every partner column.
 // ROW0: offset row (dz, dy) == (0, 0), where only dx > 0 exists.  Returns "some fast-path
 // result was ambiguous" (never when EXACT).
-template <int PX, int VAL, bool ROW0, bool EXACT>
+template <int PX, int VAL, bool ROW0, bool EXACT, bool TH05>
 __device__ __forceinline__ bool tile_votes(const float *ia, const float *ib, const bool u_ok,
                                            const double th2, const double den,
                                            const double inv_den, float (&acc)[2 * PX - 1],
@@ -90,10 +111,12 @@ __device__ __forceinline__ bool tile_votes(const float *ia, const float *ib, con
 #pragma unroll
     for (int kx = PX - 1; kx >= 0; --kx) {
         const float ta = u_ok ? ia[kx * NC - kx] : 0.0f;
+        int lim = ta < 0.0f ? 0 : (int)0x80000000;
+        asm volatile("" : "+v"(lim));   // keep it ONE v_max_i32 per vote (no select per vote)
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
             if (ROW0 && j <= kx) continue;   // offsets must be lexicographically positive
-            vote<VAL, EXACT>(th2, den, inv_den, ta, ib[j * NC - kx], acc[j - kx + PX - 1],
+            vote<VAL, EXACT, TH05>(th2, den, inv_den, ta, lim, ib[j * NC - kx], acc[j - kx + PX - 1],
                              cnt[j - kx + PX - 1], amb_min);
         }
 #ifndef PPP_V2_NOSCHED
@@ -104,8 +127,14 @@ __device__ __forceinline__ bool tile_votes(const float *ia, const float *ib, con
     return amb_min <= 8u;
 }
 
-template <typename T, int PX, int VAL>
-__global__ void __launch_bounds__(64 * V2_WAVES)
+// element at a 32-bit byte offset from a (wave-uniform) base
+template <typename T>
+__device__ __forceinline__ float ldf_at(const T *base, unsigned byte_off) {
+    return ldf(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off), 0);
+}
+
+template <typename T, int PX, int VAL, bool TH05>
+__global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
     consensus_v2_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
                         float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
                         const int n_rows, const int runs_per_line, const long long n_waves) {
@@ -114,7 +143,9 @@ __global__ void __launch_bounds__(64 * V2_WAVES)
     constexpr int NEA = (PX * K::NC + 63) / 64;      // ... of which may belong to the "about u" rows
     __shared__ float lds[V2_WAVES][K::IMG];
     __shared__ uint8_t lds_valid[V2_WAVES][2][K::NT + 2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (wave-uniform values are made scalar explicitly: the compiler cannot see that
+    // threadIdx.x >> 6 is uniform and would keep the whole tile address arithmetic in VGPRs)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // XCD-aware order: blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous
     // range of (x-run, row) work so that the rows of one x-run meet in one L2
     long long bid = blockIdx.x;
@@ -175,9 +206,11 @@ __global__ void __launch_bounds__(64 * V2_WAVES)
     //   ok_bits  bit it : the pixel the value talks about is valid and the centre is inside
     //                     the x-interior (centre foreground is tile dependent, tested later)
     //   el_off[it]      : j * V + clamped centre x  (added to the tile's row base)
+    // (32-bit BYTE offsets from a scalar row base: one VGPR per element and the
+    // saddr + voffset addressing form; the launcher checks that they fit)
     unsigned ok_bits = 0;
-    long long el_off[NE];
-    int el_cx[NE];
+    unsigned el_off[NE];
+    unsigned el_cx[NE];
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
         const int e = it * 64 + lane;
@@ -192,8 +225,8 @@ __global__ void __launch_bounds__(64 * V2_WAVES)
         }
         ok_bits |= (ok ? 1u : 0u) << it;
         const int cxc = min(max(cx, 0), G.X - 1);
-        el_cx[it] = cxc;
-        el_off[it] = (long long)j * G.V + cxc;
+        el_cx[it] = (unsigned)cxc * (unsigned)sizeof(T);
+        el_off[it] = (unsigned)(((long long)j * G.V + cxc) * (long long)sizeof(T));
     }
 
     if (w_row_ok) {
@@ -218,14 +251,15 @@ __global__ void __launch_bounds__(64 * V2_WAVES)
 #pragma unroll
             for (int it = 0; it < NE; ++it) {
                 const bool is_b = it * 64 + lane >= PX * K::NC;
-                raw[it] = ldf(pred, (is_b ? rb0 : ra0) + el_off[it]);
-                if (it < NEA) cmid[it] = ldf(mid, crow + el_cx[it]);
+                raw[it] = ldf_at(pred + (is_b ? rb0 : ra0), el_off[it]);
+                if (it < NEA) cmid[it] = ldf_at(mid + crow, el_cx[it]);
             }
         };
         bool have = next_tile(kz, ky);
         if (have) load_tile(kz, ky);
         while (have) {
             // ---- classify the loaded tile into the wave-private LDS image
+            bool big = false;   // TH05: an operand outside the verified range of the float quotient
 #pragma unroll
             for (int it = 0; it < NE; ++it) {
                 const int e = it * 64 + lane;
@@ -233,6 +267,7 @@ __global__ void __launch_bounds__(64 * V2_WAVES)
                 if (it < NEA) ok = ok && (e >= PX * K::NC || cmid[it] > G.th_gt);  // centre fg
                 const float v = raw[it];
                 const float t = v > G.th_gt ? v : (v < G.bg_lt ? -(1.0f - v) : 0.0f);
+                if (TH05) big = big || !(fabsf(t) <= 1024.0f);
                 if (e < K::IMG) img[e] = ok ? t : 0.0f;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -244,17 +279,29 @@ __global__ void __launch_bounds__(64 * V2_WAVES)
             //      ambiguous rounding -- probability ~2^-26 per vote)
             const float *ia = img + lane + (PX - 1);
             const float *ib = img + PX * K::NC + lane + (PX - 1);
-            float acc0[K::NACC];
-            unsigned cnt0[K::NACC];
+            if constexpr (TH05 && VAL == PPP_VAL_NORM_PROB_PRODUCT) {
+                // float-only quotient; a tile with an out-of-range operand (never for
+                // probabilities) takes the double divisions
+                if (__ballot(big) == 0ull) {
+                    if (row0) tile_votes<PX, VAL, true, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes<PX, VAL, false, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                } else {
+                    if (row0) tile_votes<PX, VAL, true, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes<PX, VAL, false, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                }
+            } else {
+                float acc0[K::NACC];
+                unsigned cnt0[K::NACC];
 #pragma unroll
-            for (int i = 0; i < K::NACC; ++i) { acc0[i] = acc[i]; cnt0[i] = cnt[i]; }
-            const bool amb = row0 ? tile_votes<PX, VAL, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt)
-                                  : tile_votes<PX, VAL, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
-            if (VAL == PPP_VAL_NORM_PROB_PRODUCT && __ballot(amb) != 0ull) {
+                for (int i = 0; i < K::NACC; ++i) { acc0[i] = acc[i]; cnt0[i] = cnt[i]; }
+                const bool amb = row0 ? tile_votes<PX, VAL, true, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt)
+                                      : tile_votes<PX, VAL, false, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                if (VAL == PPP_VAL_NORM_PROB_PRODUCT && __ballot(amb) != 0ull) {
 #pragma unroll
-                for (int i = 0; i < K::NACC; ++i) { acc[i] = acc0[i]; cnt[i] = cnt0[i]; }
-                if (row0) tile_votes<PX, VAL, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
-                else tile_votes<PX, VAL, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    for (int i = 0; i < K::NACC; ++i) { acc[i] = acc0[i]; cnt[i] = cnt0[i]; }
+                    if (row0) tile_votes<PX, VAL, true, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes<PX, VAL, false, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -280,15 +327,21 @@ static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float
     const long long n_waves = (long long)runs_per_line * G.bY * G.bZ * n_rows;
     const long long n_blocks = (n_waves + V2_WAVES - 1) / V2_WAVES;
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
+    // per-lane element offsets are 32-bit byte offsets within PX channel volumes
+    if (((long long)(PX - 1) * G.V + G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
     const dim3 grid((unsigned)n_blocks), block(64 * V2_WAVES);
-    if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT)
-        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT><<<grid, block, 0, s>>>(
+    if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
+        G.bg_lt <= 0.5f && !getenv("PPP_S1_NO_TH05"))
+        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, true><<<grid, block, 0, s>>>(
+            pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    else if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT)
+        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, false><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     else if (G.value_rule == PPP_VAL_PROB_PRODUCT)
-        consensus_v2_kernel<T, PX, PPP_VAL_PROB_PRODUCT><<<grid, block, 0, s>>>(
+        consensus_v2_kernel<T, PX, PPP_VAL_PROB_PRODUCT, false><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     else
-        consensus_v2_kernel<T, PX, PPP_VAL_COUNT><<<grid, block, 0, s>>>(
+        consensus_v2_kernel<T, PX, PPP_VAL_COUNT, false><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     return hipGetLastError();
 }

@@ -189,3 +189,14 @@ def test_native_mws_empty_and_all_repulsive():
     pairs = np.array([[0, 0, 0, 0, 0, 1], [0, 0, 1, 0, 0, 2]], dtype=np.uint32)
     nodes, labels, n = backend.host_mws(pairs, np.array([-0.5, -0.25], np.float32), (4, 4, 4))
     assert len(nodes) == 0 and n == 0
+
+
+def test_th05_quotient(tmp_path):
+    """The S1 kernel's float-only normalisation for TH = 0.5 equals the reference's double
+    arithmetic for every float product in [0.25, 2^22] (exhaustive, ~1 s of C)."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "th05_quotient.c")
+    exe = str(tmp_path / "th05_quotient")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
+    out = subprocess.check_output([exe]).decode().split()
+    assert int(out[0]) == 201326593 and int(out[1]) == 0
