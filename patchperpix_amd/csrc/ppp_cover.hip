@@ -24,6 +24,11 @@
 // (the selecting wave marks the (2p-1)^3 box of centres it can affect in a byte volume), the
 // recount stops at the first window row that settles "more than pixTh", and the host only
 // synchronises once per batch of rounds.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -268,6 +273,13 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
             return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (getenv("PPP_COVER_TRACE")) {   // development aid: undecided / selected patches per batch
+            std::vector<int32_t> h((size_t)n);
+            (void)hipMemcpy(h.data(), state, (size_t)n * 4, hipMemcpyDeviceToHost);
+            long long a = 0, sel = 0;
+            for (long long i = 0; i < n; ++i) { a += h[i] == 0; sel += h[i] == 1; }
+            fprintf(stderr, "cover rounds %d: undecided %lld selected %lld\n", *rounds, a, sel);
+        }
     }
     cover_unpack_kernel<<<vgrid, block, 0, s>>>(W.mbits, mask, G);
     return hipGetLastError();

@@ -29,14 +29,13 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
     rank_v2_kernel(const T *__restrict__ pred, const float *__restrict__ cons,
                    const uint8_t *__restrict__ ov, float *__restrict__ score, const ppp_box sb,
                    const Geo G, const int runs_per_line, const long long n_waves) {
-    extern __shared__ uint32_t lds_raw[];  // [R2_WAVES][3][words][64]
+    extern __shared__ uint32_t lds_raw[];  // [R2_WAVES][2][words][64]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
     if (wid >= n_waves) return;
     const int words = (G.C + 31) / 32;
-    uint32_t *Pw = lds_raw + (size_t)(wave * 3 + 0) * words * 64 + lane;
-    uint32_t *Nw = lds_raw + (size_t)(wave * 3 + 1) * words * 64 + lane;
-    uint32_t *Vw = lds_raw + (size_t)(wave * 3 + 2) * words * 64 + lane;
+    uint32_t *Pw = lds_raw + (size_t)(wave * 2 + 0) * words * 64 + lane;
+    uint32_t *Nw = lds_raw + (size_t)(wave * 2 + 1) * words * 64 + lane;
 
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0;
     const int xr = (int)(wid % runs_per_line);
@@ -73,7 +72,7 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                     if (valid && val < G.bg_lt) n |= bit;
                 }
             }
-            Pw[w * 64] = p; Nw[w * 64] = n; Vw[w * 64] = v;
+            Pw[w * 64] = p; Nw[w * 64] = n;   // (V is only needed for |V|)
             nP += __popc(p); nV += __popc(v);
         }
     }
@@ -110,63 +109,92 @@ __global__ void __launch_bounds__(64 * R2_WAVES)
                     pb_z = cons + (((long long)az * G.wy + ay) * G.wx + ax - 1) * plane_stride +
                            ((long long)(-G.rz) * sZc + (long long)(-G.ry) * sYc - PX / 2);
                 }
-                for (int bz = 0; bz < G.pz; ++bz, pf_z += step_z, pb_z += sZc - step_z) {
-                    const float *pf_y = pf_z, *pb_y = pb_z;
-                    for (int by = 0; by < G.py; ++by, pf_y += step_y, pb_y += sYc - step_y) {
-                        const int b0 = (bz * G.py + by) * PX;
-                        // PX-bit fields of P and N starting at bit b0 (may straddle two words)
-                        const int w0 = b0 >> 5, sh = b0 & 31;
-                        uint64_t p64 = Pw[w0 * 64], n64 = Nw[w0 * 64];
-                        if (sh + PX > 32) {
-                            p64 |= (uint64_t)Pw[(w0 + 1) * 64] << 32;
-                            n64 |= (uint64_t)Nw[(w0 + 1) * 64] << 32;
-                        }
-                        uint32_t pf = (uint32_t)(p64 >> sh) & ((1u << PX) - 1u);
-                        uint32_t nf = (uint32_t)(n64 >> sh) & ((1u << PX) - 1u);
-                        // pos votes only for b > a
-                        const int row_cmp = b0 - (a - ax);   // (<0: row before a's, 0: same row, >0: after)
-                        if (row_cmp < 0) pf = 0;
-                        else if (row_cmp == 0) pf &= ~((2u << ax) - 1u);   // keep bits j > ax
-                        uint32_t need = pa ? (pf | nf) : 0u;
-                        if (row_cmp == 0) need &= ~(1u << ax);             // b == a never votes
-                        if (__ballot(need != 0) == 0) continue;
-                        // Addresses.  forward (b > a): key (b - a, z_a) -> plane rises by one per j;
-                        // backward (b < a): key (a - b, z_b) -> plane falls by one, base moves by +1.
-                        // Two scalar base pointers per group, one scalar 64-bit add per element
-                        // (this loop is bound by the scalar ALU, not by the vector one).
-                        // Gathers + ordered accumulation of one group.  MODE is the position of
-                        // the partner row relative to a's row: -1 before (all b < a, backward
-                        // keys), +1 after (all b > a, forward keys), 0 the same row (mixed).
-                        // Keeping it a compile-time constant removes the per-element scalar
-                        // selects (this loop is bound by the scalar ALU).
-                        auto run_group = [&](auto mode_tag) {
-                            constexpr int MODE = decltype(mode_tag)::value;
-                            const float *pf_ptr = pf_y, *pb_ptr = pb_y;
-                            float v[PX];
+                // The partner rows (bz, by) are walked as one flattened sequence r = 0..R-1,
+                // software-pipelined by one row: the gathers of row r+1 are in flight while
+                // row r is accumulated (two row buffers, loop unrolled by two).  The kernel is
+                // bound by memory-level parallelism (every gather misses L2), so doubling the
+                // loads in flight per wave is what matters.  MODE (position of the partner
+                // row relative to a's row: -1 before, 0 same, +1 after) stays a compile-time
+                // constant of the gather / accumulate bodies (scalar-ALU pressure).
+                const int R = G.pz * G.py, ra = az * G.py + ay;
+                struct RowBuf { float v[PX]; uint32_t pf, nf; };
+                // row cursor of the issue stream
+                int ibz = 0, iby = 0;
+                const float *pf_row_z = pf_z, *pb_row_z = pb_z, *pf_row = pf_z, *pb_row = pb_z;
+                auto gather = [&](auto mode_tag, RowBuf &B, const float *pf_y, const float *pb_y) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    const float *pf_ptr = pf_y, *pb_ptr = pb_y;
 #pragma unroll
-                            for (int j = 0; j < PX; ++j) {
-                                const bool back = MODE < 0 || (MODE == 0 && j < ax);
-                                const bool skip = MODE == 0 && j == ax;
-                                const float *src = MODE < 0 ? pb_ptr : (MODE > 0 ? pf_ptr : (back ? pb_ptr : pf_ptr));
-                                v[j] = (fg && !skip) ? src[laneC] : 0.0f;
-                                if (MODE >= 0) pf_ptr += plane_stride;
-                                if (MODE <= 0) pb_ptr += 1 - plane_stride;
-                            }
-#pragma unroll
-                            for (int j = 0; j < PX; ++j) {
-                                const bool is_p = (pf >> j) & 1u, is_n = (nf >> j) & 1u;
-                                const bool use = pa && (is_p || is_n) && !(MODE == 0 && j == ax);
-                                float c = v[j];
-                                if (COUNT_POS_NEG) c = (c != 0.0f) ? copysignf(1.0f, c) : (is_p ? -1.0f : 1.0f);
-                                // acc += c for a foreground partner, acc -= c for a background one
-                                const float term = is_p ? c : -c;
-                                acc = acc + (use ? term : 0.0f);
-                            }
-                        };
-                        if (row_cmp < 0) run_group(std::integral_constant<int, -1>{});
-                        else if (row_cmp > 0) run_group(std::integral_constant<int, 1>{});
-                        else run_group(std::integral_constant<int, 0>{});
+                    for (int j = 0; j < PX; ++j) {
+                        const bool back = MODE < 0 || (MODE == 0 && j < ax);
+                        const bool skip = MODE == 0 && j == ax;
+                        const float *src = MODE < 0 ? pb_ptr : (MODE > 0 ? pf_ptr : (back ? pb_ptr : pf_ptr));
+                        B.v[j] = (fg && !skip) ? src[laneC] : 0.0f;
+                        if (MODE >= 0) pf_ptr += plane_stride;
+                        if (MODE <= 0) pb_ptr += 1 - plane_stride;
                     }
+                };
+                // masks of the cursor row + its gathers; advances the cursor; false = no lane
+                // needs the row (nothing issued)
+                auto issue = [&](RowBuf &B) -> bool {
+                    const int r = ibz * G.py + iby;
+                    const int b0 = r * PX;
+                    // PX-bit fields of P and N starting at bit b0 (may straddle two words)
+                    const int w0 = b0 >> 5, sh = b0 & 31;
+                    uint64_t p64 = Pw[w0 * 64], n64 = Nw[w0 * 64];
+                    if (sh + PX > 32) {
+                        p64 |= (uint64_t)Pw[(w0 + 1) * 64] << 32;
+                        n64 |= (uint64_t)Nw[(w0 + 1) * 64] << 32;
+                    }
+                    uint32_t pf = (uint32_t)(p64 >> sh) & ((1u << PX) - 1u);
+                    const uint32_t nf = (uint32_t)(n64 >> sh) & ((1u << PX) - 1u);
+                    // pos votes only for b > a
+                    if (r < ra) pf = 0;
+                    else if (r == ra) pf &= ~((2u << ax) - 1u);   // keep bits j > ax
+                    uint32_t need = pa ? (pf | nf) : 0u;
+                    if (r == ra) need &= ~(1u << ax);             // b == a never votes
+                    const bool any = __ballot(need != 0) != 0;
+                    if (any) {
+                        B.pf = pf; B.nf = nf;
+                        if (r < ra) gather(std::integral_constant<int, -1>{}, B, pf_row, pb_row);
+                        else if (r > ra) gather(std::integral_constant<int, 1>{}, B, pf_row, pb_row);
+                        else gather(std::integral_constant<int, 0>{}, B, pf_row, pb_row);
+                    }
+                    // advance the cursor (running base pointers: one scalar 64-bit add per step)
+                    if (++iby == G.py) {
+                        iby = 0; ++ibz;
+                        pf_row_z += step_z; pb_row_z += sZc - step_z;
+                        pf_row = pf_row_z; pb_row = pb_row_z;
+                    } else {
+                        pf_row += step_y; pb_row += sYc - step_y;
+                    }
+                    return any;
+                };
+                // ordered accumulation of one buffered row r
+                auto consume = [&](const RowBuf &B, const int r) {
+                    auto body = [&](auto mode_tag) {
+                        constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            const bool is_p = (B.pf >> j) & 1u, is_n = (B.nf >> j) & 1u;
+                            const bool use = pa && (is_p || is_n) && !(MODE == 0 && j == ax);
+                            float c = B.v[j];
+                            if (COUNT_POS_NEG) c = (c != 0.0f) ? copysignf(1.0f, c) : (is_p ? -1.0f : 1.0f);
+                            // acc += c for a foreground partner, acc -= c for a background one
+                            const float term = is_p ? c : -c;
+                            acc = acc + (use ? term : 0.0f);
+                        }
+                    };
+                    if (r == ra) body(std::integral_constant<int, 0>{});
+                    else body(std::integral_constant<int, 1>{});   // (MODE only matters on a's row)
+                };
+                RowBuf bufA, bufB;
+                bool anyA = issue(bufA), anyB = false;
+                for (int r = 0; r < R; r += 2) {
+                    if (r + 1 < R) anyB = issue(bufB);
+                    if (anyA) consume(bufA, r);
+                    if (r + 2 < R) anyA = issue(bufA);
+                    if (r + 1 < R && anyB) consume(bufB, r + 1);
                 }
             }
     if (fg) {
@@ -181,7 +209,7 @@ static hipError_t launch_r2(const T *pred, const float *cons, const uint8_t *ov,
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
     const int runs_per_line = (sX + 63) / 64;
     const long long n_waves = (long long)runs_per_line * sY * sZ;
-    const size_t per_wave = (size_t)3 * ((G.C + 31) / 32) * 64 * sizeof(uint32_t);
+    const size_t per_wave = (size_t)2 * ((G.C + 31) / 32) * 64 * sizeof(uint32_t);
     int waves = R2_WAVES;
     while (waves > 1 && waves * per_wave > 40 * 1024) waves >>= 1;   // keep >= 4 blocks per CU
     if (waves * per_wave > 64 * 1024) return hipErrorNotSupported;
