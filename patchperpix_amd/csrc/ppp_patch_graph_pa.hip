@@ -93,6 +93,28 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     uint32_t *fbw = faw + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3);          // [words][PA_THREADS]
     __shared__ int s_nu;
 
+    // ---- The range / intersection / stored conditions of a whole (y2o, x2o) candidate plane
+    // are evaluated at once as bit masks, bit (y2o - y_first) * PX + x2o, for chunks of RPC rows
+    // (one chunk unless PX = 9).  Per-axis masks are expanded once per pixel row / pixel: EY*
+    // repeat a y bit over the PX bits of its row, RX repeats the x mask in every row.
+    typedef unsigned long long u64;
+    constexpr uint32_t RM = (1u << PX) - 1u;
+    constexpr int RPC = 64 / PX;                         // candidate rows per 64-bit chunk
+    constexpr int NCH = (PX + RPC - 1) / RPC;            // chunks (the launcher checks py <= NCH * RPC)
+    auto expand_y = [&](uint32_t m, int c) -> u64 {
+        u64 e = 0;
+        for (int j = 0; j < RPC; ++j) e |= ((m >> (c * RPC + j)) & 1u) ? ((u64)RM << (PX * j)) : 0ull;
+        return e;
+    };
+    // x mask repeated in every row, by doubling (rows beyond the chunk are harmless: every use
+    // is ANDed with an EY mask, which is clear there)
+    auto repeat_x = [&](uint32_t m) -> u64 {
+        u64 e = m;
+#pragma unroll
+        for (int n = 1; n < RPC; n *= 2) e |= e << (PX * n);
+        return e;
+    };
+
     // ---- which (patch, chunk) is this workgroup?  binary search in the chunk prefix sums
     int g;
     {
@@ -179,6 +201,9 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
 
     const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
     const long long baseA = ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0);
+    // (pixel indices come out of LDS but are workgroup-uniform: readfirstlane keeps the row
+    // address arithmetic on the scalar unit and the staging loads in the saddr + voffset form)
+    auto pixel = [&](int k) -> int { return __builtin_amdgcn_readfirstlane((int)ulist[k]); };
     auto row_of = [&](int r1) -> const float * {
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
         return S + (baseA + (long long)(z1o - G.rz) * sZ + (long long)(y1o - G.ry) * sY + (x1o - PX / 2)) * W;
@@ -192,7 +217,7 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     // ---- stage the first row
     float st[NST];
     if (n_u > 0) {
-        const float *src = row_of(ulist[0]);
+        const float *src = row_of(pixel(0));
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int e = tid + i * PA_THREADS;
@@ -201,47 +226,29 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     }
     __syncthreads();
 
-    // ---- The range / intersection / stored conditions of a whole (y2o, x2o) candidate plane
-    // are evaluated at once as bit masks, bit (y2o - y_first) * PX + x2o, for chunks of RPC rows
-    // (one chunk unless PX = 9).  Per-axis masks are expanded once per pixel row / pixel: EY*
-    // repeat a y bit over the PX bits of its row, RX repeats the x mask in every row.
-    typedef unsigned long long u64;
-    constexpr uint32_t RM = (1u << PX) - 1u;
-    constexpr int RPC = 64 / PX;                         // candidate rows per 64-bit chunk
-    constexpr int NCH = (PX + RPC - 1) / RPC;            // chunks (the launcher checks py <= NCH * RPC)
-    auto expand_y = [&](uint32_t m, int c) -> u64 {
-        u64 e = 0;
-        for (int j = 0; j < RPC; ++j) e |= ((m >> (c * RPC + j)) & 1u) ? ((u64)RM << (PX * j)) : 0ull;
-        return e;
-    };
-    // x mask repeated in every row, by doubling (rows beyond the chunk are harmless: every use
-    // is ANDed with an EY mask, which is clear there)
-    auto repeat_x = [&](uint32_t m) -> u64 {
-        u64 e = m;
-#pragma unroll
-        for (int n = 1; n < RPC; n *= 2) e |= e << (PX * n);
-        return e;
-    };
     int prev_z1o = -1, prev_y1o = -1;
     AxisMasks mz = axis_masks(dz, 0, G.pz), my = axis_masks(dy, 0, G.py);
     u64 EYf[NCH], EYbk[NCH], EYpos[NCH], EYzero[NCH], EYst[NCH], EYin[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) EYf[c] = EYbk[c] = EYpos[c] = EYzero[c] = EYst[c] = EYin[c] = 0ull;
     for (int k = 0; k < n_u; ++k) {
-        const int r1 = ulist[k];
+        const int r1 = pixel(k);
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
         const float *cur = rowbuf + (k & 1) * WB + PA_PAD;
         // ---- fetch the next row into registers while this one is consumed
         const bool more = k + 1 < n_u;
         if (more) {
-            const float *src = row_of(ulist[k + 1]);
+            const float *src = row_of(pixel(k + 1));
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int e = tid + i * PA_THREADS;
                 st[i] = e < W ? src[e] : 0.0f;
             }
         }
-        if (wave_live) {
+        // union of the lanes' candidate ranges: -p <= d + b - a <= p (wave-uniform)
+        const int z_lo = max(0, z1o - dz_hi - G.pz), z_hi = min(G.pz - 1, z1o - dz_lo + G.pz);
+        const int y_lo = max(0, y1o - dy_hi - G.py), y_hi = min(G.py - 1, y1o - dy_lo + G.py);
+        if (wave_live && z_lo <= z_hi && y_lo <= y_hi) {
             PA_STAT(0, lane == 0 ? 1 : 0);
             PA_STAT(5, live ? 1 : 0);
             if (z1o != prev_z1o) { mz = axis_masks(dz, z1o, G.pz); prev_z1o = z1o; }
@@ -254,15 +261,16 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
                     EYzero[c] = expand_y(my.zero, c); EYst[c] = expand_y(my.st, c); EYin[c] = expand_y(my.in, c);
                 }
             }
-            const AxisMasks mx = axis_masks(dx, x1o, PX);
+            const int q0x = dx - x1o;
             const bool in_b = abs(x1o - PX / 2 - dx) <= PX / 2 && abs(y1o - G.ry - dy) <= G.ry &&
                               abs(z1o - G.rz - dz) <= G.rz;
+            // (a workgroup table of these masks in LDS, indexed by q0x, was measured: fewer
+            // VALU instructions but 4 % slower -- five dependent LDS reads at the head of
+            // every pixel step)
+            const AxisMasks mx = axis_masks(dx, x1o, PX);
             const u64 RXf = repeat_x(mx.f), RXbk = repeat_x(mx.bk), RXst = repeat_x(mx.st),
                       RXin = in_b ? repeat_x(mx.in) : 0ull, RXnn = repeat_x(mx.pos | mx.zero),
                       RXzero = repeat_x(mx.zero);
-            // union of the lanes' candidate ranges: -p <= d + b - a <= p
-            const int z_lo = max(0, z1o - dz_hi - G.pz), z_hi = min(G.pz - 1, z1o - dz_lo + G.pz);
-            const int y_lo = max(0, y1o - dy_hi - G.py), y_hi = min(G.py - 1, y1o - dy_lo + G.py);
             for (int z2o = z_lo; z2o <= z_hi; ++z2o) {
                 const uint32_t zb = 1u << z2o;
                 const bool z_f = mz.f & zb, z_bk = mz.bk & zb, z_pos = mz.pos & zb, z_zero = mz.zero & zb,
@@ -323,7 +331,7 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
                     const u64 add = stored & valid;
                     if (__ballot(add != 0ull) == 0ull) continue;
                     // this lane's offset into the staged row for candidate (y2o = 0, x2o = 0)
-                    const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + mx.q0;
+                    const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + q0x;
                     for (int y2o = ya; y2o <= yb; ++y2o) {
                         const uint32_t rb = (uint32_t)(add >> (PX * (y2o - c_first))) & RM;
                         if (__ballot(rb != 0u) == 0ull) continue;
@@ -392,10 +400,20 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     if (W > (cube + threads - 1) / threads * threads) return hipErrorNotSupported;
     // candidate planes are handled as ceil(px / (64 / px)) 64-bit chunks of 64 / px rows
     if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;
-    const size_t lds = (size_t)(2 * WB + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3) + words * threads) * 4;
-    if (lds > 64 * 1024 || n_blocks >= (1ll << 31)) return hipErrorNotSupported;
+    const size_t lds = (size_t)(2 * WB + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3) +
+                                ((words * threads + 1) & ~1)) * 4;
+    if (lds > 80 * 1024 || n_blocks >= (1ll << 31)) return hipErrorNotSupported;
+    // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
 #define PPP_PA_CASE(P)                                                                             \
     case P:                                                                                        \
+        if (lds > 64 * 1024) {                                                                     \
+            hipError_t ea = dtype == PPP_F16                                                       \
+                ? hipFuncSetAttribute((const void *)patch_graph_pa_kernel<__half, P>,              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)        \
+                : hipFuncSetAttribute((const void *)patch_graph_pa_kernel<float, P>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            if (ea != hipSuccess) return ea;                                                       \
+        }                                                                                          \
         if (dtype == PPP_F16)                                                                      \
             patch_graph_pa_kernel<__half, P><<<dim3((unsigned)n_blocks), dim3(threads), lds, s>>>(    \
                 (const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, G); \
