@@ -199,6 +199,25 @@ def main():
     if rank == 0 and roofline is not None and args.workload == "flylight140_p7" and world == 1 \
             and not args.slabs:
         roofline.update(pmc_traffic("consensus_v2_kernel"))
+    # The kernel that takes most of the step is S5 (patch graph).  SURVEY 8d's secondary figure
+    # for it: n_pairs * (2 * C * elem + visited * 4) bytes -- both patches' channel vectors and
+    # the consensus entries a pair visits; `visited` is not counted at run time, so the
+    # figure below is the lower bound without it (reported next to the S1 roofline, which is
+    # the one the metric names).
+    roofline_pg = None
+    if ev.get("patch_graph") and backend.NOTES.get("n_pairs"):
+        pg_ms = float(np.sum(ev["patch_graph"]))
+        pg_bytes = float(backend.NOTES["n_pairs"]) * 2.0 * C * 2.0 * args.steps
+        ach = pg_bytes / (pg_ms * 1e-3) / 1e9
+        roofline_pg = {"bound": "hbm", "kernel": "patch_graph_pa_kernel", "achieved": ach,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                       "traffic": None, "avg_ms": pg_ms / len(ev["patch_graph"]),
+                       "launches": len(ev["patch_graph"]),
+                       "pairs_per_s": float(backend.NOTES["n_pairs"]) * args.steps / (pg_ms * 1e-3),
+                       "note": "VALU-issue bound (PMC: 72 % VALU busy, profiles/): per-lane "
+                               "candidate masks, 12 % of the executed add slots are useful"}
+        if rank == 0 and args.workload == "flylight140_p7" and world == 1 and not args.slabs:
+            roofline_pg.update(pmc_traffic("patch_graph_pa_kernel"))
     if rank == 0:
         out = {
             "metric": "Mvoxels/sec assembled (vote_instances)", "value": value,
@@ -211,6 +230,7 @@ def main():
                        "instances_found": int(len(np.unique(inst)) - 1),
                        "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus},
             "roofline": roofline,
+            "roofline_patch_graph": roofline_pg,
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
             "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
                               for k, v in (host_times or {}).items()},

@@ -16,7 +16,13 @@ exactly: the order-defined global stages (ranking, greedy cover, thinning, compo
 on globally gathered data, identically on every rank; only the voxel-local stages (S1 consensus,
 S2 scores, S5 pair affinities, painting) are sharded.
 
-Halos along z (rz = pz // 2; y and x are not split):
+A z-slab can further be cut into y/x tiles (``_yx_tiles=(ny, nx)``; single-process tiling of
+volumes whose one-slice-thick slab would still not fit, e.g. 512^3 with 9^3 patches).  The same
+halo rules hold per axis, except that y and x need the "pairs" growth on BOTH sides: a stored
+consensus offset is lexicographically positive, i.e. its z component is >= 0 but its y / x
+components take either sign, so the earlier voxel of a pair can lie on the high y / x side.
+
+Halos along z (rz = pz // 2):
   scores of centres   [z0, z1)            need consensus bases [z0 - rz, z1 + rz)
   pairs with A in     [z0, z1)            need consensus bases [z0 - rz - (pz-1), z1 + rz)
   consensus of bases  [b0, b1)            needs the prediction on [b0 - 2 rz, b1 + 2 rz)
@@ -44,6 +50,12 @@ def plan_slabs(Z, n_slabs):
     n_slabs = max(1, min(int(n_slabs), int(Z)))
     edges = np.linspace(0, Z, n_slabs + 1).round().astype(int)
     return [(int(edges[i]), int(edges[i + 1])) for i in range(n_slabs) if edges[i + 1] > edges[i]]
+
+
+def plan_yx(Y, X, ny, nx):
+    """ny x nx tiles (y0, y1, x0, x1) covering [0, Y) x [0, X)."""
+    ys, xs = plan_slabs(Y, ny), plan_slabs(X, nx)
+    return [(y0, y1, x0, x1) for (y0, y1) in ys for (x0, x1) in xs]
 
 
 def slabs_of_rank(slabs, rank, world):
@@ -167,35 +179,55 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             np.count_nonzero(foreground[radslice]) == 0:
         return early()
 
-    flags = {k: v for k, v in kw.items() if k not in ("cons_box", "cons_layout", "origin")}
+    flags = {k: v for k, v in kw.items()
+             if k not in ("cons_box", "cons_layout", "origin", "_yx_tiles")}
+    ny_t, nx_t = kw.get("_yx_tiles") or (1, 1)
+    # tiles of patch centres (z0, z1, y0, y1, x0, x1): the rank's z-slabs, each cut in y / x
+    my_tiles = [(z0, z1) + t for (z0, z1) in my_slabs for t in plan_yx(Y, X, ny_t, nx_t)]
     local_shape = (Zl, Y, X)
 
-    def params(box_z=None):
-        box = None if box_z is None else (box_z[0] - lo, 0, 0, box_z[1] - lo, Y, X)
+    def params(box=None):
+        """box: global (z0, z1, y0, y1, x0, x1) of consensus base voxels, or None."""
+        if box is not None:
+            box = (box[0] - lo, box[2], box[4], box[1] - lo, box[3], box[5])
         return backend.make_params(local_shape, ps, cons_box=box, origin=(lo, 0, 0), **flags)
 
     Pg = backend.make_params(shape, ps, **flags)          # global geometry (pairs, labels)
     ov_local = torch.from_numpy(
         np.ascontiguousarray((overlap_mask[lo:hi] > 0).astype(np.uint8))).to(dev)
-    keep_cons = len(my_slabs) == 1 and kw.get("_keep_cons", True)
+    keep_cons = len(my_tiles) == 1 and kw.get("_keep_cons", True)
     kept = {}
+    dims = (Z, Y, X)
 
-    def bases_for_pairs(z0, z1):
-        return max(0, z0 - rz - (ps[0] - 1)), min(Z, z1 + rz)
+    def bases_for_scores(t):
+        """consensus bases the scores of the centres in tile t read: t grown by the radius"""
+        return tuple(v for a in range(3) for v in
+                     (max(0, t[2 * a] - int(rad[a])), min(dims[a], t[2 * a + 1] + int(rad[a]))))
+
+    def bases_for_pairs(t):
+        """... the pairs with patch A in t read: the voxel-major rows S[u][q], u in win(A), are
+        built from the stored (positive) offsets, S[u][q < 0] = cons[-q][u + q]; u + q lies up
+        to p-1 below u in z and up to p-1 on either side in y / x"""
+        b = []
+        for a in range(3):
+            g = ps[a] - 1
+            b += [max(0, t[2 * a] - int(rad[a]) - g),
+                  min(dims[a], t[2 * a + 1] + int(rad[a]) + (g if a > 0 else 0))]
+        return tuple(b)
 
     # ---- stage A: consensus + scores per slab --------------------------------------------
     score_dev = torch.zeros(shape, dtype=torch.float32, device=dev)
-    for (z0, z1) in my_slabs:
-        bz = bases_for_pairs(z0, z1) if keep_cons else (max(0, z0 - rz), min(Z, z1 + rz))
-        P = params(bz)
+    for t in my_tiles:
+        z0, z1, y0, y1, x0, x1 = t
+        P = params(bases_for_pairs(t) if keep_cons else bases_for_scores(t))
         with backend.host_timer("s1_consensus"):
             cons = ops.consensus(pred_local, ov_local, P)
         with backend.host_timer("s2_rank"):
             sc = ops.rank_patches(pred_local, cons, ov_local, P,
-                                  (z0 - lo, 0, 0, z1 - lo, Y, X))
-        score_dev[z0:z1] = sc[z0 - lo:z1 - lo]
+                                  (z0 - lo, y0, x0, z1 - lo, y1, x1))
+        score_dev[z0:z1, y0:y1, x0:x1] = sc[z0 - lo:z1 - lo, y0:y1, x0:x1]
         if keep_cons:
-            kept[(z0, z1)] = (cons, P)
+            kept[t] = (cons, P)
         del cons, sc
     comm.all_reduce_sum(score_dev)
 
@@ -282,17 +314,23 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     aff = torch.zeros((n_rows,), dtype=torch.float32, device=dev)
     shift = torch.tensor([lo, 0, 0, lo, 0, 0], dtype=torch.int32, device=dev)
     with backend.host_timer("s5_patch_graph"):
-        for (z0, z1) in my_slabs:
+        for t in my_tiles:
+            z0, z1, y0, y1, x0, x1 = t
             with backend.host_timer("s5a_select_rows"):
-                idx = torch.nonzero((rows[:, 0] >= z0) & (rows[:, 0] < z1)).reshape(-1)
+                own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
+                if ny_t > 1 or nx_t > 1:
+                    own &= (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
+                           (rows[:, 2] >= x0) & (rows[:, 2] < x1)
+                idx = torch.nonzero(own).reshape(-1)
+                del own
                 if idx.numel() == 0:
                     continue
                 rows_l = (rows[idx] - shift).contiguous()
             with backend.host_timer("s5b_consensus"):
                 if keep_cons:
-                    cons, P = kept.pop((z0, z1))
+                    cons, P = kept.pop(t)
                 else:
-                    P = params(bases_for_pairs(z0, z1))
+                    P = params(bases_for_pairs(t))
                     cons = ops.consensus(pred_local, ov_local, P)
             with backend.host_timer("s5c_patch_graph"):
                 a = ops.patch_graph(pred_local, cons, rows_l, P)
@@ -357,10 +395,40 @@ def slabs_needed(shape, patchshape, free_bytes, safety=0.6):
     return Z
 
 
+def tiles_needed(shape, patchshape, free_bytes, safety=0.6):
+    """(n_slabs, ny, nx): z-slabs first (slabs_needed); when even thin slabs do not fit, the
+    longest tile edge among y / x is halved until the working set of one tile (3x the compact
+    consensus on the tile grown by the pairs halo) fits `free_bytes`."""
+    pz, py, px = [int(p) for p in patchshape]
+    planes = ((2 * pz - 1) * (2 * py - 1) * (2 * px - 1) - 1) // 2
+    Z, Y, X = [int(v) for v in shape]
+    budget = safety * free_bytes
+
+    def fits(tz, ty, tx):
+        bz = min(Z, tz + 2 * (pz // 2) + pz - 1)
+        by = min(Y, ty + 2 * (py // 2) + 2 * (py - 1))
+        bx = min(X, tx + 2 * (px // 2) + 2 * (px - 1))
+        return 3.0 * planes * 4 * bz * by * bx <= budget
+
+    n = slabs_needed(shape, patchshape, free_bytes, safety)
+    ny = nx = 1
+    # thin slabs waste most of their work on halos: keep the slab at least ~4 radii thick
+    min_tz = min(Z, max(8 * (pz // 2), 8))
+    while (-(-Z // n) < min_tz or not fits(-(-Z // n), -(-Y // ny), -(-X // nx))) and (ny < Y or nx < X):
+        n = min(n, max(1, Z // min_tz))
+        if fits(-(-Z // n), -(-Y // ny), -(-X // nx)):
+            break
+        if -(-Y // ny) >= -(-X // nx) and ny < Y:
+            ny *= 2
+        else:
+            nx *= 2
+    return n, min(ny, Y), min(nx, X)
+
+
 def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,
                           **kw):
     """Single-process tiling: the whole prediction is resident, the consensus lives for one
-    z-slab at a time."""
+    z-slab (or y/x tile of it, ``_yx_tiles``) at a time."""
     pred = backend.to_device_pred(pred_affs)
     shape = tuple(int(s) for s in pred.shape[1:])
     slabs = plan_slabs(shape[0], n_slabs)

@@ -118,12 +118,15 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     # Volumes whose consensus does not fit in HBM are assembled slab by slab (identical result,
     # patchperpix_amd/tiling.py); `_n_slabs` forces a slab count.
     n_slabs = kwargs.get("_n_slabs")
+    yx_tiles = kwargs.get("_yx_tiles")
     if n_slabs is None and not kwargs.get("save_consensus", False):
         from .. import tiling
         # free HBM + what the caching allocator holds but has not handed out
         avail = torch.cuda.mem_get_info()[0] + \
             (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
-        n_slabs = tiling.slabs_needed(shape, patchshape, avail)
+        n_slabs, ny_t, nx_t = tiling.tiles_needed(shape, patchshape, avail)
+        if yx_tiles is None and (ny_t > 1 or nx_t > 1):
+            yx_tiles = (ny_t, nx_t)
     # With nothing to store or load between the stages, the single-slab case takes the same
     # code path: it keeps the ranked patch list on the device instead of materialising the
     # reference's host lists between the stage functions (PPP_PIPELINE=stages keeps them).
@@ -132,11 +135,13 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
                                             "termAfterThinCover", "termAfterPatchGraph",
                                             "save_consensus", "blockwise")) \
         and os.environ.get("PPP_PIPELINE", "fused") != "stages"
-    if n_slabs and (n_slabs > 1 or plain) and not kwargs.get("graphToInst") \
+    if n_slabs and (n_slabs > 1 or yx_tiles or plain) and not kwargs.get("graphToInst") \
             and kwargs.get("aff_graph") is None and not kwargs.get("pad_with_ps", False):
         from .. import tiling
         logger.info("assembling in %d z-slabs", n_slabs)
-        kw = {k: v for k, v in kwargs.items() if k != "_n_slabs"}
+        kw = {k: v for k, v in kwargs.items() if k not in ("_n_slabs", "_yx_tiles")}
+        if yx_tiles:
+            kw["_yx_tiles"] = tuple(int(v) for v in yx_tiles)
         return tiling.assemble(pred_affs, 0, shape, foreground, mask_to_cover, numinst,
                                patchshape, tiling.plan_slabs(shape[0], n_slabs), **kw)
     radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))

@@ -56,6 +56,40 @@ def test_sequential_slabs_equal_whole_volume_cpu(n_slabs, thin):
     assert np.array_equal(aff.view(np.uint32), ref["aff"].view(np.uint32))
 
 
+@pytest.mark.parametrize("n_slabs,yx", [(2, (2, 2)), (1, (3, 2)), (3, (1, 2))])
+def test_yx_tiles_equal_whole_volume_cpu(n_slabs, yx):
+    """z-slabs cut further into y/x tiles (the 512^3 / 9^3 single-GPU case): same result."""
+    import torch
+    from oracle_ops import OracleOps
+    c, ps, kw = make_case(seed=63, shape=(20, 17, 19))
+    ref = whole_volume(c, ps, kw)
+    ops = OracleOps(**kw)
+    slabs = tiling.plan_slabs(c["pred"].shape[1], n_slabs)
+    pairs, aff = tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                                 c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                                 slabs, ops=ops, return_intermediates=True, _yx_tiles=yx, **kw)
+    assert np.array_equal(pairs, ref["pairs"])
+    assert np.array_equal(aff.view(np.uint32), ref["aff"].view(np.uint32))
+    inst, fg = tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                               c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                               slabs, ops=ops, _yx_tiles=yx, **kw)
+    assert np.array_equal(inst, ref["instances"]) and inst.any()
+
+
+def test_tiles_needed():
+    # fits whole: one tile
+    assert tiling.tiles_needed((140, 140, 140), (7, 7, 7), 250e9) == (1, 1, 1)
+    # 256^3 / 7^3: z-slabs suffice
+    n, ny, nx = tiling.tiles_needed((256, 256, 256), (7, 7, 7), 200e9)
+    assert n > 1 and (ny, nx) == (1, 1)
+    # 512^3 / 9^3 next to a 196 GB prediction: needs y/x tiles, and every tile fits
+    n, ny, nx = tiling.tiles_needed((512, 512, 512), (9, 9, 9), 90e9)
+    assert ny > 1 and nx > 1
+    planes = (17 ** 3 - 1) // 2
+    box = [min(512, -(-512 // k) + g) for k, g in ((n, 16), (ny, 24), (nx, 24))]
+    assert 3.0 * planes * 4 * box[0] * box[1] * box[2] <= 0.6 * 90e9
+
+
 WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
@@ -108,3 +142,25 @@ def test_sequential_slabs_equal_whole_volume_gpu(n_slabs):
                                           n_slabs, **kw)
     assert np.array_equal(got, want)
     assert got.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_slabs,yx", [(2, (2, 2)), (1, (2, 3))])
+def test_yx_tiles_equal_whole_volume_gpu(n_slabs, yx):
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    c = synth.make_case((30, 34, 38), (5, 5, 5), seed=64, cell=[8, 8, 8], overlap_frac=0.02)
+    ps, kw = [5, 5, 5], dict(FLYLIGHT)
+    want_p, want_a = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(),
+                                        c["foreground"].copy(), c["numinst"].copy(), ps,
+                                        **dict(kw, return_intermediates=True, _n_slabs=1))
+    got_p, got_a = tiling.to_instance_seg_tiled(c["pred"].copy(), c["foreground"].copy(),
+                                                c["foreground"].copy(), c["numinst"].copy(), ps,
+                                                n_slabs, return_intermediates=True, _yx_tiles=yx, **kw)
+    assert np.array_equal(got_p, want_p)
+    assert np.array_equal(got_a.view(np.uint32), want_a.view(np.uint32))
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), ps, **dict(kw, _n_slabs=1))
+    got, _ = tiling.to_instance_seg_tiled(c["pred"].copy(), c["foreground"].copy(),
+                                          c["foreground"].copy(), c["numinst"].copy(), ps,
+                                          n_slabs, _yx_tiles=yx, **kw)
+    assert np.array_equal(got, want) and got.any()
