@@ -17,6 +17,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -82,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slabs", type=int, default=None,
                     help="force the number of z-slabs of the single-GPU tiled path")
+    ap.add_argument("--yx", type=int, nargs=2, default=None, metavar=("NY", "NX"),
+                    help="cut every z-slab into NY x NX tiles (single-GPU tiled path)")
     args = ap.parse_args()
 
     import torch
@@ -113,6 +116,9 @@ def main():
 
         if args.slabs:
             kw["_n_slabs"] = args.slabs
+        if args.yx:
+            kw["_yx_tiles"] = tuple(args.yx)
+            kw.setdefault("_n_slabs", 1)
 
         def step():
             inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps, **kw)
@@ -228,7 +234,9 @@ def main():
                        "pred_dtype": "f16 resident, widened to f32 in registers",
                        "flags": "flylight default.toml [vote_instances]",
                        "instances_found": int(len(np.unique(inst)) - 1),
-                       "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus},
+                       "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
+                       "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus if not args.yx else
+                       "z-slabs x%d, yx tiles %dx%d" % ((args.slabs or 1,) + tuple(args.yx))},
             "roofline": roofline,
             "roofline_patch_graph": roofline_pg,
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
