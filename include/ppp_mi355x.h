@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PPP_ABI_VERSION 2
+#define PPP_ABI_VERSION 3
 
 enum ppp_error {
     PPP_OK = 0,
@@ -173,6 +173,35 @@ int ppp_label_components(const uint32_t *d_pairs, const float *d_aff, uint64_t n
                          const uint32_t *d_nodes, uint64_t n_nodes, uint32_t *d_node_key,
                          void *d_work, const ppp_params *p, void *stream);
 
+/* The same labelling in STREAMING form: the pair rows of a large volume need not exist at
+ * the same time (tile by tile on one GPU), nor on one device (every rank labels the rows of
+ * its own patches; the forests are merged afterwards -- the boundary-label merge).  Both
+ * stitch_patch_graph.py's "one global graph from per-block pair lists" (:110-399) and
+ * setAffgraph + connected_components (see above) are covered.
+ *   ppp_label_begin        state of every node of d_nodes (parent = itself, no key)
+ *   ppp_label_add          a batch of rows with their affinities; the row ids are GLOBAL
+ *                          positions in the canonical pair list (d_row_ids int64[n], or
+ *                          first_row_id + i when d_row_ids is NULL).  Order-free: atomicMin of
+ *                          2*id+side on the nodes of rows with aff != 0, lock-free unions
+ *                          (CAS hooking under the smaller root) for rows with aff > 0.
+ *   ppp_label_union_edges  unions given as node pairs (linear voxel indices, int64): how
+ *                          another rank's forest (node, parent[node]) is merged
+ *   ppp_label_finish       d_node_key int64[n_nodes]: the component's order key (smallest
+ *                          2*id+side of a member with a positive edge) or PPP_LABEL_NONE_KEY
+ * Workspace (ppp_label_workspace_bytes): four volumes indexed by linear voxel index,
+ * parent u32[V] | has_positive_edge u32[V] | firstpos u64[V] | key u64[V]; callers that merge
+ * ranks read / write the node entries of these arrays directly.                           */
+#define PPP_LABEL_NONE_KEY (1ull << 62)
+int ppp_label_begin(const uint32_t *d_nodes, uint64_t n_nodes, void *d_work, const ppp_params *p,
+                    void *stream);
+int ppp_label_add(const uint32_t *d_pairs, const float *d_aff, const int64_t *d_row_ids,
+                  int64_t first_row_id, uint64_t n_pairs, void *d_work, const ppp_params *p,
+                  void *stream);
+int ppp_label_union_edges(const int64_t *d_a, const int64_t *d_b, uint64_t n, void *d_work,
+                          const ppp_params *p, void *stream);
+int ppp_label_finish(const uint32_t *d_nodes, uint64_t n_nodes, int64_t *d_node_key, void *d_work,
+                     const ppp_params *p, void *stream);
+
 /* ppp_paint_instances: for every node k (d_nodes u32[n_nodes][3]) with label
  * d_labels[k] > 0, write the label into every voxel of its window whose patch value is
  * > TH, keeping the maximum label per voxel ("later components overwrite earlier ones",
@@ -232,6 +261,20 @@ int ppp_patch_pairs_count(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps
 int ppp_patch_pairs_fill(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
                          const int64_t *d_offsets, int64_t n_pair_rows, int32_t include_single,
                          uint32_t *d_rows, const ppp_params *p, void *stream);
+/* The rows of a SUBSET of first patches (the patches of one tile / one rank; the blockwise
+ * form of computeAndStorePatchPairs, stitch_patch_graph.py:209-248).  d_subset int64[m]:
+ * indices into the x-sorted list.  count: d_counts[d_subset[k]] only.  fill: rows of subset
+ * entry k start at local row d_local_offsets[k]; d_row_ids receives the GLOBAL row id of every
+ * local row (d_global_offsets[i] + j; the self pair of patch i has id n_rows_total + i and
+ * local position n_local_rows + k).                                                       */
+int ppp_patch_pairs_count_subset(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                                 const int64_t *d_subset, int64_t m, int64_t *d_counts,
+                                 const ppp_params *p, void *stream);
+int ppp_patch_pairs_fill_subset(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                                const int64_t *d_subset, int64_t m, const int64_t *d_local_offsets,
+                                const int64_t *d_global_offsets, int64_t n_local_rows,
+                                int64_t n_rows_total, int32_t include_single, uint32_t *d_rows,
+                                int64_t *d_row_ids, const ppp_params *p, void *stream);
 /* sort keys (int64) that group pair rows by patch offset B - A, then by position of A: an
  * argsort of them is a good d_order for ppp_patch_graph                                    */
 int ppp_pair_sort_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,

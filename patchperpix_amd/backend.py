@@ -17,8 +17,9 @@ F32, F16 = 0, 1
 BG_INV_TH, BG_HALF_TH, BG_LESS_THAN_TH = 0, 1, 2
 VAL_COUNT, VAL_PROB_PRODUCT, VAL_NORM_PROB_PRODUCT = 0, 1, 2
 CONS_COMPACT, CONS_REFERENCE, CONS_VOXEL_MAJOR = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 NONE_KEY = 0xFFFFFFFF
+NONE_KEY64 = 1 << 62      # PPP_LABEL_NONE_KEY (streaming labels, int64 keys)
 
 
 class Box(ctypes.Structure):
@@ -84,6 +85,24 @@ _SIGNATURES = {
                                             ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.POINTER(Params),
                                             ctypes.c_void_p]),
+    "ppp_label_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_label_add": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p,
+                                     ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_label_union_edges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                             ctypes.c_void_p, ctypes.POINTER(Params),
+                                             ctypes.c_void_p]),
+    "ppp_label_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_pairs_count_subset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                    ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_pairs_fill_subset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                   ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_patch_pairs_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.POINTER(Params),
                                              ctypes.c_void_p]),
@@ -455,6 +474,105 @@ def device_patch_pairs(sorted_zyx, P, max_ps_dist=2, include_single=True):
                                          _dev_ptr(offsets), n_rows, 1 if include_single else 0,
                                          _dev_ptr(rows), ctypes.byref(P), _stream()))
     return rows
+
+
+def pair_counts_subset(sorted_zyx, subset, P, max_ps_dist=2):
+    """Number of partners j > i of the patches listed in `subset` (device int64 indices into the
+    x-sorted list).  Returns device int64 [n], zero outside the subset."""
+    torch = _torch()
+    n = int(sorted_zyx.shape[0])
+    counts = torch.zeros((max(n, 1),), dtype=torch.int64, device=sorted_zyx.device)
+    m = int(subset.numel())
+    if n and m:
+        with _timed("patch_pairs"):
+            check(lib().ppp_patch_pairs_count_subset(_dev_ptr(sorted_zyx), n, int(max_ps_dist),
+                                                     _dev_ptr(subset), m, _dev_ptr(counts),
+                                                     ctypes.byref(P), _stream()))
+    return counts[:n]
+
+
+def pairs_subset(sorted_zyx, subset, counts, goffsets, n_rows_total, P, max_ps_dist=2,
+                 include_single=True):
+    """Pair rows of the patches in `subset` (device int64 [m], ascending) written compactly, in
+    the canonical order, with their GLOBAL row ids: rows int32 [r (+ m), 6], ids int64 [r (+ m)].
+    counts / goffsets: device int64 [n] (partners per patch, exclusive scan over all patches)."""
+    torch = _torch()
+    n, m = int(sorted_zyx.shape[0]), int(subset.numel())
+    if m == 0:
+        return None, None
+    local_counts = counts[subset]
+    ends = torch.cumsum(local_counts, 0)
+    n_local = int(ends[-1].item())
+    total = n_local + (m if include_single else 0)
+    if total == 0:
+        return None, None
+    local_off = (ends - local_counts).contiguous()
+    rows = torch.empty((total, 6), dtype=torch.int32, device=sorted_zyx.device)
+    gid = torch.empty((total,), dtype=torch.int64, device=sorted_zyx.device)
+    with _timed("patch_pairs"):
+        check(lib().ppp_patch_pairs_fill_subset(
+            _dev_ptr(sorted_zyx), n, int(max_ps_dist), _dev_ptr(subset.contiguous()), m,
+            _dev_ptr(local_off), _dev_ptr(goffsets.contiguous()), n_local, int(n_rows_total),
+            1 if include_single else 0, _dev_ptr(rows), _dev_ptr(gid), ctypes.byref(P), _stream()))
+    return rows, gid
+
+
+class LabelState:
+    """Streaming union-find over the selected patches (ppp_label_begin / _add / _finish).
+    The workspace is a torch tensor, so the node entries of its four volumes (parent u32,
+    has-positive-edge u32, firstpos u64, key u64, all indexed by linear voxel index) can be
+    read and written with torch indexing when ranks merge their forests."""
+
+    def __init__(self, nodes, P):
+        torch = _torch()
+        self.torch, self.P, self.nodes = torch, P, nodes.contiguous()
+        self.n = int(nodes.shape[0])
+        V = int(P.Z) * int(P.Y) * int(P.X)
+        self.V = V
+        nbytes = int(lib().ppp_label_workspace_bytes(ctypes.byref(P)))
+        self.work = torch.empty((nbytes,), dtype=torch.uint8, device=nodes.device)
+        self.parent = self.work[:4 * V].view(torch.int32)
+        self.haspos = self.work[4 * V:8 * V].view(torch.int32)
+        self.firstpos = self.work[8 * V:16 * V].view(torch.int64)
+        n64 = nodes.to(torch.int64)
+        self.lin = (n64[:, 0] * int(P.Y) + n64[:, 1]) * int(P.X) + n64[:, 2]
+        with _timed("label_components"):
+            check(lib().ppp_label_begin(_dev_ptr(self.nodes), self.n, _dev_ptr(self.work),
+                                        ctypes.byref(P), _stream()))
+
+    def add(self, rows, aff, gid=None, first_id=0):
+        n = int(rows.shape[0])
+        if n == 0:
+            return
+        with _timed("label_components"):
+            check(lib().ppp_label_add(_dev_ptr(rows), _dev_ptr(aff), _dev_ptr(gid), int(first_id), n,
+                                      _dev_ptr(self.work), ctypes.byref(self.P), _stream()))
+
+    def export(self):
+        """(parent, firstpos, haspos) of the nodes: int64 [n] linear voxel index of the node's
+        parent, int64 [n], int32 [n]."""
+        return (self.parent[self.lin].to(self.torch.int64) & 0xFFFFFFFF,
+                self.firstpos[self.lin].clone(), self.haspos[self.lin].clone())
+
+    def merge(self, parents, firstpos, haspos):
+        """parents: int64 [k, n] forests of k ranks (this rank's included or not); firstpos /
+        haspos: the element-wise MIN / MAX over all ranks."""
+        for row in parents.reshape(-1, self.n):
+            with _timed("label_components"):
+                check(lib().ppp_label_union_edges(_dev_ptr(self.lin.contiguous()),
+                                                  _dev_ptr(row.contiguous()), self.n,
+                                                  _dev_ptr(self.work), ctypes.byref(self.P), _stream()))
+        self.firstpos[self.lin] = firstpos
+        self.haspos[self.lin] = haspos.to(self.torch.int32)
+
+    def finish(self):
+        """int64 [n]: order key of the node's component, NONE_KEY64 = not in a component."""
+        keys = self.torch.empty((self.n,), dtype=self.torch.int64, device=self.nodes.device)
+        if self.n:
+            with _timed("label_components"):
+                check(lib().ppp_label_finish(_dev_ptr(self.nodes), self.n, _dev_ptr(keys),
+                                             _dev_ptr(self.work), ctypes.byref(self.P), _stream()))
+        return keys
 
 
 def patch_graph(pred, cons, pairs, P, order=None):

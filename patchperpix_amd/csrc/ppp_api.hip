@@ -224,7 +224,56 @@ int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_
 
 size_t ppp_label_workspace_bytes(const ppp_params *p) {
     if (!p) return 0;
-    return (size_t)3 * sizeof(uint32_t) * (size_t)p->Z * p->Y * p->X;
+    return (size_t)24 * (size_t)p->Z * p->Y * p->X;
+}
+
+int ppp_label_begin(const uint32_t *d_nodes, uint64_t n_nodes, void *d_work, const ppp_params *p,
+                    void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n_nodes == 0) return PPP_OK;
+    if (!d_nodes || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.V >= (1ll << 32)) return fail(PPP_ERR_UNSUPPORTED, "more than 2^32-1 voxels");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_label_begin(d_nodes, n_nodes, d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_label_begin");
+}
+
+int ppp_label_add(const uint32_t *d_pairs, const float *d_aff, const int64_t *d_row_ids,
+                  int64_t first_row_id, uint64_t n_pairs, void *d_work, const ppp_params *p,
+                  void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n_pairs == 0) return PPP_OK;
+    if (!d_pairs || !d_aff || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_label_add(d_pairs, d_aff, (const long long *)d_row_ids,
+                                         (long long)first_row_id, n_pairs, d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_label_add");
+}
+
+int ppp_label_union_edges(const int64_t *d_a, const int64_t *d_b, uint64_t n, void *d_work,
+                          const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n == 0) return PPP_OK;
+    if (!d_a || !d_b || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_label_union_edges((const long long *)d_a, (const long long *)d_b, n,
+                                                 d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_label_union_edges");
+}
+
+int ppp_label_finish(const uint32_t *d_nodes, uint64_t n_nodes, int64_t *d_node_key, void *d_work,
+                     const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n_nodes == 0) return PPP_OK;
+    if (!d_nodes || !d_node_key || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_label_finish(d_nodes, n_nodes, (long long *)d_node_key, nullptr,
+                                            d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_label_finish");
 }
 
 int ppp_label_components(const uint32_t *d_pairs, const float *d_aff, uint64_t n_pairs,
@@ -259,6 +308,39 @@ int ppp_patch_pairs_count(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_pairs_count(d_sorted_zyx, n, box, l1max, d_counts, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_pairs_count");
+}
+
+int ppp_patch_pairs_count_subset(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                                 const int64_t *d_subset, int64_t m, int64_t *d_counts,
+                                 const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n == 0 || m == 0) return PPP_OK;
+    if (!d_sorted_zyx || !d_counts || !d_subset) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    int box[3], l1max;
+    PPP_TRY(pair_box(p, max_ps_dist, box, &l1max));
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pairs_count(d_sorted_zyx, n, box, l1max, d_counts, (hipStream_t)stream, d_subset, m);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_pairs_count_subset");
+}
+
+int ppp_patch_pairs_fill_subset(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,
+                                const int64_t *d_subset, int64_t m, const int64_t *d_local_offsets,
+                                const int64_t *d_global_offsets, int64_t n_local_rows,
+                                int64_t n_rows_total, int32_t include_single, uint32_t *d_rows,
+                                int64_t *d_row_ids, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (n == 0 || m == 0) return PPP_OK;
+    if (!d_sorted_zyx || !d_subset || !d_local_offsets || !d_global_offsets || !d_rows || !d_row_ids)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    int box[3], l1max;
+    PPP_TRY(pair_box(p, max_ps_dist, box, &l1max));
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pairs_subset(d_sorted_zyx, n, box, l1max, d_subset, m, d_local_offsets,
+                                            d_global_offsets, n_local_rows, n_rows_total, include_single,
+                                            d_rows, (long long *)d_row_ids, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_pairs_fill_subset");
 }
 
 int ppp_patch_pairs_fill(const int32_t *d_sorted_zyx, int64_t n, int32_t max_ps_dist,

@@ -24,7 +24,21 @@ hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n,
                         const uint32_t *nodes, uint64_t n_nodes, uint32_t *node_key, void *work,
                         const Geo &G, hipStream_t s);
 hipError_t launch_pairs_count(const int32_t *pts, int64_t n, const int *box, int l1max,
-                              int64_t *counts, hipStream_t s);
+                              int64_t *counts, hipStream_t s, const int64_t *subset = nullptr,
+                              int64_t m = 0);
+hipError_t launch_pairs_subset(const int32_t *pts, int64_t n, const int *box, int l1max,
+                               const int64_t *subset, int64_t m, const int64_t *local_off,
+                               const int64_t *gid_off, int64_t n_local_rows, int64_t n_rows_total,
+                               int include_single, uint32_t *rows, long long *gid, hipStream_t s);
+size_t label_workspace_bytes(const Geo &G);
+hipError_t launch_label_begin(const uint32_t *nodes, uint64_t n_nodes, void *work, const Geo &G,
+                              hipStream_t s);
+hipError_t launch_label_add(const uint32_t *pairs, const float *aff, const long long *gid,
+                            long long gid0, uint64_t n, void *work, const Geo &G, hipStream_t s);
+hipError_t launch_label_union_edges(const long long *ea, const long long *eb, uint64_t n,
+                                    void *work, const Geo &G, hipStream_t s);
+hipError_t launch_label_finish(const uint32_t *nodes, uint64_t n_nodes, long long *key64,
+                               uint32_t *key32, void *work, const Geo &G, hipStream_t s);
 hipError_t launch_pairs_fill(const int32_t *pts, int64_t n, const int *box, int l1max,
                              const int64_t *offsets, int64_t n_pair_rows, int include_single,
                              uint32_t *rows, hipStream_t s);

@@ -21,31 +21,29 @@
 namespace ppp {
 
 static constexpr uint32_t NONE = 0xFFFFFFFFu;
+// 64-bit order keys (2 * global row id + side); "none" is a value that survives a signed
+// MIN all-reduce between ranks
+static constexpr unsigned long long NONE64 = PPP_LABEL_NONE_KEY;
 
 __device__ __forceinline__ uint32_t node_of(const Geo &G, const uint32_t *row) {
     return (uint32_t)(((long long)row[0] * G.Y + row[1]) * G.X + row[2]);
 }
 
-__global__ void label_init_kernel(const uint32_t *__restrict__ pairs, const float *__restrict__ aff,
-                                  uint64_t n, uint32_t *parent, uint32_t *firstpos,
-                                  uint32_t *cckey, const Geo G) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t u = node_of(G, pairs + i * 6), v = node_of(G, pairs + i * 6 + 3);
-    // every node that occurs in any row gets a defined state (all writers agree)
-    parent[u] = u; parent[v] = v;
-    firstpos[u] = NONE; firstpos[v] = NONE;
-    cckey[u] = NONE; cckey[v] = NONE;
+// Workspace: four volumes touched only at node positions
+//   parent u32[V] | haspos u32[V] | firstpos u64[V] | cckey u64[V]
+struct LabelWork {
+    uint32_t *parent, *haspos;
+    unsigned long long *firstpos, *cckey;
+};
+__host__ __device__ __forceinline__ LabelWork label_carve(void *work, long long V) {
+    LabelWork W;
+    W.parent = (uint32_t *)work;
+    W.haspos = W.parent + V;
+    W.firstpos = (unsigned long long *)(W.haspos + V);
+    W.cckey = W.firstpos + V;
+    return W;
 }
-
-__global__ void label_firstpos_kernel(const uint32_t *__restrict__ pairs,
-                                      const float *__restrict__ aff, uint64_t n,
-                                      uint32_t *firstpos, const Geo G) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || aff[i] == 0.0f) return;
-    atomicMin(&firstpos[node_of(G, pairs + i * 6)], (uint32_t)(2 * i));
-    atomicMin(&firstpos[node_of(G, pairs + i * 6 + 3)], (uint32_t)(2 * i + 1));
-}
+size_t label_workspace_bytes(const Geo &G) { return (size_t)G.V * 24; }
 
 __device__ __forceinline__ uint32_t find_root(uint32_t *parent, uint32_t x) {
     // parents only ever decrease, so chasing them terminates
@@ -57,12 +55,7 @@ __device__ __forceinline__ uint32_t find_root(uint32_t *parent, uint32_t x) {
     return x;
 }
 
-__global__ void label_union_kernel(const uint32_t *__restrict__ pairs,
-                                   const float *__restrict__ aff, uint64_t n, uint32_t *parent,
-                                   const Geo G) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !(aff[i] > 0.0f)) return;
-    uint32_t a = node_of(G, pairs + i * 6), b = node_of(G, pairs + i * 6 + 3);
+__device__ __forceinline__ void unite(uint32_t *parent, uint32_t a, uint32_t b) {
     while (true) {
         a = find_root(parent, a);
         b = find_root(parent, b);
@@ -78,57 +71,109 @@ __global__ void label_union_kernel(const uint32_t *__restrict__ pairs,
     }
 }
 
-__global__ void label_key_kernel(const uint32_t *__restrict__ pairs,
-                                 const float *__restrict__ aff, uint64_t n, uint32_t *parent,
-                                 const uint32_t *__restrict__ firstpos, uint32_t *cckey,
-                                 const Geo G) {
+// begin: every node of the caller's list gets a defined state
+__global__ void label_begin_kernel(const uint32_t *__restrict__ nodes, uint64_t n_nodes,
+                                   LabelWork W, const Geo G) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !(aff[i] > 0.0f)) return;
+    if (i >= n_nodes) return;
+    const uint32_t x = node_of(G, nodes + i * 3);
+    W.parent[x] = x; W.haspos[x] = 0u; W.firstpos[x] = NONE64; W.cckey[x] = NONE64;
+}
+
+// add: a batch of rows with their GLOBAL row ids (gid == nullptr: ids are gid0 + i).
+// Order-free: atomicMin for the first appearance among rows with aff != 0, lock-free unions
+// for the rows with aff > 0.
+__global__ void label_add_kernel(const uint32_t *__restrict__ pairs, const float *__restrict__ aff,
+                                 const long long *__restrict__ gid, const long long gid0,
+                                 uint64_t n, LabelWork W, const Geo G) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = aff[i];
+    if (a == 0.0f) return;
     const uint32_t u = node_of(G, pairs + i * 6), v = node_of(G, pairs + i * 6 + 3);
-    atomicMin(&cckey[find_root(parent, u)], firstpos[u]);
-    atomicMin(&cckey[find_root(parent, v)], firstpos[v]);
+    const unsigned long long g = (unsigned long long)(gid ? gid[i] : gid0 + (long long)i);
+    atomicMin(&W.firstpos[u], 2ull * g);
+    atomicMin(&W.firstpos[v], 2ull * g + 1ull);
+    if (a > 0.0f) {
+        W.haspos[u] = 1u; W.haspos[v] = 1u;
+        unite(W.parent, u, v);
+    }
 }
 
+// unions given as node pairs (linear voxel indices): merging another rank's forest
+__global__ void label_union_edges_kernel(const long long *__restrict__ ea,
+                                         const long long *__restrict__ eb, uint64_t n,
+                                         LabelWork W) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (ea[i] != eb[i]) unite(W.parent, (uint32_t)ea[i], (uint32_t)eb[i]);
+}
+
+// finish: key(component) = min over its members WITH a positive edge of firstpos(member)
+__global__ void label_key_kernel(const uint32_t *__restrict__ nodes, uint64_t n_nodes,
+                                 LabelWork W, const Geo G) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t x = node_of(G, nodes + i * 3);
+    if (W.haspos[x]) atomicMin(&W.cckey[find_root(W.parent, x)], W.firstpos[x]);
+}
 __global__ void label_emit_kernel(const uint32_t *__restrict__ nodes, uint64_t n_nodes,
-                                  uint32_t *parent, const uint32_t *__restrict__ cckey,
-                                  const uint32_t *__restrict__ firstpos,
-                                  uint32_t *__restrict__ out, const Geo G) {
+                                  LabelWork W, long long *__restrict__ out64,
+                                  uint32_t *__restrict__ out32, const Geo G) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const uint32_t x = node_of(G, nodes + i * 3);
-    // a node without any positive edge is its own root and its key stayed NONE
-    out[i] = cckey[find_root(parent, x)];
+    // a node without any positive edge is its own root and its key stayed "none"
+    const unsigned long long k = W.cckey[find_root(W.parent, x)];
+    if (out64) out64[i] = (long long)k;
+    if (out32) out32[i] = k == NONE64 ? NONE : (uint32_t)k;
 }
 
-__global__ void label_init_nodes_kernel(const uint32_t *__restrict__ nodes, uint64_t n_nodes,
-                                        uint32_t *parent, uint32_t *firstpos, uint32_t *cckey,
-                                        const Geo G) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const uint32_t x = node_of(G, nodes + i * 3);
-    parent[x] = x; firstpos[x] = NONE; cckey[x] = NONE;
+hipError_t launch_label_begin(const uint32_t *nodes, uint64_t n_nodes, void *work, const Geo &G,
+                              hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    label_begin_kernel<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, s>>>(
+        nodes, n_nodes, label_carve(work, G.V), G);
+    return hipGetLastError();
+}
+hipError_t launch_label_add(const uint32_t *pairs, const float *aff, const long long *gid,
+                            long long gid0, uint64_t n, void *work, const Geo &G, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    label_add_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        pairs, aff, gid, gid0, n, label_carve(work, G.V), G);
+    return hipGetLastError();
+}
+hipError_t launch_label_union_edges(const long long *ea, const long long *eb, uint64_t n,
+                                    void *work, const Geo &G, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    label_union_edges_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        ea, eb, n, label_carve(work, G.V));
+    return hipGetLastError();
+}
+hipError_t launch_label_finish(const uint32_t *nodes, uint64_t n_nodes, long long *key64,
+                               uint32_t *key32, void *work, const Geo &G, hipStream_t s) {
+    if (n_nodes == 0) return hipSuccess;
+    const dim3 gn((unsigned)((n_nodes + 255) / 256)), block(256);
+    const LabelWork W = label_carve(work, G.V);
+    label_key_kernel<<<gn, block, 0, s>>>(nodes, n_nodes, W, G);
+    label_emit_kernel<<<gn, block, 0, s>>>(nodes, n_nodes, W, key64, key32, G);
+    return hipGetLastError();
 }
 
+// one-shot form (all rows at once, row ids = positions)
 hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n,
                         const uint32_t *nodes, uint64_t n_nodes, uint32_t *node_key, void *work,
                         const Geo &G, hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
-    uint32_t *parent = (uint32_t *)work;
-    uint32_t *firstpos = parent + G.V;
-    uint32_t *cckey = firstpos + G.V;
-    const dim3 block(256);
-    const dim3 gn((unsigned)((n_nodes + 255) / 256));
-    // nodes that never occur in a row still need a defined state for the emit pass
-    label_init_nodes_kernel<<<gn, block, 0, s>>>(nodes, n_nodes, parent, firstpos, cckey, G);
+    hipError_t e;
+    if ((e = launch_label_begin(nodes, n_nodes, work, G, s)) != hipSuccess) return e;
+    // rows may mention nodes outside the caller's list: give them a state as well
     if (n) {
-        const dim3 grid((unsigned)((n + 255) / 256));
-        label_init_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, firstpos, cckey, G);
-        label_firstpos_kernel<<<grid, block, 0, s>>>(pairs, aff, n, firstpos, G);
-        label_union_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, G);
-        label_key_kernel<<<grid, block, 0, s>>>(pairs, aff, n, parent, firstpos, cckey, G);
+        const uint32_t *ends = pairs;
+        if ((e = launch_label_begin(ends, 2 * n, work, G, s)) != hipSuccess) return e;
+        if ((e = launch_label_add(pairs, aff, nullptr, 0, n, work, G, s)) != hipSuccess) return e;
     }
-    label_emit_kernel<<<gn, block, 0, s>>>(nodes, n_nodes, parent, cckey, firstpos, node_key, G);
-    return hipGetLastError();
+    return launch_label_finish(nodes, n_nodes, nullptr, node_key, work, G, s);
 }
 
 // ---- paint ----------------------------------------------------------------------------

@@ -19,9 +19,13 @@ template <bool FILL>
 __global__ void __launch_bounds__(256)
     pairs_kernel(const int32_t *__restrict__ pts, const int64_t n, const int bz, const int by,
                  const int bx, const int l1max, int64_t *__restrict__ counts,
-                 const int64_t *__restrict__ offsets, uint32_t *__restrict__ rows) {
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (i >= n) return;
+                 const int64_t *__restrict__ offsets, uint32_t *__restrict__ rows,
+                 const int64_t *__restrict__ subset, const int64_t m) {
+    // (subset != nullptr: only the m listed patches are scanned -- the count pass of a rank
+    // that owns part of the volume)
+    const int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (k >= (subset ? m : n)) return;
+    const int64_t i = subset ? subset[k] : k;
     const int lane = threadIdx.x & 63;
     const int z = pts[i * 3], y = pts[i * 3 + 1], x = pts[i * 3 + 2];
     int64_t out = FILL ? offsets[i] : 0;
@@ -58,11 +62,76 @@ __global__ void self_pairs_kernel(const int32_t *__restrict__ pts, const int64_t
     for (int k = 0; k < 3; ++k) rows[i * 6 + k] = rows[i * 6 + 3 + k] = (uint32_t)pts[i * 3 + k];
 }
 
+// Rows of a SUBSET of the first patches (the patches of one tile), written compactly:
+// subset[k] = index i into the x-sorted list, local_off[k] = first local row of i,
+// gid_off[i] = first GLOBAL row of i (exclusive scan of all counts); gid receives the global
+// row id of every local row.  Same scan and order as pairs_kernel.
+__global__ void __launch_bounds__(256)
+    pairs_subset_kernel(const int32_t *__restrict__ pts, const int64_t n, const int bz,
+                        const int by, const int bx, const int l1max,
+                        const int64_t *__restrict__ subset, const int64_t m,
+                        const int64_t *__restrict__ local_off, const int64_t *__restrict__ gid_off,
+                        uint32_t *__restrict__ rows, long long *__restrict__ gid) {
+    const int64_t k = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (k >= m) return;
+    const int64_t i = subset[k];
+    const int lane = threadIdx.x & 63;
+    const int z = pts[i * 3], y = pts[i * 3 + 1], x = pts[i * 3 + 2];
+    int64_t out = local_off[k];
+    const int64_t shift = gid_off[i] - out;
+    for (int64_t j0 = i + 1; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        bool hit = false;
+        int jz = 0, jy = 0, jx = 0;
+        bool beyond = true;
+        if (j < n) {
+            jz = pts[j * 3]; jy = pts[j * 3 + 1]; jx = pts[j * 3 + 2];
+            beyond = jx - x > bx;
+            const int az = abs(jz - z), ay = abs(jy - y), ax = abs(jx - x);
+            hit = !beyond && az <= bz && ay <= by && ax <= bx && az + ay + ax <= l1max;
+        }
+        const unsigned long long mk = __ballot(hit);
+        if (hit) {
+            const int64_t r = out + __popcll(mk & ((1ull << lane) - 1ull));
+            uint32_t *row = rows + r * 6;
+            row[0] = (uint32_t)z; row[1] = (uint32_t)y; row[2] = (uint32_t)x;
+            row[3] = (uint32_t)jz; row[4] = (uint32_t)jy; row[5] = (uint32_t)jx;
+            gid[r] = r + shift;
+        }
+        out += __popcll(mk);
+        if (__ballot(beyond) == ~0ull) break;
+    }
+}
+__global__ void self_pairs_subset_kernel(const int32_t *__restrict__ pts,
+                                         const int64_t *__restrict__ subset, const int64_t m,
+                                         const int64_t gid_self0, uint32_t *__restrict__ rows,
+                                         long long *__restrict__ gid) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int64_t i = subset[k];
+    for (int c = 0; c < 3; ++c) rows[k * 6 + c] = rows[k * 6 + 3 + c] = (uint32_t)pts[i * 3 + c];
+    gid[k] = gid_self0 + i;
+}
+
+hipError_t launch_pairs_subset(const int32_t *pts, int64_t n, const int *box, int l1max,
+                               const int64_t *subset, int64_t m, const int64_t *local_off,
+                               const int64_t *gid_off, int64_t n_local_rows, int64_t n_rows_total,
+                               int include_single, uint32_t *rows, long long *gid, hipStream_t s) {
+    if (n == 0 || m == 0) return hipSuccess;
+    pairs_subset_kernel<<<dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s>>>(
+        pts, n, box[0], box[1], box[2], l1max, subset, m, local_off, gid_off, rows, gid);
+    if (include_single)
+        self_pairs_subset_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s>>>(
+            pts, subset, m, n_rows_total, rows + n_local_rows * 6, gid + n_local_rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_pairs_count(const int32_t *pts, int64_t n, const int *box, int l1max,
-                              int64_t *counts, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    pairs_kernel<false><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(
-        pts, n, box[0], box[1], box[2], l1max, counts, nullptr, nullptr);
+                              int64_t *counts, hipStream_t s, const int64_t *subset, int64_t m) {
+    const int64_t waves = subset ? m : n;
+    if (n == 0 || waves == 0) return hipSuccess;
+    pairs_kernel<false><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(
+        pts, n, box[0], box[1], box[2], l1max, counts, nullptr, nullptr, subset, m);
     return hipGetLastError();
 }
 
@@ -71,7 +140,7 @@ hipError_t launch_pairs_fill(const int32_t *pts, int64_t n, const int *box, int 
                              uint32_t *rows, hipStream_t s) {
     if (n == 0) return hipSuccess;
     pairs_kernel<true><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(
-        pts, n, box[0], box[1], box[2], l1max, nullptr, offsets, rows);
+        pts, n, box[0], box[1], box[2], l1max, nullptr, offsets, rows, nullptr, 0);
     if (include_single)
         self_pairs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
             pts, n, rows + n_pair_rows * 6);

@@ -32,6 +32,7 @@ use local coordinates; ``ppp_params.origin_z`` carries the global offset (the pe
 of the patch-graph kernel is the only thing that depends on absolute coordinates).
 """
 import logging
+import os
 
 import numpy as np
 
@@ -80,6 +81,15 @@ class LocalComm:
     def all_reduce_sum(self, t):
         return t
 
+    def all_reduce_min(self, t):
+        return t
+
+    def all_reduce_max(self, t):
+        return t
+
+    def all_gather(self, t):
+        return t.reshape((1,) + tuple(t.shape))
+
 
 class TorchDistComm:
     """torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU)."""
@@ -95,6 +105,23 @@ class TorchDistComm:
         if self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def all_reduce_min(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t
+
+    def all_reduce_max(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def all_gather(self, t):
+        """[world, ...] stack of every rank's `t` (same shape everywhere)."""
+        import torch
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.stack(parts, 0)
 
 
 # ------------------------------------------------------------------------------------------
@@ -122,6 +149,18 @@ class DeviceOps:
 
     def patch_graph(self, pred, cons, rows, P):
         return backend.patch_graph_auto(pred, cons, rows, P)
+
+    # streaming pair rows / labels: the rows of a tile exist only while the tile is worked on
+    def pair_counts(self, sorted_zyx, subset, P, max_ps_dist):
+        return backend.pair_counts_subset(sorted_zyx, subset, P, max_ps_dist=max_ps_dist)
+
+    def pairs_subset(self, sorted_zyx, subset, counts, goffsets, n_rows_total, P, max_ps_dist,
+                     include_single):
+        return backend.pairs_subset(sorted_zyx, subset, counts, goffsets, n_rows_total, P,
+                                    max_ps_dist=max_ps_dist, include_single=include_single)
+
+    def label_state(self, nodes, P):
+        return backend.LabelState(nodes, P)
 
     def rank_order(self, score_dev, foreground, ps):
         """(lin int64, scores float32) of the ranked list, device tensors."""
@@ -295,26 +334,88 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     order = np.argsort(sel_coords[:, 2], kind="stable")
     nodes = np.ascontiguousarray(sel_coords[order].astype(np.int32))
     nodes_dev = torch.from_numpy(nodes).to(dev)
-    if kw.get("selected_patch_pairs") is not None:
+    max_ps = kw.get("max_total_patch_distance_in_ps_multiples", 2)
+    shift = torch.tensor([lo, 0, 0, lo, 0, 0], dtype=torch.int32, device=dev)
+    streaming = not want_inter and not kw.get("mws") and kw.get("selected_patch_pairs") is None \
+        and kw.get("_stream_pairs", os.environ.get("PPP_STREAM_PAIRS", "1") != "0") \
+        and hasattr(ops, "label_state")
+    state = None
+    if streaming:
+        # ---- stage C (streaming): the pair rows of a tile are enumerated, scored and fed to
+        # the union-find while the tile's consensus is alive; they are never gathered.  A row
+        # belongs to the tile (hence the rank) of its first patch; its GLOBAL row id -- the
+        # position it would have in the canonical list -- comes from the exclusive scan of the
+        # per-patch partner counts, which every rank computes for its own patches only.
+        def tile_subset(t):
+            z0, z1, y0, y1, x0, x1 = t
+            own = (nodes_dev[:, 0] >= z0) & (nodes_dev[:, 0] < z1)
+            if ny_t > 1 or nx_t > 1:
+                own &= (nodes_dev[:, 1] >= y0) & (nodes_dev[:, 1] < y1) & \
+                       (nodes_dev[:, 2] >= x0) & (nodes_dev[:, 2] < x1)
+            return torch.nonzero(own).reshape(-1)
+
+        subsets = [tile_subset(t) for t in my_tiles]
+        with backend.host_timer("pairs"):
+            counts = ops.pair_counts(nodes_dev, torch.cat(subsets) if subsets else
+                                     torch.zeros((0,), dtype=torch.int64, device=dev), Pg, max_ps)
+            comm.all_reduce_sum(counts)
+            ends = torch.cumsum(counts, 0)
+            n_pair_rows = int(ends[-1].item()) if len(nodes) else 0
+            goffsets = (ends - counts).contiguous()
+            del ends
+        n_rows = n_pair_rows + (len(nodes) if kw["includeSinglePatchCCS"] else 0)
+        if n_rows == 0:
+            return early()
+        backend.note("n_selected", len(nodes))
+        backend.note("n_pairs", n_rows)
+        state = ops.label_state(nodes_dev, Pg)
+        with backend.host_timer("s5_patch_graph"):
+            for t, subset in zip(my_tiles, subsets):
+                with backend.host_timer("s5a_select_rows"):
+                    rows_t, gid_t = ops.pairs_subset(nodes_dev, subset, counts, goffsets, n_pair_rows,
+                                                     Pg, max_ps, kw["includeSinglePatchCCS"])
+                    if rows_t is None:
+                        continue
+                    rows_l = (rows_t - shift).contiguous()
+                with backend.host_timer("s5b_consensus"):
+                    if keep_cons:
+                        cons, P = kept.pop(t)
+                    else:
+                        P = params(bases_for_pairs(t))
+                        cons = ops.consensus(pred_local, ov_local, P)
+                with backend.host_timer("s5c_patch_graph"):
+                    a = ops.patch_graph(pred_local, cons, rows_l, P)
+                with backend.host_timer("s6_label_paint"):
+                    state.add(rows_t, a, gid_t)
+                del cons, rows_l, rows_t, gid_t, a
+        kept.clear()
+        del counts, goffsets, subsets
+        if comm.world > 1:
+            # boundary-label merge: every rank's forest (node -> parent) is gathered and united
+            # with the own one; first appearances / "has a positive edge" are reduced
+            par, fp, hp = state.export()
+            state.merge(comm.all_gather(par), comm.all_reduce_min(fp), comm.all_reduce_max(hp))
+            del par, fp, hp
+        rows = None
+    elif kw.get("selected_patch_pairs") is not None:
         rows_host = np.ascontiguousarray(
             np.array(kw["selected_patch_pairs"], dtype=np.uint32).reshape(-1, 6))
         rows = torch.from_numpy(rows_host.view(np.int32)).to(dev) if len(rows_host) else None
     else:
         with backend.host_timer("pairs"):
-            rows = ops.patch_pairs(nodes_dev, Pg,
-                                   kw.get("max_total_patch_distance_in_ps_multiples", 2),
-                                   kw["includeSinglePatchCCS"])
-    if rows is None:
+            rows = ops.patch_pairs(nodes_dev, Pg, max_ps, kw["includeSinglePatchCCS"])
+    if state is None and rows is None:
         return early()
-    n_rows = int(rows.shape[0])
-    backend.note("n_selected", len(nodes))
-    backend.note("n_pairs", n_rows)
+    if state is None:
+        n_rows = int(rows.shape[0])
+        backend.note("n_selected", len(nodes))
+        backend.note("n_pairs", n_rows)
 
-    # ---- stage C: pair affinities, each pair on the rank / slab that owns patch A ----------
-    aff = torch.zeros((n_rows,), dtype=torch.float32, device=dev)
-    shift = torch.tensor([lo, 0, 0, lo, 0, 0], dtype=torch.int32, device=dev)
+    # ---- stage C (materialised list: intermediates wanted, injected pairs, mutex watershed):
+    # pair affinities, each pair on the rank / tile that owns patch A
+    aff = None if state is not None else torch.zeros((n_rows,), dtype=torch.float32, device=dev)
     with backend.host_timer("s5_patch_graph"):
-        for t in my_tiles:
+        for t in (my_tiles if state is None else []):
             z0, z1, y0, y1, x0, x1 = t
             with backend.host_timer("s5a_select_rows"):
                 own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
@@ -338,7 +439,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 aff[idx] = a
             del cons, rows_l, idx, a
     kept.clear()
-    comm.all_reduce_sum(aff)
+    if state is None:
+        comm.all_reduce_sum(aff)
     if want_inter:
         return rows.cpu().numpy().view(np.uint32), aff.cpu().numpy()
 
@@ -350,8 +452,13 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(dev)
             labels = torch.from_numpy(labels.astype(np.int32)).to(dev)
         else:
-            keys = ops.label_components(rows, aff, nodes_dev, Pg)
-            valid = keys != backend.NONE_KEY
+            if state is not None:
+                keys = state.finish()
+                valid = keys != backend.NONE_KEY64
+                state = None
+            else:
+                keys = ops.label_components(rows, aff, nodes_dev, Pg)
+                valid = keys != backend.NONE_KEY
             # component ids in the order of their keys (= networkx's component order)
             uniq, inverse = torch.unique(keys[valid], sorted=True, return_inverse=True)
             lab_nodes = nodes_dev[valid]

@@ -66,6 +66,60 @@ class OracleOps:
                                   max_ps_dist=max_ps_dist)
         return None if rows is None else torch.from_numpy(rows.view(np.int32).copy())
 
+    # -- streaming pairs / labels (same contracts as backend.pair_counts_subset, pairs_subset,
+    #    LabelState; plain Python over the oracle's canonical pair list)
+    def _all_rows(self, sorted_zyx, P, max_ps_dist):
+        pts = sorted_zyx.numpy()
+        memo = getattr(self, "_rows_memo", None)
+        if memo is not None and memo[0] == (pts.tobytes(), max_ps_dist):
+            return memo[1]
+        out = self._all_rows_uncached(pts, P, max_ps_dist)
+        self._rows_memo = ((pts.tobytes(), max_ps_dist), out)
+        return out
+
+    def _all_rows_uncached(self, pts, P, max_ps_dist):
+        _, rows = orc.patch_pairs(pts, self._ps(P), include_single=False, max_ps_dist=max_ps_dist)
+        rows = np.zeros((0, 6), np.uint32) if rows is None else rows
+        index = {tuple(int(v) for v in c): i for i, c in enumerate(pts)}
+        owner = np.array([index[tuple(int(v) for v in r[:3])] for r in rows], dtype=np.int64)
+        return pts, rows, owner
+
+    def pair_counts(self, sorted_zyx, subset, P, max_ps_dist):
+        pts, rows, owner = self._all_rows(sorted_zyx, P, max_ps_dist)
+        counts = np.bincount(owner, minlength=len(pts)).astype(np.int64)
+        keep = np.zeros(len(pts), dtype=bool)
+        keep[subset.numpy()] = True
+        counts[~keep] = 0
+        return torch.from_numpy(counts)
+
+    def pairs_subset(self, sorted_zyx, subset, counts, goffsets, n_rows_total, P, max_ps_dist,
+                     include_single):
+        pts, rows, owner = self._all_rows(sorted_zyx, P, max_ps_dist)
+        sub = subset.numpy()
+        if len(sub) == 0:
+            return None, None
+        assert np.all(np.diff(sub) > 0)
+        keep = np.zeros(len(pts), dtype=bool)
+        keep[sub] = True
+        sel = np.flatnonzero(keep[owner])          # canonical order is kept
+        # the global ids must agree with the scan of the all-reduced counts
+        g = goffsets.numpy()
+        c = counts.numpy()
+        gid = np.concatenate([g[i] + np.arange(c[i]) for i in sub]) if len(sub) else np.zeros(0, np.int64)
+        assert np.array_equal(gid, sel)
+        out_rows, out_gid = rows[sel], gid.astype(np.int64)
+        if include_single:
+            selfs = np.concatenate([pts[sub], pts[sub]], axis=1).astype(np.uint32)
+            out_rows = np.concatenate([out_rows, selfs], axis=0)
+            out_gid = np.concatenate([out_gid, int(n_rows_total) + sub.astype(np.int64)])
+        if len(out_rows) == 0:
+            return None, None
+        return torch.from_numpy(np.ascontiguousarray(out_rows).view(np.int32).copy()), \
+            torch.from_numpy(out_gid)
+
+    def label_state(self, nodes, P):
+        return OracleLabelState(nodes.numpy(), (P.Z, P.Y, P.X))
+
     def patch_graph(self, pred, cons, rows, P):
         full = self._ref_layout(cons, P)
         kw = dict(self.kw, origin=(P.origin_z, P.origin_y, P.origin_x))
@@ -128,3 +182,68 @@ class OracleOps:
             if remaining < 1:
                 break
         return torch.from_numpy(selected.astype(bool))
+
+
+class OracleLabelState:
+    """backend.LabelState in NumPy: union-find over node indices, first appearances among rows
+    with aff != 0, "has a positive edge"; keys as in oracle.connected_components."""
+    NONE = backend.NONE_KEY64
+
+    def __init__(self, nodes, shape):
+        self.nodes = nodes
+        Z, Y, X = shape
+        self.lin = (nodes[:, 0].astype(np.int64) * Y + nodes[:, 1]) * X + nodes[:, 2]
+        self.of_lin = {int(l): i for i, l in enumerate(self.lin)}
+        n = len(nodes)
+        self.parent = np.arange(n)
+        self.firstpos = np.full(n, self.NONE, dtype=np.int64)
+        self.haspos = np.zeros(n, dtype=np.int32)
+        self.YX = (Y, X)
+
+    def _find(self, x):
+        while self.parent[x] != x:
+            self.parent[x] = self.parent[self.parent[x]]
+            x = self.parent[x]
+        return x
+
+    def _union(self, a, b):
+        a, b = self._find(a), self._find(b)
+        if a != b:
+            self.parent[max(a, b)] = min(a, b)
+
+    def add(self, rows, aff, gid=None, first_id=0):
+        r = rows.numpy().view(np.uint32).astype(np.int64)
+        a = aff.numpy()
+        g = gid.numpy() if gid is not None else first_id + np.arange(len(r))
+        Y, X = self.YX
+        for i in range(len(r)):
+            if a[i] == 0:
+                continue
+            u = self.of_lin[int((r[i, 0] * Y + r[i, 1]) * X + r[i, 2])]
+            v = self.of_lin[int((r[i, 3] * Y + r[i, 4]) * X + r[i, 5])]
+            self.firstpos[u] = min(self.firstpos[u], 2 * int(g[i]))
+            self.firstpos[v] = min(self.firstpos[v], 2 * int(g[i]) + 1)
+            if a[i] > 0:
+                self.haspos[u] = self.haspos[v] = 1
+                self._union(u, v)
+
+    def export(self):
+        par = np.array([self.lin[self._find(i)] for i in range(len(self.nodes))], dtype=np.int64)
+        return torch.from_numpy(par), torch.from_numpy(self.firstpos.copy()), \
+            torch.from_numpy(self.haspos.copy())
+
+    def merge(self, parents, firstpos, haspos):
+        for row in parents.numpy().reshape(-1, len(self.nodes)):
+            for i, l in enumerate(row):
+                self._union(i, self.of_lin[int(l)])
+        self.firstpos = firstpos.numpy().copy()
+        self.haspos = haspos.numpy().astype(np.int32).copy()
+
+    def finish(self):
+        n = len(self.nodes)
+        key = np.full(n, self.NONE, dtype=np.int64)
+        for i in range(n):
+            if self.haspos[i]:
+                r = self._find(i)
+                key[r] = min(key[r], self.firstpos[i])
+        return torch.from_numpy(np.array([key[self._find(i)] for i in range(n)], dtype=np.int64))
