@@ -250,6 +250,35 @@ int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin
                    int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
                    const ppp_params *p, void *stream, int32_t *rounds);
 
+/* The same rounds one step at a time, for a cover SHARDED over ranks by z (every rank: its
+ * own slices + a halo of p-1 slices, local coordinates, origin_z = first global slice).
+ *   ppp_cover_open    d_lin int64[n]: LOCAL linear index of the rank's own ranked patches (rank
+ *                     order), d_rank_id int32[n]: their GLOBAL rank (what neighbours compare
+ *                     with); d_state / d_cleared as in ppp_cover_pass, but indexed locally
+ *   ppp_cover_step    PPP_COVER_COUNT / _FILTER / _SELECT (d_bits u32[n][words] local table;
+ *                     global_z: slices of the whole volume, for the interior test)
+ *   ppp_cover_alive   *alive = some own patch was undecided at the last count (host sync)
+ *   ppp_cover_zone    export (import = 0) / import (1) of the local slices [z_lo, z_hi) around
+ *                     a slab boundary: d_rank int32 (own slices [own_lo, own_hi), INT32_MAX
+ *                     elsewhere -> MIN over ranks), d_mask u8 0/1 and d_clean u8 (1 = not dirty)
+ *                     (-> MIN over ranks); d_rank or the d_mask/d_clean pair may be NULL
+ *   ppp_cover_close   the running mask back into d_mask (bytes whose bit was cleared -> 0)
+ * Workspace: ppp_cover_workspace_bytes of the LOCAL geometry.                               */
+#define PPP_COVER_COUNT 0
+#define PPP_COVER_FILTER 1
+#define PPP_COVER_SELECT 2
+int ppp_cover_open(const uint8_t *d_mask, const int64_t *d_lin, const int32_t *d_rank_id, int64_t n,
+                   const int32_t *d_state, int32_t *d_cleared, void *d_work, const ppp_params *p,
+                   void *stream);
+int ppp_cover_step(int32_t what, const uint32_t *d_bits, int32_t pix_th, int32_t *d_state,
+                   int32_t *d_cleared, void *d_work, int32_t global_z, const ppp_params *p,
+                   void *stream);
+int ppp_cover_alive(void *d_work, const ppp_params *p, void *stream, int32_t *alive);
+int ppp_cover_close(uint8_t *d_mask, void *d_work, const ppp_params *p, void *stream);
+int ppp_cover_zone(int32_t import, void *d_work, int32_t z_lo, int32_t z_hi, int32_t own_lo,
+                   int32_t own_hi, int32_t *d_rank, uint8_t *d_mask, uint8_t *d_clean,
+                   const ppp_params *p, void *stream);
+
 /* --- patch pairs on the device ---------------------------------------------------------
  * replaces computeAndStorePatchPairs (aff_patch_graph.py:43-110).  d_sorted_zyx int32[n][3]
  * is the selected list stably sorted by x (aff_patch_graph.py:45).  Two calls: count the

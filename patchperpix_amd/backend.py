@@ -130,6 +130,20 @@ _SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_cover_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_cover_step": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int32, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_cover_alive": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_cover_close": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
+                                       ctypes.c_void_p]),
+    "ppp_cover_zone": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_synth_pred": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_uint64, ctypes.POINTER(Params),
@@ -667,6 +681,54 @@ def cover_pass_device(mask, bits, lin, state, pix_th, P):
                                    _dev_ptr(state), _dev_ptr(cleared), _dev_ptr(work),
                                    ctypes.byref(P), _stream(), ctypes.byref(rounds)))
     return cleared, int(rounds.value)
+
+
+class CoverShard:
+    """One rank's share of the greedy cover rounds (ppp_cover_open / _step / _zone / _close):
+    local mask uint8 (Zl, Y, X) device tensor (own slices + halo), the own ranked patches (local
+    linear indices, global ranks, local bit table), local params with origin_z = first slice."""
+    COUNT, FILTER, SELECT = 0, 1, 2
+
+    def __init__(self, mask, lin_local, rank_id, bits, P, global_z):
+        torch = _torch()
+        self.torch, self.P, self.mask = torch, P, mask
+        self.lin, self.rank_id, self.bits = lin_local.contiguous(), rank_id.contiguous(), bits
+        self.n = int(lin_local.numel())
+        self.gz = int(global_z)
+        nbytes = int(lib().ppp_cover_workspace_bytes(self.n, ctypes.byref(P)))
+        self.work = torch.empty((nbytes,), dtype=torch.uint8, device=mask.device)
+        self.state = self.cleared = None
+
+    def open(self, state):
+        """state int32 [n]: 0 takes part, 1 selected in an earlier pass, 2 never."""
+        self.state = state.contiguous()
+        self.cleared = self.torch.empty(max(self.n, 1), dtype=self.torch.int32, device=self.mask.device)
+        with _timed("cover"):
+            check(lib().ppp_cover_open(_dev_ptr(self.mask), _dev_ptr(self.lin), _dev_ptr(self.rank_id),
+                                       self.n, _dev_ptr(self.state), _dev_ptr(self.cleared),
+                                       _dev_ptr(self.work), ctypes.byref(self.P), _stream()))
+
+    def step(self, what, pix_th=0):
+        with _timed("cover"):
+            check(lib().ppp_cover_step(int(what), _dev_ptr(self.bits), int(pix_th), _dev_ptr(self.state),
+                                       _dev_ptr(self.cleared), _dev_ptr(self.work), self.gz,
+                                       ctypes.byref(self.P), _stream()))
+
+    def alive(self):
+        a = ctypes.c_int32(0)
+        check(lib().ppp_cover_alive(_dev_ptr(self.work), ctypes.byref(self.P), _stream(), ctypes.byref(a)))
+        return a.value != 0
+
+    def zone(self, imp, z_lo, z_hi, own, rank=None, mask=None, clean=None):
+        with _timed("cover"):
+            check(lib().ppp_cover_zone(1 if imp else 0, _dev_ptr(self.work), int(z_lo), int(z_hi),
+                                       int(own[0]), int(own[1]), _dev_ptr(rank), _dev_ptr(mask),
+                                       _dev_ptr(clean), ctypes.byref(self.P), _stream()))
+
+    def close(self):
+        with _timed("cover"):
+            check(lib().ppp_cover_close(_dev_ptr(self.mask), _dev_ptr(self.work), ctypes.byref(self.P),
+                                        _stream()))
 
 
 def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True, voxel_offset=0):

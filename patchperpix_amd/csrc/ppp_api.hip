@@ -465,4 +465,65 @@ int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_pass");
 }
 
+/* ---- sharded cover: the rounds of ppp_cover_pass one step at a time on a rank's z-range ---- */
+static int cover_geo(const ppp_params *p, ppp::Geo *G) {
+    PPP_TRY(make_geo(p, G));
+    if (G->px > 32) return fail(PPP_ERR_UNSUPPORTED, "the cover needs patch rows of at most 32 voxels");
+    return need_device();
+}
+
+int ppp_cover_open(const uint8_t *d_mask, const int64_t *d_lin, const int32_t *d_rank_id, int64_t n,
+                   const int32_t *d_state, int32_t *d_cleared, void *d_work, const ppp_params *p,
+                   void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_mask || !d_work || (n > 0 && (!d_lin || !d_rank_id || !d_state || !d_cleared)))
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e = ppp::cover_open(d_mask, (const long long *)d_lin, d_rank_id, n, d_state, d_cleared,
+                                   d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_open");
+}
+
+int ppp_cover_step(int32_t what, const uint32_t *d_bits, int32_t pix_th, int32_t *d_state,
+                   int32_t *d_cleared, void *d_work, int32_t global_z, const ppp_params *p,
+                   void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e;
+    if (what == PPP_COVER_COUNT) e = ppp::cover_step_count(d_bits, pix_th, d_state, d_work, G, (hipStream_t)stream);
+    else if (what == PPP_COVER_FILTER) e = ppp::cover_step_filter(d_work, G, (hipStream_t)stream);
+    else if (what == PPP_COVER_SELECT) e = ppp::cover_step_select(d_bits, d_state, d_cleared, d_work, global_z, G, (hipStream_t)stream);
+    else return fail(PPP_ERR_INVALID_ARG, "unknown cover step %d", what);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_step");
+}
+
+int ppp_cover_alive(void *d_work, const ppp_params *p, void *stream, int32_t *alive) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_work || !alive) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e = ppp::cover_alive(d_work, G, alive, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_alive");
+}
+
+int ppp_cover_close(uint8_t *d_mask, void *d_work, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_mask || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e = ppp::cover_close(d_mask, d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_close");
+}
+
+int ppp_cover_zone(int32_t import, void *d_work, int32_t z_lo, int32_t z_hi, int32_t own_lo,
+                   int32_t own_hi, int32_t *d_rank, uint8_t *d_mask, uint8_t *d_clean,
+                   const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_work || z_lo < 0 || z_hi > G.Z || z_lo > z_hi || ((d_mask == nullptr) != (d_clean == nullptr)))
+        return fail(PPP_ERR_INVALID_ARG, "bad zone");
+    hipError_t e = import ? ppp::cover_zone_import(d_work, z_lo, z_hi, d_rank, d_mask, d_clean, G, (hipStream_t)stream)
+                          : ppp::cover_zone_export(d_work, z_lo, z_hi, own_lo, own_hi, d_rank, d_mask, d_clean, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_zone");
+}
+
 }  // extern "C"

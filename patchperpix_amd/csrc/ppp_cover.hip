@@ -41,6 +41,8 @@ struct CoverWork {
     uint8_t *dirty;                      // [V]
     uint32_t *mbits;                     // [Z*Y][XW] running mask, one bit per voxel
     int32_t *counters;                   // [COVER_BATCH]
+    int32_t *loc_vol;                    // [V] sharded cover only: index into the rank's own
+                                         // state / cleared / bits tables, -1 off the own centres
 };
 
 // words per row of the bit mask: one spare word so a window may be read as two words
@@ -101,10 +103,14 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                        uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
-                       int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive, const Geo G) {
+                       int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
+                       const int32_t *__restrict__ loc_vol, const Geo G) {
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const bool in = v < G.V;
-    const int k = in ? rank_vol[v] : RANK_NONE;
+    int k = in ? rank_vol[v] : RANK_NONE;
+    // sharded: rank_vol holds GLOBAL ranks (also of the neighbour's patches in the halo);
+    // only the own centres are worked on, through their local table index
+    if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
     bool alive = k != RANK_NONE;
     const bool marked = in && dirty[v] != 0;
     if (marked) dirty[v] = 0;
@@ -169,11 +175,14 @@ __global__ void __launch_bounds__(256)
     cover_select_kernel(uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                         const int32_t *__restrict__ nbr_min, int32_t *__restrict__ state,
                         int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
-                        uint8_t *__restrict__ dirty, const Geo G) {
+                        uint8_t *__restrict__ dirty, const int32_t *__restrict__ loc_vol,
+                        const int gZ, const Geo G) {
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int k = v < G.V ? rank_vol[v] : RANK_NONE;
-    unsigned long long todo = __ballot(k != RANK_NONE && nbr_min[v] == k);
+    int k = v < G.V ? rank_vol[v] : RANK_NONE;
+    bool ready = k != RANK_NONE && nbr_min[v] == k;
+    if (loc_vol && ready) { k = loc_vol[v]; ready = k >= 0; }   // own centres only; local index
+    unsigned long long todo = __ballot(ready);
     const int words = (G.C + 31) / 32, XW = row_words(G);
     while (todo) {
         const int src = __builtin_ctzll(todo);
@@ -196,7 +205,9 @@ __global__ void __launch_bounds__(256)
             if (cl) {
                 atomicAnd(row + (start >> 5), ~(cl << sh));
                 if (sh && (cl >> (32 - sh))) atomicAnd(row + (start >> 5) + 1, ~(cl >> (32 - sh)));
-                if (z >= G.rz && z < G.Z - G.rz && y >= G.ry && y < G.Y - G.ry) cleared += __popc(cl & xin);
+                // (interior of the WHOLE volume: gZ slices, this buffer starts at slice G.oz)
+                if (z + G.oz >= G.rz && z + G.oz < gZ - G.rz && y >= G.ry && y < G.Y - G.ry)
+                    cleared += __popc(cl & xin);
             }
         }
         for (int o = 32; o > 0; o >>= 1) cleared += __shfl_xor(cleared, o);
@@ -222,7 +233,7 @@ static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 size_t cover_workspace_bytes(long long n, const Geo &G) {
     (void)n;
-    return 3 * up256((size_t)G.V * 4) + up256((size_t)G.V) +
+    return 4 * up256((size_t)G.V * 4) + up256((size_t)G.V) +
            up256((size_t)G.Z * G.Y * row_words(G) * 4) + 256;
 }
 
@@ -234,7 +245,8 @@ static CoverWork carve(void *work, const Geo &G) {
     W.tmp = (int32_t *)p;      p += up256((size_t)G.V * 4);
     W.dirty = (uint8_t *)p;    p += up256((size_t)G.V);
     W.mbits = (uint32_t *)p;   p += up256((size_t)G.Z * G.Y * row_words(G) * 4);
-    W.counters = (int32_t *)p;
+    W.counters = (int32_t *)p; p += 256;
+    W.loc_vol = (int32_t *)p;
     return W;
 }
 
@@ -258,13 +270,13 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
-                                                       W.counters + r, G);
+                                                       W.counters + r, nullptr, G);
             // x, then y, then z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
             cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.rank_vol, W.nbr_min, G.V, G.X, 1, G.px - 1);
             cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.nbr_min, W.tmp, G.V, G.Y, G.X, G.py - 1);
             cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.tmp, W.nbr_min, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
-                                                        W.dirty, G);
+                                                        W.dirty, nullptr, G.Z + G.oz, G);
         }
         *rounds += COVER_BATCH;
         // "any patch undecided" at the start of the batch's last round; if none, that round
@@ -282,6 +294,145 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
         }
     }
     cover_unpack_kernel<<<vgrid, block, 0, s>>>(W.mbits, mask, G);
+    return hipGetLastError();
+}
+
+// ---- the same rounds, one step at a time, on the z-range of one rank (sharded cover) -------
+//
+// Every rank keeps the round state (rank volume, bit mask, dirty marks) for its own slices
+// plus a halo of p-1 slices and works on its OWN patch centres only.  What a round needs from
+// the neighbours lives in the "zones" of 2(p-1) slices around every slab boundary; they are
+// made consistent twice per round by the caller (all-reduces of small buffers):
+//   after count  : rank volume -- every slice is owned by one rank, the others contribute
+//                  INT_MAX, MIN combines;
+//   after select : mask (a voxel stays set only if nobody cleared it: MIN of 0/1 bytes) and
+//                  dirty marks (kept inverted so that MIN combines them as well).
+// Ready patches of two ranks never overlap (each sees the other's rank in its halo), so the
+// combined mask is exactly what one device would hold.
+__global__ void __launch_bounds__(256)
+    cover_init_local_kernel(const long long *__restrict__ lin, const int32_t *__restrict__ rankid,
+                            const int32_t *__restrict__ state, int n, int32_t *__restrict__ rank_vol,
+                            int32_t *__restrict__ loc_vol) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    loc_vol[lin[i]] = i;
+    if (state[i] == 0) rank_vol[lin[i]] = rankid[i];
+}
+
+hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *rankid, long long n,
+                      const int32_t *state, int32_t *cleared, void *work, const Geo &G, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    hipError_t e;
+    if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetD32Async((hipDeviceptr_t)W.loc_vol, 0xFFFFFFFF, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;
+    if (n && (e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
+    const dim3 block(256);
+    const long long n_words = (long long)G.Z * G.Y * row_words(G);
+    cover_pack_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(mask, W.mbits, G);
+    if (n)
+        cover_init_local_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(
+            lin, rankid, state, (int)n, W.rank_vol, W.loc_vol);
+    return hipGetLastError();
+}
+
+hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, void *work,
+                            const Geo &G, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    hipError_t e;
+    if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
+    cover_count_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
+        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, G);
+    return hipGetLastError();
+}
+
+hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
+    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.rank_vol, W.nbr_min, G.V, G.X, 1, G.px - 1);
+    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.nbr_min, W.tmp, G.V, G.Y, G.X, G.py - 1);
+    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.tmp, W.nbr_min, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+    return hipGetLastError();
+}
+
+hipError_t cover_step_select(const uint32_t *bits, int32_t *state, int32_t *cleared, void *work,
+                             int gZ, const Geo &G, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    cover_select_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
+        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, G);
+    return hipGetLastError();
+}
+
+hipError_t cover_alive(void *work, const Geo &G, int32_t *alive, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    hipError_t e;
+    if ((e = hipMemcpyAsync(alive, W.counters, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
+
+hipError_t cover_close(uint8_t *mask, void *work, const Geo &G, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    cover_unpack_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(W.mbits, mask, G);
+    return hipGetLastError();
+}
+
+// zone = local slices [z_lo, z_hi); the rank owns the local slices [own_lo, own_hi)
+__global__ void __launch_bounds__(256)
+    cover_zone_export_kernel(const int32_t *__restrict__ rank_vol, const uint32_t *__restrict__ mbits,
+                             const uint8_t *__restrict__ dirty, const int z_lo, const int z_hi,
+                             const int own_lo, const int own_hi, int32_t *__restrict__ out_rank,
+                             uint8_t *__restrict__ out_mask, uint8_t *__restrict__ out_clean,
+                             const Geo G) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long plane = (long long)G.Y * G.X;
+    if (t >= (long long)(z_hi - z_lo) * plane) return;
+    const int z = z_lo + (int)(t / plane);
+    const long long v = (long long)z * plane + t % plane;
+    const int x = (int)(v % G.X);
+    const long long row = v / G.X;
+    if (out_rank) out_rank[t] = (z >= own_lo && z < own_hi) ? rank_vol[v] : 0x7FFFFFFF;
+    if (out_mask) {
+        out_mask[t] = (mbits[row * row_words(G) + (x >> 5)] >> (x & 31)) & 1u;
+        out_clean[t] = dirty[v] ? 0 : 1;
+    }
+}
+__global__ void __launch_bounds__(256)
+    cover_zone_import_kernel(int32_t *__restrict__ rank_vol, uint32_t *__restrict__ mbits,
+                             uint8_t *__restrict__ dirty, const int z_lo, const int z_hi,
+                             const int32_t *__restrict__ in_rank, const uint8_t *__restrict__ in_mask,
+                             const uint8_t *__restrict__ in_clean, const Geo G) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long plane = (long long)G.Y * G.X;
+    if (t >= (long long)(z_hi - z_lo) * plane) return;
+    const int z = z_lo + (int)(t / plane);
+    const long long v = (long long)z * plane + t % plane;
+    const int x = (int)(v % G.X);
+    const long long row = v / G.X;
+    if (in_rank) rank_vol[v] = in_rank[t] == 0x7FFFFFFF ? RANK_NONE : in_rank[t];
+    if (in_mask) {
+        if (!in_mask[t]) atomicAnd(&mbits[row * row_words(G) + (x >> 5)], ~(1u << (x & 31)));
+        if (!in_clean[t]) dirty[v] = 1;
+    }
+}
+hipError_t cover_zone_export(void *work, int z_lo, int z_hi, int own_lo, int own_hi,
+                             int32_t *out_rank, uint8_t *out_mask, uint8_t *out_clean,
+                             const Geo &G, hipStream_t s) {
+    CoverWork W = carve(work, G);
+    const long long n = (long long)(z_hi - z_lo) * G.Y * G.X;
+    if (n <= 0) return hipSuccess;
+    cover_zone_export_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        W.rank_vol, W.mbits, W.dirty, z_lo, z_hi, own_lo, own_hi, out_rank, out_mask, out_clean, G);
+    return hipGetLastError();
+}
+hipError_t cover_zone_import(void *work, int z_lo, int z_hi, const int32_t *in_rank,
+                             const uint8_t *in_mask, const uint8_t *in_clean, const Geo &G,
+                             hipStream_t s) {
+    CoverWork W = carve(work, G);
+    const long long n = (long long)(z_hi - z_lo) * G.Y * G.X;
+    if (n <= 0) return hipSuccess;
+    cover_zone_import_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        W.rank_vol, W.mbits, W.dirty, z_lo, z_hi, in_rank, in_mask, in_clean, G);
     return hipGetLastError();
 }
 

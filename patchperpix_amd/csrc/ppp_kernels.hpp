@@ -64,4 +64,20 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
                           int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
                           hipStream_t s, int *rounds);
 
+hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *rankid, long long n,
+                      const int32_t *state, int32_t *cleared, void *work, const Geo &G, hipStream_t s);
+hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, void *work,
+                            const Geo &G, hipStream_t s);
+hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s);
+hipError_t cover_step_select(const uint32_t *bits, int32_t *state, int32_t *cleared, void *work,
+                             int gZ, const Geo &G, hipStream_t s);
+hipError_t cover_alive(void *work, const Geo &G, int32_t *alive, hipStream_t s);
+hipError_t cover_close(uint8_t *mask, void *work, const Geo &G, hipStream_t s);
+hipError_t cover_zone_export(void *work, int z_lo, int z_hi, int own_lo, int own_hi,
+                             int32_t *out_rank, uint8_t *out_mask, uint8_t *out_clean,
+                             const Geo &G, hipStream_t s);
+hipError_t cover_zone_import(void *work, int z_lo, int z_hi, const int32_t *in_rank,
+                             const uint8_t *in_mask, const uint8_t *in_clean, const Geo &G,
+                             hipStream_t s);
+
 }  // namespace ppp

@@ -98,30 +98,37 @@ class TorchDistComm:
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # gloo moves device tensors through the host (tests: several ranks sharing one GPU)
+        self.via_host = dist.get_backend(group) == "gloo"
+
+    def _reduce(self, t, op):
+        if self.world > 1:
+            if self.via_host and t.is_cuda:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=op, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=op, group=self.group)
+        return t
 
     def all_reduce_sum(self, t):
         """In-place sum over ranks.  Every element is non-zero on at most one rank (each voxel,
         candidate or pair row has one owner), so the sum is an exact gather."""
-        if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self._reduce(t, self.dist.ReduceOp.SUM)
 
     def all_reduce_min(self, t):
-        if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
-        return t
+        return self._reduce(t, self.dist.ReduceOp.MIN)
 
     def all_reduce_max(self, t):
-        if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return t
+        return self._reduce(t, self.dist.ReduceOp.MAX)
 
     def all_gather(self, t):
         """[world, ...] stack of every rank's `t` (same shape everywhere)."""
         import torch
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t.contiguous(), group=self.group)
-        return torch.stack(parts, 0)
+        src = t.cpu() if (self.via_host and t.is_cuda) else t.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(parts, src, group=self.group)
+        return torch.stack(parts, 0).to(t.device)
 
 
 # ------------------------------------------------------------------------------------------
@@ -162,6 +169,9 @@ class DeviceOps:
     def label_state(self, nodes, P):
         return backend.LabelState(nodes, P)
 
+    def cover_shard(self, mask_local, lin_local, rank_id, bits, P_local, global_z):
+        return backend.CoverShard(mask_local, lin_local, rank_id, bits, P_local, global_z)
+
     def rank_order(self, score_dev, foreground, ps):
         """(lin int64, scores float32) of the ranked list, device tensors."""
         return backend.rank_order_device(score_dev, foreground, ps, to_host=False)
@@ -180,6 +190,115 @@ class DeviceOps:
 
     def paint(self, pred, nodes, labels, inst, P):
         return backend.paint_instances(pred, nodes, labels, inst, P)
+
+
+# ------------------------------------------------------------------------------------------
+# the greedy cover, sharded by z over the ranks
+# ------------------------------------------------------------------------------------------
+COVER_BATCH = 8          # rounds between two "is anybody still undecided" all-reduces
+INT32_MAX = 0x7FFFFFFF
+
+
+def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, never, pix_ths,
+                  radslice, own_bits, make_local_params):
+    """The priority-parallel greedy cover (csrc/ppp_cover.hip) with the volume split by z: every
+    rank runs the rounds on its own slices + a halo of pz-1 slices and decides its OWN patches;
+    twice per round the 2(pz-1) slices around every slab boundary are made consistent by a MIN
+    all-reduce of a small buffer (rank volume after the count step; mask and dirty marks after
+    the select step).  Same result as the replicated / sequential cover: identical on every rank.
+
+    my_range (z0, z1), ranges: every rank's (z0, z1) in rank order (contiguous, ascending);
+    lin_t int64 [n] / never bool [n]: the global ranked list (replicated, on ops.device);
+    own_bits(idx) -> the patch bits of the listed ranked patches (all of them own);
+    make_local_params(a, b) -> ppp_params for the local buffer of global slices [a, b).
+    Returns selected bool [n] (device tensor)."""
+    import torch
+    dev = ops.device
+    Z, Y, X = [int(v) for v in shape]
+    h = int(ps[0]) - 1
+    z0, z1 = my_range
+    a, b = max(0, z0 - h), min(Z, z1 + h)
+    plane = Y * X
+    n = int(lin_t.numel())
+    cz = torch.div(lin_t, plane, rounding_mode="floor")
+    own_idx = torch.nonzero((cz >= z0) & (cz < z1)).reshape(-1)          # ascending = rank order
+    del cz
+    mask_loc = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover[a:b]) != 0)
+                                .astype(np.uint8)).to(dev)
+    shard = ops.cover_shard(mask_loc, (lin_t[own_idx] - a * plane).contiguous(),
+                            own_idx.to(torch.int32), own_bits(own_idx), make_local_params(a, b), Z)
+    # zones around the internal slab boundaries (global slices), and which of them touch me
+    bounds = [int(r[1]) for r in ranges[:-1]]
+    zones = [(max(0, zb - h), min(Z, zb + h)) for zb in bounds]
+    mine = [i for i, zb in enumerate(bounds) if zb == z0 or zb == z1]
+    zlen = 2 * h * plane
+    rank_buf = torch.empty((max(len(zones), 1), zlen), dtype=torch.int32, device=dev)
+    mask_buf = torch.empty((max(len(zones), 1), 2, zlen), dtype=torch.uint8, device=dev)
+    own_loc = (z0 - a, z1 - a)
+
+    def exchange(with_rank):
+        if not zones:
+            return
+        buf = rank_buf if with_rank else mask_buf
+        buf.fill_(INT32_MAX if with_rank else 1)
+        for i in mine:
+            lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
+            if with_rank:
+                shard.zone(False, lo_z, hi_z, own_loc, rank=rank_buf[i])
+            else:
+                shard.zone(False, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+        comm.all_reduce_min(buf)
+        for i in mine:
+            lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
+            if with_rank:
+                shard.zone(True, lo_z, hi_z, own_loc, rank=rank_buf[i])
+            else:
+                shard.zone(True, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+
+    remaining = int(np.count_nonzero(np.asarray(mask_to_cover)[tuple(radslice)]))
+    selected = torch.zeros(n, dtype=torch.bool, device=dev)
+    total_rounds = 0
+    for pix_th in pix_ths:
+        if remaining <= 0:
+            break
+        # every pass restarts at rank 0 (the reference passes rpidx by value)
+        state_g = torch.where(selected, 1, torch.where(never, 2, 0)).to(torch.int32)
+        shard.open(state_g[own_idx])
+        alive = True
+        while alive:
+            for _ in range(COVER_BATCH):
+                shard.step(shard.COUNT, pix_th)
+                exchange(True)
+                shard.step(shard.FILTER)
+                shard.step(shard.SELECT)
+                exchange(False)
+            total_rounds += COVER_BATCH
+            flag = torch.tensor([1 if shard.alive() else 0], dtype=torch.int32, device=dev)
+            alive = int(comm.all_reduce_max(flag).item()) > 0
+        shard.close()
+        # decisions and cleared-interior counts of all ranks (every entry has one owner)
+        st = torch.zeros(n, dtype=torch.int32, device=dev)
+        cl = torch.zeros(n, dtype=torch.int32, device=dev)
+        if own_idx.numel():
+            st[own_idx] = shard.state[:own_idx.numel()]
+            cl[own_idx] = shard.cleared[:own_idx.numel()]
+        comm.all_reduce_sum(st)
+        comm.all_reduce_sum(cl)
+        idx = torch.nonzero((st == 1) & ~selected).flatten()              # rank order
+        left = remaining - torch.cumsum(cl[idx].long(), 0)
+        done = torch.nonzero(left <= 0).flatten()
+        if done.numel():
+            # the sequential loop ends right after the patch that empties the interior
+            idx = idx[:int(done[0].item()) + 1]
+            remaining = 0
+        elif idx.numel():
+            remaining = int(left[-1].item())
+        selected[idx] = True
+        if remaining < 1:
+            break
+    backend.note("cover_rounds", total_rounds)
+    backend.note("cover_sharded", comm.world)
+    return selected
 
 
 # ------------------------------------------------------------------------------------------
@@ -301,8 +420,47 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     elif kw.get("skipSelection", False):
         sel_coords = coords_t.cpu().numpy()
     else:
+        # sharded over the ranks when every rank owns one contiguous z-range of at least
+        # 2(pz-1) slices (PPP_COVER_SHARDED=0: every rank runs the whole cover)
+        ranges = None
+        if comm.world > 1 and hasattr(ops, "cover_shard") and \
+                kw.get("_shard_cover", os.environ.get("PPP_COVER_SHARDED", "1") != "0"):
+            mine_r = torch.tensor([my_slabs[0][0], my_slabs[-1][1]], dtype=torch.int64, device=dev)
+            ranges = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
+            ok = all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in ranges) and \
+                all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)) and \
+                all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
+            if not ok:
+                ranges = None
         with backend.host_timer("s3_cover"):
             from .vote_instances import foreground_cover as fc
+            if ranges is not None:
+                never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
+                if overlap_mask.any():
+                    ov_g = torch.from_numpy(np.ascontiguousarray(overlap_mask.reshape(-1) > 0)).to(dev)
+                    never |= ov_g[lin_t]
+                    del ov_g
+                thr = kw.get("score_threshold", False)
+                if isinstance(thr, float):
+                    below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
+                    if below.numel():
+                        never[int(below[0].item()):] = True
+
+                def own_bits(idx):
+                    loc = coords_t[idx].clone()
+                    loc[:, 0] -= lo
+                    return ops.patch_bits(pred_local, loc.contiguous(), kw["fc_threshold"], params())
+
+                def local_params(a, b):
+                    return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
+
+                selected = sharded_cover(ops, comm, shape, ps, ranges[comm.rank], ranges,
+                                         mask_to_cover, lin_t, never, fc._pix_thresholds(ps, kw),
+                                         radslice, own_bits, local_params)
+                del never
+                sel_coords = coords_t[selected].cpu().numpy()
+        if ranges is None:
+          with backend.host_timer("s3_cover"):
             bits = gathered_bits(coords_t, kw["fc_threshold"])
             # patches the loop never looks at (foreground_cover.py:136-141): centre on an
             # overlap voxel; everything from the first score below score_threshold on

@@ -109,6 +109,9 @@ inst, fg = tiling.assemble(pred_local, lo, c["foreground"].shape, c["foreground"
                            c["foreground"].copy(), c["numinst"], ps, mine,
                            comm=tiling.TorchDistComm(), ops=OracleOps(**kw), _cover_chunk=700, **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+from patchperpix_amd import backend
+np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
+        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0)]))
 dist.destroy_process_group()
 """
 
@@ -127,6 +130,9 @@ def test_two_ranks_gloo_equal_whole_volume(tmp_path, n_slabs):
     for r in range(2):
         inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
         assert np.array_equal(inst, ref["instances"]), "rank %d differs" % r
+        # the cover ran sharded (z-halo exchange per round), the labels were merged
+        notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
+        assert notes[0] == 2 and notes[1] > 0
 
 
 @pytest.mark.gpu
@@ -164,3 +170,54 @@ def test_yx_tiles_equal_whole_volume_gpu(n_slabs, yx):
                                           c["foreground"].copy(), c["numinst"].copy(), ps,
                                           n_slabs, _yx_tiles=yx, **kw)
     assert np.array_equal(got, want) and got.any()
+
+
+GPU_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from patchperpix_amd import synth, tiling, backend
+from patchperpix_amd.flags import FLYLIGHT
+torch.cuda.set_device(0)                      # every rank on the one GPU of the box
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+shape, ps = {shape!r}, {ps!r}
+c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+kw = dict(FLYLIGHT)
+Z = shape[0]
+slabs = tiling.plan_slabs(Z, world)
+mine = tiling.slabs_of_rank(slabs, rank, world)
+lo, hi = tiling.local_range(mine, Z, ps)
+pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi])).cuda()
+inst, fg = tiling.assemble(pred_local, lo, shape, c["foreground"].copy(), c["foreground"].copy(),
+                           c["numinst"], list(ps), mine, comm=tiling.TorchDistComm(), **kw)
+np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
+        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0)]))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world):
+    """The multi-rank path with the REAL kernels: `world` processes on the one GPU of the box,
+    gloo as the transport (RCCL needs one device per rank): sharded cover with z-halo exchange,
+    per-rank pair rows, merged label forests -- same instance map as one process."""
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    shape, ps = (72, 26, 30), (5, 5, 5)
+    c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), list(ps), **dict(FLYLIGHT, _n_slabs=1))
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                           "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                           "--master-port", "29593", str(script)], env=env, timeout=900)
+    assert want.any()
+    for r in range(world):
+        inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
+        assert np.array_equal(inst, want), "rank %d differs" % r
+        notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
+        assert notes[0] == world and notes[1] > 0
