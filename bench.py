@@ -34,13 +34,16 @@ WORKLOADS = {
     # reduced variants for quick checks
     "synth64_p5": ((64, 64, 64), (5, 5, 5), (12, 12, 12)),
     "synth96_p7": ((96, 96, 96), (7, 7, 7), (18, 18, 18)),
+    # the global volume of a 2- / 3-rank run of synth64_p5 (checks of the multi-rank path)
+    "synth64x2_p5": ((128, 64, 64), (5, 5, 5), (12, 12, 12)),
+    "synth64x3_p5": ((192, 64, 64), (5, 5, 5), (12, 12, 12)),
     # large volumes: the consensus no longer fits, the path tiles itself into z-slabs
     "synth256_p7": ((256, 256, 256), (7, 7, 7), (18, 18, 18)),
     "synth256_p9": ((256, 256, 256), (9, 9, 9), (24, 24, 24)),
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
 }
-CPU_SAMPLE = {"flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
+CPU_SAMPLE = {"synth64x2_p5": (24, 24, 24), "synth64x3_p5": (24, 24, 24), "flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
               "synth256_p7": (28, 28, 28), "synth256_p9": (26, 26, 26),
               "synth64_p5": (24, 24, 24), "synth512_p9": (26, 26, 26)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -96,11 +99,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # PPP_BENCH_ONE_GPU=1 (a check of the multi-rank path on a 1-GPU box): every rank on device 0,
+    # gloo as the transport -- numbers from such a run mean nothing
+    one_gpu = os.environ.get("PPP_BENCH_ONE_GPU", "0") == "1"
+    torch.cuda.set_device(0 if one_gpu else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL
+        dist.init_process_group("gloo" if one_gpu else "nccl")  # "nccl" = RCCL
     n_gpus = max(args.gpus, world)
 
     shape, ps, cell = WORKLOADS[args.workload]
@@ -155,6 +161,7 @@ def main():
         inst = step()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -172,7 +179,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if one_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ev = backend.event_times_ms()
