@@ -423,8 +423,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         # sharded over the ranks when every rank owns one contiguous z-range of at least
         # 2(pz-1) slices (PPP_COVER_SHARDED=0: every rank runs the whole cover)
         ranges = None
-        if comm.world > 1 and hasattr(ops, "cover_shard") and \
-                kw.get("_shard_cover", os.environ.get("PPP_COVER_SHARDED", "1") != "0"):
+        shard_env = os.environ.get("PPP_COVER_SHARDED", "1")     # "force": also with one rank
+        if (comm.world > 1 or shard_env == "force") and hasattr(ops, "cover_shard") and \
+                kw.get("_shard_cover", shard_env != "0"):
             mine_r = torch.tensor([my_slabs[0][0], my_slabs[-1][1]], dtype=torch.int64, device=dev)
             ranges = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
             ok = all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in ranges) and \

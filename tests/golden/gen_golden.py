@@ -381,12 +381,16 @@ CASES = {
                      {}),
     "c3d_p7_cells": ((16, 18, 20), (7, 7, 7), dict(kind="cells", seed=13, cell=[9, 9, 9]),
                      {}),
+    # the patch shapes of BASELINE configs [2]/[3] (9^3) and [0] (wormbodies 2-d 25x25)
+    "c3d_p9_cells": ((14, 15, 16), (9, 9, 9), dict(kind="cells", seed=14, cell=[7, 8, 8]), {}),
+    "c2d_p25_cells": ((1, 40, 44), (1, 25, 25), dict(kind="cells", seed=15, cell=[1, 14, 14]),
+                      {}),
     "c3d_empty": ((10, 10, 10), (3, 3, 3), dict(kind="empty", seed=0), {}),
     "c3d_single_patch": ((3, 3, 3), (3, 3, 3), dict(kind="cells", seed=1, cell=[9, 9, 9]),
                          {}),
 }
 # cases whose consensus array is too big to commit: keep a SHA-256 of the float bits
-HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells"}
+HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells", "c3d_p9_cells", "c2d_p25_cells"}
 # cases that are ALSO run through the reference's NumPy path (cuda=False; int16 +-1 votes,
 # SURVEY 8c "recipe A").  Different arithmetic from the kernels: only the final instance map
 # is stored, to document that both semantics agree on well separated instances.

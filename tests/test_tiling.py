@@ -116,8 +116,9 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("n_slabs", [4, 2])   # 2 slabs per rank / one slab per rank (kept consensus)
-def test_two_ranks_gloo_equal_whole_volume(tmp_path, n_slabs):
+# 2 slabs per rank / one slab per rank (kept consensus) / three ranks (a rank with two neighbours)
+@pytest.mark.parametrize("n_slabs,world", [(4, 2), (2, 2), (3, 3)])
+def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world):
     c, ps, kw = make_case()
     ref = whole_volume(c, ps, kw)
     script = tmp_path / "worker.py"
@@ -125,14 +126,14 @@ def test_two_ranks_gloo_equal_whole_volume(tmp_path, n_slabs):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", OMP_NUM_THREADS="1",
                PPP_TEST_SLABS=str(n_slabs))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                           "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                            "--master-port", "29591", str(script)], env=env, timeout=900)
-    for r in range(2):
+    for r in range(world):
         inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
         assert np.array_equal(inst, ref["instances"]), "rank %d differs" % r
         # the cover ran sharded (z-halo exchange per round), the labels were merged
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
-        assert notes[0] == 2 and notes[1] > 0
+        assert notes[0] == world and notes[1] > 0
 
 
 @pytest.mark.gpu
