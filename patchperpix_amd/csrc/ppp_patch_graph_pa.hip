@@ -36,8 +36,26 @@ __device__ unsigned long long pa_stats[8];   // steps, planes, rows, useful slot
 // threads (= pair rows) per workgroup: the [words][threads] foreground bits of the B patches and
 // two row buffers must fit 64 KB of LDS
 template <int PX> struct PaCfg {
-    static constexpr int THREADS = 256;
-    static constexpr int MIN_WAVES = PX <= 7 ? 5 : 2;   // waves per SIMD the register budget must allow
+#ifndef PPP_PA_MINWAVES7
+#define PPP_PA_MINWAVES7 7
+#endif
+#ifndef PPP_PA_THREADS9
+#define PPP_PA_THREADS9 256
+#endif
+    static constexpr int THREADS = PX >= 9 ? PPP_PA_THREADS9 : 256;
+#ifndef PPP_PA_SINGLE_BUF_FROM
+#define PPP_PA_SINGLE_BUF_FROM 7
+#endif
+    // Occupancy is what this kernel lacks (measured, 140^3 / 7^3 and 128^3 / 9^3):
+    //   7^3: two row buffers + 5 waves/SIMD (91 VGPRs) 621 ms; ONE buffer (two barriers per
+    //        pixel, 21 KB LDS -> 7 workgroups per CU) + 7 waves/SIMD (72 VGPRs, 20 spilled)
+    //        588 ms; one buffer at 5 waves: no change -- the second barrier is free
+    //   9^3: two buffers (64 KB, 2 workgroups per CU) 7.6 s; one buffer (45 KB, 3 per CU) 6.0 s;
+    //        512-thread workgroups at 4 waves/SIMD: 6.0 s
+    // so PX >= 7 takes one row buffer.
+    static constexpr int ROW_BUFS = PX >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
+    // waves per SIMD the register budget must allow
+    static constexpr int MIN_WAVES = PX <= 7 ? PPP_PA_MINWAVES7 : (THREADS == 512 ? 4 : (ROW_BUFS == 1 ? 3 : 2));
 };
 static constexpr int PA_PAD = 16;      // floats of slack either side of the staged row
 
@@ -87,8 +105,9 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     const int WB = (W + 2 * PA_PAD + 3) & ~3;                     // floats per row buffer
     // staged floats per thread (the launcher checks W <= NST * PA_THREADS)
     constexpr int NST = ((2 * PX - 1) * (2 * PX - 1) * (2 * PX - 1) + PA_THREADS - 1) / PA_THREADS;
-    float *rowbuf = reinterpret_cast<float *>(lds_raw);           // [2][WB]
-    uint32_t *faw = lds_raw + 2 * WB;                             // [words]
+    constexpr int ROW_BUFS = PaCfg<PX>::ROW_BUFS;
+    float *rowbuf = reinterpret_cast<float *>(lds_raw);           // [ROW_BUFS][WB]
+    uint32_t *faw = lds_raw + ROW_BUFS * WB;                      // [words]
     uint16_t *ulist = reinterpret_cast<uint16_t *>(faw + ((words + 3) & ~3));   // [C] pixels of F_A
     uint32_t *fbw = faw + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3);          // [words][PA_THREADS]
     __shared__ int s_nu;
@@ -234,7 +253,7 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     for (int k = 0; k < n_u; ++k) {
         const int r1 = pixel(k);
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
-        const float *cur = rowbuf + (k & 1) * WB + PA_PAD;
+        const float *cur = rowbuf + (ROW_BUFS == 2 ? (k & 1) * WB : 0) + PA_PAD;
         // ---- fetch the next row into registers while this one is consumed
         const bool more = k + 1 < n_u;
         if (more) {
@@ -351,8 +370,9 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
             }
         }
         // ---- publish the next row
+        if (ROW_BUFS == 1) __syncthreads();   // everybody is done reading the only buffer
         if (more) {
-            float *dst = rowbuf + ((k + 1) & 1) * WB + PA_PAD;
+            float *dst = rowbuf + (ROW_BUFS == 2 ? ((k + 1) & 1) * WB : 0) + PA_PAD;
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int e = tid + i * PA_THREADS;
@@ -400,7 +420,8 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     if (W > (cube + threads - 1) / threads * threads) return hipErrorNotSupported;
     // candidate planes are handled as ceil(px / (64 / px)) 64-bit chunks of 64 / px rows
     if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;
-    const size_t lds = (size_t)(2 * WB + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3) +
+    const int row_bufs = G.px >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
+    const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3) +
                                 ((words * threads + 1) & ~1)) * 4;
     if (lds > 80 * 1024 || n_blocks >= (1ll << 31)) return hipErrorNotSupported;
     // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
