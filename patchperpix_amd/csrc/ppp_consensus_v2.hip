@@ -34,6 +34,9 @@
 namespace ppp {
 
 static constexpr int V2_WAVES = 4;
+#ifndef PPP_S1_PREFETCH
+#define PPP_S1_PREFETCH(PX) ((PX) >= 9)
+#endif
 #ifndef PPP_S1_MINWAVES
 #define PPP_S1_MINWAVES(PX) ((PX) <= 7 ? 3 : 2)   // waves per SIMD the register budget must allow
 #endif
@@ -255,9 +258,15 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
                 if (it < NEA) cmid[it] = ldf_at(mid + crow, el_cx[it]);
             }
         };
+        // Register prefetch of the next tile (24-32 VGPRs) only where the kernel runs at two
+        // waves per SIMD anyway (9^3).  At 7^3 dropping it frees the registers for a third
+        // wave WITHOUT spilling: 124 -> 102 ms (the spilled variant moved 22 GB of scratch
+        // per launch); the load latency is covered by the other waves.
+        constexpr bool PREFETCH = PPP_S1_PREFETCH(PX);
         bool have = next_tile(kz, ky);
-        if (have) load_tile(kz, ky);
+        if (PREFETCH && have) load_tile(kz, ky);
         while (have) {
+            if (!PREFETCH) load_tile(kz, ky);
             // ---- classify the loaded tile into the wave-private LDS image
             bool big = false;   // TH05: an operand outside the verified range of the float quotient
 #pragma unroll
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
             __builtin_amdgcn_wave_barrier();
             // ---- prefetch the next tile; its latency hides behind this tile's votes
             have = next_tile(kz, ky);
-            if (have) load_tile(kz, ky);
+            if (PREFETCH && have) load_tile(kz, ky);
             // ---- votes (fast path; redo the tile with true divisions if any lane saw an
             //      ambiguous rounding -- probability ~2^-26 per vote)
             const float *ia = img + lane + (PX - 1);
