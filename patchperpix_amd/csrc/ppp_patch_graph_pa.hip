@@ -52,6 +52,7 @@ template <int PX> struct PaCfg {
     //        588 ms; one buffer at 5 waves: no change -- the second barrier is free
     //   9^3: two buffers (64 KB, 2 workgroups per CU) 7.6 s; one buffer (45 KB, 3 per CU) 6.0 s;
     //        512-thread workgroups at 4 waves/SIMD: 6.0 s
+    //   (dropping the register prefetch of the next row instead: 632 ms / 6.5 s -- worse)
     // so PX >= 7 takes one row buffer.
     static constexpr int ROW_BUFS = PX >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
     // waves per SIMD the register budget must allow
