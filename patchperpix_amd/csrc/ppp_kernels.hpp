@@ -12,6 +12,8 @@ hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uin
                        float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
 hipError_t launch_rank_v2(const void *pred, int dtype, const float *cons, const uint8_t *ov,
                           float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
+hipError_t launch_rank_v3(const void *pred, int dtype, const float *cons, const uint8_t *ov,
+                          float *score, const ppp_box &sb, const Geo &G, int kz, hipStream_t s);
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
                               const uint32_t *pairs, const uint32_t *order, uint64_t n,
                               float *aff, const Geo &G, hipStream_t s);
