@@ -435,34 +435,6 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 ranges = None
         with backend.host_timer("s3_cover"):
             from .vote_instances import foreground_cover as fc
-            if ranges is not None:
-                never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
-                if overlap_mask.any():
-                    ov_g = torch.from_numpy(np.ascontiguousarray(overlap_mask.reshape(-1) > 0)).to(dev)
-                    never |= ov_g[lin_t]
-                    del ov_g
-                thr = kw.get("score_threshold", False)
-                if isinstance(thr, float):
-                    below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
-                    if below.numel():
-                        never[int(below[0].item()):] = True
-
-                def own_bits(idx):
-                    loc = coords_t[idx].clone()
-                    loc[:, 0] -= lo
-                    return ops.patch_bits(pred_local, loc.contiguous(), kw["fc_threshold"], params())
-
-                def local_params(a, b):
-                    return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
-
-                selected = sharded_cover(ops, comm, shape, ps, ranges[comm.rank], ranges,
-                                         mask_to_cover, lin_t, never, fc._pix_thresholds(ps, kw),
-                                         radslice, own_bits, local_params)
-                del never
-                sel_coords = coords_t[selected].cpu().numpy()
-        if ranges is None:
-          with backend.host_timer("s3_cover"):
-            bits = gathered_bits(coords_t, kw["fc_threshold"])
             # patches the loop never looks at (foreground_cover.py:136-141): centre on an
             # overlap voxel; everything from the first score below score_threshold on
             never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
@@ -475,9 +447,24 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
                 if below.numel():
                     never[int(below[0].item()):] = True
-            selected = ops.greedy_cover(mask_to_cover, bits, lin_t, rscores_t, never,
-                                        fc._pix_thresholds(ps, kw), radslice, Pg, kw)
-            del bits, never
+            if ranges is not None:
+                def own_bits(idx):
+                    loc = coords_t[idx].clone()
+                    loc[:, 0] -= lo
+                    return ops.patch_bits(pred_local, loc.contiguous(), kw["fc_threshold"], params())
+
+                def local_params(a, b):
+                    return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
+
+                selected = sharded_cover(ops, comm, shape, ps, ranges[comm.rank], ranges,
+                                         mask_to_cover, lin_t, never, fc._pix_thresholds(ps, kw),
+                                         radslice, own_bits, local_params)
+            else:
+                bits = gathered_bits(coords_t, kw["fc_threshold"])
+                selected = ops.greedy_cover(mask_to_cover, bits, lin_t, rscores_t, never,
+                                            fc._pix_thresholds(ps, kw), radslice, Pg, kw)
+                del bits
+            del never
             sel_coords = coords_t[selected].cpu().numpy()
     if not kw.get("skipThinCover") and len(sel_coords) > 0:
         with backend.host_timer("s4_thin"):
