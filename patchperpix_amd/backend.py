@@ -182,6 +182,9 @@ def lib():
                 "HIP library %s is missing -- build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` "
                 "(patchperpix_amd has no CPU fallback)" % path)
+        # torch first: it brings its own libamdhip64, and a second HIP runtime loaded BEFORE it
+        # (through this library) leaves the process without a visible device
+        _torch()
         L = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI is incomplete
