@@ -5,7 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + sys.argv[1:]
 import bench  # noqa: E402
 from patchperpix_amd import backend  # noqa: E402
 
