@@ -252,7 +252,7 @@ def main():
                               for k, v in (host_times or {}).items()},
             "workload_stats": dict(backend.NOTES),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args.workload, ps, cell, kw)
         print(json.dumps(out))
     if dist is not None:
