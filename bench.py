@@ -37,6 +37,7 @@ WORKLOADS = {
     # the global volume of a 2- / 3-rank run of synth64_p5 (checks of the multi-rank path)
     "synth64x2_p5": ((128, 64, 64), (5, 5, 5), (12, 12, 12)),
     "synth64x3_p5": ((192, 64, 64), (5, 5, 5), (12, 12, 12)),
+    "synth64x8_p5": ((512, 64, 64), (5, 5, 5), (12, 12, 12)),
     # large volumes: the consensus no longer fits, the path tiles itself into z-slabs
     "synth256_p7": ((256, 256, 256), (7, 7, 7), (18, 18, 18)),
     "synth256_p9": ((256, 256, 256), (9, 9, 9), (24, 24, 24)),
@@ -44,7 +45,7 @@ WORKLOADS = {
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
 }
-CPU_SAMPLE = {"synth64x2_p5": (24, 24, 24), "synth64x3_p5": (24, 24, 24), "flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
+CPU_SAMPLE = {"synth64x8_p5": (24, 24, 24), "synth64x2_p5": (24, 24, 24), "synth64x3_p5": (24, 24, 24), "flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
               "synth256_p7": (28, 28, 28), "synth256_p9": (26, 26, 26), "synth128_p9": (26, 26, 26),
               "synth64_p5": (24, 24, 24), "synth512_p9": (26, 26, 26)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
