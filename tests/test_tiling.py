@@ -100,6 +100,8 @@ from oracle_ops import OracleOps
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 c, ps, kw = make_case()
+import json
+kw.update(json.loads(os.environ.get("PPP_TEST_KW", "{{}}")))
 Z = c["pred"].shape[1]
 slabs = tiling.plan_slabs(Z, int(os.environ.get("PPP_TEST_SLABS", "4")))
 mine = tiling.slabs_of_rank(slabs, rank, world)
@@ -116,15 +118,20 @@ dist.destroy_process_group()
 """
 
 
-# 2 slabs per rank / one slab per rank (kept consensus) / three ranks (a rank with two neighbours)
-@pytest.mark.parametrize("n_slabs,world", [(4, 2), (2, 2), (3, 3)])
-def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world):
+# 2 slabs per rank / one slab per rank (kept consensus) / three ranks (a rank with two
+# neighbours) / several cover passes (pixel thresholds 10, 0) with thinning
+@pytest.mark.parametrize("n_slabs,world,extra", [
+    (4, 2, {}), (2, 2, {}), (3, 3, {}),
+    (2, 2, {"select_patches_for_sparse_data": False, "skipThinCover": False})])
+def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra):
+    import json
     c, ps, kw = make_case()
+    kw.update(extra)
     ref = whole_volume(c, ps, kw)
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(repo=REPO, out=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", OMP_NUM_THREADS="1",
-               PPP_TEST_SLABS=str(n_slabs))
+               PPP_TEST_SLABS=str(n_slabs), PPP_TEST_KW=json.dumps(extra))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                            "--master-port", "29591", str(script)], env=env, timeout=900)
