@@ -37,7 +37,7 @@ __device__ unsigned long long pa_stats[8];   // steps, planes, rows, useful slot
 // two row buffers must fit 64 KB of LDS
 template <int PX> struct PaCfg {
 #ifndef PPP_PA_MINWAVES7
-#define PPP_PA_MINWAVES7 7
+#define PPP_PA_MINWAVES7 8
 #endif
 #ifndef PPP_PA_THREADS9
 #define PPP_PA_THREADS9 256
@@ -53,12 +53,14 @@ template <int PX> struct PaCfg {
     //   9^3: two buffers (64 KB, 2 workgroups per CU) 7.6 s; one buffer (45 KB, 3 per CU) 6.0 s;
     //        512-thread workgroups at 4 waves/SIMD: 6.0 s
     //   (dropping the register prefetch of the next row instead: 632 ms / 6.5 s -- worse)
+    //   7^3 with the pixel list replaced by a scalar bit iterator and 8 floats of row padding:
+    //        20.2 KB of LDS -> 8 workgroups per CU, 8 waves/SIMD (64 VGPRs, 22 spilled): 542 ms
     // so PX >= 7 takes one row buffer.
     static constexpr int ROW_BUFS = PX >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
     // waves per SIMD the register budget must allow
     static constexpr int MIN_WAVES = PX <= 7 ? PPP_PA_MINWAVES7 : (THREADS == 512 ? 4 : (ROW_BUFS == 1 ? 3 : 2));
 };
-static constexpr int PA_PAD = 16;      // floats of slack either side of the staged row
+static constexpr int PA_PAD = 8;       // floats of slack either side of the staged row (a masked row read overshoots by < PX)
 
 // bits b in [0, n) with lo <= b <= hi
 __device__ __forceinline__ uint32_t rmask(int lo, int hi, int n) {
@@ -109,9 +111,7 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     constexpr int ROW_BUFS = PaCfg<PX>::ROW_BUFS;
     float *rowbuf = reinterpret_cast<float *>(lds_raw);           // [ROW_BUFS][WB]
     uint32_t *faw = lds_raw + ROW_BUFS * WB;                      // [words]
-    uint16_t *ulist = reinterpret_cast<uint16_t *>(faw + ((words + 3) & ~3));   // [C] pixels of F_A
-    uint32_t *fbw = faw + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3);          // [words][PA_THREADS]
-    __shared__ int s_nu;
+    uint32_t *fbw = faw + ((words + 3) & ~3);                     // [words][PA_THREADS]
 
     // ---- The range / intersection / stored conditions of a whole (y2o, x2o) candidate plane
     // are evaluated at once as bit masks, bit (y2o - y_first) * PX + x2o, for chunks of RPC rows
@@ -198,15 +198,22 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
         for (int w = 0; w < words; ++w) fbw[w * PA_THREADS + tid] = 0u;
     }
     __syncthreads();
-    // list of the pixels of A that are in F_A, raster order
-    if (tid == 0) {
-        int n = 0;
-        for (int r = 0; r < G.C; ++r)
-            if ((faw[r >> 5] >> (r & 31)) & 1u) ulist[n++] = (uint16_t)r;
-        s_nu = n;
-    }
-    __syncthreads();
-    const int n_u = s_nu;
+    // the pixels of A that are in F_A are walked in raster order straight off the bit words
+    // (scalar bit iterator: the word in an SGPR, s_ff1 / clear-lowest per pixel; no list in LDS)
+    int n_u = 0;
+    for (int w = 0; w < words; ++w) n_u += __popc(faw[w]);
+    n_u = __builtin_amdgcn_readfirstlane(n_u);
+    int it_w = -1;
+    uint32_t it_m = 0;
+    auto next_pixel = [&]() -> int {
+        while (it_m == 0u) {
+            ++it_w;
+            it_m = it_w < words ? (uint32_t)__builtin_amdgcn_readfirstlane((int)faw[it_w]) : 1u;
+        }
+        const int r = it_w * 32 + __builtin_ctz(it_m);
+        it_m &= it_m - 1u;
+        return r;
+    };
 
     // wave-uniform bounds of the lanes' patch offsets (idle lanes excluded)
     int dz_lo = live ? dz : (1 << 20), dz_hi = live ? dz : -(1 << 20);
@@ -221,9 +228,8 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
 
     const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
     const long long baseA = ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0);
-    // (pixel indices come out of LDS but are workgroup-uniform: readfirstlane keeps the row
-    // address arithmetic on the scalar unit and the staging loads in the saddr + voffset form)
-    auto pixel = [&](int k) -> int { return __builtin_amdgcn_readfirstlane((int)ulist[k]); };
+    // (pixel indices are workgroup-uniform scalars: the row address arithmetic stays on the
+    // scalar unit and the staging loads take the saddr + voffset form)
     auto row_of = [&](int r1) -> const float * {
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
         return S + (baseA + (long long)(z1o - G.rz) * sZ + (long long)(y1o - G.ry) * sY + (x1o - PX / 2)) * W;
@@ -236,8 +242,9 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
 
     // ---- stage the first row
     float st[NST];
+    int r_next = n_u > 0 ? next_pixel() : 0;
     if (n_u > 0) {
-        const float *src = row_of(pixel(0));
+        const float *src = row_of(r_next);
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int e = tid + i * PA_THREADS;
@@ -252,13 +259,14 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) EYf[c] = EYbk[c] = EYpos[c] = EYzero[c] = EYst[c] = EYin[c] = 0ull;
     for (int k = 0; k < n_u; ++k) {
-        const int r1 = pixel(k);
+        const int r1 = r_next;
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
         const float *cur = rowbuf + (ROW_BUFS == 2 ? (k & 1) * WB : 0) + PA_PAD;
         // ---- fetch the next row into registers while this one is consumed
         const bool more = k + 1 < n_u;
         if (more) {
-            const float *src = row_of(pixel(k + 1));
+            r_next = next_pixel();
+            const float *src = row_of(r_next);
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int e = tid + i * PA_THREADS;
@@ -422,8 +430,7 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     // candidate planes are handled as ceil(px / (64 / px)) 64-bit chunks of 64 / px rows
     if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;
     const int row_bufs = G.px >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
-    const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + (((G.C + 1) / 2 + 3) & ~3) +
-                                ((words * threads + 1) & ~1)) * 4;
+    const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + ((words * threads + 1) & ~1)) * 4;
     if (lds > 80 * 1024 || n_blocks >= (1ll << 31)) return hipErrorNotSupported;
     // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
 #define PPP_PA_CASE(P)                                                                             \
