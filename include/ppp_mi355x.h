@@ -229,6 +229,10 @@ int ppp_cons_to_voxel_major(const float *d_cons_compact, float *d_cons_voxel_maj
 int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres,
                    uint64_t n, double thresh, uint32_t *d_bits, const ppp_params *p,
                    void *stream);
+/* the same bits for every voxel, d_bits_vol u32[Z*Y*X][ceil(C/32)] (the prediction is read once,
+ * coalesced; callers with many centres gather their rows from it)                          */
+int ppp_patch_bits_volume(const void *d_pred, int pred_dtype, double thresh, uint32_t *d_bits_vol,
+                          const ppp_params *p, void *stream);
 
 /* --- greedy foreground cover on the device ---------------------------------------------
  * ppp_cover_pass: one pass of computeForegroundCoverLoop (foreground_cover.py:111-180) as an

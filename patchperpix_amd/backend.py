@@ -122,6 +122,8 @@ _SIGNATURES = {
     "ppp_patch_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_double, ctypes.c_void_p,
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_bits_volume": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                             ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_pair_group_keys": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                            ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_patch_graph_by_patch_chunk": (ctypes.c_int32, [ctypes.POINTER(Params)]),
@@ -661,9 +663,28 @@ def patch_bits(pred, centres, thresh, P):
     torch = _torch()
     n = int(centres.shape[0])
     words = (P.pz * P.py * P.px + 31) // 32
+    V = int(P.Z) * int(P.Y) * int(P.X)
+    dense = n * 16 >= V and os.environ.get("PPP_PATCH_BITS", "auto") != "sparse"
+    if dense:
+        # many centres (the cover candidates): one coalesced pass over the prediction for all
+        # voxels, then a row gather -- instead of one cache line per (centre, channel)
+        try:
+            vol = torch.empty((V, words), dtype=torch.int32, device=pred.device)
+        except RuntimeError:          # no room for the per-voxel table: per-centre gathers
+            dense = False
+    if dense:
+        with _timed("patch_bits"):
+            check(lib().ppp_patch_bits_volume(_dev_ptr(pred), pred_dtype_code(pred), float(thresh),
+                                              _dev_ptr(vol), ctypes.byref(P), _stream()))
+            c = centres.to(torch.int64)
+            lin = (c[:, 0] * int(P.Y) + c[:, 1]) * int(P.X) + c[:, 2]
+            bits = vol[lin]
+        del vol
+        return bits
     bits = torch.empty((n, words), dtype=torch.int32, device=pred.device)
-    check(lib().ppp_patch_bits(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(centres), n,
-                               float(thresh), _dev_ptr(bits), ctypes.byref(P), _stream()))
+    with _timed("patch_bits"):
+        check(lib().ppp_patch_bits(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(centres), n,
+                                   float(thresh), _dev_ptr(bits), ctypes.byref(P), _stream()))
     return bits
 
 

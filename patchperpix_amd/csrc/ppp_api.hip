@@ -428,6 +428,17 @@ int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_bits");
 }
 
+int ppp_patch_bits_volume(const void *d_pred, int pred_dtype, double thresh, uint32_t *d_bits_vol,
+                          const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_bits_vol) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_patch_bits_volume(d_pred, pred_dtype, (float)thresh, d_bits_vol, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_bits_volume");
+}
+
 int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
                    float hi, float lo, float noise, uint64_t voxel_offset, const ppp_params *p,
                    void *stream) {

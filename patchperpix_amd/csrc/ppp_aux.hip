@@ -38,6 +38,37 @@ hipError_t launch_patch_bits(const void *pred, int dtype, const uint32_t *centre
     return hipGetLastError();
 }
 
+// The same bits for EVERY voxel of the volume, bits_vol u32[V][words]: thread per voxel (lanes
+// along x: every channel plane is read once, coalesced).  The wave-per-centre kernel above
+// touches one cache line per (centre, channel) -- 48 GB for the 2.2 M cover candidates of the
+// 140^3 benchmark; this one reads the 1.9 GB prediction once and the caller gathers the rows of
+// its centres.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    patch_bits_volume_kernel(const T *__restrict__ pred, float thresh, uint32_t *__restrict__ bits_vol,
+                             const Geo G) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    const int words = (G.C + 31) / 32;
+    int r = 0;
+    for (int w = 0; w < words; ++w) {
+        uint32_t m = 0;
+        for (int b = 0; b < 32 && r < G.C; ++b, ++r)
+            m |= (ldf(pred, (long long)r * G.V + v) > thresh ? 1u : 0u) << b;
+        bits_vol[v * words + w] = m;
+    }
+}
+
+hipError_t launch_patch_bits_volume(const void *pred, int dtype, float thresh, uint32_t *bits_vol,
+                                    const Geo &G, hipStream_t s) {
+    const dim3 grid((unsigned)((G.V + 255) / 256));
+    if (dtype == PPP_F16)
+        patch_bits_volume_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, thresh, bits_vol, G);
+    else
+        patch_bits_volume_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)pred, thresh, bits_vol, G);
+    return hipGetLastError();
+}
+
 // ---- synthetic prediction (patchperpix_amd/synth.py::pred_from_labels) ------------------
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;

@@ -57,6 +57,8 @@ hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo 
                                     hipStream_t s);
 hipError_t launch_patch_bits(const void *pred, int dtype, const uint32_t *centres, uint64_t n,
                              float thresh, uint32_t *bits, const Geo &G, hipStream_t s);
+hipError_t launch_patch_bits_volume(const void *pred, int dtype, float thresh, uint32_t *bits_vol,
+                                    const Geo &G, hipStream_t s);
 hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
                         float lo, float noise, unsigned long long voxel_offset, const Geo &G,
                         hipStream_t s);

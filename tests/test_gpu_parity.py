@@ -351,3 +351,28 @@ def test_device_cover_matches_sequential_loop(variant, torch_cuda, monkeypatch):
         out[mode] = sel.coords
     assert len(out["host"]) > 20
     assert np.array_equal(out["device"], out["host"])
+
+
+@pytest.mark.gpu
+def test_patch_bits_dense_equals_per_centre(monkeypatch):
+    """backend.patch_bits picks a per-voxel pass + row gather for many centres: same words as the
+    wave-per-centre kernel, and as NumPy."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    shape, ps = (12, 14, 37), (5, 5, 5)
+    c = synth.make_case(shape, ps, seed=71, cell=[6, 6, 6])
+    P = backend.make_params(shape, ps, **dict(FLYLIGHT))
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    rng = np.random.default_rng(5)
+    centres = np.stack([rng.integers(0, s, size=3000) for s in shape], axis=1).astype(np.int32)
+    ct = torch.from_numpy(centres).cuda()
+    dense = backend.patch_bits(pred, ct, 0.5, P).cpu().numpy().view(np.uint32)
+    monkeypatch.setenv("PPP_PATCH_BITS", "sparse")
+    sparse = backend.patch_bits(pred, ct, 0.5, P).cpu().numpy().view(np.uint32)
+    assert np.array_equal(dense, sparse)
+    vals = c["pred"].astype(np.float16).astype(np.float32)[:, centres[:, 0], centres[:, 1], centres[:, 2]].T > np.float32(0.5)
+    want = np.zeros_like(dense)
+    for r in range(vals.shape[1]):
+        want[:, r // 32] |= vals[:, r].astype(np.uint32) << np.uint32(r % 32)
+    assert np.array_equal(dense, want)
