@@ -129,10 +129,19 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
     // x mask repeated in every row, by doubling (rows beyond the chunk are harmless: every use
     // is ANDed with an EY mask, which is clear there)
     auto repeat_x = [&](uint32_t m) -> u64 {
+#ifdef PPP_PA_REPEAT_BY_DOUBLING
         u64 e = m;
 #pragma unroll
         for (int n = 1; n < RPC; n *= 2) e |= e << (PX * n);
         return e;
+#else
+        // one multiply by the constant with a 1 at the start of every row (the PX-bit fields
+        // do not overlap, so there are no carries); rows >= RPC are not needed
+        u64 rep = 0;
+#pragma unroll
+        for (int j = 0; j < RPC; ++j) rep |= 1ull << (PX * j);
+        return (u64)m * rep;
+#endif
     };
 
     // ---- which (patch, chunk) is this workgroup?  binary search in the chunk prefix sums
