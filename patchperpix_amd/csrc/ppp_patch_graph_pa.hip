@@ -314,34 +314,37 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
                            z_st = mz.st & zb, z_in = mz.in & zb;
                 if (__ballot(z_f || z_bk || z_in) == 0ull) continue;
                 const int qz = mz.q0 + z2o;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
+                // one chunk of candidate rows; M = mask word: 64 bits, or 32 bits for a last
+                // chunk of few rows (9^3: rows 7-8, 18 bits) -- half the mask arithmetic
+                auto chunk = [&](auto mtag, const int c) {
+                    using M = decltype(mtag);
                     const int c_first = c * RPC;                       // first row of the chunk
                     const int c_rows = min(RPC, G.py - c_first);
-                    if (NCH > 1 && c_rows <= 0) break;
+                    if (c_rows <= 0) return;
                     const int ya = max(y_lo, c_first), yb = min(y_hi, c_first + c_rows - 1);
-                    if (ya > yb) continue;
+                    if (ya > yb) return;
                     // forward orientation (pixel z1 before z2 in raster order <=> q >= 0
                     // lexicographically) and the position of q == 0 (never stored)
-                    const u64 fwd = z_pos ? ~0ull : (z_zero ? (EYpos[c] | (EYzero[c] & RXnn)) : 0ull);
-                    const u64 range = (z_f ? (EYf[c] & RXf & fwd) : 0ull) | (z_bk ? (EYbk[c] & RXbk & ~fwd) : 0ull);
-                    const u64 inter = z_in ? (EYin[c] & RXin) : 0ull;
-                    u64 stored = z_st ? (EYst[c] & RXst & range) : 0ull;
-                    if (z_zero) stored &= ~(EYzero[c] & RXzero);
-                    if (__ballot((range | inter) != 0ull) == 0ull) continue;
+                    const M fwd = z_pos ? (M)~(M)0 : (z_zero ? (M)((M)EYpos[c] | ((M)EYzero[c] & (M)RXnn)) : (M)0);
+                    const M range = (z_f ? (M)((M)EYf[c] & (M)RXf & fwd) : (M)0) |
+                                    (z_bk ? (M)((M)EYbk[c] & (M)RXbk & (M)~fwd) : (M)0);
+                    const M inter = z_in ? (M)((M)EYin[c] & (M)RXin) : (M)0;
+                    M stored = z_st ? (M)((M)EYst[c] & (M)RXst & range) : (M)0;
+                    if (z_zero) stored &= (M) ~((M)EYzero[c] & (M)RXzero);
+                    if (__ballot((M)(range | inter) != (M)0) == 0ull) return;
                     PA_STAT(1, lane == 0 ? 1 : 0);
                     // foreground bits of patch B on these candidate rows
-                    u64 valid;
+                    M valid;
                     {
                         const int nb = c_rows * PX;
                         const int o = (z2o * G.py + c_first) * PX, w0 = o >> 5, sh = o & 31;
                         const uint32_t lo = fbw[w0 * PA_THREADS + tid];
                         const uint32_t mi = w0 + 1 < words ? fbw[(w0 + 1) * PA_THREADS + tid] : 0u;
                         const uint32_t hi = w0 + 2 < words ? fbw[(w0 + 2) * PA_THREADS + tid] : 0u;
-                        valid = ((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull);
-                        valid &= nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+                        valid = (M)(((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull));
+                        valid &= nb >= (int)(8 * sizeof(M)) ? (M)~(M)0 : (M)(((M)1 << nb) - (M)1);
                     }
-                    if (__ballot(inter != 0ull) != 0ull) {
+                    if (__ballot(inter != (M)0) != 0ull) {
                         // thinning inside the patch intersection: the LCG advances on every
                         // foreground candidate of the intersection, in candidate order
                         for (int y2o = ya; y2o <= yb; ++y2o) {
@@ -361,12 +364,12 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
                                 // down to 0.2f's predecessor * 2^32 (checked exhaustively around it)
                                 if (hit && nxt >= 858993441u) drop |= xb;
                             }
-                            valid &= ~((u64)drop << bp);
+                            valid &= (M) ~((M)drop << bp);
                         }
                     }
-                    fg_cnt += __popcll(range & valid);
-                    const u64 add = stored & valid;
-                    if (__ballot(add != 0ull) == 0ull) continue;
+                    fg_cnt += sizeof(M) == 8 ? __popcll((u64)(range & valid)) : __popc((uint32_t)(range & valid));
+                    const M add = stored & valid;
+                    if (__ballot(add != (M)0) == 0ull) return;
                     // this lane's offset into the staged row for candidate (y2o = 0, x2o = 0)
                     const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + q0x;
                     for (int y2o = ya; y2o <= yb; ++y2o) {
@@ -384,6 +387,13 @@ __global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
                             acc += __int_as_float(__float_as_int(rowq[t]) & sel);
                         }
                     }
+                };
+                // the last chunk of the 9-row planes holds (PX - (NCH-1) RPC) rows
+                constexpr bool LAST32 = NCH > 1 && (PX - (NCH - 1) * RPC) * PX <= 32;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (LAST32 && c == NCH - 1) chunk(uint32_t{}, c);
+                    else chunk(u64{}, c);
                 }
             }
         }
