@@ -29,12 +29,18 @@ __global__ void __launch_bounds__(256)
 
 hipError_t launch_patch_bits(const void *pred, int dtype, const uint32_t *centres, uint64_t n,
                              float thresh, uint32_t *bits, const Geo &G, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 3) / 4));
-    if (dtype == PPP_F16)
-        patch_bits_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, centres, n, thresh, bits, G);
-    else
-        patch_bits_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)pred, centres, n, thresh, bits, G);
+    // a wave per centre: at most 2^24 centres per launch (64 work-items each; grid limit 2^32)
+    const int words = (G.C + 31) / 32;
+    for (uint64_t k0 = 0; k0 < n; k0 += (1ull << 24)) {
+        const uint64_t m = n - k0 < (1ull << 24) ? n - k0 : (1ull << 24);
+        const dim3 grid((unsigned)((m + 3) / 4));
+        if (dtype == PPP_F16)
+            patch_bits_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, centres + k0 * 3, m, thresh,
+                                                                bits + k0 * words, G);
+        else
+            patch_bits_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)pred, centres + k0 * 3, m, thresh,
+                                                               bits + k0 * words, G);
+    }
     return hipGetLastError();
 }
 
@@ -61,6 +67,7 @@ __global__ void __launch_bounds__(256)
 
 hipError_t launch_patch_bits_volume(const void *pred, int dtype, float thresh, uint32_t *bits_vol,
                                     const Geo &G, hipStream_t s) {
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
     const dim3 grid((unsigned)((G.V + 255) / 256));
     if (dtype == PPP_F16)
         patch_bits_volume_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, thresh, bits_vol, G);
@@ -106,6 +113,7 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
                         float lo, float noise, unsigned long long voxel_offset, const Geo &G,
                         hipStream_t s) {
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
     const dim3 grid((unsigned)((G.V + 255) / 256), (unsigned)G.C);
     const uint32_t seed_mix = (uint32_t)(((unsigned long long)seed * 0x9E3779B1ull) & 0xFFFFFFFFull);
     if (dtype == PPP_F16)

@@ -36,6 +36,15 @@ struct Geo {
     int oz, oy, ox;     // global coordinate of local voxel (0,0,0)
 };
 
+// A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch
+// does NOT fail, it silently runs part of the grid.  Every launcher whose grid grows with the
+// volume either chunks its work or refuses with this check.
+static inline bool grid_too_big(unsigned long long blocks, unsigned threads) {
+    return blocks * (unsigned long long)threads >= (1ull << 32);
+}
+#define PPP_GRID_CHECK(blocks, threads) \
+    do { if (::ppp::grid_too_big((unsigned long long)(blocks), (unsigned)(threads))) return hipErrorInvalidConfiguration; } while (0)
+
 template <typename T>
 __device__ __forceinline__ float ldf(const T *p, long long i);
 template <>

@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, float *cons,
                             float *cnt, const Geo &G, hipStream_t s) {
     const dim3 block(256);
+    PPP_GRID_CHECK((G.BV + 255) / 256, 256);
     const dim3 grid((unsigned)((G.BV + 255) / 256), (unsigned)G.n_planes);
     if (G.layout == PPP_CONS_REFERENCE) {
         // planes the reference never writes stay zero
@@ -137,6 +138,7 @@ hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo 
     const size_t bytes = (size_t)(G.pz > 1 ? 2 * G.pz : 1) * G.nsy * G.nsx * G.V * sizeof(float);
     hipError_t e = hipMemsetAsync(ref, 0, bytes, s);
     if (e != hipSuccess) return e;
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
     const dim3 grid((unsigned)((G.V + 255) / 256), (unsigned)G.n_planes);
     cons_expand_kernel<<<grid, dim3(256), 0, s>>>(compact, ref, G);
     return hipGetLastError();
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_cons_to_voxel_major(const float *compact, float *S, const Geo &G,
                                       hipStream_t s) {
     const int W = (2 * G.pz - 1) * G.wy * G.wx;
+    PPP_GRID_CHECK((G.BV + 63) / 64, 256);
     const dim3 grid((unsigned)((G.BV + 63) / 64), (unsigned)((W + 63) / 64));
     cons_voxel_major_kernel<<<grid, dim3(256), 0, s>>>(compact, S, G, W);
     return hipGetLastError();

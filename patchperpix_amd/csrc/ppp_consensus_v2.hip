@@ -336,6 +336,7 @@ static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float
     const long long n_waves = (long long)runs_per_line * G.bY * G.bZ * n_rows;
     const long long n_blocks = (n_waves + V2_WAVES - 1) / V2_WAVES;
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
+    PPP_GRID_CHECK(n_blocks, 64 * V2_WAVES);
     // per-lane element offsets are 32-bit byte offsets within PX channel volumes
     if (((long long)(PX - 1) * G.V + G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
     const dim3 grid((unsigned)n_blocks), block(64 * V2_WAVES);

@@ -256,6 +256,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
                           hipStream_t s, int *rounds) {
     *rounds = 0;
     if (n <= 0) return hipSuccess;
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
     CoverWork W = carve(work, G);
     hipError_t e;
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
@@ -321,6 +322,7 @@ __global__ void __launch_bounds__(256)
 
 hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *rankid, long long n,
                       const int32_t *state, int32_t *cleared, void *work, const Geo &G, hipStream_t s) {
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
     CoverWork W = carve(work, G);
     hipError_t e;
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;

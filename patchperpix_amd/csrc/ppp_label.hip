@@ -132,6 +132,7 @@ __global__ void label_emit_kernel(const uint32_t *__restrict__ nodes, uint64_t n
 hipError_t launch_label_begin(const uint32_t *nodes, uint64_t n_nodes, void *work, const Geo &G,
                               hipStream_t s) {
     if (n_nodes == 0) return hipSuccess;
+    PPP_GRID_CHECK((n_nodes + 255) / 256, 256);
     label_begin_kernel<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, s>>>(
         nodes, n_nodes, label_carve(work, G.V), G);
     return hipGetLastError();
@@ -139,6 +140,7 @@ hipError_t launch_label_begin(const uint32_t *nodes, uint64_t n_nodes, void *wor
 hipError_t launch_label_add(const uint32_t *pairs, const float *aff, const long long *gid,
                             long long gid0, uint64_t n, void *work, const Geo &G, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    PPP_GRID_CHECK((n + 255) / 256, 256);
     label_add_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
         pairs, aff, gid, gid0, n, label_carve(work, G.V), G);
     return hipGetLastError();
@@ -146,6 +148,7 @@ hipError_t launch_label_add(const uint32_t *pairs, const float *aff, const long 
 hipError_t launch_label_union_edges(const long long *ea, const long long *eb, uint64_t n,
                                     void *work, const Geo &G, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    PPP_GRID_CHECK((n + 255) / 256, 256);
     label_union_edges_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
         ea, eb, n, label_carve(work, G.V));
     return hipGetLastError();
@@ -202,12 +205,17 @@ hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,
                         const uint32_t *labels, uint64_t n, uint32_t *inst, const Geo &G,
                         hipStream_t s) {
     if (n == 0) return hipSuccess;
-    const uint64_t total = n * (uint64_t)G.C;
-    const dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == PPP_F16)
-        paint_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, nodes, labels, n, inst, G.th_rn, G);
-    else
-        paint_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)pred, nodes, labels, n, inst, G.th_rn, G);
+    // a thread per (node, patch pixel): chunks of nodes that stay below the 2^32 grid limit
+    const uint64_t per = ((1ull << 31) / (uint64_t)G.C) & ~255ull;
+    for (uint64_t k0 = 0; k0 < n; k0 += per) {
+        const uint64_t m = n - k0 < per ? n - k0 : per;
+        const uint64_t total = m * (uint64_t)G.C;
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (dtype == PPP_F16)
+            paint_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, nodes + k0 * 3, labels + k0, m, inst, G.th_rn, G);
+        else
+            paint_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)pred, nodes + k0 * 3, labels + k0, m, inst, G.th_rn, G);
+    }
     return hipGetLastError();
 }
 

@@ -118,6 +118,7 @@ hipError_t launch_pairs_subset(const int32_t *pts, int64_t n, const int *box, in
                                const int64_t *gid_off, int64_t n_local_rows, int64_t n_rows_total,
                                int include_single, uint32_t *rows, long long *gid, hipStream_t s) {
     if (n == 0 || m == 0) return hipSuccess;
+    PPP_GRID_CHECK((m + 3) / 4, 256);
     pairs_subset_kernel<<<dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s>>>(
         pts, n, box[0], box[1], box[2], l1max, subset, m, local_off, gid_off, rows, gid);
     if (include_single)
@@ -130,6 +131,7 @@ hipError_t launch_pairs_count(const int32_t *pts, int64_t n, const int *box, int
                               int64_t *counts, hipStream_t s, const int64_t *subset, int64_t m) {
     const int64_t waves = subset ? m : n;
     if (n == 0 || waves == 0) return hipSuccess;
+    PPP_GRID_CHECK((waves + 3) / 4, 256);
     pairs_kernel<false><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s>>>(
         pts, n, box[0], box[1], box[2], l1max, counts, nullptr, nullptr, subset, m);
     return hipGetLastError();
@@ -139,6 +141,7 @@ hipError_t launch_pairs_fill(const int32_t *pts, int64_t n, const int *box, int 
                              const int64_t *offsets, int64_t n_pair_rows, int include_single,
                              uint32_t *rows, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    PPP_GRID_CHECK((n + 3) / 4, 256);
     pairs_kernel<true><<<dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s>>>(
         pts, n, box[0], box[1], box[2], l1max, nullptr, offsets, rows, nullptr, 0);
     if (include_single)
@@ -178,6 +181,7 @@ __global__ void pair_group_keys_kernel(const uint32_t *__restrict__ rows, const 
 hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
                                   hipStream_t s) {
     if (n == 0) return hipSuccess;
+    PPP_GRID_CHECK((n + 255) / 256, 256);
     pair_group_keys_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(rows, n, keys, G);
     return hipGetLastError();
 }
@@ -185,6 +189,7 @@ hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *key
 hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
                             hipStream_t s) {
     if (n == 0) return hipSuccess;
+    PPP_GRID_CHECK((n + 255) / 256, 256);
     pair_keys_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(rows, n, keys, G);
     return hipGetLastError();
 }

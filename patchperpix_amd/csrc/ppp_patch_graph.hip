@@ -435,6 +435,7 @@ hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
     const size_t lds_bytes = (size_t)PG_WAVES * 2 * ((G.C + 31) / 32) * 64 * sizeof(uint32_t);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const uint64_t per_block = 64ull * PG_WAVES;
+    PPP_GRID_CHECK((n + per_block - 1) / per_block, 64 * PG_WAVES);
     const dim3 grid((unsigned)((n + per_block - 1) / per_block));
     static const bool vm_generic = getenv("PPP_PATCH_GRAPH_GENERIC") != nullptr;
     if (G.layout == PPP_CONS_VOXEL_MAJOR && !vm_generic &&

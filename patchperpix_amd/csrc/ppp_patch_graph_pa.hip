@@ -450,7 +450,8 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;
     const int row_bufs = G.px >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
     const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + ((words * threads + 1) & ~1)) * 4;
-    if (lds > 80 * 1024 || n_blocks >= (1ll << 31)) return hipErrorNotSupported;
+    if (lds > 80 * 1024 || n_blocks >= (1ll << 31) || grid_too_big((unsigned long long)n_blocks, threads))
+        return hipErrorNotSupported;
     // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
 #define PPP_PA_CASE(P)                                                                             \
     case P:                                                                                        \

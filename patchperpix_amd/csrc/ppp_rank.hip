@@ -101,6 +101,7 @@ hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uin
         const hipError_t e2 = launch_rank_v2(pred, dtype, cons, ov, score, sb, G, s);
         if (e2 != hipErrorNotSupported) return e2;
     }
+    PPP_GRID_CHECK((n + 255) / 256, 256);
     const dim3 grid((unsigned)((n + 255) / 256));
     if (dtype == PPP_F16)
         rank_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)pred, cons, ov, score, sb, G);

@@ -214,6 +214,7 @@ static hipError_t launch_r2(const T *pred, const float *cons, const uint8_t *ov,
     while (waves > 1 && waves * per_wave > 40 * 1024) waves >>= 1;   // keep >= 4 blocks per CU
     if (waves * per_wave > 64 * 1024) return hipErrorNotSupported;
     const size_t lds = waves * per_wave;
+    PPP_GRID_CHECK((n_waves + waves - 1) / waves, 64 * waves);
     const dim3 grid((unsigned)((n_waves + waves - 1) / waves)), block(64 * waves);
     if (G.count_pos_neg)
         rank_v2_kernel<T, PX, true><<<grid, block, lds, s>>>(pred, cons, ov, score, sb, G, runs_per_line, n_waves);

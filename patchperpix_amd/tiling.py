@@ -411,8 +411,14 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         comm.all_reduce_sum(bits)
         return bits
 
+    debug_crc = os.environ.get("PPP_DEBUG_CRC") == "1"     # development aid (tools/cover_repro.py)
+    if debug_crc:
+        import zlib
+        backend.note("crc_scores", zlib.crc32(score_dev.cpu().numpy().tobytes()))
     with backend.host_timer("sort"):
         lin_t, rscores_t = ops.rank_order(score_dev, foreground, ps)
+    if debug_crc:
+        backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
     del score_dev
     coords_t = torch.stack([lin_t // (Y * X), (lin_t // X) % Y, lin_t % X], dim=1).to(torch.int32)
     if kw.get("selected_patches") is not None:
@@ -466,6 +472,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 del bits
             del never
             sel_coords = coords_t[selected].cpu().numpy()
+            if debug_crc:
+                backend.note("crc_selected", zlib.crc32(np.ascontiguousarray(sel_coords).tobytes()))
+                if os.environ.get("PPP_STOP_AFTER_COVER") == "1":
+                    return early()
     if not kw.get("skipThinCover") and len(sel_coords) > 0:
         with backend.host_timer("s4_thin"):
             bits = gathered_bits(torch.from_numpy(np.ascontiguousarray(sel_coords)).to(dev),

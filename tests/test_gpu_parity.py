@@ -376,3 +376,26 @@ def test_patch_bits_dense_equals_per_centre(monkeypatch):
     for r in range(vals.shape[1]):
         want[:, r // 32] |= vals[:, r].astype(np.uint32) << np.uint32(r % 32)
     assert np.array_equal(dense, want)
+
+
+@pytest.mark.gpu
+def test_patch_bits_more_centres_than_one_launch_holds(monkeypatch):
+    """A HIP grid holds < 2^32 work-items: the wave-per-centre kernel (64 per centre) is launched
+    in chunks of 2^24 centres.  (An unchunked launch silently ran part of the grid and left the
+    rest of the table uninitialised -- found at 512^3 / 9^3, 1.2e8 cover candidates.)"""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    shape, ps = (10, 12, 33), (3, 3, 3)
+    c = synth.make_case(shape, ps, seed=72, cell=[5, 5, 5])
+    P = backend.make_params(shape, ps, **dict(FLYLIGHT))
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    n = (1 << 24) + 4097
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    ct = torch.stack([torch.randint(0, s, (n,), device="cuda", generator=g, dtype=torch.int32)
+                      for s in shape], 1).contiguous()
+    dense = backend.patch_bits(pred, ct, 0.5, P)
+    monkeypatch.setenv("PPP_PATCH_BITS", "sparse")
+    sparse = backend.patch_bits(pred, ct, 0.5, P)
+    assert torch.equal(dense, sparse)
