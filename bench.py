@@ -31,6 +31,7 @@ WORKLOADS = {
     # the global volume of an 8-rank weak-scaling run on one device (how the replicated global
     # stages grow with N; run with --slabs 8)
     "flylight140x8_p7": ((1120, 140, 140), (7, 7, 7), (18, 18, 18)),
+    "flylight140x2_p7": ((280, 140, 140), (7, 7, 7), (18, 18, 18)),
     # BASELINE.json configs[0]: wormbodies 2-d, 25x25 patch, one 696x520 image (generic kernels)
     "worm2d_p25": ((1, 520, 696), (1, 25, 25), (1, 40, 40)),
     # reduced variants for quick checks
@@ -47,7 +48,7 @@ WORKLOADS = {
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
 }
-CPU_SAMPLE = {"worm2d_p25": (1, 60, 60), "synth64x8_p5": (24, 24, 24), "synth64x2_p5": (24, 24, 24), "synth64x3_p5": (24, 24, 24), "flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
+CPU_SAMPLE = {"worm2d_p25": (1, 60, 60), "synth64x8_p5": (24, 24, 24), "synth64x2_p5": (24, 24, 24), "synth64x3_p5": (24, 24, 24), "flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "flylight140x2_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
               "synth256_p7": (28, 28, 28), "synth256_p9": (26, 26, 26), "synth128_p9": (26, 26, 26),
               "synth64_p5": (24, 24, 24), "synth512_p9": (26, 26, 26)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
