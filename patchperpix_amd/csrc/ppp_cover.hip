@@ -168,6 +168,56 @@ __global__ void __launch_bounds__(256)
     out[v] = m;
 }
 
+// x and y passes of the running minimum in one kernel: a block owns 8 rows x 64 columns of one
+// z-slice, stages them with their (ry, rx) apron in LDS, takes the minimum along x into a second
+// LDS array and then along y (one launch and one volume round trip less per round).
+static constexpr int MF_TY = 8, MF_TX = 64;
+__global__ void __launch_bounds__(256)
+    cover_minfilter_xy_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, const Geo G,
+                              const int rx, const int ry) {
+    extern __shared__ int32_t mf_lds[];
+    const int W = MF_TX + 2 * rx, H = MF_TY + 2 * ry;
+    int32_t *a = mf_lds;            // [H][W]   input tile with apron
+    int32_t *b = mf_lds + H * W;    // [H][MF_TX] minimum along x
+    const int x0 = blockIdx.x * MF_TX, y0 = blockIdx.y * MF_TY, z = blockIdx.z;
+    const long long zbase = (long long)z * G.Y * G.X;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int yy = y0 - ry + i / W, xx = x0 - rx + i % W;
+        a[i] = (yy >= 0 && yy < G.Y && xx >= 0 && xx < G.X) ? in[zbase + (long long)yy * G.X + xx] : RANK_NONE;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * MF_TX; i += 256) {
+        const int r = i / MF_TX, c = i % MF_TX;
+        int32_t m = RANK_NONE;
+        for (int d = 0; d <= 2 * rx; ++d) m = min(m, a[r * W + c + d]);
+        b[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MF_TY * MF_TX; i += 256) {
+        const int r = i / MF_TX, c = i % MF_TX;
+        const int yy = y0 + r, xx = x0 + c;
+        if (yy >= G.Y || xx >= G.X) continue;
+        int32_t m = RANK_NONE;
+        for (int d = 0; d <= 2 * ry; ++d) m = min(m, b[(r + d) * MF_TX + c]);
+        out[zbase + (long long)yy * G.X + xx] = m;
+    }
+}
+
+// the three passes (x+y fused, then z) : in -> tmp -> out
+static void minfilter_3d(const int32_t *in, int32_t *tmp, int32_t *out, const Geo &G, hipStream_t s) {
+    const int rx = G.px - 1, ry = G.py - 1;
+    const dim3 grid((unsigned)((G.X + MF_TX - 1) / MF_TX), (unsigned)((G.Y + MF_TY - 1) / MF_TY), (unsigned)G.Z);
+    const size_t lds = (size_t)((MF_TY + 2 * ry) * (MF_TX + 2 * rx) + (MF_TY + 2 * ry) * MF_TX) * sizeof(int32_t);
+    const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
+    if (lds <= 48 * 1024 && G.Y <= 65535 * MF_TY && G.Z <= 65535) {
+        cover_minfilter_xy_kernel<<<grid, block, lds, s>>>(in, tmp, G, rx, ry);
+    } else {
+        cover_minfilter_kernel<<<vgrid, block, 0, s>>>(in, out, G.V, G.X, 1, rx);
+        cover_minfilter_kernel<<<vgrid, block, 0, s>>>(out, tmp, G.V, G.Y, G.X, ry);
+    }
+    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(tmp, out, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+}
+
 // Thread per voxel: the best ranked undecided patch of its neighbourhood selects itself; its
 // wave clears the voxels (lane per window row) and marks the centres whose counts may have
 // changed.  Selected patches never share a voxel, but they may share a mask word.
@@ -272,10 +322,8 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
                                                        W.counters + r, nullptr, G);
-            // x, then y, then z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
-            cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.rank_vol, W.nbr_min, G.V, G.X, 1, G.px - 1);
-            cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.nbr_min, W.tmp, G.V, G.Y, G.X, G.py - 1);
-            cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.tmp, W.nbr_min, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+            // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
+            minfilter_3d(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
                                                         W.dirty, nullptr, G.Z + G.oz, G);
         }
@@ -351,10 +399,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
 
 hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s) {
     CoverWork W = carve(work, G);
-    const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
-    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.rank_vol, W.nbr_min, G.V, G.X, 1, G.px - 1);
-    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.nbr_min, W.tmp, G.V, G.Y, G.X, G.py - 1);
-    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(W.tmp, W.nbr_min, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+    minfilter_3d(W.rank_vol, W.tmp, W.nbr_min, G, s);
     return hipGetLastError();
 }
 
