@@ -114,6 +114,9 @@ CASES = [
     ((1, 70, 75), (1, 25, 25), dict(seed=26, cell=[1, 30, 30]),
      dict(patch_threshold=0.9, vi_bg_use_inv_th=True, vi_bg_use_less_than_th=False,
           overlapping_inst=False)),     # wormbodies-like 2-d shape: the generic kernels
+    # anisotropic patches through the specialised kernels (px = 7 / 9, pz, py smaller)
+    ((10, 16, 30), (3, 5, 7), dict(seed=27, cell=[4, 7, 9], overlap_frac=0.02), {}),
+    ((12, 17, 21), (5, 9, 9), dict(seed=28, cell=[6, 11, 11]), {}),
 ]
 
 
