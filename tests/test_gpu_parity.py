@@ -402,3 +402,25 @@ def test_patch_bits_more_centres_than_one_launch_holds(monkeypatch):
     monkeypatch.setenv("PPP_PATCH_BITS", "sparse")
     sparse = backend.patch_bits(pred, ct, 0.5, P)
     assert torch.equal(dense, sparse)
+
+
+@pytest.mark.gpu
+def test_consensus_out_of_range_operands_take_exact_divisions(torch_cuda):
+    """TH = 0.5: the float-only vote normalisation is checked for products up to 2^22; a tile with
+    an operand above 1024 (never for probabilities) must fall back to the double divisions --
+    still bit-identical to the oracle."""
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd import synth
+    from tests_flags import FLYLIGHT
+    shape, ps = (12, 14, 70), (5, 5, 5)
+    c = synth.make_case(shape, ps, seed=31, cell=[6, 6, 6])
+    kw = dict(FLYLIGHT)
+    pred = c["pred"].astype(np.float32)
+    rng = np.random.default_rng(31)
+    big = rng.random(pred.shape) < 0.002
+    pred[big & (pred > 0.5)] *= 3000.0          # "foreground" values far outside [0, 1]
+    pred[big & (pred < 0.5)] -= 2500.0          # and "background" ones (1 - v is large)
+    ov = 1 * (c["numinst"] > 1)
+    cons_ref = orc.consensus(pred, ov, ps, **kw)
+    o = _stage_outputs(torch_cuda, pred, ov, ps, kw)
+    assert np.array_equal(_bits(o["cons"]), _bits(orc.positive_planes(cons_ref, ps)))
