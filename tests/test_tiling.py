@@ -18,6 +18,12 @@ from patchperpix_amd.flags import FLYLIGHT
 
 def make_case(seed=61, shape=(44, 12, 13), ps=(3, 3, 3)):
     c = synth.make_case(shape, ps, seed=seed, cell=[5, 5, 5], overlap_frac=0.02)
+    if os.environ.get("PPP_TEST_EMPTY_TOP") == "1":
+        # nothing above slice 24: a rank whose slab holds no patch at all
+        z = 24
+        c["pred"][:, z:] = 0.05
+        c["foreground"][z:] = False
+        c["numinst"][z:] = 0
     return c, list(ps), dict(FLYLIGHT)
 
 
@@ -122,9 +128,13 @@ dist.destroy_process_group()
 # neighbours) / several cover passes (pixel thresholds 10, 0) with thinning
 @pytest.mark.parametrize("n_slabs,world,extra", [
     (4, 2, {}), (2, 2, {}), (3, 3, {}),
-    (2, 2, {"select_patches_for_sparse_data": False, "skipThinCover": False})])
-def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra):
+    (2, 2, {"select_patches_for_sparse_data": False, "skipThinCover": False}),
+    (2, 2, {"_empty_top": True})])
+def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypatch):
     import json
+    extra = dict(extra)
+    if extra.pop("_empty_top", False):
+        monkeypatch.setenv("PPP_TEST_EMPTY_TOP", "1")     # (inherited by the workers)
     c, ps, kw = make_case()
     kw.update(extra)
     ref = whole_volume(c, ps, kw)
@@ -191,6 +201,8 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 shape, ps = {shape!r}, {ps!r}
 c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+if os.environ.get("PPP_TEST_EMPTY_TOP") == "1":      # the last rank's slab holds nothing
+    c["pred"][:, 36:] = 0.05; c["foreground"][36:] = False; c["numinst"][36:] = 0
 kw = dict(FLYLIGHT)
 Z = shape[0]
 slabs = tiling.plan_slabs(Z, world)
@@ -207,19 +219,24 @@ dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world):
+@pytest.mark.parametrize("world,empty_top", [(2, False), (3, False), (2, True)])
+def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top):
     """The multi-rank path with the REAL kernels: `world` processes on the one GPU of the box,
     gloo as the transport (RCCL needs one device per rank): sharded cover with z-halo exchange,
     per-rank pair rows, merged label forests -- same instance map as one process."""
     from patchperpix_amd.vote_instances import vote_instances as vi
     shape, ps = (72, 26, 30), (5, 5, 5)
     c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+    if empty_top:
+        c["pred"][:, 36:] = 0.05
+        c["foreground"][36:] = False
+        c["numinst"][36:] = 0
     want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
                                  c["numinst"].copy(), list(ps), **dict(FLYLIGHT, _n_slabs=1))
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", OMP_NUM_THREADS="1",
+               PPP_TEST_EMPTY_TOP="1" if empty_top else "0")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                            "--master-port", "29593", str(script)], env=env, timeout=900)
