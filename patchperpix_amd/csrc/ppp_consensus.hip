@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(256)
     const int Lc = (W - 1) / 2;
     const long long v0 = (long long)blockIdx.x * 64;
     const int L0 = blockIdx.y * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (wave index made scalar: the offset arithmetic of a tile row is wave-uniform)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long v = v0 + lane;
     int bx = 0, by = 0, bz = 0;
     if (v < G.BV) {
