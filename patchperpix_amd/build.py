@@ -32,10 +32,28 @@ def is_stale():
 
 
 def build_library(force=False, verbose=False):
+    """Every translation unit is compiled on its own (in parallel, objects under csrc/_obj/),
+    then linked: a full build takes as long as the slowest file instead of their sum."""
     if not force and not is_stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + os.environ.get("PPP_EXTRA_FLAGS", "").split() + sources() + ["-o", LIB]
+    extra = os.environ.get("PPP_EXTRA_FLAGS", "").split()
+    objdir = os.path.join(CSRC, "_obj", os.path.basename(LIB))
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + cflags + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
