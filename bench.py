@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="flylight140_p7", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", default="shipped", choices=["shipped", "cc", "nothin_cc"],
+                    help="flag set (patchperpix_amd/flags.py): shipped = default.toml "
+                         "[vote_instances] (mws + thinning), cc = mws off, nothin_cc = "
+                         "kernels-only pipeline")
     ap.add_argument("--slabs", type=int, default=None,
                     help="force the number of z-slabs of the single-GPU tiled path")
     ap.add_argument("--yx", type=int, nargs=2, default=None, metavar=("NY", "NX"),
@@ -97,7 +101,7 @@ def main():
 
     import torch
     from patchperpix_amd import backend
-    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd import flags as flagsets
     from patchperpix_amd.vote_instances import vote_instances as vi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,7 +119,7 @@ def main():
     n_gpus = max(args.gpus, world)
 
     shape, ps, cell = WORKLOADS[args.workload]
-    kw = dict(FLYLIGHT)
+    kw = dict(flagsets.FLAG_SETS[args.flags])
     from patchperpix_amd import tiling
     if world == 1:
         P = backend.make_params(shape, ps, **kw)
@@ -241,10 +245,10 @@ def main():
             "metric": "Mvoxels/sec assembled (vote_instances)", "value": value,
             "unit": "Mvoxels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 in, f32 accumulate", "data": "synthetic",
             "config": {"workload": args.workload, "volume": list(shape), "patchshape": list(ps),
                        "pred_dtype": "f16 resident, widened to f32 in registers",
-                       "flags": "flylight default.toml [vote_instances]",
+                       "flag_set": args.flags, "flags": flagsets.describe(kw),
                        "instances_found": int(len(np.unique(inst)) - 1),
                        "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
                        "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus if not args.yx else

@@ -315,6 +315,21 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     (pairs, aff) with return_intermediates, with the reference's early-outs.
     """
     import torch
+    # flags the slab pipeline does not implement are refused, never ignored (the caller --
+    # to_instance_seg -- applies skeletonize_foreground to the mask before it gets here)
+    for opt in ("skipConsensus", "skipRanking", "termAfterThinCover", "termAfterPatchGraph",
+                "save_consensus", "graphToInst", "debug", "isbiHack", "pad_with_ps",
+                "mark_close_neighboorhood", "select_patches_overlap_neighborhood",
+                "one_instance_per_channel", "no_overlap_per_channel", "sparse_labels"):
+        if kw.get(opt, False):
+            raise NotImplementedError("%s is not supported by the tiled / multi-rank assembly" % opt)
+    if kw.get("aff_graph") is not None:
+        raise NotImplementedError("aff_graph input is not supported by the tiled assembly")
+    if kw.get("max_total_patch_distance_in_ps_multiples", 2) > 2:
+        raise NotImplementedError("the slab halo is sized for "
+                                  "max_total_patch_distance_in_ps_multiples <= 2")
+    if not my_slabs:
+        raise ValueError("this rank owns no z-slab (more ranks than slabs)")
     comm = comm or LocalComm()
     ops = ops or DeviceOps()
     dev = ops.device
@@ -738,6 +753,12 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
         mask = clean_mask(foreground, ndimage.generate_binary_structure(3, 1),
                           kw["ignore_small_comps"])
     if kw.get("only_bb", False) and mask.any():
+        if kw.get("skeletonize_foreground"):
+            # stitch_patch_graph.py:756-759: the bounding box is that of the SKELETON of the
+            # cleaned mask (the cover mask itself is not thinned in blockwise mode,
+            # vote_instances.py:219)
+            from .vote_instances.vote_instances import _skeletonize
+            mask = _skeletonize(mask)
         nz = np.nonzero(mask)
         rad = patchshape // 2
         bb = tuple(slice(max(0, int(nz[i].min()) - int(rad[i])),

@@ -75,6 +75,19 @@ def get_arguments(check_required=True, argv=None):
     return args
 
 
+def _skeletonize(mask):
+    """skimage.morphology.skeletonize_3d of the mask (vote_instances.py:219-224,
+    stitch_patch_graph.py:757-760).  scikit-image is a dependency of the reference that this
+    image lacks; without it the option raises -- it is never silently ignored."""
+    try:
+        from skimage.morphology import skeletonize_3d
+    except ImportError as e:
+        raise NotImplementedError(
+            "skeletonize_foreground needs scikit-image (skimage.morphology.skeletonize_3d), "
+            "which is not installed") from e
+    return skeletonize_3d(mask) > 0
+
+
 def _pad(a, rad, channels=False):
     width = [(int(r), int(r)) for r in rad]
     if channels:
@@ -115,6 +128,10 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
 
     pred_affs = backend.to_device_pred(pred_affs)   # host->HBM once; f16 stays f16 (exact)
     shape = tuple(foreground.shape)
+    # vote_instances.py:219-224: the mask is thinned BEFORE anything else looks at it, so this
+    # happens ahead of the dispatch to the tiled path (which must cover the same mask)
+    if not kwargs.get('blockwise', False) and kwargs.get('skeletonize_foreground'):
+        mask_to_cover = _skeletonize(mask_to_cover)
     # Volumes whose consensus does not fit in HBM are assembled slab by slab (identical result,
     # patchperpix_amd/tiling.py); `_n_slabs` forces a slab count.
     n_slabs = kwargs.get("_n_slabs")
@@ -131,7 +148,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     # code path: it keeps the ranked patch list on the device instead of materialising the
     # reference's host lists between the stage functions (PPP_PIPELINE=stages keeps them).
     plain = kwargs.get("save_no_intermediates", False) and not kwargs.get("debug", False) \
-        and not any(kwargs.get(k) for k in ("skeletonize_foreground", "skipConsensus", "skipRanking",
+        and not any(kwargs.get(k) for k in ("skipConsensus", "skipRanking",
                                             "termAfterThinCover", "termAfterPatchGraph",
                                             "save_consensus", "blockwise")) \
         and os.environ.get("PPP_PIPELINE", "fused") != "stages"
@@ -146,13 +163,6 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
                                patchshape, tiling.plan_slabs(shape[0], n_slabs), **kw)
     radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
     overlap_mask = 1 * (numinst > 1)
-
-    if not kwargs.get('blockwise', False) and kwargs.get('skeletonize_foreground'):
-        try:
-            from skimage.morphology import skeletonize_3d
-        except ImportError as e:
-            raise RuntimeError("skeletonize_foreground needs scikit-image") from e
-        mask_to_cover = skeletonize_3d(mask_to_cover) > 0
 
     mask_to_cover[overlap_mask > 0] = 0
     instances = np.zeros(shape, dtype=np.uint16)

@@ -385,12 +385,18 @@ CASES = {
     "c3d_p9_cells": ((14, 15, 16), (9, 9, 9), dict(kind="cells", seed=14, cell=[7, 8, 8]), {}),
     "c2d_p25_cells": ((1, 40, 44), (1, 25, 25), dict(kind="cells", seed=15, cell=[1, 14, 14]),
                       {}),
+    # the shipped flylight flags (default.toml:134,141: thinning + mutex watershed) at p = 5 / 7
+    "c3d_p5_thin_mws": ((16, 16, 16), (5, 5, 5), dict(kind="cells", seed=16, cell=[7, 7, 7]),
+                        dict(skipThinCover=False, mws=True)),
+    "c3d_p7_thin_mws": ((16, 18, 20), (7, 7, 7), dict(kind="cells", seed=17, cell=[9, 9, 9]),
+                        dict(skipThinCover=False, mws=True)),
     "c3d_empty": ((10, 10, 10), (3, 3, 3), dict(kind="empty", seed=0), {}),
     "c3d_single_patch": ((3, 3, 3), (3, 3, 3), dict(kind="cells", seed=1, cell=[9, 9, 9]),
                          {}),
 }
 # cases whose consensus array is too big to commit: keep a SHA-256 of the float bits
-HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells", "c3d_p9_cells", "c2d_p25_cells"}
+HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells", "c3d_p9_cells", "c2d_p25_cells",
+                  "c3d_p5_thin_mws", "c3d_p7_thin_mws"}
 # cases that are ALSO run through the reference's NumPy path (cuda=False; int16 +-1 votes,
 # SURVEY 8c "recipe A").  Different arithmetic from the kernels: only the final instance map
 # is stored, to document that both semantics agree on well separated instances.

@@ -264,7 +264,7 @@ def test_large_volume_consistency(torch_cuda):
     workgroup-per-patch patch-graph kernels agree bit for bit, and the 3-slab tiled assembly
     equals the untiled one."""
     from patchperpix_amd import backend, synth, tiling
-    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
     from patchperpix_amd.vote_instances import vote_instances as vi
     torch = torch_cuda
     shape, ps = (96, 96, 96), (7, 7, 7)
@@ -424,3 +424,30 @@ def test_consensus_out_of_range_operands_take_exact_divisions(torch_cuda):
     cons_ref = orc.consensus(pred, ov, ps, **kw)
     o = _stage_outputs(torch_cuda, pred, ov, ps, kw)
     assert np.array_equal(_bits(o["cons"]), _bits(orc.positive_planes(cons_ref, ps)))
+
+
+@pytest.mark.gpu
+def test_paint_more_nodes_than_one_launch_holds():
+    """ppp_paint_instances runs a thread per (node, patch pixel) and therefore chunks its nodes
+    below the 2^32 work-items a HIP grid holds (2^31 / C nodes per launch): a node list just
+    over one chunk paints the same volume as the same nodes painted in two explicit calls."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    shape, ps = (14, 16, 40), (9, 9, 9)
+    c = synth.make_case(shape, ps, seed=73, cell=[7, 8, 8])
+    P = backend.make_params(shape, ps, **dict(FLYLIGHT))
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    per = ((1 << 31) // 729) & ~255
+    n = per + 5003
+    k = torch.arange(n, device="cuda", dtype=torch.int64)
+    nodes = torch.stack([4 + k % 6, 4 + (k // 6) % 8, 4 + (k // 48) % 32], 1).to(torch.int32).contiguous()
+    labels = (1 + k % 60000).to(torch.int32)
+    labels[per:] = 60001 + torch.arange(n - per, device="cuda", dtype=torch.int32)   # the tail wins
+    one = torch.zeros(shape, dtype=torch.int32, device="cuda")
+    backend.paint_instances(pred, nodes, labels, one, P)
+    two = torch.zeros(shape, dtype=torch.int32, device="cuda")
+    backend.paint_instances(pred, nodes[:per].contiguous(), labels[:per].contiguous(), two, P)
+    backend.paint_instances(pred, nodes[per:].contiguous(), labels[per:].contiguous(), two, P)
+    assert torch.equal(one, two)
+    assert int(one.max().item()) > 60000

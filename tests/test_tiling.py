@@ -13,7 +13,7 @@ import pytest
 
 from conftest import REPO
 from patchperpix_amd import synth, tiling
-from patchperpix_amd.flags import FLYLIGHT
+from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
 
 
 def make_case(seed=61, shape=(44, 12, 13), ps=(3, 3, 3)):
@@ -190,12 +190,99 @@ def test_yx_tiles_equal_whole_volume_gpu(n_slabs, yx):
     assert np.array_equal(got, want) and got.any()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_slabs,yx", [("c3d_p7_cells", 2, (2, 2)), ("c3d_p9_cells", 2, (2, 2)),
+                                             ("c3d_p9_cells", 1, (3, 2)), ("c3d_p7_thin_mws", 2, (2, 2)),
+                                             ("c3d_p5_thin_mws", 3, (2, 2))])
+def test_tiles_reproduce_goldens_gpu(name, n_slabs, yx):
+    """z-slabs x y/x tiles at 7^3 and 9^3 (two-chunk 81-bit candidate planes, pairs halo on both
+    sides in y / x) against the reference's own outputs: pair rows, affinities (bit patterns)
+    and the instance map of the golden cases, thinning + mutex watershed included."""
+    from conftest import Golden
+    g = Golden(name)
+    ps, kw = g.patchshape, dict(g.kw, cuda=True, save_no_intermediates=True, sample=1.0,
+                                debug=False, isbiHack=False, result_folder="/tmp",
+                                affinities="golden.zarr")
+    got_p, got_a = tiling.to_instance_seg_tiled(
+        g.pred.copy(), g.foreground.copy(), g.foreground.copy(), g.numinst.copy(), ps, n_slabs,
+        return_intermediates=True, _yx_tiles=yx, **kw)
+    assert np.array_equal(got_p, g["pairs"])
+    assert np.array_equal(got_a.view(np.uint32), g["aff"].view(np.uint32))
+    got, _ = tiling.to_instance_seg_tiled(
+        g.pred.copy(), g.foreground.copy(), g.foreground.copy(), g.numinst.copy(), ps, n_slabs,
+        _yx_tiles=yx, **kw)
+    assert np.array_equal(got, g["instances"]) and got.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ps,shape,cell,n_slabs,yx,flagset", [
+    ((7, 7, 7), (30, 34, 38), 10, 2, (2, 2), "nothin_cc"),
+    ((7, 7, 7), (30, 34, 38), 10, 3, (2, 3), "shipped"),
+    ((9, 9, 9), (28, 30, 34), 11, 2, (2, 2), "nothin_cc"),
+    ((9, 9, 9), (28, 30, 34), 11, 1, (3, 2), "shipped"),
+    ((9, 9, 9), (40, 26, 28), 11, 4, None, "cc"),
+])
+def test_tiles_equal_whole_volume_p7_p9_gpu(ps, shape, cell, n_slabs, yx, flagset):
+    """The tile grids BASELINE configs [2]/[3] run on (9^3: 64-bit row ids, two-chunk planes),
+    forced on volumes small enough to assemble untiled as well: same pair rows, same affinity
+    bits, same instance map -- with the kernels-only, the connected-components and the shipped
+    (thinning + mutex watershed) flag sets."""
+    from patchperpix_amd import flags as flagsets
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    c = synth.make_case(shape, ps, seed=71, cell=[cell] * 3, overlap_frac=0.02)
+    kw = dict(flagsets.FLAG_SETS[flagset])
+    extra = dict(_yx_tiles=yx) if yx else {}
+    want_p, want_a = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(),
+                                        c["foreground"].copy(), c["numinst"].copy(), list(ps),
+                                        **dict(kw, return_intermediates=True, _n_slabs=1))
+    got_p, got_a = tiling.to_instance_seg_tiled(c["pred"].copy(), c["foreground"].copy(),
+                                                c["foreground"].copy(), c["numinst"].copy(), list(ps),
+                                                n_slabs, return_intermediates=True, **extra, **kw)
+    assert np.array_equal(got_p, want_p)
+    assert np.array_equal(got_a.view(np.uint32), want_a.view(np.uint32))
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), list(ps), **dict(kw, _n_slabs=1))
+    got, _ = tiling.to_instance_seg_tiled(c["pred"].copy(), c["foreground"].copy(),
+                                          c["foreground"].copy(), c["numinst"].copy(), list(ps),
+                                          n_slabs, **extra, **kw)
+    assert np.array_equal(got, want) and got.any()
+
+
+@pytest.mark.gpu
+def test_tiles_vs_oracle_p7_gpu():
+    """Tiled 7^3 assembly against the CPU oracle's whole-volume result (shipped flags)."""
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd.flags import FLYLIGHT as SHIPPED
+    shape, ps = (20, 22, 24), (7, 7, 7)
+    c = synth.make_case(shape, ps, seed=72, cell=[9, 9, 9], overlap_frac=0.02)
+    kw = dict(SHIPPED)
+    ref = orc.to_instance_seg(c["pred"], c["foreground"], c["foreground"].copy(), c["numinst"],
+                              list(ps), **kw)
+    got, _ = tiling.to_instance_seg_tiled(c["pred"].copy(), c["foreground"].copy(),
+                                          c["foreground"].copy(), c["numinst"].copy(), list(ps),
+                                          2, _yx_tiles=(2, 2), **kw)
+    assert np.array_equal(got, ref["instances"]) and got.any()
+
+
+def test_tiled_path_refuses_flags_it_does_not_honour():
+    """the tiled dispatch must not silently drop flags."""
+    import torch
+    c, ps, kw = make_case()
+    for flag in ("skipRanking", "termAfterThinCover", "one_instance_per_channel"):
+        with pytest.raises(NotImplementedError):
+            tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                            c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                            tiling.plan_slabs(c["pred"].shape[1], 2), ops=object(),
+                            **dict(kw, **{flag: True}))
+
+
 GPU_WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {repo!r})
 from patchperpix_amd import synth, tiling, backend
-from patchperpix_amd.flags import FLYLIGHT
+from patchperpix_amd import flags as flagsets
+FLYLIGHT = flagsets.FLAG_SETS[os.environ.get("PPP_TEST_FLAGSET", "nothin_cc")]
 torch.cuda.set_device(0)                      # every rank on the one GPU of the box
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -219,13 +306,18 @@ dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,empty_top", [(2, False), (3, False), (2, True)])
-def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top):
+@pytest.mark.parametrize("world,empty_top,ps,flagset", [
+    (2, False, (5, 5, 5), "nothin_cc"), (3, False, (5, 5, 5), "nothin_cc"),
+    (2, True, (5, 5, 5), "nothin_cc"), (2, False, (7, 7, 7), "shipped"),
+    (3, False, (7, 7, 7), "cc")])
+def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps, flagset):
     """The multi-rank path with the REAL kernels: `world` processes on the one GPU of the box,
     gloo as the transport (RCCL needs one device per rank): sharded cover with z-halo exchange,
     per-rank pair rows, merged label forests -- same instance map as one process."""
     from patchperpix_amd.vote_instances import vote_instances as vi
-    shape, ps = (72, 26, 30), (5, 5, 5)
+    from patchperpix_amd import flags as flagsets
+    FLYLIGHT = flagsets.FLAG_SETS[flagset]
+    shape = (72, 26, 30)
     c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
     if empty_top:
         c["pred"][:, 36:] = 0.05
@@ -236,7 +328,7 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top):
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", OMP_NUM_THREADS="1",
-               PPP_TEST_EMPTY_TOP="1" if empty_top else "0")
+               PPP_TEST_EMPTY_TOP="1" if empty_top else "0", PPP_TEST_FLAGSET=flagset)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                            "--master-port", "29593", str(script)], env=env, timeout=900)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import bench
 from patchperpix_amd import backend
-from patchperpix_amd.flags import FLYLIGHT
+from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
 from patchperpix_amd.vote_instances import foreground_cover as fc
 shape, ps, cell = bench.WORKLOADS["flylight140_p7"]
 kw = dict(FLYLIGHT)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from patchperpix_amd import backend
-from patchperpix_amd.flags import FLYLIGHT
+from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
 from patchperpix_amd.vote_instances import vote_instances as vi
 a = sys.argv[1:]
 shape = tuple(int(v) for v in a[0:3]); p = int(a[3]); ps = (p, p, p)

@@ -11,7 +11,7 @@ import torch
 
 import bench
 from patchperpix_amd import backend
-from patchperpix_amd.flags import FLYLIGHT
+from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
 
 name = sys.argv[1] if len(sys.argv) > 1 else "flylight140_p7"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2

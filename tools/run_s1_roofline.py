@@ -20,7 +20,7 @@ import torch
 
 import bench
 from patchperpix_amd import backend
-from patchperpix_amd.flags import FLYLIGHT
+from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
 
 a = sys.argv[1:]
 shape = tuple(int(v) for v in a[0:3]) if len(a) >= 3 else (512, 512, 512)
