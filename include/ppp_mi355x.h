@@ -254,6 +254,25 @@ int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin
                    int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
                    const ppp_params *p, void *stream, int32_t *rounds);
 
+/* --- S4: set-cover thinning on the device -------------------------------------------------
+ * replaces thinOutForegroundCover (foreground_cover.py:183-256, sample == 1.0; a host loop in the
+ * reference): while the interior of the running mask is not empty, keep the first patch that
+ * covers the most still uncovered voxels and clear them.  Exact priority-parallel form of that
+ * loop (csrc/ppp_cover.hip): rounds of count / 3-d neighbourhood minimum of the key
+ * (count descending, index ascending) / keep-and-clear, then the stop rule from the kept
+ * patches' keys and cleared-interior counts.
+ *   d_mask  u8  [Z][Y][X]        mask_to_cover (not modified)
+ *   d_bits  u32 [n][ceil(C/32)]  ppp_patch_bits(fc_threshold) of the selected patches, in the
+ *                                order of the selected list (= rank order)
+ *   d_lin   i64 [n]              linear centre index of selected patch k
+ *   d_keep  u8  [n]              out: 1 = kept
+ *   d_work  ppp_thin_workspace_bytes(n, p) bytes
+ * *rounds (may be NULL): number of parallel rounds.  Synchronises the stream.               */
+int64_t ppp_thin_workspace_bytes(int64_t n, const ppp_params *p);
+int ppp_thin_cover(const uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
+                   uint8_t *d_keep, void *d_work, const ppp_params *p, void *stream,
+                   int32_t *rounds);
+
 /* The same rounds one step at a time, for a cover SHARDED over ranks by z (every rank: its
  * own slices + a halo of p-1 slices, local coordinates, origin_z = first global slice).
  *   ppp_cover_open    d_lin int64[n]: LOCAL linear index of the rank's own ranked patches (rank

@@ -132,6 +132,11 @@ _SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_thin_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.POINTER(Params)]),
+    "ppp_thin_cover": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.POINTER(Params), ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_int32)]),
     "ppp_cover_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
@@ -705,6 +710,27 @@ def cover_pass_device(mask, bits, lin, state, pix_th, P):
                                    _dev_ptr(state), _dev_ptr(cleared), _dev_ptr(work),
                                    ctypes.byref(P), _stream(), ctypes.byref(rounds)))
     return cleared, int(rounds.value)
+
+
+def thin_cover_device(mask, bits, lin, P):
+    """Set-cover thinning on the device (ppp_thin_cover; foreground_cover.py:183-256).
+    mask uint8 (Z,Y,X) device tensor = mask_to_cover (not modified), bits int32 [n, words] /
+    lin int64 [n]: the selected patches in list order.  Returns keep, bool [n] device tensor."""
+    torch = _torch()
+    n = int(lin.numel())
+    keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=mask.device)
+    if n == 0:
+        return keep[:0].bool()
+    nbytes = int(lib().ppp_thin_workspace_bytes(n, ctypes.byref(P)))
+    check(min(nbytes, 0))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=mask.device)
+    rounds = ctypes.c_int32(0)
+    with _timed("thin_cover"):
+        check(lib().ppp_thin_cover(_dev_ptr(mask), _dev_ptr(bits.contiguous()), _dev_ptr(lin.contiguous()),
+                                   n, _dev_ptr(keep), _dev_ptr(work), ctypes.byref(P), _stream(),
+                                   ctypes.byref(rounds)))
+    note("thin_rounds", rounds.value)
+    return keep[:n].bool()
 
 
 class CoverShard:

@@ -476,6 +476,31 @@ int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_pass");
 }
 
+int64_t ppp_thin_workspace_bytes(int64_t n, const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return (int64_t)ppp::thin_workspace_bytes(n < 0 ? 0 : n, G);
+}
+
+int ppp_thin_cover(const uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
+                   uint8_t *d_keep, void *d_work, const ppp_params *p, void *stream,
+                   int32_t *rounds) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (rounds) *rounds = 0;
+    if (n <= 0) return PPP_OK;
+    if (n > 0x7F000000LL) return fail(PPP_ERR_INVALID_ARG, "too many selected patches for ppp_thin_cover");
+    if (G.px > 32) return fail(PPP_ERR_UNSUPPORTED, "ppp_thin_cover needs patch rows of at most 32 voxels");
+    if (!d_mask || !d_bits || !d_lin || !d_keep || !d_work)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    int r = 0;
+    hipError_t e = ppp::run_thin_cover(d_mask, d_bits, (const long long *)d_lin, n, d_keep, d_work, G,
+                                       (hipStream_t)stream, &r);
+    if (rounds) *rounds = r;
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_thin_cover");
+}
+
 /* ---- sharded cover: the rounds of ppp_cover_pass one step at a time on a rank's z-range ---- */
 static int cover_geo(const ppp_params *p, ppp::Geo *G) {
     PPP_TRY(make_geo(p, G));

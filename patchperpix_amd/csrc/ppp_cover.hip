@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "ppp_kernels.hpp"
@@ -153,14 +154,20 @@ __global__ void __launch_bounds__(256)
     if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
 }
 
+// "no patch here" of a filter volume: the largest value of the element type's byte pattern 0x7F..
+template <typename T> struct FilterNone;
+template <> struct FilterNone<int32_t> { static constexpr int32_t value = 0x7F7F7F7F; };
+template <> struct FilterNone<long long> { static constexpr long long value = 0x7F7F7F7F7F7F7F7Fll; };
+
 // 1-d running minimum of width 2*radius+1 along one axis (stride in elements, n along axis)
+template <typename T>
 __global__ void __launch_bounds__(256)
-    cover_minfilter_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+    cover_minfilter_kernel(const T *__restrict__ in, T *__restrict__ out,
                            const long long V, const int n, const long long stride, const int radius) {
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (v >= V) return;
     const int pos = (int)((v / stride) % n);
-    int32_t m = RANK_NONE;
+    T m = FilterNone<T>::value;
     for (int d = -radius; d <= radius; ++d) {
         const int q = pos + d;
         if (q >= 0 && q < n) m = min(m, in[v + (long long)d * stride]);
@@ -172,13 +179,16 @@ __global__ void __launch_bounds__(256)
 // z-slice, stages them with their (ry, rx) apron in LDS, takes the minimum along x into a second
 // LDS array and then along y (one launch and one volume round trip less per round).
 static constexpr int MF_TY = 8, MF_TX = 64;
+template <typename T>
 __global__ void __launch_bounds__(256)
-    cover_minfilter_xy_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, const Geo G,
+    cover_minfilter_xy_kernel(const T *__restrict__ in, T *__restrict__ out, const Geo G,
                               const int rx, const int ry) {
-    extern __shared__ int32_t mf_lds[];
+    extern __shared__ long long mf_lds_raw[];
+    const T RANK_NONE = FilterNone<T>::value;
+    T *mf_lds = reinterpret_cast<T *>(mf_lds_raw);
     const int W = MF_TX + 2 * rx, H = MF_TY + 2 * ry;
-    int32_t *a = mf_lds;            // [H][W]   input tile with apron
-    int32_t *b = mf_lds + H * W;    // [H][MF_TX] minimum along x
+    T *a = mf_lds;            // [H][W]   input tile with apron
+    T *b = mf_lds + H * W;    // [H][MF_TX] minimum along x
     const int x0 = blockIdx.x * MF_TX, y0 = blockIdx.y * MF_TY, z = blockIdx.z;
     const long long zbase = (long long)z * G.Y * G.X;
     for (int i = threadIdx.x; i < H * W; i += 256) {
@@ -188,7 +198,7 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     for (int i = threadIdx.x; i < H * MF_TX; i += 256) {
         const int r = i / MF_TX, c = i % MF_TX;
-        int32_t m = RANK_NONE;
+        T m = RANK_NONE;
         for (int d = 0; d <= 2 * rx; ++d) m = min(m, a[r * W + c + d]);
         b[i] = m;
     }
@@ -197,25 +207,26 @@ __global__ void __launch_bounds__(256)
         const int r = i / MF_TX, c = i % MF_TX;
         const int yy = y0 + r, xx = x0 + c;
         if (yy >= G.Y || xx >= G.X) continue;
-        int32_t m = RANK_NONE;
+        T m = RANK_NONE;
         for (int d = 0; d <= 2 * ry; ++d) m = min(m, b[(r + d) * MF_TX + c]);
         out[zbase + (long long)yy * G.X + xx] = m;
     }
 }
 
 // the three passes (x+y fused, then z) : in -> tmp -> out
-static void minfilter_3d(const int32_t *in, int32_t *tmp, int32_t *out, const Geo &G, hipStream_t s) {
+template <typename T>
+static void minfilter_3d(const T *in, T *tmp, T *out, const Geo &G, hipStream_t s) {
     const int rx = G.px - 1, ry = G.py - 1;
     const dim3 grid((unsigned)((G.X + MF_TX - 1) / MF_TX), (unsigned)((G.Y + MF_TY - 1) / MF_TY), (unsigned)G.Z);
-    const size_t lds = (size_t)((MF_TY + 2 * ry) * (MF_TX + 2 * rx) + (MF_TY + 2 * ry) * MF_TX) * sizeof(int32_t);
+    const size_t lds = (size_t)((MF_TY + 2 * ry) * (MF_TX + 2 * rx) + (MF_TY + 2 * ry) * MF_TX) * sizeof(T);
     const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
     if (lds <= 48 * 1024 && G.Y <= 65535 * MF_TY && G.Z <= 65535) {
-        cover_minfilter_xy_kernel<<<grid, block, lds, s>>>(in, tmp, G, rx, ry);
+        cover_minfilter_xy_kernel<T><<<grid, block, lds, s>>>(in, tmp, G, rx, ry);
     } else {
-        cover_minfilter_kernel<<<vgrid, block, 0, s>>>(in, out, G.V, G.X, 1, rx);
-        cover_minfilter_kernel<<<vgrid, block, 0, s>>>(out, tmp, G.V, G.Y, G.X, ry);
+        cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(in, out, G.V, G.X, 1, rx);
+        cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(out, tmp, G.V, G.Y, G.X, ry);
     }
-    cover_minfilter_kernel<<<vgrid, block, 0, s>>>(tmp, out, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+    cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(tmp, out, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
 }
 
 // Thread per voxel: the best ranked undecided patch of its neighbourhood selects itself; its
@@ -323,7 +334,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
             cover_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
                                                        W.counters + r, nullptr, G);
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
-            minfilter_3d(W.rank_vol, W.tmp, W.nbr_min, G, s);
+            minfilter_3d<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
                                                         W.dirty, nullptr, G.Z + G.oz, G);
         }
@@ -344,6 +355,267 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
     }
     cover_unpack_kernel<<<vgrid, block, 0, s>>>(W.mbits, mask, G);
     return hipGetLastError();
+}
+
+// ---- S4: set-cover thinning of the selected patches, on the device --------------------------
+//
+// Reference: foreground_cover.py:183-256 (thinOutForegroundCover, sample == 1.0).  Its loop picks,
+// while the interior of the running mask is not empty, the FIRST patch with the largest number
+// of still uncovered voxels (np.argmax over len(set_i), sets = window & (pred > fc_threshold) &
+// running mask), keeps it and clears its voxels.  That is a greedy cover with the DYNAMIC
+// priority key_i = (count_i descending, index_i ascending).
+//
+// Priority-parallel form (exact).  Counts only shrink, so the best key of the sequential loop
+// never improves over time.  A patch whose key beats the key of every undecided patch within
+// p-1 of it (the only patches whose windows intersect its own) can not be overtaken: none of
+// them can become the global best while it is undecided with an unchanged count, and its count
+// only changes when one of them is kept.  So it is kept by the sequential loop with exactly its
+// current count, and all such local winners of a round may be kept at once (they never overlap:
+// keys are distinct).  The sequential ORDER of the kept patches is the order of their keys at
+// the time they were kept (strictly worsening along the loop), so the loop's stop rule ("interior
+// empty", tested before every pick) is applied afterwards: sort the kept patches by (count
+// descending, index ascending), cut after the one at which the cumulative number of cleared
+// interior voxels reaches the initial interior count.  A patch with count 0 is never a winner;
+// when every count is 0 but the interior is not empty the reference's argmax returns patch 0 and
+// its empty index tuple zeroes the whole mask (:210-216), which ends the loop: keep[0] = 1.
+//
+// Kernels: same volume sweeps as the cover above; the rank volume becomes a 64-bit key volume
+//   key = (THIN_MAXC - count) << 32 | index       (smaller is better; NONE = 0x7F7F..)
+// and the ready test is "my key is the minimum of my (p-1)-neighbourhood".
+static constexpr long long THIN_NONE = FilterNone<long long>::value;
+static constexpr long long THIN_MAXC = 1ll << 20;
+
+struct ThinWork {
+    long long *key_vol, *nbr_min, *tmp;  // [V] each
+    uint8_t *dirty;                      // [V]
+    uint32_t *mbits;                     // [Z*Y][XW]
+    int32_t *counters;                   // [COVER_BATCH]
+    unsigned long long *interior;        // [1] set interior voxels of the mask
+    int32_t *state, *sel_count, *cleared;  // [n] each
+};
+
+size_t thin_workspace_bytes(long long n, const Geo &G) {
+    return 3 * up256((size_t)G.V * 8) + up256((size_t)G.V) +
+           up256((size_t)G.Z * G.Y * row_words(G) * 4) + 256 + 256 + 3 * up256((size_t)(n > 0 ? n : 1) * 4);
+}
+
+static ThinWork carve_thin(void *work, long long n, const Geo &G) {
+    ThinWork W;
+    char *p = (char *)work;
+    W.key_vol = (long long *)p; p += up256((size_t)G.V * 8);
+    W.nbr_min = (long long *)p; p += up256((size_t)G.V * 8);
+    W.tmp = (long long *)p;     p += up256((size_t)G.V * 8);
+    W.dirty = (uint8_t *)p;     p += up256((size_t)G.V);
+    W.mbits = (uint32_t *)p;    p += up256((size_t)G.Z * G.Y * row_words(G) * 4);
+    W.counters = (int32_t *)p;  p += 256;
+    W.interior = (unsigned long long *)p; p += 256;
+    const size_t per = up256((size_t)(n > 0 ? n : 1) * 4);
+    W.state = (int32_t *)p;     p += per;
+    W.sel_count = (int32_t *)p; p += per;
+    W.cleared = (int32_t *)p;
+    return W;
+}
+
+__global__ void __launch_bounds__(256)
+    thin_init_kernel(const long long *__restrict__ lin, int n, long long *__restrict__ key_vol) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) key_vol[lin[k]] = (THIN_MAXC << 32) | (long long)k;   // count not known yet
+}
+
+// set voxels of the bit mask that are interior voxels of the volume (thread per mask word)
+__global__ void __launch_bounds__(256)
+    thin_interior_kernel(const uint32_t *__restrict__ mbits, unsigned long long *__restrict__ total,
+                         const Geo G) {
+    const int XW = row_words(G);
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    int c = 0;
+    if (t < (long long)G.Z * G.Y * XW) {
+        const int w = (int)(t % XW);
+        const long long row = t / XW;
+        const int y = (int)(row % G.Y), z = (int)(row / G.Y);
+        if (z >= G.rz && z < G.Z - G.rz && y >= G.ry && y < G.Y - G.ry) {
+            const int lo = max(G.rx - w * 32, 0), hi = min(G.X - G.rx - w * 32, 32);   // bits [lo, hi)
+            if (lo < hi) {
+                const uint32_t m = (hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+                c = __popc(mbits[t] & m);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int sum = part[0] + part[1] + part[2] + part[3];
+        if (sum) atomicAdd(total, (unsigned long long)sum);
+    }
+}
+
+// Thread per voxel: an undecided patch centred here whose neighbourhood changed is recounted in
+// full; a patch that covers nothing any more is retired.
+__global__ void __launch_bounds__(256)
+    thin_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
+                      uint8_t *__restrict__ dirty, int32_t *__restrict__ state,
+                      long long *__restrict__ key_vol, int32_t *__restrict__ n_alive, const Geo G) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const bool in = v < G.V;
+    const long long key = in ? key_vol[v] : THIN_NONE;
+    bool alive = key != THIN_NONE;
+    const bool marked = in && dirty[v] != 0;
+    if (marked) dirty[v] = 0;
+    if (alive && marked) {
+        const int k = (int)(key & 0xFFFFFFFFll);
+        const int words = (G.C + 31) / 32, XW = row_words(G);
+        int cz, cy, cx;
+        centre_of(G, v, cz, cy, cx);
+        const uint32_t *b = bits + (long long)k * words;
+        const int start = cx - G.rx, wi = start >> 5, sh = start & 31;
+        const bool two = sh + G.px > 32;
+        const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
+        unsigned long long win = b[0] | ((unsigned long long)(words > 1 ? b[1] : 0u) << 32);
+        int have = 64, next = 2, hits = 0;
+        for (int dz = 0; dz < G.pz; ++dz) {
+            const uint32_t *row = mbits + ((long long)(cz + dz - G.rz) * G.Y + (cy - G.ry)) * XW + wi;
+            for (int dy = 0; dy < G.py; ++dy, row += XW) {
+                unsigned long long mw = row[0];
+                if (two) mw |= (unsigned long long)row[1] << 32;
+                hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                win >>= G.px;
+                have -= G.px;
+                if (have <= 32) {
+                    win |= (unsigned long long)(next < words ? b[next] : 0u) << have;
+                    ++next;
+                    have += 32;
+                }
+            }
+        }
+        if (hits == 0) {
+            alive = false;
+            state[k] = 2;
+            key_vol[v] = THIN_NONE;
+        } else {
+            key_vol[v] = ((THIN_MAXC - (long long)hits) << 32) | (long long)k;
+        }
+    }
+    if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+}
+
+// Thread per voxel: the patch with the best key of its neighbourhood keeps itself; its wave
+// clears the voxels and marks the centres whose counts may have changed.
+__global__ void __launch_bounds__(256)
+    thin_select_kernel(uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
+                       const long long *__restrict__ nbr_min, int32_t *__restrict__ state,
+                       long long *__restrict__ key_vol, int32_t *__restrict__ sel_count,
+                       int32_t *__restrict__ cleared_interior, uint8_t *__restrict__ dirty,
+                       const Geo G) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long key = v < G.V ? key_vol[v] : THIN_NONE;
+    const bool ready = key != THIN_NONE && nbr_min[v] == key;
+    unsigned long long todo = __ballot(ready);
+    const int words = (G.C + 31) / 32, XW = row_words(G);
+    const int k = (int)(key & 0xFFFFFFFFll);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int kk = __shfl(k, src);
+        const long long cc = v - lane + src;
+        int cz, cy, cx;
+        centre_of(G, cc, cz, cy, cx);
+        const uint32_t *b = bits + (long long)kk * words;
+        const int start = cx - G.rx, sh = start & 31;
+        uint32_t xin = 0;
+        for (int i = 0; i < G.px; ++i)
+            if (start + i >= G.rx && start + i < G.X - G.rx) xin |= 1u << i;
+        int cleared = 0;
+        for (int r = lane; r < G.pz * G.py; r += 64) {
+            const int z = cz + r / G.py - G.rz, y = cy + r % G.py - G.ry;
+            uint32_t *row = mbits + ((long long)z * G.Y + y) * XW;
+            const uint32_t cl = bit_window(row, start, G.px, XW) & bit_window(b, r * G.px, G.px, words);
+            if (cl) {
+                atomicAnd(row + (start >> 5), ~(cl << sh));
+                if (sh && (cl >> (32 - sh))) atomicAnd(row + (start >> 5) + 1, ~(cl >> (32 - sh)));
+                if (z >= G.rz && z < G.Z - G.rz && y >= G.ry && y < G.Y - G.ry)
+                    cleared += __popc(cl & xin);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) cleared += __shfl_xor(cleared, o);
+        const int z0 = max(cz - (G.pz - 1), 0), z1 = min(cz + G.pz - 1, G.Z - 1);
+        const int y0 = max(cy - (G.py - 1), 0), y1 = min(cy + G.py - 1, G.Y - 1);
+        const int x0 = max(cx - (G.px - 1), 0), x1 = min(cx + G.px - 1, G.X - 1);
+        const int ny = y1 - y0 + 1, nx = x1 - x0 + 1;
+        const int rows = (z1 - z0 + 1) * ny;
+        for (int row = lane; row < rows; row += 64) {
+            uint8_t *d = dirty + vox(G, z0 + row / ny, y0 + row % ny, x0);
+            for (int x = 0; x < nx; ++x) d[x] = 1;
+        }
+        if (lane == src) {
+            state[kk] = 1;
+            key_vol[cc] = THIN_NONE;
+            sel_count[kk] = (int32_t)(THIN_MAXC - (key >> 32));
+            cleared_interior[kk] = cleared;
+        }
+    }
+}
+
+// keep u8 [n] (device).  Synchronises the stream.
+hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
+                          uint8_t *keep, void *work, const Geo &G, hipStream_t s, int *rounds) {
+    *rounds = 0;
+    if (n <= 0) return hipSuccess;
+    if (n >= (1ll << 31) || G.C >= THIN_MAXC) return hipErrorInvalidValue;
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
+    ThinWork W = carve_thin(work, n, G);
+    hipError_t e;
+    if ((e = hipMemsetD32Async((hipDeviceptr_t)W.key_vol, 0x7F7F7F7F, (size_t)G.V * 2, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.state, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.sel_count, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.interior, 0, 8, s)) != hipSuccess) return e;
+    const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
+    const long long n_words = (long long)G.Z * G.Y * row_words(G);
+    cover_pack_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(mask, W.mbits, G);
+    thin_interior_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(W.mbits, W.interior, G);
+    thin_init_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(lin, (int)n, W.key_vol);
+    int32_t n_alive = 1;
+    while (n_alive > 0) {
+        if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
+        for (int r = 0; r < COVER_BATCH; ++r) {
+            thin_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, W.state, W.key_vol,
+                                                      W.counters + r, G);
+            minfilter_3d<long long>(W.key_vol, W.tmp, W.nbr_min, G, s);
+            thin_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, W.state, W.key_vol,
+                                                       W.sel_count, W.cleared, W.dirty, G);
+        }
+        *rounds += COVER_BATCH;
+        if ((e = hipMemcpyAsync(&n_alive, W.counters + COVER_BATCH - 1, 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
+            return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    // ---- the stop rule: kept patches in the order the sequential loop picks them
+    std::vector<int32_t> st((size_t)n), cnt((size_t)n), clr((size_t)n);
+    unsigned long long interior = 0;
+    if ((e = hipMemcpyAsync(st.data(), W.state, (size_t)n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(cnt.data(), W.sel_count, (size_t)n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(clr.data(), W.cleared, (size_t)n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(&interior, W.interior, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    std::vector<long long> order;
+    for (long long i = 0; i < n; ++i)
+        if (st[(size_t)i] == 1) order.push_back(((THIN_MAXC - (long long)cnt[(size_t)i]) << 32) | i);
+    std::sort(order.begin(), order.end());
+    std::vector<uint8_t> k8((size_t)n, 0);
+    long long remaining = (long long)interior;
+    for (size_t j = 0; j < order.size() && remaining > 0; ++j) {
+        const long long i = order[j] & 0xFFFFFFFFll;
+        k8[(size_t)i] = 1;
+        remaining -= clr[(size_t)i];
+    }
+    if (remaining > 0) k8[0] = 1;   // every count is 0 with voxels left: np.argmax picks patch 0
+    if ((e = hipMemcpyAsync(keep, k8.data(), (size_t)n, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    return hipStreamSynchronize(s);
 }
 
 // ---- the same rounds, one step at a time, on the z-range of one rank (sharded cover) -------
@@ -399,7 +671,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
 
 hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s) {
     CoverWork W = carve(work, G);
-    minfilter_3d(W.rank_vol, W.tmp, W.nbr_min, G, s);
+    minfilter_3d<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
     return hipGetLastError();
 }
 

@@ -68,6 +68,10 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
                           int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
                           hipStream_t s, int *rounds);
 
+size_t thin_workspace_bytes(long long n, const Geo &G);
+hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
+                          uint8_t *keep, void *work, const Geo &G, hipStream_t s, int *rounds);
+
 hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *rankid, long long n,
                       const int32_t *state, int32_t *cleared, void *work, const Geo &G, hipStream_t s);
 hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, void *work,

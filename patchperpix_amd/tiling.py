@@ -185,6 +185,11 @@ class DeviceOps:
         sel, _ = fc.greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P)
         return sel
 
+    def thin_cover(self, mask_to_cover, bits, lin, P):
+        mask = self.torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
+                                     .astype(np.uint8)).to(self.device)
+        return backend.thin_cover_device(mask, bits, lin, P)
+
     def label_components(self, rows, aff, nodes, P):
         return backend.label_components(rows, aff, nodes, P)
 
@@ -492,13 +497,23 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 if os.environ.get("PPP_STOP_AFTER_COVER") == "1":
                     return early()
     if not kw.get("skipThinCover") and len(sel_coords) > 0:
+        if kw.get("sample", 1.0) < 1.0:
+            raise NotImplementedError("sample < 1 uses unseeded random sampling in the reference")
         with backend.host_timer("s4_thin"):
-            bits = gathered_bits(torch.from_numpy(np.ascontiguousarray(sel_coords)).to(dev),
-                                 kw["fc_threshold"]).cpu().numpy().view(np.uint32)
+            sel_t = torch.from_numpy(np.ascontiguousarray(sel_coords)).to(dev)
+            bits = gathered_bits(sel_t, kw["fc_threshold"])
             sel_lin = (sel_coords[:, 0].astype(np.int64) * Y + sel_coords[:, 1]) * X + sel_coords[:, 2]
-            keep = backend.host_thin_cover(np.ascontiguousarray(mask_to_cover).astype(np.uint8),
-                                           ps, np.ascontiguousarray(sel_lin), bits)
+            if hasattr(ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
+                    and ps[2] <= 32:
+                # replicated: every rank thins the same global list on its own device
+                keep = ops.thin_cover(mask_to_cover, bits, torch.from_numpy(sel_lin).to(dev), Pg)
+                keep = keep.cpu().numpy()
+            else:
+                keep = backend.host_thin_cover(np.ascontiguousarray(mask_to_cover).astype(np.uint8),
+                                               ps, np.ascontiguousarray(sel_lin),
+                                               bits.cpu().numpy().view(np.uint32))
             sel_coords = sel_coords[keep]
+            del bits, sel_t
     del lin_t, rscores_t, coords_t
 
     # ---- pairs (global coordinates; replicated, it is cheap) -------------------------------

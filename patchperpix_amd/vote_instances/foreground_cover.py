@@ -162,8 +162,17 @@ def thinOutForegroundCover(mask_to_cover, selected_patches_list, radslice, pred_
     sel = PatchList.from_any(selected_patches_list)
     P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
     mask = np.ascontiguousarray(mask_to_cover).astype(np.uint8)
-    bits = _bits_for(pred_affs, sel.coords, kwargs["fc_threshold"], P)
-    keep = backend.host_thin_cover(mask, patchshape, sel.lin(mask.shape), bits)
+    if os.environ.get("PPP_THIN", "device") != "host" and int(patchshape[2]) <= 32:
+        import torch
+        dev = pred_affs.device
+        c = torch.from_numpy(np.ascontiguousarray(sel.coords, dtype=np.int32)).to(dev)
+        bits_d = backend.patch_bits(pred_affs, c, kwargs["fc_threshold"], P)
+        keep = backend.thin_cover_device(torch.from_numpy((mask != 0).astype(np.uint8)).to(dev), bits_d,
+                                         torch.from_numpy(sel.lin(mask.shape)).to(dev), P)
+        keep = keep.cpu().numpy()
+    else:
+        bits = _bits_for(pred_affs, sel.coords, kwargs["fc_threshold"], P)
+        keep = backend.host_thin_cover(mask, patchshape, sel.lin(mask.shape), bits)
     out = sel[np.flatnonzero(keep)]
     logger.info("num_selected: %s", len(out))
     return out, len(out)

@@ -451,3 +451,47 @@ def test_paint_more_nodes_than_one_launch_holds():
     backend.paint_instances(pred, nodes[per:].contiguous(), labels[per:].contiguous(), two, P)
     assert torch.equal(one, two)
     assert int(one.max().item()) > 60000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,ps,cell", [((40, 44, 48), (5, 5, 5), 9), ((36, 40, 44), (7, 7, 7), 12),
+                                           ((1, 90, 100), (1, 9, 9), 14)])
+def test_device_thinning_equals_host_loop(shape, ps, cell):
+    """ppp_thin_cover (priority-parallel rounds on the device) keeps exactly the patches the
+    sequential set-cover loop keeps (ppp_host_thin_cover, itself pinned to the reference by the
+    thinning goldens): greedy cover first, then both thinnings of the same selected list --
+    once on the full mask and once on a mask with holes the patches cannot cover."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from patchperpix_amd.vote_instances import foreground_cover as fc
+    from tests_flags import FLYLIGHT
+    c = synth.make_case(shape, ps, seed=81, cell=[min(cell, s) for s in shape], overlap_frac=0.02)
+    kw = dict(FLYLIGHT)
+    P = backend.make_params(shape, ps, **kw)
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    cons = backend.consensus(pred, ov, P)
+    score = backend.rank_patches(pred, cons, ov, P)
+    lin, sc = backend.rank_order_device(score, c["foreground"], ps, to_host=False)
+    Y, X = shape[1], shape[2]
+    coords = torch.stack([lin // (Y * X), (lin // X) % Y, lin % X], 1).to(torch.int32)
+    bits = backend.patch_bits(pred, coords, kw["fc_threshold"], P)
+    mask0 = c["foreground"].copy()
+    mask0[c["numinst"] > 1] = False
+    rad = [p // 2 for p in ps]
+    radslice = tuple(slice(r, s - r) for r, s in zip(rad, shape))
+    mask_d = torch.from_numpy(mask0.astype(np.uint8)).cuda()
+    never = torch.zeros(lin.shape, dtype=torch.bool, device="cuda")
+    sel, _ = fc.greedy_cover_device(mask_d.clone(), bits, lin, never, [0], radslice, P)
+    assert int(sel.sum()) > 30
+    sel_lin, sel_bits = lin[sel].contiguous(), bits[sel].contiguous()
+    for variant in ("full", "holes"):
+        mask = mask0.copy()
+        if variant == "holes":          # voxels no selected patch reaches: the loop's degenerate end
+            mask[radslice][::7, ::5, ::3] = True
+        want = backend.host_thin_cover(mask.astype(np.uint8), ps, sel_lin.cpu().numpy(),
+                                       sel_bits.cpu().numpy().view(np.uint32))
+        got = backend.thin_cover_device(torch.from_numpy(mask.astype(np.uint8)).cuda(), sel_bits,
+                                        sel_lin, P).cpu().numpy()
+        assert np.array_equal(got, want), variant
+        assert 0 < want.sum() <= len(want)
