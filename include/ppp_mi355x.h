@@ -372,6 +372,33 @@ int64_t ppp_host_patch_pairs(const int32_t *sel_zyx, int64_t n, const int32_t *p
 int64_t ppp_host_mws(const uint32_t *pairs, const float *aff, int64_t n_rows, const int32_t *vol,
                      int32_t *out_nodes, int32_t *out_labels, int64_t cap, int64_t *n_labels);
 
+/* ppp_host_mws_sorted: the loop of graph_mws.mws (:31-77) over an edge list that is already in
+ *   the order the reference visits it (ppp_mws_edges makes it on the device): eu / ev int32
+ *   [n_edges] node numbers, bit 31 of ev = attractive.  labels int32 [n_nodes] out (1 + position
+ *   of the node's component in the reference's output list, 0 = none).  Returns the number of
+ *   ids issued (emptied components included).                                               */
+int64_t ppp_host_mws_sorted(const int32_t *eu, const int32_t *ev, int64_t n_edges, int64_t n_nodes,
+                            int32_t *labels);
+
+/* --- order-defining stages as device sorts (rocPRIM inside the library) ------------------
+ * ppp_rank_order: all_patches + rank_patches_by_score (vote_instances.py:276,286-287,
+ *   ranked_patches.py:21-30): the interior voxels with d_foreground != 0 in raster order, stably
+ *   sorted by score descending.  d_lin int64 [capacity >= count], d_rank_score f32 (may be NULL);
+ *   *count out.  Synchronises the stream.  Workspace: ppp_rank_order_workspace_bytes(p).
+ * ppp_mws_edges: the edge list of the mutex watershed (setAffgraph + graph_mws.py:17-26): rows
+ *   with aff != 0, in networkx's edge order (first appearance of the earlier endpoint, then row),
+ *   stably sorted by |aff| descending.  Node numbers are positions in d_nodes u32 [n_nodes][3];
+ *   d_eu / d_ev int32 [n_rows] out, bit 31 of d_ev = attractive (aff > 0); *n_edges out.  The
+ *   rows must not repeat a node pair (the library's own pair lists never do).  Synchronises.  */
+int64_t ppp_rank_order_workspace_bytes(const ppp_params *p);
+int ppp_rank_order(const float *d_score, const uint8_t *d_foreground, int64_t *d_lin,
+                   float *d_rank_score, int64_t *count, void *d_work, const ppp_params *p,
+                   void *stream);
+int64_t ppp_mws_edges_workspace_bytes(int64_t n_rows, int64_t n_nodes, const ppp_params *p);
+int ppp_mws_edges(const uint32_t *d_pairs, const float *d_aff, int64_t n_rows, const uint32_t *d_nodes,
+                  int64_t n_nodes, int32_t *d_eu, int32_t *d_ev, int64_t *n_edges, void *d_work,
+                  const ppp_params *p, void *stream);
+
 /* --- synthetic input (bench / tests only; same hash as patchperpix_amd/synth.py) ------
  * fills d_pred (C,Z,Y,X) from a label volume d_labels int32 (Z,Y,X).  voxel_offset is the
  * linear index of local voxel 0 in the global volume (0 unless the buffers are a slab).    */

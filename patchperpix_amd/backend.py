@@ -132,6 +132,18 @@ _SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_host_mws_sorted": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_void_p]),
+    "ppp_rank_order_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
+    "ppp_rank_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_mws_edges_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64,
+                                                       ctypes.POINTER(Params)]),
+    "ppp_mws_edges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                     ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_thin_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.POINTER(Params)]),
     "ppp_thin_cover": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -825,6 +837,39 @@ def host_mws(pairs, aff, shape):
     return nodes[:k][keep], labels[:k][keep].astype(np.int64), int(n_labels.value)
 
 
+def mws_labels_device(rows, aff, nodes, P):
+    """Mutex watershed of the patch graph (graph_mws.py:7-85) with everything but the inherently
+    sequential loop on the device: ppp_mws_edges filters the rows with aff != 0, puts them in
+    networkx's edge order and sorts them stably by |aff| (descending); the edge list (8 bytes per
+    edge) crosses to the host once and ppp_host_mws_sorted walks it.
+    rows int32 [N, 6] / aff float32 [N] device tensors without repeated node pairs, nodes int32
+    [K, 3] device.  Returns (labels int32 [K] device tensor, 0 = no component; ids issued)."""
+    torch = _torch()
+    n, k = int(rows.shape[0]), int(nodes.shape[0])
+    labels = np.zeros((k,), dtype=np.int32)
+    if n == 0 or k == 0:
+        return torch.from_numpy(labels).to(nodes.device), 0
+    nbytes = int(lib().ppp_mws_edges_workspace_bytes(n, k, ctypes.byref(P)))
+    check(min(nbytes, 0))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=rows.device)
+    eu = torch.empty((n,), dtype=torch.int32, device=rows.device)
+    ev = torch.empty((n,), dtype=torch.int32, device=rows.device)
+    n_edges = ctypes.c_int64(0)
+    with host_timer("s6a_mws_edges"):
+        with _timed("mws_edges"):
+            check(lib().ppp_mws_edges(_dev_ptr(rows), _dev_ptr(aff), n, _dev_ptr(nodes.contiguous()), k,
+                                      _dev_ptr(eu), _dev_ptr(ev), ctypes.byref(n_edges), _dev_ptr(work),
+                                      ctypes.byref(P), _stream()))
+        ne = int(n_edges.value)
+        eu_h = eu[:ne].cpu().numpy()
+        ev_h = ev[:ne].cpu().numpy()
+    del work, eu, ev
+    with host_timer("s6b_mws_loop"):
+        issued = int(lib().ppp_host_mws_sorted(_np_ptr(eu_h), _np_ptr(ev_h), ne, k, _np_ptr(labels)))
+    note("mws_edges", ne)
+    return torch.from_numpy(labels).to(nodes.device), issued
+
+
 def host_rank_order(score, foreground, patchshape):
     score = np.ascontiguousarray(score, dtype=np.float32)
     fg = np.ascontiguousarray(foreground).astype(np.uint8)
@@ -844,22 +889,38 @@ def padded_mask(mask):
 
 
 def rank_order_device(score, foreground, patchshape, to_host=True):
-    """all_patches + rank_patches_by_score on the device: interior foreground voxels in raster
-    order, stably sorted by score descending (vote_instances.py:276,286-287,
+    """all_patches + rank_patches_by_score on the device (ppp_rank_order): interior foreground
+    voxels in raster order, stably sorted by score descending (vote_instances.py:276,286-287,
     ranked_patches.py:21-30).  score: device float32 (Z,Y,X); foreground: host bool.
     Returns (lin int64, scores float32), NumPy arrays or (to_host=False) device tensors."""
     torch = _torch()
-    r = [int(p) // 2 for p in patchshape]
-    Z, Y, X = score.shape
-    fg = torch.from_numpy(np.ascontiguousarray(np.asarray(foreground) != 0)).to(score.device)
-    m = torch.zeros((Z, Y, X), dtype=torch.bool, device=score.device)
-    m[r[0]:Z - r[0], r[1]:Y - r[1], r[2]:X - r[2]] = fg[r[0]:Z - r[0], r[1]:Y - r[1], r[2]:X - r[2]]
-    idx = torch.nonzero(m.reshape(-1)).reshape(-1)                                    # raster
-    s_sorted, order = torch.sort(score.reshape(-1)[idx], descending=True, stable=True)
-    lin = idx[order]
+    Z, Y, X = [int(v) for v in score.shape]
+    P = Params()
+    P.abi_version = ABI_VERSION
+    P.Z, P.Y, P.X = Z, Y, X
+    P.pz, P.py, P.px = [int(p) for p in patchshape]
+    P.th = P.thi = 0.5
+    P.bg_rule, P.value_rule = BG_LESS_THAN_TH, VAL_COUNT
+    P.cons_box = Box(0, 0, 0, Z, Y, X)
+    fg = torch.from_numpy(np.ascontiguousarray(np.asarray(foreground) != 0).astype(np.uint8)
+                          ).to(score.device).reshape(-1)
+    V = Z * Y * X
+    nbytes = int(lib().ppp_rank_order_workspace_bytes(ctypes.byref(P)))
+    check(min(nbytes, 0))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=score.device)
+    # the ranked list has at most one entry per interior voxel
+    cap = max(1, (Z - 2 * (P.pz // 2)) * (Y - 2 * (P.py // 2)) * (X - 2 * (P.px // 2)))
+    lin = torch.empty((min(cap, V),), dtype=torch.int64, device=score.device)
+    sc = torch.empty((min(cap, V),), dtype=torch.float32, device=score.device)
+    count = ctypes.c_int64(0)
+    with _timed("rank_order"):
+        check(lib().ppp_rank_order(_dev_ptr(score.contiguous()), _dev_ptr(fg), _dev_ptr(lin), _dev_ptr(sc),
+                                   ctypes.byref(count), _dev_ptr(work), ctypes.byref(P), _stream()))
+    n = int(count.value)
+    lin, sc = lin[:n], sc[:n]
     if to_host:
-        return lin.cpu().numpy(), s_sorted.cpu().numpy()
-    return lin, s_sorted
+        return lin.cpu().numpy(), sc.cpu().numpy()
+    return lin, sc
 
 
 def host_cover_pass(mask_running, overlap, patchshape, ranked_lin, ranked_score, bits, pix_th,

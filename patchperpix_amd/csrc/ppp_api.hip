@@ -476,6 +476,53 @@ int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_pass");
 }
 
+int64_t ppp_rank_order_workspace_bytes(const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return (int64_t)ppp::rank_order_workspace_bytes(G);
+}
+
+int ppp_rank_order(const float *d_score, const uint8_t *d_foreground, int64_t *d_lin,
+                   float *d_rank_score, int64_t *count, void *d_work, const ppp_params *p,
+                   void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (!d_score || !d_foreground || !d_lin || !count || !d_work)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    long long n = 0;
+    hipError_t e = ppp::run_rank_order(d_score, d_foreground, (long long *)d_lin, d_rank_score, &n, d_work,
+                                       G, (hipStream_t)stream);
+    *count = n;
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_rank_order");
+}
+
+int64_t ppp_mws_edges_workspace_bytes(int64_t n_rows, int64_t n_nodes, const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return (int64_t)ppp::mws_edges_workspace_bytes(n_rows, n_nodes, G);
+}
+
+int ppp_mws_edges(const uint32_t *d_pairs, const float *d_aff, int64_t n_rows, const uint32_t *d_nodes,
+                  int64_t n_nodes, int32_t *d_eu, int32_t *d_ev, int64_t *n_edges, void *d_work,
+                  const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (!n_edges) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    *n_edges = 0;
+    if (n_rows <= 0) return PPP_OK;
+    if (!d_pairs || !d_aff || !d_nodes || !d_eu || !d_ev || !d_work)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    long long ne = 0;
+    hipError_t e = ppp::run_mws_edges(d_pairs, d_aff, n_rows, d_nodes, n_nodes, d_eu, d_ev, &ne, d_work, G,
+                                      (hipStream_t)stream);
+    *n_edges = ne;
+    if (e == hipErrorInvalidValue)
+        return fail(PPP_ERR_INVALID_ARG, "ppp_mws_edges: too many rows, or a row names a voxel that is not a node");
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_mws_edges");
+}
+
 int64_t ppp_thin_workspace_bytes(int64_t n, const ppp_params *p) {
     ppp::Geo G;
     if (make_geo(p, &G) != PPP_OK) return -1;

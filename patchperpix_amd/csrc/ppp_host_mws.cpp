@@ -43,9 +43,91 @@ struct Dsu {
     }
 };
 
+// The loop of graph_mws.mws (:31-77) over edges that are already in visiting order.
+//   eu / ev [n_edges]: node numbers, bit 31 of ev = attractive; label [n_nodes] out: 1 + position
+//   of the node's component id in creation order, 0 = the node ended in no component.
+// Every node is a union-find element from the start (an unassigned node is a singleton without
+// a component id).  A root carries the list of the far endpoints of the mutex edges incident to
+// its members; "is there a mutex edge between two clusters" walks the shorter list and asks
+// whether an endpoint lives in the other cluster.  Lists are appended small-to-large on a merge
+// (duplicates are harmless).  A mutex edge inside one cluster can never matter again (clusters
+// only grow) and is not recorded.
+void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N, int32_t *label,
+               int64_t *issued) {
+    Dsu dsu;
+    dsu.parent.resize((size_t)N);
+    for (int32_t i = 0; i < N; ++i) dsu.parent[i] = i;
+    std::vector<int32_t> cc_of_root((size_t)N, 0);      // component id carried by a root (0: none)
+    std::vector<std::vector<int32_t>> mlist((size_t)N);
+    std::set<int32_t> in_use;                           // ids currently held by some node
+    std::vector<int32_t> created;                       // ids in creation order (first issue)
+    std::vector<uint8_t> ever;                          // id was issued before (ids are <= N)
+    ever.assign((size_t)N + 2, 0);
+    auto has_mutex = [&](int32_t r0, int32_t r1) {
+        const bool first_small = mlist[r0].size() <= mlist[r1].size();
+        const std::vector<int32_t> &small = first_small ? mlist[r0] : mlist[r1];
+        const int32_t other = first_small ? r1 : r0;
+        for (int32_t x : small)
+            if (dsu.find(x) == other) return true;
+        return false;
+    };
+    // r_drop's members join r_keep (which stays the root); the longer list survives
+    auto unite = [&](int32_t r_keep, int32_t r_drop) {
+        dsu.parent[r_drop] = r_keep;
+        std::vector<int32_t> &a = mlist[r_keep], &b = mlist[r_drop];
+        if (a.size() < b.size()) a.swap(b);
+        a.insert(a.end(), b.begin(), b.end());
+        std::vector<int32_t>().swap(b);
+    };
+    for (int64_t i = 0; i < n_edges; ++i) {
+        const int32_t a = eu[i], b = ev[i] & 0x7FFFFFFF;
+        const int32_t r0 = dsu.find(a), r1 = dsu.find(b);
+        if (ev[i] < 0) {                                  // attractive
+            const int32_t c0 = cc_of_root[r0], c1 = cc_of_root[r1];
+            if (c0 == 0 && c1 == 0) {
+                // both unassigned (:36-42): a new component, id = max id in use + 1
+                const int32_t id = (in_use.empty() ? 0 : *in_use.rbegin()) + 1;
+                if (r0 != r1) unite(r0, r1);
+                cc_of_root[r0] = id;
+                in_use.insert(id);
+                if (!ever[(size_t)id]) { ever[(size_t)id] = 1; created.push_back(id); }
+            } else if (c0 == 0 || c1 == 0) {
+                // the unassigned node joins unless a mutex edge links it to the component (:44-56)
+                const int32_t r_cc = c0 == 0 ? r1 : r0, r_node = c0 == 0 ? r0 : r1;
+                if (!has_mutex(r_cc, r_node)) unite(r_cc, r_node);
+            } else if (c0 != c1) {
+                // two components merge into the smaller id unless a mutex edge links them (:57-71)
+                if (!has_mutex(r0, r1)) {
+                    const int32_t keep = std::min(c0, c1), drop = std::max(c0, c1);
+                    unite(r0, r1);
+                    cc_of_root[r0] = keep;
+                    in_use.erase(drop);
+                }
+            }
+        } else if (r0 != r1) {                            // repulsive (:76-77)
+            mlist[r0].push_back(b);
+            mlist[r1].push_back(a);
+        }
+    }
+    std::vector<int32_t> label_of_id((size_t)N + 2, 0);
+    for (size_t i = 0; i < created.size(); ++i) label_of_id[(size_t)created[i]] = (int32_t)i + 1;
+    for (int32_t n = 0; n < N; ++n) label[n] = label_of_id[(size_t)cc_of_root[dsu.find(n)]];
+    *issued = (int64_t)created.size();
+}
+
 }  // namespace
 
 extern "C" {
+
+// ppp_host_mws_sorted: the watershed over an edge list that is already in visiting order (made
+// on the device by ppp_mws_edges).  labels int32 [n_nodes] out; returns the number of ids issued.
+int64_t ppp_host_mws_sorted(const int32_t *eu, const int32_t *ev, int64_t n_edges, int64_t n_nodes,
+                            int32_t *labels) {
+    int64_t issued = 0;
+    if (n_nodes <= 0) return 0;
+    watershed(eu, ev, n_edges, (int32_t)n_nodes, labels, &issued);
+    return issued;
+}
 
 // pairs u32 [n_rows][6] (A zyx, B zyx), aff f32 [n_rows], vol = volume shape (for node keys).
 // out_nodes int32 [cap][3] / out_labels int32 [cap]: every node of the graph (first-appearance
@@ -148,84 +230,25 @@ int64_t ppp_host_mws(const uint32_t *pairs, const float *aff, int64_t n_rows, co
     std::stable_sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.w > y.w; });
 
     // ---- the watershed ---------------------------------------------------------------------
-    Dsu dsu;
-    dsu.parent.resize((size_t)N);
-    for (int32_t i = 0; i < N; ++i) dsu.parent[i] = i;
-    std::vector<int32_t> cc_of_root((size_t)N, 0);      // component id carried by a root (0: none)
-    std::vector<std::vector<int32_t>> node_mutex((size_t)N);
-    std::unordered_map<int32_t, std::unordered_set<int32_t>> cc_mutex;   // id -> nodes with a mutex edge into it
-    std::unordered_map<int32_t, int32_t> root_of_cc;    // id -> root
-    std::set<int32_t> in_use;                           // ids currently held by some node
-    std::vector<int32_t> created;                       // ids in creation order (first issue)
-    std::unordered_set<int32_t> ever;
-    auto cc = [&](int32_t n) { return cc_of_root[dsu.find(n)]; };
-
-    for (const Edge &e : edges) {
-        if (e.attractive == 1) {
-            const int32_t r0 = dsu.find(e.a), r1 = dsu.find(e.b);
-            const int32_t c0 = cc_of_root[r0], c1 = cc_of_root[r1];
-            if (c0 == 0 && c1 == 0) {
-                const int32_t id = (in_use.empty() ? 0 : *in_use.rbegin()) + 1;
-                if (r0 != r1) dsu.parent[r1] = r0;
-                cc_of_root[r0] = id;
-                root_of_cc[id] = r0;
-                in_use.insert(id);
-                if (ever.insert(id).second) created.push_back(id);
-                auto &m = cc_mutex[id];
-                m.clear();
-                m.insert(node_mutex[e.a].begin(), node_mutex[e.a].end());
-                m.insert(node_mutex[e.b].begin(), node_mutex[e.b].end());
-            } else if (c0 == 0 || c1 == 0) {
-                const int32_t id = std::max(c0, c1);
-                const int32_t ena = c0 == 0 ? e.a : e.b, r_ena = c0 == 0 ? r0 : r1, r_cc = c0 == 0 ? r1 : r0;
-                auto &m = cc_mutex[id];
-                if (m.find(ena) == m.end()) {
-                    dsu.parent[r_ena] = r_cc;
-                    m.insert(node_mutex[ena].begin(), node_mutex[ena].end());
-                }
-            } else if (c0 != c1) {
-                auto &m0 = cc_mutex[c0], &m1 = cc_mutex[c1];
-                const bool first_small = m0.size() <= m1.size();
-                auto &small = first_small ? m0 : m1;
-                const int32_t big_id = first_small ? c1 : c0;
-                bool has_mutex = false;
-                for (int32_t x : small)
-                    if (cc(x) == big_id) { has_mutex = true; break; }
-                if (!has_mutex) {
-                    const int32_t keep = std::min(c0, c1), drop = std::max(c0, c1);
-                    dsu.parent[r1] = r0;
-                    cc_of_root[r0] = keep;
-                    root_of_cc[keep] = r0;
-                    root_of_cc.erase(drop);
-                    in_use.erase(drop);
-                    // union of the two mutex sets under `keep`, moving the smaller one
-                    auto &big = first_small ? m1 : m0;
-                    big.insert(small.begin(), small.end());
-                    if (&big != &cc_mutex[keep]) cc_mutex[keep].swap(big);
-                    cc_mutex[drop].clear();
-                }
-            }
-        } else {
-            node_mutex[e.a].push_back(e.b);
-            node_mutex[e.b].push_back(e.a);
-            const int32_t ca = cc(e.a), cb = cc(e.b);
-            if (ca != 0) cc_mutex[ca].insert(e.b);
-            if (cb != 0) cc_mutex[cb].insert(e.a);
-        }
+    std::vector<int32_t> eu(edges.size()), ev(edges.size());
+    for (size_t i = 0; i < edges.size(); ++i) {
+        eu[i] = edges[i].a;
+        ev[i] = edges[i].b | (edges[i].attractive == 1 ? (int32_t)0x80000000 : 0);
     }
+    std::vector<Edge>().swap(edges);
+    std::vector<int32_t> label((size_t)N);
+    int64_t issued = 0;
+    watershed(eu.data(), ev.data(), (int64_t)eu.size(), N, label.data(), &issued);
 
     // ---- labels ------------------------------------------------------------------------------
-    std::unordered_map<int32_t, int32_t> label_of_id;
-    for (size_t i = 0; i < created.size(); ++i) label_of_id[created[i]] = (int32_t)i + 1;
     for (int32_t n = 0; n < N; ++n) {
         const int64_t k = node_key[n];
         out_nodes[3 * (int64_t)n + 0] = (int32_t)(k / (Y * X));
         out_nodes[3 * (int64_t)n + 1] = (int32_t)((k / X) % Y);
         out_nodes[3 * (int64_t)n + 2] = (int32_t)(k % X);
-        const int32_t id = cc(n);
-        out_labels[n] = id == 0 ? 0 : label_of_id[id];
+        out_labels[n] = label[(size_t)n];
     }
-    if (n_labels) *n_labels = (int64_t)created.size();
+    if (n_labels) *n_labels = issued;
     return N;
 }
 

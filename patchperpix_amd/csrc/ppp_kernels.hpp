@@ -68,6 +68,14 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
                           int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
                           hipStream_t s, int *rounds);
 
+size_t rank_order_workspace_bytes(const Geo &G);
+hipError_t run_rank_order(const float *score, const uint8_t *fg, long long *lin, float *out_score,
+                          long long *n_out, void *work, const Geo &G, hipStream_t s);
+size_t mws_edges_workspace_bytes(long long n_rows, long long n_nodes, const Geo &G);
+hipError_t run_mws_edges(const uint32_t *rows, const float *aff, long long n_rows, const uint32_t *nodes,
+                         long long n_nodes, int32_t *out_u, int32_t *out_v, long long *n_edges, void *work,
+                         const Geo &G, hipStream_t s);
+
 size_t thin_workspace_bytes(long long n, const Geo &G);
 hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
                           uint8_t *keep, void *work, const Geo &G, hipStream_t s, int *rounds);

@@ -190,6 +190,9 @@ class DeviceOps:
                                      .astype(np.uint8)).to(self.device)
         return backend.thin_cover_device(mask, bits, lin, P)
 
+    def mws_labels(self, rows, aff, nodes, P):
+        return backend.mws_labels_device(rows, aff, nodes, P)
+
     def label_components(self, rows, aff, nodes, P):
         return backend.label_components(rows, aff, nodes, P)
 
@@ -632,7 +635,14 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
 
     # ---- stage D: components (replicated) and painting of the own slabs ---------------------
     with backend.host_timer("s6_label_paint"):
-        if kw.get("mws"):
+        if kw.get("mws") and kw.get("selected_patch_pairs") is None and hasattr(ops, "mws_labels"):
+            # the library's own pair list never repeats a node pair: edge order and |aff| sort on
+            # the device, only the sequential loop on the host (replicated on every rank)
+            lab_all, n_labels = ops.mws_labels(rows, aff, nodes_dev, Pg)
+            held = lab_all > 0
+            lab_nodes, labels = nodes_dev[held], lab_all[held]
+            del lab_all, held
+        elif kw.get("mws"):
             lab_nodes, labels, n_labels = backend.host_mws(rows.cpu().numpy().view(np.uint32),
                                                            aff.cpu().numpy(), shape)
             lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(dev)

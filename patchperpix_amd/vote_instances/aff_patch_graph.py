@@ -23,6 +23,7 @@ class PatchPairs:
         self.rows_dev = rows_dev                       # device int32 [N, 6]
         self.nodes = np.ascontiguousarray(nodes_host, dtype=np.int32).reshape(-1, 3)
         self._host = None
+        self.unique_pairs = False      # True for lists made by computeAndStorePatchPairs
 
     @staticmethod
     def from_host(rows, device):
@@ -123,6 +124,7 @@ def computeAndStorePatchPairs(selected_patches_list, patchshape, **kwargs):
         logger.info("Sorry, no patch pairs in sample! Returning...")
         return None
     pairs = PatchPairs(rows, sorted_zyx)
+    pairs.unique_pairs = True
     logger.info("num pairs (incl single patch ccs) %s", len(pairs))
     if not kwargs["save_no_intermediates"]:
         np.save(os.path.join(kwargs["result_folder"], "selected_patch_pairs.npy"), pairs.numpy())

@@ -26,7 +26,16 @@ def component_labels(affinity_graph, shape, device, P, **kwargs):
     here.  ``mws=True``: mutex watershed on the host (ppp_host_mws)."""
     import torch
     if kwargs["mws"]:
-        # native (csrc/ppp_host_mws.cpp); graph_mws.mws_from_pairs is the same in Python
+        po = getattr(affinity_graph, "pairs_obj", None)
+        if po is not None and getattr(po, "unique_pairs", False) and len(po.nodes):
+            # pair list made by this package (no repeated node pair): edge order + |aff| sort on
+            # the device (ppp_mws_edges), the sequential loop on the host (ppp_host_mws_sorted)
+            nodes_dev = torch.from_numpy(po.nodes).to(device)
+            lab, _ = backend.mws_labels_device(po.rows_dev, affinity_graph.aff_dev, nodes_dev, P)
+            lab = lab.cpu().numpy()
+            return po.nodes[lab > 0], lab[lab > 0].astype(np.int64)
+        # anything else (injected / loaded pair lists): csrc/ppp_host_mws.cpp does all of it on
+        # the host; graph_mws.mws_from_pairs is the same in Python
         nodes, labels, _ = backend.host_mws(affinity_graph.pairs, affinity_graph.aff, shape)
         return nodes, labels
     nodes = affinity_graph.pairs_obj.nodes

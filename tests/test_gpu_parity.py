@@ -495,3 +495,56 @@ def test_device_thinning_equals_host_loop(shape, ps, cell):
                                         sel_lin, P).cpu().numpy()
         assert np.array_equal(got, want), variant
         assert 0 < want.sum() <= len(want)
+
+
+@pytest.mark.gpu
+def test_device_rank_order_equals_host(torch_cuda):
+    """ppp_rank_order (rocPRIM select + stable descending radix sort inside the library) ==
+    ppp_host_rank_order (C++ stable sort) == the oracle's rank_by_score, on scores with many
+    ties, negative values and both zeros."""
+    import torch
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd import backend
+    rng = np.random.default_rng(17)
+    shape, ps = (20, 23, 70), (5, 5, 5)
+    score = rng.integers(-3, 4, size=shape).astype(np.float32) * 0.25
+    score[rng.random(shape) < 0.1] = -0.0
+    fg = rng.random(shape) < 0.7
+    lin_d, sc_d = backend.rank_order_device(torch.from_numpy(score).cuda(), fg, ps)
+    lin_h = backend.host_rank_order(score, fg, ps)
+    assert np.array_equal(lin_d, lin_h)
+    assert np.array_equal(sc_d.view(np.uint32), score.reshape(-1)[lin_h].view(np.uint32))
+    coords = orc.interior_fg_coords(fg, np.array([2, 2, 2]))
+    ranked, _ = orc.rank_by_score(coords, score)
+    want = (ranked[:, 0].astype(np.int64) * shape[1] + ranked[:, 1]) * shape[2] + ranked[:, 2]
+    assert np.array_equal(lin_d, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c3d_p3_thin_mws", "c3d_p5_thin_mws", "c3d_p7_thin_mws"])
+def test_device_mws_edges_and_loop_match_host_mws(name):
+    """ppp_mws_edges (device: networkx edge order + stable |aff| sort) + ppp_host_mws_sorted give
+    every node the label ppp_host_mws (pinned to the reference by the mws goldens) gives it --
+    on the golden pair lists and on the same lists with tied |aff| values."""
+    import torch
+    from conftest import Golden
+    from patchperpix_amd import backend
+    g = Golden(name)
+    pairs = np.ascontiguousarray(g["pairs"].astype(np.uint32))
+    shape = g.foreground.shape
+    P = backend.make_params(shape, g.patchshape, **dict(g.kw))
+    nodes = np.unique(pairs.reshape(-1, 3), axis=0).astype(np.int32)
+    rng = np.random.default_rng(3)
+    for variant in ("golden", "ties"):
+        aff = np.ascontiguousarray(g["aff"].astype(np.float32))
+        if variant == "ties":       # few distinct magnitudes: the order is decided by the tie rules
+            aff = (np.round(aff * 4) / 4).astype(np.float32) * rng.choice([1.0, -1.0], size=len(aff)).astype(np.float32)
+        want_nodes, want_labels, want_n = backend.host_mws(pairs, aff, shape)
+        lab, issued = backend.mws_labels_device(torch.from_numpy(pairs.view(np.int32)).cuda(),
+                                                torch.from_numpy(aff).cuda(),
+                                                torch.from_numpy(nodes).cuda(), P)
+        lab = lab.cpu().numpy()
+        got = {tuple(n): int(l) for n, l in zip(nodes[lab > 0], lab[lab > 0])}
+        want = {tuple(n): int(l) for n, l in zip(want_nodes, want_labels)}
+        assert got == want, variant
+        assert issued == want_n
