@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- Mvoxels/s assembled by vote_instances on MI355X (BASELINE.json metric).
 
-One "step" = one full pass of the hot path (consensus -> ranking -> cover -> pairs ->
-patch graph -> labelling) over one synthetic prediction volume that is already resident in
-HBM when the timed region starts.  Prints ONE JSON line ("Measurement").
+One "step" = one full pass of the hot path (consensus -> ranking -> greedy cover -> set-cover
+thinning -> pairs -> patch graph -> mutex watershed / components -> painting) over one synthetic
+prediction volume that is already resident in HBM when the timed region starts.  Prints ONE
+JSON line ("Measurement").
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--flags SET]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: ONE volume, N times taller than
-the 1-GPU workload (weak scaling), is split into z-slabs with patch-radius halos
-(patchperpix_amd/tiling.py); the ranks meet in four RCCL all-reduces and every rank ends with
-the complete instance map -- see DESIGN.md "Multi-GPU".
+The timed workload runs the flag set named by --flags; the default, ``shipped``, is the
+reference's flylight default.toml [vote_instances] (mutex watershed and thinning on; exact
+entries in the JSON's config.flags).  At N = 1 the same line also carries
+  * ``variants``: ms per step of the other flag sets (mws off; mws and thinning off),
+  * ``roofline`` for the scoring kernel S1 on the timed workload (HIP events of this run),
+  * ``roofline_north_star``: the same kernel on BASELINE configs[2] (512^3 volume, 9^3 patch,
+    float16 prediction resident), one pass over all base voxels, measured in this run,
+  * ``cpu_baseline``: the CPU oracle (C, -O3) on host cores -- one thread and all threads.
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: ONE volume, split into z-slabs
+with patch-radius halos (patchperpix_amd/tiling.py); --scaling weak (default) makes it N times
+taller than the 1-GPU workload, --scaling strong keeps the 1-GPU volume.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -48,9 +58,7 @@ WORKLOADS = {
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
 }
-CPU_SAMPLE = {"worm2d_p25": (1, 60, 60), "synth64x8_p5": (24, 24, 24), "synth64x2_p5": (24, 24, 24), "synth64x3_p5": (24, 24, 24), "flylight140_p7": (28, 28, 28), "flylight140x8_p7": (28, 28, 28), "flylight140x2_p7": (28, 28, 28), "synth96_p7": (28, 28, 28),
-              "synth256_p7": (28, 28, 28), "synth256_p9": (26, 26, 26), "synth128_p9": (26, 26, 26),
-              "synth64_p5": (24, 24, 24), "synth512_p9": (26, 26, 26)}
+NORTH_STAR = ((512, 512, 512), (9, 9, 9), (24, 24, 24))   # BASELINE.json configs[2]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -82,17 +90,92 @@ def device_labels(torch, shape, cell, seed, z_offset=0):
     return lab.to(torch.int32).contiguous()
 
 
+def source_sha16():
+    """Fingerprint of the kernel sources: ties a committed rocprof summary to the code it
+    was taken from (profiles/*.meta.json)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "patchperpix_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def s1_roofline(ev_ms, base_voxels, C, kernel="consensus_v2_kernel"):
+    """algorithmic bytes of S1 = the prediction block read once, (2 C + 1) bytes per
+    base voxel with the float16 prediction resident (+ the overlap mask); outputs excluded."""
+    total_ms = float(np.sum(ev_ms))
+    alg = (2.0 * C + 1.0) * base_voxels
+    ach = alg / (total_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": alg / len(ev_ms), "launches": len(ev_ms),
+            "avg_ms": total_ms / len(ev_ms),
+            "pair_votes_per_s_upper": C * (C - 1) / 2.0 * base_voxels / (total_ms * 1e-3),
+            "note": "the kernel is bound by vector-instruction issue, not by HBM: C(C-1)/2 pair "
+                    "votes per foreground voxel at ~11 VALU instructions each (DESIGN.md section 4)"}
+
+
+def north_star_s1(torch, backend, kw):
+    """One pass of the scoring kernel over BASELINE configs[2] (512^3, 9^3, dense foreground,
+    float16 prediction resident in HBM): slabs of 16 slices of base voxels into one reused
+    consensus buffer (the 1.3 TB consensus of that volume cannot exist at once)."""
+    shape, ps, cell = NORTH_STAR
+    C = int(np.prod(ps))
+    T = 16
+    planes = ((2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1) - 1) // 2
+    need = 2.0 * C * np.prod(shape) + 5.0 * np.prod(shape) + planes * 4.0 * T * shape[1] * shape[2]
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0]
+    if need > 0.95 * free:
+        return {"skipped": "needs %.0f GB of HBM, %.0f GB free" % (need / 1e9, free / 1e9)}
+    P = backend.make_params(shape, ps, **kw)
+    labels = device_labels(torch, shape, cell, seed=0)
+    pred = backend.synth_pred(labels, P, seed=0, f16=True)
+    fg_frac = float((labels != 0).float().mean().item())
+    del labels
+    ov = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    times, voxels = [], 0
+    for z0 in range(0, shape[0], T):
+        z1 = min(shape[0], z0 + T)
+        Pb = backend.make_params(shape, ps, cons_box=(z0, 0, 0, z1, shape[1], shape[2]), **kw)
+        a_ev, b_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_ev.record(torch.cuda.current_stream())
+        cons = backend.consensus(pred, ov, Pb)
+        b_ev.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        times.append(a_ev.elapsed_time(b_ev))
+        voxels += (z1 - z0) * shape[1] * shape[2]
+        del cons
+    del pred, ov
+    torch.cuda.empty_cache()
+    r = s1_roofline(times, voxels, C)
+    r.update({"workload": "synth512_p9 (BASELINE configs[2]): one S1 pass over all base voxels",
+              "volume": list(shape), "patchshape": list(ps), "foreground_fraction": fg_frac,
+              "slab_thickness": T, "total_ms": float(np.sum(times)),
+              "Mvoxels_per_s_S1_only": voxels / (float(np.sum(times)) * 1e-3) / 1e6})
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="flylight140_p7", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", default="shipped", choices=["shipped", "cc", "nothin_cc"],
                     help="flag set (patchperpix_amd/flags.py): shipped = default.toml "
                          "[vote_instances] (mws + thinning), cc = mws off, nothin_cc = "
                          "kernels-only pipeline")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the volume grows with N (N x taller), strong = the "
+                         "1-GPU volume is split over the ranks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the S1 pass over the 512^3 / 9^3 volume (about half a minute)")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--slabs", type=int, default=None,
                     help="force the number of z-slabs of the single-GPU tiled path")
     ap.add_argument("--yx", type=int, nargs=2, default=None, metavar=("NY", "NX"),
@@ -128,21 +211,21 @@ def main():
         fg_host = (labels != 0).cpu().numpy()
         numinst = fg_host.astype(np.uint8)
         gshape = shape
-
+        del labels
+        tile_kw = {}
         if args.slabs:
-            kw["_n_slabs"] = args.slabs
+            tile_kw["_n_slabs"] = args.slabs
         if args.yx:
-            kw["_yx_tiles"] = tuple(args.yx)
-            kw.setdefault("_n_slabs", 1)
+            tile_kw["_yx_tiles"] = tuple(args.yx)
+            tile_kw.setdefault("_n_slabs", 1)
 
-        def step():
-            inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps, **kw)
+        def step(flag_kw=kw):
+            inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps,
+                                         **dict(flag_kw, **tile_kw))
             return inst
     else:
-        # ONE volume, `world` times taller than the 1-GPU workload (weak scaling), split into
-        # z-slabs: rank r holds the prediction of its slab + halo only; the ranks meet in four
-        # RCCL all-reduces (scores, cover bits, pair affinities, painted slabs)
-        gshape = (shape[0] * world, shape[1], shape[2])
+        # ONE volume split into z-slabs: rank r holds the prediction of its slab + halo only
+        gshape = (shape[0] * world, shape[1], shape[2]) if args.scaling == "weak" else shape
         slabs = tiling.plan_slabs(gshape[0], world)
         mine = tiling.slabs_of_rank(slabs, rank, world)
         lo, hi = tiling.local_range(mine, gshape[0], ps)
@@ -160,9 +243,9 @@ def main():
         numinst = fg_host.astype(np.uint8)
         comm = tiling.TorchDistComm()
 
-        def step():
+        def step(flag_kw=kw):
             inst, _ = tiling.assemble(pred, lo, gshape, fg_host.copy(), fg_host.copy(), numinst,
-                                      ps, mine, comm=comm, **kw)
+                                      ps, mine, comm=comm, **flag_kw)
             return inst
     torch.cuda.synchronize()
 
@@ -192,59 +275,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ev = backend.event_times_ms()
+    notes = dict(backend.NOTES)
     backend.EVENTS = None
     backend.HOST_TIMES = None
 
-    V = float(np.prod(shape))
     C = int(np.prod(ps))
     value = float(np.prod(gshape)) * args.steps / dt / 1e6
-    # Roofline of the scoring kernel (S1 consensus).  Algorithmic bytes per base voxel: the
-    # prediction block read once (f16 resident: 2*C) + the overlap mask (1); outputs excluded
-    # (SURVEY 8d).  A launch processes the base voxels of its consensus box (the whole volume
-    # when untiled; the tiled path launches S1 per slab, twice where it recomputes the
-    # consensus for the patch-graph stage).
-    s1_total_ms = float(np.sum(ev["consensus"])) if ev.get("consensus") else None
-    s1_voxels = backend.NOTES.get("s1_base_voxels", 0)
     roofline = None
-    if s1_total_ms:
-        alg_bytes = (2.0 * C + 1.0) * s1_voxels
-        achieved = alg_bytes / (s1_total_ms * 1e-3) / 1e9
-        votes = float(C) * (C - 1) / 2.0 * s1_voxels   # upper bound: every voxel foreground
-        roofline = {"bound": "hbm", "kernel": "consensus_v2_kernel", "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / len(ev["consensus"]),
-                    "launches": len(ev["consensus"]),
-                    "avg_ms": s1_total_ms / len(ev["consensus"]),
-                    "note": "VALU-bound (PMC: profiles/): C(C-1)/2 pair votes per voxel",
-                    "pair_votes_per_s_upper": votes / (s1_total_ms * 1e-3)}
-
-    if rank == 0 and roofline is not None and args.workload == "flylight140_p7" and world == 1 \
-            and not args.slabs:
-        roofline.update(pmc_traffic("consensus_v2_kernel"))
-    # The kernel that takes most of the step is S5 (patch graph).  SURVEY 8d's secondary figure
-    # for it: n_pairs * (2 * C * elem + visited * 4) bytes -- both patches' channel vectors and
-    # the consensus entries a pair visits; `visited` is not counted at run time, so the
-    # figure below is the lower bound without it (reported next to the S1 roofline, which is
-    # the one the metric names).
-    roofline_pg = None
-    if ev.get("patch_graph") and backend.NOTES.get("n_pairs"):
-        pg_ms = float(np.sum(ev["patch_graph"]))
-        pg_bytes = float(backend.NOTES["n_pairs"]) * 2.0 * C * 2.0 * args.steps
-        ach = pg_bytes / (pg_ms * 1e-3) / 1e9
-        roofline_pg = {"bound": "hbm", "kernel": "patch_graph_pa_kernel", "achieved": ach,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                       "traffic": None, "avg_ms": pg_ms / len(ev["patch_graph"]),
-                       "launches": len(ev["patch_graph"]),
-                       "pairs_per_s": float(backend.NOTES["n_pairs"]) * args.steps / (pg_ms * 1e-3),
-                       "note": "VALU-issue bound (PMC: 72 % VALU busy, profiles/): per-lane "
-                               "candidate masks, 12 % of the executed add slots are useful"}
+    if ev.get("consensus"):
+        roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C)
+        roofline["workload"] = args.workload
         if rank == 0 and args.workload == "flylight140_p7" and world == 1 and not args.slabs:
-            roofline_pg.update(pmc_traffic("patch_graph_pa_kernel"))
+            roofline.update(pmc_traffic("consensus_v2_kernel"))
+    # Secondary figures for the other two big kernels.  S2 (ranking): the consensus it sums +
+    # the prediction block once, 4 * planes + 2 * C bytes per voxel.  S5 (patch graph): both
+    # patches' channel vectors per dispatched pair row, SURVEY 8(d)'s bound without `visited`.
+    roofline_other = {}
+    if ev.get("rank_patches"):
+        planes = ((2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1) - 1) // 2
+        ms = float(np.sum(ev["rank_patches"]))
+        b = (4.0 * planes + 2.0 * C) * notes.get("s1_base_voxels", 0)
+        roofline_other["rank_patches"] = {
+            "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["rank_patches"]),
+            "launches": len(ev["rank_patches"])}
+    if ev.get("patch_graph") and notes.get("n_pairs"):
+        ms = float(np.sum(ev["patch_graph"]))
+        rows = float(notes.get("s5_rows_dispatched", notes["n_pairs"] * args.steps))
+        b = rows * 2.0 * C * 2.0
+        roofline_other["patch_graph"] = {
+            "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["patch_graph"]),
+            "launches": len(ev["patch_graph"]), "pair_rows_per_s": rows / (ms * 1e-3),
+            "pair_rows_in_list_per_step": notes["n_pairs"]}
+    out = None
     if rank == 0:
         out = {
             "metric": "Mvoxels/sec assembled (vote_instances)", "value": value,
             "unit": "Mvoxels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f16 in, f32 accumulate", "data": "synthetic",
             "config": {"workload": args.workload, "volume": list(shape), "patchshape": list(ps),
                        "pred_dtype": "f16 resident, widened to f32 in registers",
@@ -254,59 +324,189 @@ def main():
                        "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus if not args.yx else
                        "z-slabs x%d, yx tiles %dx%d" % ((args.slabs or 1,) + tuple(args.yx))},
             "roofline": roofline,
-            "roofline_patch_graph": roofline_pg,
+            "roofline_other_kernels": roofline_other,
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
             "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
                               for k, v in (host_times or {}).items()},
-            "workload_stats": dict(backend.NOTES),
+            "workload_stats": {k: (v // args.steps if k in ("s1_base_voxels", "s5_rows_dispatched") else v)
+                               for k, v in notes.items()},
         }
-        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(args.workload, ps, cell, kw)
+    if world == 1:
+        # ---- the other flag sets on the same volume (a few steps each)
+        if not args.no_variants:
+            variants = {}
+            for name in ("shipped", "cc", "nothin_cc"):
+                if name == args.flags:
+                    continue
+                vkw = dict(flagsets.FLAG_SETS[name])
+                step(vkw)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_v = 2
+                for _ in range(n_v):
+                    vinst = step(vkw)
+                torch.cuda.synchronize()
+                vdt = (time.perf_counter() - t1) / n_v
+                variants[name] = {"ms_per_step": vdt * 1e3, "value": float(np.prod(gshape)) / vdt / 1e6,
+                                  "instances_found": int(len(np.unique(vinst)) - 1),
+                                  "differs_in": {k: vkw[k] for k in ("mws", "skipThinCover")}}
+            out["variants"] = variants
+        del pred
+        # ---- the north-star shape of the scoring kernel, in this run
+        if not args.no_north_star and args.workload == "flylight140_p7":
+            out["roofline_north_star"] = north_star_s1(torch, backend, kw)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ps, cell, kw)
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
 def pmc_traffic(kernel):
-    """HBM traffic of `kernel` per launch from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE, separate passes, in KiB).
-    Raw counter values; on gfx950 FETCH_SIZE under-reports wide (16 B/lane) streaming reads by
-    2x and is uncalibrated for the narrow loads of this kernel (MI355X_MICROARCH.md, HBM)."""
+    """HBM traffic of `kernel` per launch from the newest committed rocprofv3 PMC passes
+    (profiles/*_pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE, separate --pmc passes, KiB) --
+    only when that profile was taken from the kernel sources of THIS tree (its .meta.json holds
+    their fingerprint); otherwise traffic stays null.  Calibration (MI355X_MICROARCH.md: counters
+    are exact for some access widths, halved for 16 B / lane streaming reads, uncalibrated
+    otherwise): the transpose kernel of the same profile moves a known byte count with this
+    kernel's access width; its counter / true-bytes ratios are reported next to the raw values."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_write.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.txt")),
+                   key=os.path.getmtime)
     if not files:
-        return {"traffic": None}
-    vals = {}
-    for ln in open(files[-1]):
-        if kernel in ln:
-            parts = ln.split()
-            for name in ("FETCH_SIZE", "WRITE_SIZE"):
-                if name in parts:
-                    vals[name] = float(parts[parts.index(name) + 1]) * 1024.0
+        return {"traffic": None, "traffic_note": "no PMC profile committed"}
+    f = files[-1]
+    meta_f = f.replace("_pmc_fetch_write.txt", ".meta.json")
+    meta = json.load(open(meta_f)) if os.path.exists(meta_f) else {}
+    if meta.get("src_sha16") != source_sha16():
+        return {"traffic": None, "traffic_note": "newest PMC profile (%s) was taken from other kernel "
+                "sources: rerun tools/profile_round.sh" % os.path.relpath(f, ROOT)}
+    vals, calib = {}, {}
+    for ln in open(f):
+        parts = ln.split()
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            if name in parts:
+                v = float(parts[parts.index(name) + 1]) * 1024.0
+                if kernel in ln:
+                    vals[name] = v
+                if "cons_voxel_major_kernel" in ln:
+                    calib[name] = v
     if len(vals) < 2:
-        return {"traffic": None}
-    return {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "traffic_read": vals["FETCH_SIZE"],
-            "traffic_write": vals["WRITE_SIZE"],
-            "traffic_source": os.path.relpath(files[-1], ROOT) + " (flylight140_p7, raw counters)"}
+        return {"traffic": None, "traffic_note": "kernel not in %s" % os.path.relpath(f, ROOT)}
+    out = {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "traffic_read": vals["FETCH_SIZE"],
+           "traffic_write": vals["WRITE_SIZE"],
+           "traffic_source": os.path.relpath(f, ROOT) + " (raw counters, per launch)"}
+    if len(calib) == 2 and meta.get("transpose_true_read_bytes"):
+        out["counter_over_true_bytes"] = {
+            "read": calib["FETCH_SIZE"] / meta["transpose_true_read_bytes"],
+            "write": calib["WRITE_SIZE"] / meta["transpose_true_write_bytes"],
+            "from": "cons_voxel_major_kernel of the same profile (4 B / lane coalesced loads and stores)"}
+    return out
 
 
-def cpu_baseline(workload, ps, cell, kw):
-    """The CPU oracle (a port of the reference's kernel arithmetic + host stages) timed on a
-    bounded sample of the same generator, one host core."""
+def cpu_baseline(ps, cell, kw):
+    """The CPU oracle -- the restatement of the reference's kernels in C (gcc -O3, OpenMP) with the
+    host stages in the package's host C++ -- on bounded samples of the same generator and flags:
+    (i) one thread on a 32^3 sample, (ii) all host cores on a 64^3 sample."""
     from oracle import ppp_oracle as orc
     from patchperpix_amd import synth
-    sshape = CPU_SAMPLE[workload]
-    lab = synth.cell_labels(sshape, cell, seed=0)
-    pred = synth.pred_from_labels(lab, ps, seed=0)
-    fg = lab != 0
     orc.lib()
-    t0 = time.perf_counter()
-    orc.to_instance_seg(pred, fg, fg.copy(), fg.astype(np.uint8), ps, **kw)
-    dt = time.perf_counter() - t0
-    return {"value": float(np.prod(sshape)) / dt / 1e6, "unit": "Mvoxels/s", "cores": 1,
-            "kind": "port", "seconds": dt,
-            "sample": "%s sub-volume of the same generator, %s patch, full pipeline "
-                      "(oracle/ppp_oracle)" % ("x".join(map(str, sshape)), "x".join(map(str, ps)))}
+    cores = os.cpu_count() or 1
+    out = {"unit": "Mvoxels/s", "kind": "port",
+           "what": "oracle/ppp_oracle.c (gcc -O3 -fopenmp; S1 in gather form over offset planes, "
+                   "S2 over centres, S5 over pair rows) + host stages (ppp_host_* C++, one thread)"}
+    runs = []
+    for threads, sshape in ((1, (32, 32, 32)), (cores, (64, 64, 64))):
+        sshape = tuple(min(s, 64) if p > 1 else 1 for s, p in zip(sshape, ps))
+        if ps[0] == 1:
+            sshape = (1, 96, 96) if threads == 1 else (1, 192, 192)
+        lab = synth.cell_labels(sshape, cell, seed=0)
+        pred = synth.pred_from_labels(lab, ps, seed=0)
+        fg = lab != 0
+        orc.set_threads(threads)
+        t0 = time.perf_counter()
+        inst = cpu_pipeline(orc, pred, fg, ps, kw)
+        dt = time.perf_counter() - t0
+        runs.append({"threads": threads, "sample": "x".join(map(str, sshape)), "seconds": dt,
+                     "value": float(np.prod(sshape)) / dt / 1e6,
+                     "instances_found": int(len(np.unique(inst)) - 1)})
+    orc.set_threads(0)
+    out["single_thread"], out["all_cores"] = runs
+    # the headline of this object: all cores (the stronger baseline)
+    out.update(value=runs[1]["value"], cores=runs[1]["threads"],
+               sample="%s sub-volume of the same generator, %s patch, flags as timed, full pipeline"
+                      % (runs[1]["sample"], "x".join(map(str, ps))))
+    return out
+
+
+def cpu_pipeline(orc, pred, fg, ps, kw):
+    """to_instance_seg on the CPU: the oracle's C loops for S1 / S2 / S5, the library's HOST
+    functions (no device involved) for sort, cover, thinning, pairs and the mutex watershed,
+    NumPy for the patch bits and the painting."""
+    from patchperpix_amd import backend
+    shape = fg.shape
+    rad = [p // 2 for p in ps]
+    numinst = fg.astype(np.uint8)
+    ov = 1 * (numinst > 1)
+    mask = fg.copy()
+    cons = orc.consensus_planes(pred, ov, ps, **kw)
+    score = orc.rank(pred, cons, ov, ps, **kw)
+    lin = backend.host_rank_order(score, fg, ps)
+    if len(lin) == 0:
+        return np.zeros(shape, np.uint16)
+    C = int(np.prod(ps))
+    words = (C + 31) // 32
+
+    def bits_of(lin_idx):
+        vals = pred.reshape(C, -1)[:, lin_idx] > np.float32(kw["fc_threshold"])      # [C, n]
+        out = np.zeros((len(lin_idx), words), dtype=np.uint32)
+        for r in range(C):
+            out[:, r // 32] |= vals[r].astype(np.uint32) << np.uint32(r % 32)
+        return out
+
+    bits = bits_of(lin)
+    running, _owner = backend.padded_mask(mask)
+    selected = np.zeros(len(lin), dtype=np.uint8)
+    radslice = tuple(slice(r, s - r) for r, s in zip(rad, shape))
+    remaining = int(np.count_nonzero(running[radslice]))
+    backend.host_cover_pass(running, np.ascontiguousarray(ov > 0).astype(np.uint8), ps, lin,
+                            score.reshape(-1)[lin], bits, 0, None, selected, remaining)
+    sel = np.flatnonzero(selected)
+    if not kw.get("skipThinCover") and len(sel):
+        keep = backend.host_thin_cover(mask.astype(np.uint8), ps, lin[sel], bits[sel])
+        sel = sel[keep]
+    sel_lin = lin[sel]
+    coords = np.stack(np.unravel_index(sel_lin, shape), axis=1).astype(np.int32)
+    _, pairs = backend.host_patch_pairs(coords, ps, kw.get("max_total_patch_distance_in_ps_multiples", 2),
+                                        kw["includeSinglePatchCCS"])
+    if pairs is None:
+        return np.zeros(shape, np.uint16)
+    aff = orc.patch_graph(pred, cons, pairs, ps, **kw)
+    if kw.get("mws"):
+        nodes, labels, _ = backend.host_mws(pairs, aff, shape)
+    else:
+        # components of the positive edges (any component order: a baseline only counts them)
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        P64 = pairs.astype(np.int64)
+        a_lin = (P64[:, 0] * shape[1] + P64[:, 1]) * shape[2] + P64[:, 2]
+        b_lin = (P64[:, 3] * shape[1] + P64[:, 4]) * shape[2] + P64[:, 5]
+        pos = aff > 0
+        uniq, inv = np.unique(np.concatenate([a_lin[pos], b_lin[pos]]), return_inverse=True)
+        k = int(pos.sum())
+        g = coo_matrix((np.ones(k), (inv[:k], inv[k:])), shape=(len(uniq), len(uniq)))
+        _, comp = connected_components(g, directed=False)
+        nodes = np.stack(np.unravel_index(uniq, shape), axis=1)
+        labels = comp + 1
+    inst = np.zeros(shape, np.uint16)
+    th = np.float32(kw["patch_threshold"])
+    order = np.argsort(labels, kind="stable")          # later components overwrite earlier ones
+    for c, lab in zip(np.asarray(nodes)[order], np.asarray(labels)[order]):
+        win = tuple(slice(int(v) - r, int(v) + r + 1) for v, r in zip(c, rad))
+        patch = pred[(slice(None),) + tuple(int(v) for v in c)].reshape(ps)
+        inst[win][patch > th] = lab
+    return inst
 
 
 if __name__ == "__main__":

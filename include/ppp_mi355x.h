@@ -332,7 +332,11 @@ int ppp_patch_pairs_fill_subset(const int32_t *d_sorted_zyx, int64_t n, int32_t 
 int ppp_pair_sort_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
                        const ppp_params *p, void *stream);
 /* sort keys (int64) for ppp_patch_graph_by_patch: key >> 18 is the linear index of patch A (the
- * group), the low bits order a group's rows (intersecting windows first, then by B - A)    */
+ * group), the low bits order a group's rows (intersecting windows first, then by B - A).
+ * Rows whose patches are too far apart to share a stored consensus offset (|B - A|_i >
+ * 2 (p_i - 1) on some axis) get PPP_PAIR_KEY_FAR: their affinity is exactly 0.0 whatever the
+ * data, so a caller that pre-zeroes d_aff leaves them out of the groups.                    */
+#define PPP_PAIR_KEY_FAR 0x7FFFFFFFFFFFFFFFll
 int ppp_pair_group_keys(const uint32_t *d_rows, uint64_t n_rows, int64_t *d_keys,
                         const ppp_params *p, void *stream);
 

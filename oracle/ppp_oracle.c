@@ -162,11 +162,83 @@ void ppp_oracle_fill_consensus(const float *pred, const uint8_t *overlap, float 
             for (int x = 0; x < P->X; x++) fill_one(&g, pred, overlap, cons, cnt, z, y, x);
 }
 
+/* ---- S1 in gather form: one consensus entry at a time ------------------------------
+ * The same numbers as ppp_oracle_fill_consensus (+ count pass + normalisation), organised so
+ * that many cores can share the work WITHOUT atomics and without changing a bit: every key
+ * (offset q, base voxel u) receives at most one vote per patch centre,
+ * so its value is the float sum of those votes in raster order of the centres -- which is what
+ * the serial scatter loop produces.  Threads take whole offset planes.  For a centre c that
+ * holds both voxels, with pe = pred[pixel of u][c] (earlier pixel), pl = pred[pixel of u+q][c]:
+ *   pe > TH and pl > TH      -> +value(pe, pl)        (fillConsensusArray.cu:94-113, b > a)
+ *   pe > TH and pl is bg     -> -value(pe, 1 - pl)    (:114-166, b > a: key at the first pixel)
+ *   pl > TH and pe is bg     -> -value(pl, 1 - pe)    (:114-166, b <= a: key at the second pixel)
+ * cons (reference layout) is fully written for the lexicographically positive planes; cnt may
+ * be NULL.  normalise: cons /= cnt where cnt != 0 (normConsensusArray.cu:23). */
+void ppp_oracle_fill_consensus_planes(const float *pred, const uint8_t *ov, float *cons, float *cnt,
+                                      int normalise, const ppp_oracle_params *P) {
+    geom g = make_geom(P);
+    const size_t V = g.V;
+    const int wy = 2 * P->py - 1, wx = 2 * P->px - 1;
+    const long n_off = (long)P->pz * wy * wx;
+    const float *mid = pred + (size_t)g.mid * V;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long o = 0; o < n_off; o++) {
+        const int dz = (int)(o / (wy * wx)), dy = (int)((o / wx) % wy) - (P->py - 1),
+                  dx = (int)(o % wx) - (P->px - 1);
+        if (dz == 0 && (dy < 0 || (dy == 0 && dx <= 0))) continue; /* not lexicographically > 0 */
+        const size_t pl_off = plane(&g, dz + P->pz - 1, dy + P->py - 1, dx + P->px - 1);
+        const int q_lin = (dz * P->py + dy) * P->px + dx; /* channel of the later pixel - earlier */
+        for (int uz = 0; uz + dz < P->Z; uz++)
+            for (int uy = (dy < 0 ? -dy : 0); uy < P->Y - (dy > 0 ? dy : 0); uy++)
+                for (int ux = (dx < 0 ? -dx : 0); ux < P->X - (dx > 0 ? dx : 0); ux++) {
+                    const size_t u = vox(&g, uz, uy, ux), w = vox(&g, uz + dz, uy + dy, ux + dx);
+                    if ((double)mid[u] <= P->th || (double)mid[w] <= P->th) continue;
+                    if (P->use_overlap && (ov[u] != 0 || ov[w] != 0)) continue;
+                    /* centres whose window holds u and u + q, inside the interior */
+                    int z0 = uz + dz - g.rz, z1 = uz + g.rz;
+                    int y0 = (dy > 0 ? uy + dy : uy) - g.ry, y1 = (dy > 0 ? uy : uy + dy) + g.ry;
+                    int x0 = (dx > 0 ? ux + dx : ux) - g.rx, x1 = (dx > 0 ? ux : ux + dx) + g.rx;
+                    if (z0 < g.rz) z0 = g.rz;
+                    if (y0 < g.ry) y0 = g.ry;
+                    if (x0 < g.rx) x0 = g.rx;
+                    if (z1 > P->Z - g.rz - 1) z1 = P->Z - g.rz - 1;
+                    if (y1 > P->Y - g.ry - 1) y1 = P->Y - g.ry - 1;
+                    if (x1 > P->X - g.rx - 1) x1 = P->X - g.rx - 1;
+                    float sum = 0.0f, n = 0.0f;
+                    for (int cz = z0; cz <= z1; cz++)
+                        for (int cy = y0; cy <= y1; cy++)
+                            for (int cx = x0; cx <= x1; cx++) {
+                                const size_t c = vox(&g, cz, cy, cx);
+                                if ((double)mid[c] <= P->th) continue;
+                                const int a = ((uz - cz + g.rz) * P->py + (uy - cy + g.ry)) * P->px +
+                                              (ux - cx + g.rx);
+                                const float pe = pred[(size_t)a * V + c];
+                                const float pl = pred[(size_t)(a + q_lin) * V + c];
+                                if ((double)pe > P->th) {
+                                    if ((double)pl > P->th) {
+                                        sum = sum + vote_value(P, pe, pl);
+                                        n = n + 1.0f;
+                                    } else if (is_bg(P, pl)) {
+                                        sum = sum + (-vote_value(P, pe, 1 - pl));
+                                        n = n + 1.0f;
+                                    }
+                                } else if ((double)pl > P->th && is_bg(P, pe)) {
+                                    sum = sum + (-vote_value(P, pl, 1 - pe));
+                                    n = n + 1.0f;
+                                }
+                            }
+                    cons[pl_off + u] = (normalise && n != 0) ? sum / n : sum;
+                    if (cnt) cnt[pl_off + u] = n;
+                }
+    }
+}
+
 /* ---- normalisation (normConsensusArray.cu:5-28) -------------------------------- */
 void ppp_oracle_norm_consensus(const float *pred, float *cons, const float *cnt,
                                const ppp_oracle_params *P) {
     geom g = make_geom(P);
     const size_t n_planes = (size_t)P->nsz * P->nsy * P->nsx;
+#pragma omp parallel for schedule(static)
     for (size_t v = 0; v < g.V; v++) {
         if ((double)pred[(size_t)g.mid * g.V + v] <= P->th) continue;
         for (size_t o = 0; o < n_planes; o++) {
@@ -183,6 +255,8 @@ void ppp_oracle_rank_patches(const float *pred, const float *cons, const uint8_t
                              float *score, const ppp_oracle_params *P) {
     geom g = make_geom(P);
     const size_t V = g.V;
+    /* every centre is independent (own accumulator, own output): threads over (z, y) lines */
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int cz = 0; cz < P->Z; cz++)
         for (int cy = 0; cy < P->Y; cy++)
             for (int cx = 0; cx < P->X; cx++) {
@@ -250,6 +324,8 @@ void ppp_oracle_patch_graph(const float *pred, const float *cons, const uint32_t
                             uint64_t n_pairs, float *aff, const ppp_oracle_params *P) {
     geom g = make_geom(P);
     const size_t V = g.V;
+    /* every pair row is independent */
+#pragma omp parallel for schedule(dynamic, 64)
     for (uint64_t id = 0; id < n_pairs; id++) {
         const int az = (int)pairs[id * 6 + 0], ay = (int)pairs[id * 6 + 1],
                   ax = (int)pairs[id * 6 + 2];

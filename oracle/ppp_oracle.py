@@ -48,7 +48,7 @@ def build(force=False):
     src = os.path.join(_HERE, "ppp_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         os.makedirs(out_dir, exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fPIC",
+        subprocess.check_call(["gcc", "-O3", "-fopenmp", "-std=c11", "-ffp-contract=off", "-fPIC",
                                "-shared", src, "-o", so, "-lm"])
     return so
 
@@ -59,7 +59,7 @@ def lib():
         _LIB = ctypes.CDLL(build())
         for name in ("ppp_oracle_fill_consensus", "ppp_oracle_norm_consensus",
                      "ppp_oracle_rank_patches", "ppp_oracle_patch_graph",
-                     "ppp_oracle_consensus_and_rank"):
+                     "ppp_oracle_consensus_and_rank", "ppp_oracle_fill_consensus_planes"):
             getattr(_LIB, name).restype = None
     return _LIB
 
@@ -150,6 +150,31 @@ def consensus(pred, overlap_mask, patchshape, **kw):
         L.ppp_oracle_fill_consensus(pp, op, cons.ctypes.data_as(ctypes.c_void_p), None,
                                     ctypes.byref(P))
     return cons
+
+
+def consensus_planes(pred, overlap_mask, patchshape, **kw):
+    """The same array as ``consensus`` from the gather form of S1 (one entry at a time, threads
+    over offset planes, ppp_oracle_fill_consensus_planes): what bench.py's cpu_baseline times on
+    all host cores.  tests/test_oracle_golden.py checks it against ``consensus`` bit for bit."""
+    pred, pp = _f32(pred)
+    P = make_params(pred.shape[1:], patchshape, **kw)
+    ov, op = _u8(overlap_mask if P.use_overlap else None)
+    shape = (P.nsz, P.nsy, P.nsx) + tuple(pred.shape[1:])
+    cons = np.zeros(shape, dtype=np.float32)
+    if not kw.get("consensus_norm_aff", True):
+        assert not kw.get("consensus_interleaved_cnt", True), \
+            "consensus aff not normalized so no computation required"
+    lib().ppp_oracle_fill_consensus_planes(pp, op, cons.ctypes.data_as(ctypes.c_void_p), None,
+                                           1 if kw.get("consensus_norm_aff", True) else 0,
+                                           ctypes.byref(P))
+    return cons
+
+
+def set_threads(n):
+    """Number of OpenMP threads of the oracle's C loops (0 = all cores)."""
+    import ctypes.util
+    omp = ctypes.CDLL(ctypes.util.find_library("gomp") or "libgomp.so.1")
+    omp.omp_set_num_threads(int(n) if n else os.cpu_count())
 
 
 def rank(pred, cons, overlap_mask, patchshape, **kw):

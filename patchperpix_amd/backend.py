@@ -20,6 +20,7 @@ CONS_COMPACT, CONS_REFERENCE, CONS_VOXEL_MAJOR = 0, 1, 2
 ABI_VERSION = 3
 NONE_KEY = 0xFFFFFFFF
 NONE_KEY64 = 1 << 62      # PPP_LABEL_NONE_KEY (streaming labels, int64 keys)
+PAIR_KEY_FAR = 0x7FFFFFFFFFFFFFFF   # PPP_PAIR_KEY_FAR
 
 
 class Box(ctypes.Structure):
@@ -454,6 +455,13 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
         keys = torch.empty((n,), dtype=torch.int64, device=pairs.device)
         check(lib().ppp_pair_group_keys(_dev_ptr(pairs), n, _dev_ptr(keys), ctypes.byref(Pv), _stream()))
         keys, order = torch.sort(keys)
+        # rows that cannot share a stored consensus offset keep the zero aff was created with
+        n_live = int(torch.searchsorted(keys, torch.tensor([PAIR_KEY_FAR], dtype=torch.int64,
+                                                           device=keys.device)).item())
+        note_add("s5_rows_dispatched", n_live)
+        if n_live == 0:
+            return aff
+        keys, order = keys[:n_live], order[:n_live]
     keys >>= 18                                   # linear index of patch A
     _, counts = torch.unique_consecutive(keys, return_counts=True)
     del keys

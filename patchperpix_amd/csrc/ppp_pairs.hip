@@ -175,7 +175,13 @@ __global__ void pair_group_keys_kernel(const uint32_t *__restrict__ rows, const 
                          (dx + 2 * G.px);
     const int64_t apart = (abs(dz) >= G.pz || abs(dy) >= G.py || abs(dx) >= G.px) ? 1 : 0;
     const int64_t lin = ((int64_t)r[0] * G.Y + r[1]) * G.X + r[2];
-    keys[i] = (lin << 18) | (apart << 17) | (dkey & 0x1FFFF);
+    // A pair whose centres are more than 2(p-1) apart on some axis has no pixel pair within the
+    // stored consensus offsets (|q_i| <= p_i - 1 needs |d_i| <= 2(p_i - 1)): its sum stays 0 and
+    // the kernel's result is exactly 0.0 (computePatchGraph.cu:88-133 only counts such
+    // candidates).  Such rows -- 36 % of the list at max_ps_dist = 2 -- get the largest key: they
+    // sort behind every group and are not dispatched (the caller pre-zeroes d_aff).
+    const bool far = abs(dz) > 2 * (G.pz - 1) || abs(dy) > 2 * (G.py - 1) || abs(dx) > 2 * (G.px - 1);
+    keys[i] = far ? PPP_PAIR_KEY_FAR : ((lin << 18) | (apart << 17) | (dkey & 0x1FFFF));
 }
 
 hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,

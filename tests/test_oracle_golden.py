@@ -105,3 +105,18 @@ def test_reference_numpy_path_agrees_on_separated_instances(name):
     assert both.sum() > 0.9 * max((a > 0).sum(), (b > 0).sum())
     assert len(np.unique(a[a > 0])) == len(np.unique(b[b > 0])) == 2
     assert same_partition(np.where(both, a, 0), np.where(both, b, 0))
+
+
+def test_gather_form_consensus_equals_scatter_form(golden):
+    """ppp_oracle_fill_consensus_planes (S1 as a gather over offset planes, the form the CPU
+    baseline runs on all cores) == the serial scatter restatement, bit for bit, on every golden
+    (all background rules, value rules, overlap on / off, 2-d and 3-d)."""
+    from oracle import ppp_oracle as orc
+    g = golden
+    if g.has("early_out") and int(g["early_out"]):
+        pytest.skip("early-out case")
+    if int(np.prod(g.patchshape)) > 400:
+        pytest.skip("serial scatter form too slow for this patch size here")
+    a = orc.consensus(g.pred, g.overlap_mask, g.patchshape, **g.kw)
+    b = orc.consensus_planes(g.pred, g.overlap_mask, g.patchshape, **g.kw)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
