@@ -149,6 +149,15 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
  *                      chunk = ppp_patch_graph_by_patch_chunk(p) (rows per workgroup, 0 if
  *                      the patch shape is unsupported); n_blocks = d_chunk_offsets[n_groups] */
 int32_t ppp_patch_graph_by_patch_chunk(const ppp_params *p);
+/* A second, smaller workgroup size for lists with few rows per patch (e.g. after set-cover
+ * thinning): ppp_patch_graph_by_patch_chunked takes the chunk the caller built
+ * d_chunk_offsets with -- either of the two values above.                                 */
+int32_t ppp_patch_graph_by_patch_chunk_small(const ppp_params *p);
+int ppp_patch_graph_by_patch_chunked(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                                     const uint32_t *d_pairs, const uint32_t *d_order,
+                                     const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                                     int32_t n_groups, int64_t n_blocks, int32_t chunk, float *d_aff,
+                                     const ppp_params *p, void *stream);
 int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
                              const uint32_t *d_pairs, const uint32_t *d_order,
                              const int64_t *d_group_start, const int64_t *d_chunk_offsets,

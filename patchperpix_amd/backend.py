@@ -81,6 +81,12 @@ _SIGNATURES = {
                                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                 ctypes.c_void_p, ctypes.POINTER(Params),
                                                 ctypes.c_void_p]),
+    "ppp_patch_graph_by_patch_chunk_small": (ctypes.c_int32, [ctypes.POINTER(Params)]),
+    "ppp_patch_graph_by_patch_chunked": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                        ctypes.c_int32, ctypes.c_void_p,
+                                                        ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_label_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "ppp_label_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
@@ -470,16 +476,21 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     chunk = int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv)))
     if chunk <= 0:
         raise RuntimeError("libppp_mi355x: no per-patch kernel for this patch shape")
+    # few rows per patch (thinned covers): one- or two-wave workgroups
+    small = int(lib().ppp_patch_graph_by_patch_chunk_small(ctypes.byref(Pv)))
+    mode = os.environ.get("PPP_PA_CHUNK", "auto")
+    if mode == "small" or (mode == "auto" and n_live <= 1.5 * small * int(counts.shape[0])):
+        chunk = small
     chunk_offsets = torch.cat([zero, torch.cumsum((counts + chunk - 1) // chunk, 0)])
     n_groups = int(counts.shape[0])
     n_blocks = int(chunk_offsets[-1].item())
     order32 = order.to(torch.int32)
     del order
     with _timed("patch_graph"):
-        check(lib().ppp_patch_graph_by_patch(
+        check(lib().ppp_patch_graph_by_patch_chunked(
             _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
             _dev_ptr(order32), _dev_ptr(group_start.contiguous()),
-            _dev_ptr(chunk_offsets.contiguous()), n_groups, n_blocks, _dev_ptr(aff),
+            _dev_ptr(chunk_offsets.contiguous()), n_groups, n_blocks, chunk, _dev_ptr(aff),
             ctypes.byref(Pv), _stream()))
     return aff
 

@@ -196,14 +196,20 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
 int32_t ppp_patch_graph_by_patch_chunk(const ppp_params *p) {
     ppp::Geo G;
     if (make_geo(p, &G) != PPP_OK) return -1;
-    return ppp::patch_graph_pa_chunk(G);
+    return ppp::patch_graph_pa_chunk(G, false);
 }
 
-int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
-                             const uint32_t *d_pairs, const uint32_t *d_order,
-                             const int64_t *d_group_start, const int64_t *d_chunk_offsets,
-                             int32_t n_groups, int64_t n_blocks, float *d_aff,
-                             const ppp_params *p, void *stream) {
+int32_t ppp_patch_graph_by_patch_chunk_small(const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return ppp::patch_graph_pa_chunk(G, true);
+}
+
+int ppp_patch_graph_by_patch_chunked(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                                     const uint32_t *d_pairs, const uint32_t *d_order,
+                                     const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                                     int32_t n_groups, int64_t n_blocks, int32_t chunk, float *d_aff,
+                                     const ppp_params *p, void *stream) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     PPP_TRY(check_dtype(pred_dtype));
@@ -216,10 +222,20 @@ int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_
     hipError_t e = ppp::launch_patch_graph_pa(d_pred, pred_dtype, d_cons_vm, d_pairs, d_order,
                                               (const long long *)d_group_start,
                                               (const long long *)d_chunk_offsets, n_groups, n_blocks,
-                                              d_aff, G, (hipStream_t)stream);
+                                              chunk, d_aff, G, (hipStream_t)stream);
     if (e == hipErrorNotSupported)
-        return fail(PPP_ERR_UNSUPPORTED, "no per-patch kernel for this patch shape");
+        return fail(PPP_ERR_UNSUPPORTED, "no per-patch kernel for this patch shape / chunk size");
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph_by_patch");
+}
+
+int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                             const uint32_t *d_pairs, const uint32_t *d_order,
+                             const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                             int32_t n_groups, int64_t n_blocks, float *d_aff,
+                             const ppp_params *p, void *stream) {
+    return ppp_patch_graph_by_patch_chunked(d_pred, pred_dtype, d_cons_vm, d_pairs, d_order, d_group_start,
+                                            d_chunk_offsets, n_groups, n_blocks,
+                                            ppp_patch_graph_by_patch_chunk(p), d_aff, p, stream);
 }
 
 size_t ppp_label_workspace_bytes(const ppp_params *p) {

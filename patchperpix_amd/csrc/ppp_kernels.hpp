@@ -17,11 +17,11 @@ hipError_t launch_rank_v3(const void *pred, int dtype, const float *cons, const 
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
                               const uint32_t *pairs, const uint32_t *order, uint64_t n,
                               float *aff, const Geo &G, hipStream_t s);
-int patch_graph_pa_chunk(const Geo &G);
+int patch_graph_pa_chunk(const Geo &G, bool small = false);
 hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, const uint32_t *rows,
                                  const uint32_t *order, const long long *group_start,
                                  const long long *chunk_offsets, int n_groups, long long n_blocks,
-                                 float *aff, const Geo &G, hipStream_t s);
+                                 int chunk, float *aff, const Geo &G, hipStream_t s);
 hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n,
                         const uint32_t *nodes, uint64_t n_nodes, uint32_t *node_key, void *work,
                         const Geo &G, hipStream_t s);

@@ -59,6 +59,13 @@ template <int PX> struct PaCfg {
     static constexpr int ROW_BUFS = PX >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
     // waves per SIMD the register budget must allow
     static constexpr int MIN_WAVES = PX <= 7 ? PPP_PA_MINWAVES7 : (THREADS == 512 ? 4 : (ROW_BUFS == 1 ? 3 : 2));
+    // Small workgroups for lists with few rows per patch (after set-cover thinning a patch has
+    // ~60 dispatched rows at 7^3): with 256 threads three of four waves only stage and wait
+    // (29 % of the issued instructions on the thinned 140^3 volume), and the 11 KB of B-patch
+    // bits they reserve cap the CU at 8 workgroups.  One or two waves: 11.6 KB -> 13 per CU, and
+    // a register budget without spills.
+    static constexpr int THREADS_SMALL = PX >= 9 ? 128 : 64;
+    static constexpr int MIN_WAVES_SMALL = PX >= 9 ? 2 : 4;
 };
 static constexpr int PA_PAD = 8;       // floats of slack either side of the staged row (a masked row read overshoots by < PX)
 
@@ -93,15 +100,15 @@ __device__ __forceinline__ AxisMasks axis_masks(int dd, int a, int p) {
     return m;
 }
 
-template <typename T, int PX>
-__global__ void __launch_bounds__(PaCfg<PX>::THREADS, PaCfg<PX>::MIN_WAVES)
+template <typename T, int PX, int PA_THREADS>
+__global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ? PaCfg<PX>::MIN_WAVES
+                                                                               : PaCfg<PX>::MIN_WAVES_SMALL)
     patch_graph_pa_kernel(const T *__restrict__ pred, const float *__restrict__ S,
                           const uint32_t *__restrict__ rows, const uint32_t *__restrict__ order,
                           const long long *__restrict__ group_start,
                           const long long *__restrict__ chunk_offsets, const int n_groups,
                           float *__restrict__ aff, const Geo G) {
     extern __shared__ uint32_t lds_raw[];
-    constexpr int PA_THREADS = PaCfg<PX>::THREADS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int words = (G.C + 31) / 32;
     const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
@@ -423,23 +430,40 @@ extern "C" void ppp_pa_stats(unsigned long long *out) {
 }
 #endif
 
-int patch_graph_pa_chunk(const Geo &G) {
+int patch_graph_pa_chunk(const Geo &G, bool small) {
     switch (G.px) {
-    case 3: return PaCfg<3>::THREADS;
-    case 5: return PaCfg<5>::THREADS;
-    case 7: return PaCfg<7>::THREADS;
-    case 9: return PaCfg<9>::THREADS;
+    case 3: return small ? PaCfg<3>::THREADS_SMALL : PaCfg<3>::THREADS;
+    case 5: return small ? PaCfg<5>::THREADS_SMALL : PaCfg<5>::THREADS;
+    case 7: return small ? PaCfg<7>::THREADS_SMALL : PaCfg<7>::THREADS;
+    case 9: return small ? PaCfg<9>::THREADS_SMALL : PaCfg<9>::THREADS;
     }
     return 0;
+}
+
+template <typename T, int PX, int THREADS>
+static hipError_t launch_pa(const T *pred, const float *S, const uint32_t *rows, const uint32_t *order,
+                            const long long *group_start, const long long *chunk_offsets, int n_groups,
+                            long long n_blocks, float *aff, const Geo &G, size_t lds, hipStream_t s) {
+    // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
+    if (lds > 64 * 1024) {
+        hipError_t ea = hipFuncSetAttribute((const void *)patch_graph_pa_kernel<T, PX, THREADS>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+    }
+    patch_graph_pa_kernel<T, PX, THREADS><<<dim3((unsigned)n_blocks), dim3(THREADS), lds, s>>>(
+        pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, G);
+    return hipGetLastError();
 }
 
 hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, const uint32_t *rows,
                                  const uint32_t *order, const long long *group_start,
                                  const long long *chunk_offsets, int n_groups, long long n_blocks,
-                                 float *aff, const Geo &G, hipStream_t s) {
+                                 int chunk, float *aff, const Geo &G, hipStream_t s) {
     if (n_groups <= 0 || n_blocks <= 0) return hipSuccess;
-    const int threads = patch_graph_pa_chunk(G);
-    if (threads == 0) return hipErrorNotSupported;
+    const int threads = chunk;
+    if (threads == 0 || (threads != patch_graph_pa_chunk(G, false) && threads != patch_graph_pa_chunk(G, true)))
+        return hipErrorNotSupported;
+    const bool small = threads != patch_graph_pa_chunk(G, false);
     const int words = (G.C + 31) / 32;
     const int W = (2 * G.pz - 1) * G.wy * G.wx;
     const int WB = (W + 2 * PA_PAD + 3) & ~3;
@@ -452,24 +476,13 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + ((words * threads + 1) & ~1)) * 4;
     if (lds > 80 * 1024 || n_blocks >= (1ll << 31) || grid_too_big((unsigned long long)n_blocks, threads))
         return hipErrorNotSupported;
-    // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
-#define PPP_PA_CASE(P)                                                                             \
-    case P:                                                                                        \
-        if (lds > 64 * 1024) {                                                                     \
-            hipError_t ea = dtype == PPP_F16                                                       \
-                ? hipFuncSetAttribute((const void *)patch_graph_pa_kernel<__half, P>,              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)        \
-                : hipFuncSetAttribute((const void *)patch_graph_pa_kernel<float, P>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-            if (ea != hipSuccess) return ea;                                                       \
-        }                                                                                          \
-        if (dtype == PPP_F16)                                                                      \
-            patch_graph_pa_kernel<__half, P><<<dim3((unsigned)n_blocks), dim3(threads), lds, s>>>(    \
-                (const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, G); \
-        else                                                                                       \
-            patch_graph_pa_kernel<float, P><<<dim3((unsigned)n_blocks), dim3(threads), lds, s>>>(     \
-                (const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, G); \
-        return hipGetLastError();
+#define PPP_PA_CASE(P)                                                                                  \
+    case P:                                                                                             \
+        if (dtype == PPP_F16)                                                                           \
+            return small ? launch_pa<__half, P, PaCfg<P>::THREADS_SMALL>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
+                         : launch_pa<__half, P, PaCfg<P>::THREADS>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s); \
+        return small ? launch_pa<float, P, PaCfg<P>::THREADS_SMALL>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
+                     : launch_pa<float, P, PaCfg<P>::THREADS>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s);
     switch (G.px) {
         PPP_PA_CASE(3)
         PPP_PA_CASE(5)
