@@ -126,6 +126,16 @@ int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
                      const uint8_t *d_overlap, float *d_score, const ppp_box *score_box,
                      const ppp_params *p, void *stream);
 
+/* The same scores from a VOXEL_MAJOR consensus (p->cons_layout), row-stationary: every
+ * consensus row is staged in LDS once per tile of centres and serves all centres of the tile
+ * whose window holds its voxel (csrc/ppp_rank_vm.hip) -- the gather form above re-fetches each
+ * entry ~50 times from HBM.  Cubic patches of 3 / 5 / 7 / 9, count_pos_neg = 0; otherwise
+ * PPP_ERR_UNSUPPORTED (ppp_rank_workspace_bytes returns 0).  d_work: ppp_rank_workspace_bytes. */
+int64_t ppp_rank_workspace_bytes(const ppp_box *score_box, const ppp_params *p);
+int ppp_rank_patches_vm(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                        const uint8_t *d_overlap, float *d_score, const ppp_box *score_box,
+                        void *d_work, const ppp_params *p, void *stream);
+
 /* --- S5: patch graph (edge emission) --------------------------------------------------
  * replaces computePatchGraph_cuda (aff_patch_graph.py:113-187) + kernel computePatchGraph
  * (cuda/computePatchGraph.cu:3-136).  d_pairs u32[n_pairs][6] = (z,y,x) of patch A and B,

@@ -72,6 +72,10 @@ _SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.POINTER(Box), ctypes.POINTER(Params),
                                         ctypes.c_void_p]),
+    "ppp_rank_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(Box), ctypes.POINTER(Params)]),
+    "ppp_rank_patches_vm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Box),
+                                           ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_patch_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.c_void_p, ctypes.POINTER(Params),
@@ -427,16 +431,38 @@ def _big_empty(shape, device):
 
 
 def rank_patches(pred, cons, overlap, P, score_box=None, out=None):
-    """S2.  Returns the (Z, Y, X) float32 score volume on the device."""
+    """S2.  Returns the (Z, Y, X) float32 score volume on the device.  With a VOXEL_MAJOR
+    consensus (P.cons_layout) the row-stationary kernel runs (ppp_rank_patches_vm)."""
     torch = _torch()
     if out is None:
         out = torch.zeros(P.shape, dtype=torch.float32, device=pred.device)
     box = None if score_box is None else ctypes.byref(Box(*[int(v) for v in score_box]))
+    if P.cons_layout == CONS_VOXEL_MAJOR:
+        nbytes = int(lib().ppp_rank_workspace_bytes(box, ctypes.byref(P)))
+        check(min(nbytes, 0))
+        if nbytes == 0:
+            raise RuntimeError("libppp_mi355x: no voxel-major ranking kernel for this configuration")
+        work = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+        with _timed("rank_patches"):
+            check(lib().ppp_rank_patches_vm(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons),
+                                            _dev_ptr(overlap), _dev_ptr(out), box, _dev_ptr(work),
+                                            ctypes.byref(P), _stream()))
+        return out
     with _timed("rank_patches"):
         check(lib().ppp_rank_patches(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons),
                                      _dev_ptr(overlap), _dev_ptr(out), box, ctypes.byref(P),
                                      _stream()))
     return out
+
+
+def rank_vm_available(P):
+    """True when ppp_rank_patches_vm handles this configuration (cubic 3/5/7/9 patches, float
+    accumulation) and PPP_RANK does not ask for the gather kernel."""
+    if os.environ.get("PPP_RANK", "vm") != "vm":
+        return False
+    Pv = P.copy()
+    Pv.cons_layout = CONS_VOXEL_MAJOR
+    return int(lib().ppp_rank_workspace_bytes(None, ctypes.byref(Pv))) > 0
 
 
 def pair_order(pairs, P):
@@ -501,12 +527,18 @@ def patch_graph_auto(pred, cons_compact, pairs, P):
     on the 140^3 benchmark).  PPP_PATCH_GRAPH=pairs selects the pair-per-lane gather kernel
     with offset-grouped lanes (same bits), which is also what patch shapes without a per-patch
     specialisation use."""
-    vm, Pv = cons_to_voxel_major(cons_compact, P)
+    if P.cons_layout == CONS_VOXEL_MAJOR:
+        vm, Pv = cons_compact, P          # already re-laid out (kept from the ranking stage)
+    elif getattr(cons_compact, "_ppp_vm", None) is not None:
+        vm, Pv = cons_compact._ppp_vm     # the ranking stage of the stage pipeline left it here
+        cons_compact._ppp_vm = None
+    else:
+        vm, Pv = cons_to_voxel_major(cons_compact, P)
     if os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and \
             int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv))) > 0 and \
             max(P.pz, P.py) <= P.px:
         return patch_graph_by_patch(pred, vm, pairs, Pv)
-    return patch_graph(pred, vm, pairs, Pv, order=pair_order(pairs, P))
+    return patch_graph(pred, vm, pairs, Pv, order=pair_order(pairs, Pv))
 
 
 def device_patch_pairs(sorted_zyx, P, max_ps_dist=2, include_single=True):

@@ -179,6 +179,49 @@ int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_rank_patches");
 }
 
+static int rank_box(const ppp_box *score_box, const ppp_params *p, const ppp::Geo &G, ppp_box *sb) {
+    *sb = ppp_box{0, 0, 0, p->Z, p->Y, p->X};
+    if (score_box) *sb = *score_box;
+    if (sb->z0 < 0 || sb->y0 < 0 || sb->x0 < 0 || sb->z1 > p->Z || sb->y1 > p->Y || sb->x1 > p->X ||
+        sb->z1 <= sb->z0 || sb->y1 <= sb->y0 || sb->x1 <= sb->x0)
+        return fail(PPP_ERR_INVALID_ARG, "score_box outside the volume");
+    const ppp_box &cb = p->cons_box;
+    auto lo = [](int a, int r) { return a - r < 0 ? 0 : a - r; };
+    auto hi = [](int a, int r, int n) { return a + r > n ? n : a + r; };
+    if (lo(sb->z0, G.rz) < cb.z0 || lo(sb->y0, G.ry) < cb.y0 || lo(sb->x0, G.rx) < cb.x0 ||
+        hi(sb->z1, G.rz, p->Z) > cb.z1 || hi(sb->y1, G.ry, p->Y) > cb.y1 || hi(sb->x1, G.rx, p->X) > cb.x1)
+        return fail(PPP_ERR_INVALID_ARG, "cons_box does not cover score_box grown by the patch radius");
+    return PPP_OK;
+}
+
+int64_t ppp_rank_workspace_bytes(const ppp_box *score_box, const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    if (!ppp::rank_vm_supported(G)) return 0;
+    ppp_box sb;
+    if (rank_box(score_box, p, G, &sb) != PPP_OK) return -1;
+    return (int64_t)ppp::rank_vm_workspace_bytes(sb, G);
+}
+
+int ppp_rank_patches_vm(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                        const uint8_t *d_overlap, float *d_score, const ppp_box *score_box,
+                        void *d_work, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_cons_vm || !d_score || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    if (!ppp::rank_vm_supported(G))
+        return fail(PPP_ERR_UNSUPPORTED, "ppp_rank_patches_vm: VOXEL_MAJOR layout, cubic patches of 3/5/7/9, "
+                                         "no count_pos_neg (use ppp_rank_patches otherwise)");
+    ppp_box sb;
+    PPP_TRY(rank_box(score_box, p, G, &sb));
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_rank_vm(d_pred, pred_dtype, d_cons_vm, d_overlap, d_score, sb, d_work, G,
+                                       (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_rank_patches_vm");
+}
+
 int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
                     const uint32_t *d_pairs, const uint32_t *d_order, uint64_t n_pairs,
                     float *d_aff, const ppp_params *p, void *stream) {

@@ -1,0 +1,300 @@
+// ppp_rank_vm.hip -- S2 (patch ranking) on the VOXEL-MAJOR consensus, row-stationary.
+//
+// Reference: cuda/rankPatches.cu:28-147.  For a foreground centre c, with P / N / V the sets of
+// patch pixels that are foreground / background / valid for c (see ppp_rank_v2.hip),
+//     score(c) = sum over a in P (raster)  sum over b != a, V[b] (raster)
+//                    + cons(z_a, z_b)   if b in P and b > a
+//                    - cons(z_a, z_b)   if b in N
+// accumulated sequentially in float.  cons(z_a, z_b) is entry q = b - a of the voxel-major row
+// S[z_a][.], z_a = c + a - rad: for a fixed first pixel the whole inner loop reads ONE row.
+//
+// The gather kernel (ppp_rank_v2.hip, lane = centre) fetches every consensus entry from HBM about
+// 50 times (0.70 TB per launch on the 140^3 / 7^3 volume): a row is needed by the 343 centres
+// whose window holds its voxel, at 343 different moments.  Here the row is the stationary
+// operand: a wave owns a TILE of centres, walks the voxels u of the tile grown by the patch
+// radius in raster order, stages S[u][.] in LDS once, and lets every centre of the tile whose
+// window holds u take its step a = u - c + rad -- one lane per (centre, a), all lanes running the
+// same 343-long inner loop with compile-time LDS offsets.  Raster order of u is raster order of
+// a for every centre, so each centre's float chain is exactly the reference's.  Accumulators live
+// in LDS between the steps of a centre.  The per-centre P / N bit masks and the closed-form
+// pair count come from a coalesced pre-pass over the prediction.
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+static constexpr int RV_PAD = 8;
+
+// ---- pre-pass: per-centre masks, pair counts, border / background scores ---------------------
+// thread per centre of the score box; masks are stored word-major over the box so that the main
+// kernel's loads (lanes = neighbouring centres) coalesce
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rank_masks_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, const ppp_box sb,
+                      uint32_t *__restrict__ Pb, uint32_t *__restrict__ Nb, uint32_t *__restrict__ info,
+                      float *__restrict__ score, const Geo G) {
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const long long sbV = (long long)sX * sY * sZ;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sbV) return;
+    const int cx = sb.x0 + (int)(t % sX), cy = sb.y0 + (int)((t / sX) % sY), cz = sb.z0 + (int)(t / ((long long)sX * sY));
+    const long long lc = vox(G, cz, cy, cx);
+    const T *mid = pred + (long long)G.mid * G.V;
+    uint32_t inf = 0;
+    if (!interior(G, cz, cy, cx)) {
+        score[lc] = G.norm_rank ? -1.0f : -9999999.0f;
+    } else if (!(ldf(mid, lc) > G.th_gt)) {
+        score[lc] = 0.0f;   // the reference leaves the allocation's zero
+    } else {
+        const int words = (G.C + 31) / 32;
+        unsigned nP = 0, nV = 0;
+        int r = 0;
+        for (int w = 0; w < words; ++w) {
+            uint32_t p = 0, n = 0;
+            for (int b = 0; b < 32 && r < G.C; ++b, ++r) {
+                const int z = cz + r / (G.py * G.px) - G.rz, y = cy + (r / G.px) % G.py - G.ry,
+                          x = cx + r % G.px - G.rx;
+                const long long lz = vox(G, z, y, x);
+                const bool valid = ldf(mid, lz) > G.th_gt && (!G.use_overlap || ov[lz] == 0);
+                const float val = ldf(pred, (long long)r * G.V + lc);
+                if (valid) ++nV;
+                if (valid && val > G.th_gt) p |= 1u << b;
+                if (valid && val < G.bg_lt) n |= 1u << b;
+            }
+            Pb[(long long)w * sbV + t] = p;
+            Nb[(long long)w * sbV + t] = n;
+            nP += __popc(p);
+        }
+        // fgCnt = |P| (|V| - 1) - |P| (|P| - 1) / 2   (rankPatches.cu:139, see ppp_rank_v2.hip)
+        const unsigned fg_cnt = nP ? nP * (nV - 1u) - nP * (nP - 1u) / 2u : 0u;
+        inf = 0x80000000u | fg_cnt;
+        if (nP == 0) score[lc] = 0.0f;   // no first pixel: acc = 0, 0 / max(1, 0)
+    }
+    info[t] = inf;
+}
+
+// voxels that can be a first pixel at all: pred[mid] > TH and not an overlap voxel
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rank_valid_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, uint8_t *__restrict__ valid,
+                      const Geo G) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    valid[v] = (ldf(pred, (long long)G.mid * G.V + v) > G.th_gt && (!G.use_overlap || ov[v] == 0)) ? 1 : 0;
+}
+
+// ---- main kernel ---------------------------------------------------------------------------------
+template <int PS, int TZ, int TY, int TX>
+__global__ void __launch_bounds__(64)
+    rank_vm_kernel(const float *__restrict__ S, const uint32_t *__restrict__ Pb,
+                   const uint32_t *__restrict__ Nb, const uint32_t *__restrict__ info,
+                   const uint8_t *__restrict__ valid, float *__restrict__ score, const ppp_box sb,
+                   const Geo G, const int tiles_y, const int tiles_x) {
+    constexpr int C = PS * PS * PS, WORDS = (C + 31) / 32, R = PS / 2;
+    constexpr int WX = 2 * PS - 1, W = WX * WX * WX, LC = (W - 1) / 2;
+    constexpr int NST = (W + 63) / 64;
+    constexpr int NT = TZ * TY * TX;
+    __shared__ float rowbuf[W + 2 * RV_PAD];
+    __shared__ float accs[NT];
+    __shared__ uint32_t inf[NT];
+    constexpr int UB = (TZ + 2 * R) * (TY + 2 * R) * (TX + 2 * R);
+    __shared__ uint8_t uvalid[UB];
+    const int lane = threadIdx.x;
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const long long sbV = (long long)sX * sY * sZ;
+    // XCD-aware order: consecutive blocks are spread over the 8 XCDs by the dispatcher; give
+    // each XCD a contiguous range of tiles so that neighbouring tiles (which share halo rows)
+    // meet in the same L2
+    const int n_blocks = gridDim.x;
+    const int per_xcd = (n_blocks + 7) / 8;
+    int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (bid >= n_blocks) return;   // (per_xcd * 8 >= n_blocks: the tail ids of the last XCDs are empty)
+    const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
+    const int c0z = sb.z0 + tz_i * TZ, c0y = sb.y0 + ty_i * TY, c0x = sb.x0 + tx_i * TX;
+    const int tz = min(TZ, sb.z1 - c0z), ty = min(TY, sb.y1 - c0y), tx = min(TX, sb.x1 - c0x);
+    if (tz <= 0 || ty <= 0 || tx <= 0) return;
+
+    // sb-linear index of tile centre cl = (lz * TY + ly) * TX + lx
+    auto sb_index = [&](int lz, int ly, int lx) -> long long {
+        return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
+    };
+    bool any_active = false;
+    for (int cl = lane; cl < NT; cl += 64) {
+        const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
+        uint32_t v = 0;
+        if (lz < tz && ly < ty && lx < tx) v = info[sb_index(lz, ly, lx)];
+        inf[cl] = v;
+        accs[cl] = 0.0f;
+        any_active |= (v >> 31) != 0;
+    }
+    if (__ballot(any_active) == 0) return;
+    __syncthreads();
+
+    const long long rsY = G.bX, rsZ = (long long)G.bX * G.bY;
+    // voxels of the tile grown by the radius, clipped to the consensus box (rows outside it are
+    // rows of voxels outside the volume: no centre of the interior has them in its window)
+    const int uz0 = max(c0z - R, G.bz0), uz1 = min(c0z + tz - 1 + R, G.bz0 + G.bZ - 1);
+    const int uy0 = max(c0y - R, G.by0), uy1 = min(c0y + ty - 1 + R, G.by0 + G.bY - 1);
+    const int ux0 = max(c0x - R, G.bx0), ux1 = min(c0x + tx - 1 + R, G.bx0 + G.bX - 1);
+    {
+        const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
+        for (int k = lane; k < nu; k += 64)
+            uvalid[k] = valid[vox(G, uz0 + k / (nuy * nux), uy0 + (k / nux) % nuy, ux0 + k % nux)];
+    }
+    __syncthreads();
+    int uk = -1;
+    for (int uz = uz0; uz <= uz1; ++uz)
+        for (int uy = uy0; uy <= uy1; ++uy)
+            for (int ux = ux0; ux <= ux1; ++ux) {
+                ++uk;
+                if (uvalid[uk] == 0) continue;   // (wave-uniform: every lane reads the same byte)
+                // pixels a of this voxel whose centre c = u + R - a lies in the tile
+                const int az0 = max(0, uz + R - (c0z + tz - 1)), az1 = min(PS - 1, uz + R - c0z);
+                const int ay0 = max(0, uy + R - (c0y + ty - 1)), ay1 = min(PS - 1, uy + R - c0y);
+                const int ax0 = max(0, ux + R - (c0x + tx - 1)), ax1 = min(PS - 1, ux + R - c0x);
+                const int nz = az1 - az0 + 1, ny = ay1 - ay0 + 1, nx = ax1 - ax0 + 1;
+                if (nz <= 0 || ny <= 0 || nx <= 0) continue;
+                const int n_box = nz * ny * nx;
+                // ---- stage the row of u
+                {
+                    const float *src = S + (((long long)(uz - G.bz0) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
+#pragma unroll
+                    for (int i = 0; i < NST; ++i) {
+                        const int e = lane + i * 64;
+                        if (e < W) rowbuf[RV_PAD + e] = src[e];
+                    }
+                }
+                __syncthreads();
+                for (int i0 = 0; i0 < n_box; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool in = i < n_box;
+                    const int ii = in ? i : 0;
+                    const int ax = ax0 + ii % nx, ay = ay0 + (ii / nx) % ny, az = az0 + ii / (nx * ny);
+                    const int lz = uz + R - az - c0z, ly = uy + R - ay - c0y, lx = ux + R - ax - c0x;
+                    const int cl = (lz * TY + ly) * TX + lx;
+                    const int a = (az * PS + ay) * PS + ax;
+                    const long long t = sb_index(lz, ly, lx);
+                    bool active = in && (inf[cl] >> 31) != 0;
+                    if (active) active = ((Pb[(long long)(a >> 5) * sbV + t] >> (a & 31)) & 1u) != 0;
+                    if (__ballot(active) == 0) continue;
+                    uint32_t pw[WORDS], nw[WORDS];
+#pragma unroll
+                    for (int w = 0; w < WORDS; ++w) {
+                        pw[w] = active ? Pb[(long long)w * sbV + t] : 0u;
+                        nw[w] = active ? Nb[(long long)w * sbV + t] : 0u;
+                    }
+                    float acc = active ? accs[cl] : 0.0f;
+                    const float *row = rowbuf + RV_PAD + LC - ((az * WX + ay) * WX + ax);
+                    const int aw = a >> 5;
+                    const uint32_t above = ~((2u << (a & 31)) - 1u);   // bits of a's word above a
+#pragma unroll
+                    for (int w = 0; w < WORDS; ++w) {
+                        // b in P counts only for b > a
+                        const uint32_t pos = pw[w] & (w < aw ? 0u : (w > aw ? 0xFFFFFFFFu : above));
+                        const uint32_t neg = nw[w];
+                        const bool any_pos = __ballot(pos != 0u) != 0, any_neg = __ballot(neg != 0u) != 0;
+                        if (!any_pos && !any_neg) continue;
+                        if (!any_neg) {
+#pragma unroll
+                            for (int bb = 0; bb < 32; ++bb) {
+                                const int b = w * 32 + bb;
+                                if (b < C) {
+                                    const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
+                                    const int m = ((int)(pos << (31 - bb))) >> 31;
+                                    acc += __int_as_float(__float_as_int(row[off]) & m);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int bb = 0; bb < 32; ++bb) {
+                                const int b = w * 32 + bb;
+                                if (b < C) {
+                                    const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
+                                    const int v = __float_as_int(row[off]);
+                                    const int mp = ((int)(pos << (31 - bb))) >> 31, mn = ((int)(neg << (31 - bb))) >> 31;
+                                    acc += __int_as_float(v & mp);
+                                    acc -= __int_as_float(v & mn);
+                                }
+                            }
+                        }
+                    }
+                    if (active) accs[cl] = acc;
+                }
+                __syncthreads();
+            }
+    // ---- scores of the tile
+    for (int cl = lane; cl < NT; cl += 64) {
+        const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
+        const uint32_t v = inf[cl];
+        if (lz < tz && ly < ty && lx < tx && (v >> 31) != 0) {
+            const unsigned fg_cnt = v & 0x7FFFFFFFu;
+            const float acc = accs[cl];
+            score[vox(G, c0z + lz, c0y + ly, c0x + lx)] = G.norm_rank ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
+        }
+    }
+}
+
+static size_t up256r(size_t v) { return (v + 255) / 256 * 256; }
+
+bool rank_vm_supported(const Geo &G) {
+    return G.pz == G.py && G.py == G.px && (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9) &&
+           !G.count_pos_neg && G.layout == PPP_CONS_VOXEL_MAJOR;
+}
+
+size_t rank_vm_workspace_bytes(const ppp_box &sb, const Geo &G) {
+    const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
+    const size_t words = (size_t)(G.C + 31) / 32;
+    return 2 * up256r(words * sbV * 4) + up256r(sbV * 4) + up256r((size_t)G.V);
+}
+
+template <typename T>
+static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, float *score,
+                            const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const size_t sbV = (size_t)sX * sY * sZ;
+    const size_t words = (size_t)(G.C + 31) / 32;
+    char *p = (char *)work;
+    uint32_t *Pb = (uint32_t *)p;   p += up256r(words * sbV * 4);
+    uint32_t *Nb = (uint32_t *)p;   p += up256r(words * sbV * 4);
+    uint32_t *info = (uint32_t *)p; p += up256r(sbV * 4);
+    uint8_t *valid = (uint8_t *)p;
+    // the consensus box must hold every voxel of the volume within the radius of the score box
+    if (G.bz0 > (sb.z0 - G.rz > 0 ? sb.z0 - G.rz : 0) || G.by0 > (sb.y0 - G.ry > 0 ? sb.y0 - G.ry : 0) ||
+        G.bx0 > (sb.x0 - G.rx > 0 ? sb.x0 - G.rx : 0) ||
+        G.bz0 + G.bZ < (sb.z1 + G.rz < G.Z ? sb.z1 + G.rz : G.Z) ||
+        G.by0 + G.bY < (sb.y1 + G.ry < G.Y ? sb.y1 + G.ry : G.Y) ||
+        G.bx0 + G.bX < (sb.x1 + G.rx < G.X ? sb.x1 + G.rx : G.X))
+        return hipErrorInvalidValue;
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
+    PPP_GRID_CHECK((sbV + 255) / 256, 256);
+    rank_valid_kernel<T><<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(pred, ov, valid, G);
+    rank_masks_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, Pb, Nb, info, score, G);
+    constexpr int TZ = 8, TY = 8, TX = 8;
+    const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
+    const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
+    const long long n_blocks = (n_tiles + 7) / 8 * 8;
+    PPP_GRID_CHECK(n_blocks, 64);
+#define PPP_RV_CASE(P)                                                                                 \
+    case P:                                                                                            \
+        rank_vm_kernel<P, TZ, TY, TX><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                   \
+            S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x);                                   \
+        break;
+    switch (G.px) {
+        PPP_RV_CASE(3)
+        PPP_RV_CASE(5)
+        PPP_RV_CASE(7)
+        PPP_RV_CASE(9)
+    default:
+        return hipErrorNotSupported;
+    }
+#undef PPP_RV_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_vm(const void *pred, int dtype, const float *S, const uint8_t *ov, float *score,
+                          const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
+    if (!rank_vm_supported(G)) return hipErrorNotSupported;
+    return dtype == PPP_F16 ? launch_rv<__half>((const __half *)pred, S, ov, score, sb, work, G, s)
+                            : launch_rv<float>((const float *)pred, S, ov, score, sb, work, G, s);
+}
+
+}  // namespace ppp

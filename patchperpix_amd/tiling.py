@@ -147,6 +147,12 @@ class DeviceOps:
         return backend.rank_patches(pred, cons, ov if P.use_overlap else None, P,
                                     score_box=score_box)
 
+    def rank_on_voxel_major(self, P):
+        return backend.rank_vm_available(P)
+
+    def to_voxel_major(self, cons, P):
+        return backend.cons_to_voxel_major(cons, P)
+
     def patch_bits(self, pred, centres, thresh, P):
         return backend.patch_bits(pred, centres, thresh, P)
 
@@ -403,6 +409,14 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         P = params(bases_for_pairs(t) if keep_cons else bases_for_scores(t))
         with backend.host_timer("s1_consensus"):
             cons = ops.consensus(pred_local, ov_local, P)
+        if hasattr(ops, "to_voxel_major") and ops.rank_on_voxel_major(P):
+            # ranking and patch graph both read the voxel-major re-layout: make it once, drop
+            # the compact planes
+            with backend.host_timer("s1b_voxel_major"):
+                vm, P = ops.to_voxel_major(cons, P)
+            del cons
+            cons = vm
+            del vm
         with backend.host_timer("s2_rank"):
             sc = ops.rank_patches(pred_local, cons, ov_local, P,
                                   (z0 - lo, y0, x0, z1 - lo, y1, x1))

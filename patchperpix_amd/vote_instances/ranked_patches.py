@@ -50,6 +50,12 @@ def rank_patches_cuda(pred_affs, consensus_vote_array, patchshape, neighshape, o
     """ranked_patches.py:33-74: returns the (Z,Y,X) float32 score volume (device tensor)."""
     P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
     ov = _device_overlap(overlap_mask, pred_affs) if P.use_overlap else None
+    if P.cons_layout == backend.CONS_COMPACT and backend.rank_vm_available(P):
+        # row-stationary ranking on the voxel-major re-layout; the patch-graph stage needs the
+        # same re-layout and takes it from the consensus tensor (backend.patch_graph_auto)
+        vm, Pv = backend.cons_to_voxel_major(consensus_vote_array, P)
+        consensus_vote_array._ppp_vm = (vm, Pv)
+        return backend.rank_patches(pred_affs, vm, ov, Pv, score_box=kwargs.get("score_box"))
     return backend.rank_patches(pred_affs, consensus_vote_array, ov, P,
                                 score_box=kwargs.get("score_box"))
 

@@ -38,6 +38,12 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
     cons = backend.consensus(pred, ov, P)
     score = backend.rank_patches(pred, cons, ov, P)
     out = dict(cons=cons.cpu().numpy(), score=score.cpu().numpy(), P=P, pred=pred, cons_dev=cons)
+    if backend.rank_vm_available(P):
+        # the row-stationary ranking kernel on the voxel-major layout: same bits as the gather kernel
+        vm0, Pv0 = backend.cons_to_voxel_major(cons, P)
+        score_vm = backend.rank_patches(pred, vm0, ov, Pv0).cpu().numpy()
+        assert np.array_equal(out["score"].view(np.uint32), score_vm.view(np.uint32))
+        del vm0
     if pairs is not None and len(pairs):
         pd = _dev(torch, np.ascontiguousarray(pairs, dtype=np.uint32).view(np.int32))
         out["aff"] = backend.patch_graph(pred, cons, pd, P).cpu().numpy()          # row order
@@ -548,3 +554,36 @@ def test_device_mws_edges_and_loop_match_host_mws(name):
         want = {tuple(n): int(l) for n, l in zip(want_nodes, want_labels)}
         assert got == want, variant
         assert issued == want_n
+
+
+@pytest.mark.parametrize("ps,shape,cell", [((7, 7, 7), (40, 37, 45), 12), ((5, 5, 5), (33, 29, 70), 9),
+                                           ((9, 9, 9), (30, 27, 33), 13), ((3, 3, 3), (19, 18, 40), 6)])
+def test_rank_voxel_major_tiles_and_boxes(ps, shape, cell, torch_cuda):
+    """ppp_rank_patches_vm == ppp_rank_patches (gather kernel, pinned to goldens / oracle) on
+    volumes spanning several 8^3 centre tiles with ragged edges, with overlap voxels, for the
+    whole volume and for a score box inside a consensus box that is a proper tile."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    c = synth.make_case(shape, ps, seed=91, cell=[cell] * 3, overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    P = backend.make_params(shape, ps, **kw)
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    cons = backend.consensus(pred, ov, P)
+    want = backend.rank_patches(pred, cons, ov, P).cpu().numpy()
+    vm, Pv = backend.cons_to_voxel_major(cons, P)
+    got = backend.rank_patches(pred, vm, ov, Pv).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (want > 0).sum() > 100
+    del cons, vm
+    # a tile: centres [z0, z1) x ..., consensus box = the tile grown by the radius
+    r = ps[0] // 2
+    sb = (r + 2, r + 1, r + 3, shape[0] - r - 3, shape[1] - r - 2, shape[2] - r - 5)
+    box = (sb[0] - r, sb[1] - r, sb[2] - r, sb[3] + r, sb[4] + r, sb[5] + r)
+    Pt = backend.make_params(shape, ps, cons_box=box, **kw)
+    cons_t = backend.consensus(pred, ov, Pt)
+    vm_t, Pvt = backend.cons_to_voxel_major(cons_t, Pt)
+    got_t = backend.rank_patches(pred, vm_t, ov, Pvt, score_box=sb).cpu().numpy()
+    sl = tuple(slice(sb[i], sb[i + 3]) for i in range(3))
+    assert np.array_equal(got_t[sl].view(np.uint32), want[sl].view(np.uint32))
