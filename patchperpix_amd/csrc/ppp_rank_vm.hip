@@ -18,6 +18,9 @@
 // a for every centre, so each centre's float chain is exactly the reference's.  Accumulators live
 // in LDS between the steps of a centre.  The per-centre P / N bit masks and the closed-form
 // pair count come from a coalesced pre-pass over the prediction.
+#include <stdlib.h>
+#include <string.h>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(256)
 
 // ---- main kernel ---------------------------------------------------------------------------------
 template <int PS, int TZ, int TY, int TX>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
     rank_vm_kernel(const float *__restrict__ S, const uint32_t *__restrict__ Pb,
                    const uint32_t *__restrict__ Nb, const uint32_t *__restrict__ info,
                    const uint8_t *__restrict__ valid, float *__restrict__ score, const ppp_box sb,
@@ -95,9 +98,9 @@ __global__ void __launch_bounds__(64)
     constexpr int NT = TZ * TY * TX;
     __shared__ float rowbuf[W + 2 * RV_PAD];
     __shared__ float accs[NT];
-    __shared__ uint32_t inf[NT];
     constexpr int UB = (TZ + 2 * R) * (TY + 2 * R) * (TX + 2 * R);
-    __shared__ uint8_t uvalid[UB];
+    __shared__ uint32_t act_bits[(NT + 31) / 32];      // centre of the tile takes part
+    __shared__ uint32_t uvalid_bits[(UB + 63) / 64 * 2];   // voxel of the grown tile can be a first pixel
     const int lane = threadIdx.x;
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
     const long long sbV = (long long)sX * sY * sZ;
@@ -118,16 +121,17 @@ __global__ void __launch_bounds__(64)
         return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
     };
     bool any_active = false;
+    static_assert(NT % 64 == 0, "tile size must be a multiple of the wave size");
     for (int cl = lane; cl < NT; cl += 64) {
         const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
         uint32_t v = 0;
         if (lz < tz && ly < ty && lx < tx) v = info[sb_index(lz, ly, lx)];
-        inf[cl] = v;
+        const unsigned long long m = __ballot((v >> 31) != 0);
+        if (lane == 0) { act_bits[cl >> 5] = (uint32_t)m; act_bits[(cl >> 5) + 1] = (uint32_t)(m >> 32); }
         accs[cl] = 0.0f;
-        any_active |= (v >> 31) != 0;
+        any_active |= m != 0ull;
     }
-    if (__ballot(any_active) == 0) return;
-    __syncthreads();
+    if (!any_active) return;
 
     const long long rsY = G.bX, rsZ = (long long)G.bX * G.bY;
     // voxels of the tile grown by the radius, clipped to the consensus box (rows outside it are
@@ -135,35 +139,57 @@ __global__ void __launch_bounds__(64)
     const int uz0 = max(c0z - R, G.bz0), uz1 = min(c0z + tz - 1 + R, G.bz0 + G.bZ - 1);
     const int uy0 = max(c0y - R, G.by0), uy1 = min(c0y + ty - 1 + R, G.by0 + G.bY - 1);
     const int ux0 = max(c0x - R, G.bx0), ux1 = min(c0x + tx - 1 + R, G.bx0 + G.bX - 1);
-    {
-        const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
-        for (int k = lane; k < nu; k += 64)
-            uvalid[k] = valid[vox(G, uz0 + k / (nuy * nux), uy0 + (k / nux) % nuy, ux0 + k % nux)];
+    const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
+    for (int k0 = 0; k0 < nu; k0 += 64) {
+        const int k = k0 + lane;
+        const bool ok = k < nu && valid[vox(G, uz0 + k / (nuy * nux), uy0 + (k / nux) % nuy, ux0 + k % nux)] != 0;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) { uvalid_bits[k0 >> 5] = (uint32_t)m; uvalid_bits[(k0 >> 5) + 1] = (uint32_t)(m >> 32); }
     }
     __syncthreads();
-    int uk = -1;
-    for (int uz = uz0; uz <= uz1; ++uz)
-        for (int uy = uy0; uy <= uy1; ++uy)
-            for (int ux = ux0; ux <= ux1; ++ux) {
-                ++uk;
-                if (uvalid[uk] == 0) continue;   // (wave-uniform: every lane reads the same byte)
+    // next voxel >= k of the grown tile that can be a first pixel (nu if none); wave-uniform
+    auto next_valid = [&](int k) -> int {
+        while (k < nu) {
+            const uint32_t wbits = uvalid_bits[k >> 5] >> (k & 31);
+            if (wbits) return k + __builtin_ctz(wbits);
+            k = (k | 31) + 1;
+        }
+        return nu;
+    };
+    auto row_src = [&](int k) -> const float * {
+        const int uz = uz0 + k / (nuy * nux), uy = uy0 + (k / nux) % nuy, ux = ux0 + k % nux;
+        return S + (((long long)(uz - G.bz0) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
+    };
+    // software pipeline: the row of the next voxel travels HBM -> registers while the current
+    // row (in LDS) is consumed
+    float st[NST];
+    int uk = __builtin_amdgcn_readfirstlane(next_valid(0));
+    if (uk < nu) {
+        const float *src = row_src(uk);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = lane + i * 64;
+            if (e < W) rowbuf[RV_PAD + e] = src[e];
+        }
+    }
+    __syncthreads();
+    while (uk < nu) {
+                const int uz = uz0 + uk / (nuy * nux), uy = uy0 + (uk / nux) % nuy, ux = ux0 + uk % nux;
+                const int uk_next = __builtin_amdgcn_readfirstlane(next_valid(uk + 1));
+                if (uk_next < nu) {
+                    const float *src = row_src(uk_next);
+#pragma unroll
+                    for (int i = 0; i < NST; ++i) {
+                        const int e = lane + i * 64;
+                        st[i] = e < W ? src[e] : 0.0f;
+                    }
+                }
                 // pixels a of this voxel whose centre c = u + R - a lies in the tile
                 const int az0 = max(0, uz + R - (c0z + tz - 1)), az1 = min(PS - 1, uz + R - c0z);
                 const int ay0 = max(0, uy + R - (c0y + ty - 1)), ay1 = min(PS - 1, uy + R - c0y);
                 const int ax0 = max(0, ux + R - (c0x + tx - 1)), ax1 = min(PS - 1, ux + R - c0x);
                 const int nz = az1 - az0 + 1, ny = ay1 - ay0 + 1, nx = ax1 - ax0 + 1;
-                if (nz <= 0 || ny <= 0 || nx <= 0) continue;
-                const int n_box = nz * ny * nx;
-                // ---- stage the row of u
-                {
-                    const float *src = S + (((long long)(uz - G.bz0) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
-#pragma unroll
-                    for (int i = 0; i < NST; ++i) {
-                        const int e = lane + i * 64;
-                        if (e < W) rowbuf[RV_PAD + e] = src[e];
-                    }
-                }
-                __syncthreads();
+                const int n_box = (nz <= 0 || ny <= 0 || nx <= 0) ? 0 : nz * ny * nx;
                 for (int i0 = 0; i0 < n_box; i0 += 64) {
                     const int i = i0 + lane;
                     const bool in = i < n_box;
@@ -173,7 +199,7 @@ __global__ void __launch_bounds__(64)
                     const int cl = (lz * TY + ly) * TX + lx;
                     const int a = (az * PS + ay) * PS + ax;
                     const long long t = sb_index(lz, ly, lx);
-                    bool active = in && (inf[cl] >> 31) != 0;
+                    bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
                     if (active) active = ((Pb[(long long)(a >> 5) * sbV + t] >> (a & 31)) & 1u) != 0;
                     if (__ballot(active) == 0) continue;
                     uint32_t pw[WORDS], nw[WORDS];
@@ -219,14 +245,23 @@ __global__ void __launch_bounds__(64)
                     }
                     if (active) accs[cl] = acc;
                 }
+                // ---- publish the next row
                 __syncthreads();
-            }
+                if (uk_next < nu) {
+#pragma unroll
+                    for (int i = 0; i < NST; ++i) {
+                        const int e = lane + i * 64;
+                        if (e < W) rowbuf[RV_PAD + e] = st[i];
+                    }
+                }
+                __syncthreads();
+                uk = uk_next;
+    }
     // ---- scores of the tile
     for (int cl = lane; cl < NT; cl += 64) {
         const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
-        const uint32_t v = inf[cl];
-        if (lz < tz && ly < ty && lx < tx && (v >> 31) != 0) {
-            const unsigned fg_cnt = v & 0x7FFFFFFFu;
+        if (lz < tz && ly < ty && lx < tx && ((act_bits[cl >> 5] >> (cl & 31)) & 1u)) {
+            const unsigned fg_cnt = info[sb_index(lz, ly, lx)] & 0x7FFFFFFFu;
             const float acc = accs[cl];
             score[vox(G, c0z + lz, c0y + ly, c0x + lx)] = G.norm_rank ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
         }
@@ -268,15 +303,26 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     PPP_GRID_CHECK((sbV + 255) / 256, 256);
     rank_valid_kernel<T><<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(pred, ov, valid, G);
     rank_masks_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, Pb, Nb, info, score, G);
-    constexpr int TZ = 8, TY = 8, TX = 8;
+    // tile of centres per wave: 8 x 8 x 8 by default; PPP_RANK_TILE=8x8x16 doubles it along x
+    // (fewer row stagings per centre and fuller waves, half as many tiles to spread over the CUs)
+    static int long_tiles = -1;
+    if (long_tiles < 0) {
+        const char *e = getenv("PPP_RANK_TILE");
+        long_tiles = (e && strcmp(e, "8x8x16") == 0) ? 1 : 0;
+    }
+    const int TZ = 8, TY = 8, TX = long_tiles ? 16 : 8;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64);
 #define PPP_RV_CASE(P)                                                                                 \
     case P:                                                                                            \
-        rank_vm_kernel<P, TZ, TY, TX><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                   \
-            S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x);                                   \
+        if (long_tiles)                                                                                \
+            rank_vm_kernel<P, 8, 8, 16><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                 \
+                S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x);                               \
+        else                                                                                           \
+            rank_vm_kernel<P, 8, 8, 8><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                  \
+                S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x);                               \
         break;
     switch (G.px) {
         PPP_RV_CASE(3)
