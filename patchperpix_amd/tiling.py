@@ -90,6 +90,9 @@ class LocalComm:
     def all_gather(self, t):
         return t.reshape((1,) + tuple(t.shape))
 
+    def all_gather_slabs(self, vol, ranges):
+        return vol
+
 
 class TorchDistComm:
     """torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU)."""
@@ -129,6 +132,38 @@ class TorchDistComm:
         parts = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(parts, src, group=self.group)
         return torch.stack(parts, 0).to(t.device)
+
+    def all_gather_slabs(self, vol, ranges):
+        """vol (Z, ...) holds valid data on this rank's z-range only; ranges = every rank's
+        (z0, z1) in rank order.  One all-gather of the owned slabs (padded to the thickest one)
+        completes it on every rank: each rank sends its share once, instead of the full-volume
+        SUM all-reduce that moves ~2x the volume per rank and adds zeros."""
+        import torch
+        if self.world == 1:
+            return vol
+        if vol.dtype == torch.int16:
+            # neither RCCL nor gloo moves 16-bit integers: a gather is type-agnostic, send bytes
+            self.all_gather_slabs(vol.view(torch.uint8), ranges)
+            return vol
+        zmax = max(b - a for a, b in ranges)
+        a, b = ranges[self.rank]
+        send = torch.zeros((zmax,) + tuple(vol.shape[1:]), dtype=vol.dtype, device=vol.device)
+        send[:b - a] = vol[a:b]
+        if self.via_host and send.is_cuda:
+            send_h = send.cpu()
+            parts = [torch.empty_like(send_h) for _ in range(self.world)]
+            self.dist.all_gather(parts, send_h, group=self.group)
+            for r, (ra, rb) in enumerate(ranges):
+                if r != self.rank:
+                    vol[ra:rb] = parts[r][:rb - ra].to(vol.device)
+            return vol
+        recv = torch.empty((self.world * zmax,) + tuple(send.shape[1:]), dtype=vol.dtype, device=vol.device)
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)     # concatenated along z
+        recv = recv.view((self.world, zmax) + tuple(send.shape[1:]))
+        for r, (ra, rb) in enumerate(ranges):
+            if r != self.rank:
+                vol[ra:rb] = recv[r, :rb - ra]
+        return vol
 
 
 # ------------------------------------------------------------------------------------------
@@ -380,6 +415,16 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         return backend.make_params(local_shape, ps, cons_box=box, origin=(lo, 0, 0), **flags)
 
     Pg = backend.make_params(shape, ps, **flags)          # global geometry (pairs, labels)
+    # every rank's contiguous z-range (None when a rank's slabs are not contiguous): the owned
+    # parts of the score / instance volumes are exchanged by ONE all-gather of slabs
+    rank_ranges = None
+    if comm.world > 1:
+        contiguous = all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
+        mine_r = torch.tensor([my_slabs[0][0], my_slabs[-1][1] if contiguous else -1],
+                              dtype=torch.int64, device=dev)
+        rr = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
+        if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
+            rank_ranges = rr
     ov_local = torch.from_numpy(
         np.ascontiguousarray((overlap_mask[lo:hi] > 0).astype(np.uint8))).to(dev)
     keep_cons = len(my_tiles) == 1 and kw.get("_keep_cons", True)
@@ -424,7 +469,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         if keep_cons:
             kept[t] = (cons, P)
         del cons, sc
-    comm.all_reduce_sum(score_dev)
+    if rank_ranges is not None:
+        comm.all_gather_slabs(score_dev, rank_ranges)
+    else:
+        comm.all_reduce_sum(score_dev)
 
     # ---- stage B: ranking, greedy cover, thinning (global; identical on every rank) -------
     # The ranked list stays on the device (it has one entry per foreground voxel of the GLOBAL
@@ -469,12 +517,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         shard_env = os.environ.get("PPP_COVER_SHARDED", "1")     # "force": also with one rank
         if (comm.world > 1 or shard_env == "force") and hasattr(ops, "cover_shard") and \
                 kw.get("_shard_cover", shard_env != "0"):
-            mine_r = torch.tensor([my_slabs[0][0], my_slabs[-1][1]], dtype=torch.int64, device=dev)
-            ranges = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
-            ok = all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in ranges) and \
-                all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)) and \
-                all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
-            if not ok:
+            # (decided from gathered data only, so that every rank takes the same branch)
+            ranges = rank_ranges if comm.world > 1 else [(my_slabs[0][0], my_slabs[-1][1])]
+            if ranges is not None and not all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in ranges):
                 ranges = None
         with backend.host_timer("s3_cover"):
             from .vote_instances import foreground_cover as fc
@@ -689,9 +734,16 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             ops.paint(pred_local, loc.contiguous(), labels[near].contiguous(), inst_l, Pl)
             inst_dev[z0:z1] = inst_l[z0 - lo:z1 - lo]
             del inst_l
-        comm.all_reduce_sum(inst_dev)
-        # ids fit 16 bits (checked above): ship half the bytes to the host
-        instances = inst_dev.to(torch.int16).cpu().numpy().view(np.uint16)
+        # ids fit 16 bits (checked above): half the bytes on the wire and to the host
+        inst16 = inst_dev.to(torch.int16)
+        del inst_dev
+        if rank_ranges is not None:
+            comm.all_gather_slabs(inst16, rank_ranges)
+        else:
+            inst32 = inst16.to(torch.int32) & 0xFFFF
+            comm.all_reduce_sum(inst32)
+            inst16 = inst32.to(torch.int16)
+        instances = inst16.cpu().numpy().view(np.uint16)
     return instances, foreground.astype(np.uint8)
 
 

@@ -329,19 +329,9 @@ def do_all(aff_file, patchshape=np.array([1, 25, 25]), **kwargs):
 
 def write_result(out_fn, datasets):
     """HDF5 via h5py when it is importable (the reference's format, vote_instances.py:542-554),
-    otherwise an ``.npz`` next to it carrying the same dataset names."""
-    try:
-        import h5py
-    except ImportError:
-        np.savez_compressed(os.path.splitext(out_fn)[0] + ".npz", **datasets)
-        logger.warning("h5py not available: wrote %s.npz instead of %s",
-                       os.path.splitext(out_fn)[0], out_fn)
-        return
-    with h5py.File(out_fn, 'w') as f2:
-        for key, data in datasets.items():
-            f2.create_dataset(key, data=data, compression='gzip')
-            f2[key].attrs['offset'] = (0, 0, 0)
-            f2[key].attrs['resolution'] = (1, 1, 1)
+    otherwise a zarr store ``<stem>.zarr`` with the same dataset names, dtypes and attributes
+    (io_hdflike.write_datasets)."""
+    return io_hdflike.write_datasets(out_fn, datasets)
 
 
 def main(**kwargs):

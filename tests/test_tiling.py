@@ -338,3 +338,53 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
         assert np.array_equal(inst, want), "rank %d differs" % r
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
         assert notes[0] == world and notes[1] > 0
+
+
+RCCL_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from patchperpix_amd import synth, tiling, backend, flags as flagsets
+local = int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)                  # one rank per GPU
+dist.init_process_group("nccl")               # "nccl" is RCCL on ROCm
+rank, world = dist.get_rank(), dist.get_world_size()
+shape, ps = (72, 26, 30), (7, 7, 7)
+c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+kw = dict(flagsets.FLYLIGHT)
+slabs = tiling.plan_slabs(shape[0], world)
+mine = tiling.slabs_of_rank(slabs, rank, world)
+lo, hi = tiling.local_range(mine, shape[0], ps)
+pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi])).cuda()
+inst, fg = tiling.assemble(pred_local, lo, shape, c["foreground"].copy(), c["foreground"].copy(),
+                           c["numinst"], list(ps), mine, comm=tiling.TorchDistComm(), **kw)
+np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl(tmp_path):
+    """One rank per GPU over RCCL (backend "nccl"): z-slabs with halos, sharded cover with zone
+    MIN all-reduces, all-gather of owned score / instance slabs, merged label forests, replicated
+    thinning and mutex watershed -- same instance map as one process.  Needs two GPUs in the box
+    (skipped on the single-GPU development boxes; the same path runs there over gloo, above)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from patchperpix_amd import flags as flagsets
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    shape, ps = (72, 26, 30), (7, 7, 7)
+    c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), list(ps), **dict(flagsets.FLYLIGHT, _n_slabs=1))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(repo=REPO, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29597", OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                           "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+                           "29597", str(script)], env=env, timeout=900)
+    assert want.any()
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / ("inst_rank%d.npy" % r)), want), "rank %d differs" % r
