@@ -116,21 +116,73 @@ def decode_volume(decoder, pred_code, pred_fg, batch_size=1024, device="cuda", o
     return out.reshape((C,) + tuple(fg.shape))
 
 
+def map_decoder_state(state, decoder):
+    """Reference checkpoint -> PatchDecoder state dict, explicitly and completely.
+
+    The reference keeps the decoder as ``UnetModelWrapper.decoder = Autoencoder(...)``
+    (torch_model.py:145): its parameters are the checkpoint keys that contain ``decoder.``.  Blocks
+    are funlib.learn.torch ``ConvPass`` modules (parameters ``<block>.conv_pass.<n>.{weight,bias}``,
+    n counting convolutions AND activations, exactly like the ``Sequential`` built here) and
+    ``Upsample`` modules in ``resize_conv`` mode (one convolution each; its sub-module names on the
+    ``ppp`` branch are not known here, so the single weight / bias pair under ``up.<i>.`` is taken
+    whatever it is called).  The encoder half (``down_conv``, ``down``, ``to_code``) is not used by
+    decode and is dropped by name.  Anything else that is left over, missing, or of the wrong
+    shape raises: a decoder must never run on partly random weights."""
+    dec = {k.split("decoder.", 1)[1]: v for k, v in state.items() if "decoder." in k}
+    if not dec:
+        raise KeyError("checkpoint holds no `decoder.` parameters")
+    dec = {k: v for k, v in dec.items() if not k.startswith(("down_conv.", "down.", "to_code."))}
+    own = decoder.state_dict()
+    out, used = {}, set()
+
+    def take(src, dst):
+        if src not in dec:
+            raise KeyError("decoder parameter %s (for %s) is not in the checkpoint" % (src, dst))
+        if tuple(dec[src].shape) != tuple(own[dst].shape):
+            raise ValueError("decoder parameter %s has shape %s, expected %s" %
+                             (src, tuple(dec[src].shape), tuple(own[dst].shape)))
+        out[dst] = dec[src]
+        used.add(src)
+
+    for dst in own:
+        parts = dst.split(".")
+        if parts[0] == "from_code":                       # from_code.<n>.weight
+            take("from_code.conv_pass.%s.%s" % (parts[1], parts[2]), dst)
+        elif parts[0] == "up_conv":                       # up_conv.<i>.<n>.weight
+            take("up_conv.%s.conv_pass.%s.%s" % (parts[1], parts[2], parts[3]), dst)
+        elif parts[0] == "up":                            # up.<i>.1.<n>.weight: the stage's one conv
+            cands = [k for k in dec if k.startswith("up.%s." % parts[1]) and k.endswith("." + parts[-1])]
+            if len(cands) != 1:
+                raise KeyError("expected one %s under decoder.up.%s, found %s" % (parts[-1], parts[1], cands))
+            take(cands[0], dst)
+        else:
+            raise KeyError("unexpected parameter %s in PatchDecoder" % dst)
+    left = sorted(set(dec) - used)
+    if left:
+        raise KeyError("checkpoint decoder parameters without a counterpart: %s" % left)
+    return out
+
+
 def decode(**config):
     """decode(**cfg) of the reference (decode.py:69-130): load the decoder weights, decode every
     sample, write ``aff_key`` as float16."""
     torch = _torch()
     from .vote_instances import io_hdflike
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if not torch.cuda.is_available():
+        raise RuntimeError("patchperpix_amd.decode needs a GPU (there is no CPU fallback)")
+    device = torch.device("cuda")
     ae = dict(config.get("autoencoder") or config.get("included_ae_config") or {})
     ae.setdefault("code_units", config["code_units"])
     ae.setdefault("input_shape_squeezed",
                   tuple(int(p) for p in config["patchshape"] if int(p) > 1))
+    if ae.get("padding", "same") != "same":
+        raise NotImplementedError("decoder padding %r: only 'same' is restated" % ae.get("padding"))
     decoder = PatchDecoder(ae)
     ckpt = torch.load(config["checkpoint_file"], map_location=device)
     state = ckpt["swa_model_state_dict" if config.get("use_swa") else "model_state_dict"]
-    dec_state = {k.split("decoder.", 1)[1]: v for k, v in state.items() if "decoder." in k}
-    decoder.load_state_dict(dec_state, strict=False)
+    if config.get("use_swa"):    # AveragedModel prefixes every key with `module.` and adds n_averaged
+        state = {k.split("module.", 1)[1]: v for k, v in state.items() if k.startswith("module.")}
+    decoder.load_state_dict(map_decoder_state(state, decoder), strict=True)
     for sample in config["samples"]:
         with io_hdflike.open_container(sample, "r") as f:
             code = np.array(f[config["code_key"]])
@@ -139,10 +191,17 @@ def decode(**config):
         pred = decode_volume(decoder, code, fg, config.get("decode_batch_size", 1024), device)
         name = os.path.basename(sample).split(".")[0]
         outfn = os.path.join(config["output_folder"], name + "." + config["output_format"])
-        with io_hdflike.open_container(outfn, "a" if os.path.exists(outfn) else "w") as f:
-            data = pred.cpu().numpy().astype(np.float16)
-            if config["output_format"] == "zarr":
-                f.create(config["aff_key"], shape=data.shape, dtype=np.float16)
-                f[config["aff_key"]][:] = data
-            else:
+        data = pred.cpu().numpy().astype(np.float16)
+        if config["output_format"] == "zarr":
+            with io_hdflike.open_container(outfn, "a" if os.path.exists(outfn) else "w") as f:
+                # decode.py:104-109: no chunks / compressor given -> the container's defaults
+                ds = f.create(config["aff_key"], shape=data.shape, dtype=np.float16,
+                              chunks=(data.shape[0],) + tuple(min(int(s), 64) for s in data.shape[1:]))
+                ds.attrs["offset"] = [0] * len(config.get("voxel_size", [1] * (data.ndim - 1)))
+                ds.attrs["resolution"] = list(config.get("voxel_size", [1] * (data.ndim - 1)))
+                ds[:] = data
+        elif config["output_format"] == "hdf":
+            with io_hdflike.open_container(outfn, "a" if os.path.exists(outfn) else "w") as f:
                 f.create_dataset(config["aff_key"], data=data, compression="gzip")
+        else:
+            raise NotImplementedError(config["output_format"])

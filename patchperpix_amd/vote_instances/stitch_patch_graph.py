@@ -22,23 +22,26 @@ logger = logging.getLogger(__name__)
 
 
 def replace(array, old_values, new_values):
-    values_map = np.arange(int(array.max() + 1), dtype=new_values.dtype)
-    values_map[old_values] = new_values
-    return values_map[array]
+    """Relabel: every occurrence of old_values[i] becomes new_values[i] (lookup table over the
+    value range of `array`; same contract as stitch_patch_graph.py:38-43)."""
+    new_values = np.asarray(new_values)
+    lut = np.arange(int(np.max(array)) + 1).astype(new_values.dtype)
+    np.put(lut, np.asarray(old_values, dtype=np.int64), new_values)
+    return np.take(lut, array)
 
 
 def clean_mask(mask, structure, size):
-    """stitch_patch_graph.py:46-57: drop connected components of at most `size` voxels."""
-    labeled = ndimage.label(mask, structure)[0]
-    labels, counts = np.unique(labeled, return_counts=True)
-    labels = labels[counts <= size]
-    labeled = replace(labeled, np.array(labels), np.array([0] * len(labels)))
-    logger.info('removing %i of small components.' % len(labels))
-    return labeled > 0
+    """Mask without its connected components of at most `size` voxels
+    (stitch_patch_graph.py:46-57; `structure` is scipy.ndimage's connectivity)."""
+    labeled, n = ndimage.label(mask, structure)
+    big = np.bincount(labeled.ravel(), minlength=n + 1) > size
+    big[0] = False
+    logger.info("removing %i of small components.", int(n - np.count_nonzero(big)))
+    return big[labeled]
 
 
 def get_offset_str(offset):
-    return "_".join(str(off) for off in offset)
+    return "_".join("%s" % o for o in offset)
 
 
 def get_offsets(total_shape, chunksize):
@@ -52,71 +55,60 @@ def get_offsets(total_shape, chunksize):
 
 def load_input(io, key, offset, context, overlap, output_shape, padding=True,
                padding_mode='constant'):
-    """stitch_patch_graph.py:443-516: read block + margin, optionally padding at the borders.
-    Returns (data, padded margin per axis)."""
-    starts = [off - context[i] - overlap[i] for i, off in enumerate(offset)]
-    stops = [off + output_shape[i] + overlap[i] + context[i] for i, off in enumerate(offset)]
-    shape = io.shape[1:] if io.channel_order is not None else io.shape
-    unsqueezed = len(shape) == 2
-    if unsqueezed:
-        shape = (1,) + tuple(shape)
-    padded = np.array(context) + np.array(overlap)
-    if np.any(np.array(starts) < 0):
-        padded[np.array(starts) < 0] = 0
-    pad_left = pad_right = None
-    if padding:
-        if any(s < 0 for s in starts):
-            pad_left = tuple(abs(s) if s < 0 else 0 for s in starts)
-            starts = [max(0, s) for s in starts]
-        if any(stop > shape[i] for i, stop in enumerate(stops)):
-            pad_right = tuple(stop - shape[i] if stop > shape[i] else 0
-                              for i, stop in enumerate(stops))
-            stops = [min(shape[i], stop) for i, stop in enumerate(stops)]
-    else:
-        starts = list(np.maximum([0, 0, 0], starts))
-        stops = list(np.minimum(shape, stops))
-    if unsqueezed:
-        del starts[0]
-        del stops[0]
-    bb = tuple(slice(int(a), int(b)) for a, b in zip(starts, stops))
-    if io.channel_order is not None:
+    """One block of `key` with its margin (stitch_patch_graph.py:443-516): the window
+    [offset - context - overlap, offset + output_shape + overlap + context) per axis, read where it
+    intersects the array and -- with ``padding`` -- padded where it does not.  Returns
+    (data, margin) where margin = context + overlap, 0 on axes whose window starts before the
+    array (the reference's convention for locating the block inside the returned data)."""
+    has_channels = io.channel_order is not None
+    full = tuple(io.shape[1:] if has_channels else io.shape)
+    flat = len(full) == 2                       # 2-d data: a z axis of one slice is implied
+    if flat:
+        full = (1,) + full
+    full = np.array(full)
+    margin = np.array(context) + np.array(overlap)
+    lo = np.array(offset) - margin
+    hi = np.array(offset) + np.array(output_shape) + margin
+    before, after = np.maximum(-lo, 0), np.maximum(hi - full, 0)
+    margin = np.where(lo < 0, 0, margin)
+    lo, hi = np.maximum(lo, 0), np.minimum(hi, full)
+    spatial = [slice(int(a), int(b)) for a, b in zip(lo, hi)]
+    if flat:
+        spatial = spatial[1:]
+    bb = tuple(spatial)
+    if has_channels:
         try:
             bb = (io.channel_order[io.keys.index(key)],) + bb
         except Exception:
             pass
     data = io.read(bb, key)
-    if unsqueezed:
+    if flat:
         data = np.expand_dims(data, axis=1)
-    if pad_left is not None or pad_right is not None:
-        pad_left = (0, 0, 0) if pad_left is None else pad_left
-        pad_right = (0, 0, 0) if pad_right is None else pad_right
-        pad_width = tuple((pl, pr) for pl, pr in zip(pad_left, pad_right))
-        if io.channel_order is not None:
-            pad_width = ((0, 0),) + pad_width
-        data = np.pad(data, pad_width, mode=padding_mode)
-    return data, padded
+    if padding and (before.any() or after.any()):
+        widths = [(int(b), int(a)) for b, a in zip(before, after)]
+        if has_channels:
+            widths = [(0, 0)] + widths
+        data = np.pad(data, tuple(widths), mode=padding_mode)
+    return data, margin
 
 
 def verify_shape(offset, output, shape, chunksize):
-    """stitch_patch_graph.py:519-551: crop a block result to the volume."""
-    tmp_channel = offset[0]
-    offset = np.array(offset[1:])
-    actual = np.array(output.shape)
-    overlap = ((actual - np.array(chunksize)) / 2).astype(int)
-    starts = (offset - overlap).astype(int)
-    if np.any(starts < 0):
-        bb = tuple(slice(a, b) for a, b in
-                   zip(np.abs(np.minimum(np.zeros(len(offset), dtype=int), starts)), actual))
-        output = output[bb]
-    stops = offset + np.array(chunksize) + overlap
-    if np.any(stops > np.array(shape)):
-        bb = tuple(slice(0, dim - off if stop > dim else None)
-                   for stop, dim, off in zip(stops, shape, offset))
-        output = output[bb]
-    starts = np.maximum(np.zeros(len(offset), dtype=int), starts)
-    bounding_box = (slice(tmp_channel, tmp_channel + 1),) + tuple(
-        slice(s, s + o) for s, o in zip(starts, output.shape))
-    return np.reshape(output, (1,) + output.shape), bounding_box
+    """Fit a block result (with its overlap on every side) into the volume
+    (stitch_patch_graph.py:519-551).  offset = (channel, z, y, x); returns (output[None], box)."""
+    channel, origin = offset[0], np.array(offset[1:])
+    chunk, dims = np.array(chunksize), np.array(shape)
+    overlap = ((np.array(output.shape) - chunk) / 2).astype(int)
+    first = (origin - overlap).astype(int)
+    if (first < 0).any():                       # the block sticks out in front: drop that part
+        output = output[tuple(slice(int(max(0, -f)), None) for f in first)]
+    last = origin + chunk + overlap
+    if (last > dims).any():                     # ... or behind (the reference cuts at dim - origin)
+        output = output[tuple(slice(0, int(d - o)) if l > d else slice(0, None)
+                              for l, d, o in zip(last, dims, origin))]
+    first = np.maximum(first, 0)
+    box = (slice(channel, channel + 1),) + tuple(slice(int(f), int(f) + n)
+                                                 for f, n in zip(first, output.shape))
+    return output[np.newaxis], box
 
 
 def write_output(io_out, output, output_bounding_box):

@@ -27,19 +27,21 @@ logger = logging.getLogger(__name__)
 
 
 def replace(array, old_values, new_values):
-    values_map = np.arange(int(array.max() + 1), dtype=new_values.dtype)
-    values_map[old_values] = new_values
-    return values_map[array]
+    """Relabel through a lookup table over the value range of `array` (vote_instances.py:41-46)."""
+    new_values = np.asarray(new_values)
+    lut = np.arange(int(np.max(array)) + 1).astype(new_values.dtype)
+    np.put(lut, np.asarray(old_values, dtype=np.int64), new_values)
+    return np.take(lut, array)
 
 
 def merge_dicts(sink, source):
-    if not isinstance(sink, dict) or not isinstance(source, dict):
+    """Recursive update of `sink` with `source` (nested dicts are merged, everything else is
+    overwritten); returns `sink` (vote_instances.py:49-58)."""
+    if not (isinstance(sink, dict) and isinstance(source, dict)):
         raise TypeError('Args to merge_dicts should be dicts')
-    for k, v in source.items():
-        if isinstance(source[k], dict) and isinstance(sink.get(k), dict):
-            sink[k] = merge_dicts(sink[k], v)
-        else:
-            sink[k] = v
+    for key, value in source.items():
+        both_dicts = isinstance(value, dict) and isinstance(sink.get(key), dict)
+        sink[key] = merge_dicts(sink[key], value) if both_dicts else value
     return sink
 
 
@@ -283,18 +285,15 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
 
 
 def do_block(block, foreground, mask, numinst, **kwargs):
-    """vote_instances.py:455-483."""
-    patchshape = kwargs['patchshape']
-    del kwargs['patchshape']
-    if type(patchshape) != np.ndarray:
-        patchshape = np.array(patchshape)
-    res = to_instance_seg(block, foreground, mask, numinst, patchshape, **kwargs)
+    """One block of a blockwise run (vote_instances.py:455-483): the intermediates when asked
+    for, otherwise the instance map without its patch-radius border."""
+    patchshape = np.asarray(kwargs.pop('patchshape'))
+    result = to_instance_seg(block, foreground, mask, numinst, patchshape, **kwargs)
     if kwargs.get('return_intermediates'):
-        return res
-    instances, _ = res
-    rad = np.array([p // 2 for p in patchshape])
-    slices = tuple(slice(r, d - r) for r, d in zip(rad, instances.shape))
-    return instances[slices]
+        return result
+    instances = result[0]
+    inner = tuple(slice(int(p) // 2, n - int(p) // 2) for p, n in zip(patchshape, instances.shape))
+    return instances[inner]
 
 
 def do_all(aff_file, patchshape=np.array([1, 25, 25]), **kwargs):
@@ -335,13 +334,13 @@ def write_result(out_fn, datasets):
 
 
 def main(**kwargs):
-    """vote_instances.py:557-604."""
-    if 'check_required' in kwargs:
-        args = get_arguments(check_required=kwargs['check_required'], argv=[])
-    else:
-        args = get_arguments(argv=None if not kwargs else [])
-    args = vars(args)
-    if len(kwargs) > 0:
+    """Whole-volume driver (vote_instances.py:557-604): command-line arguments overridden by
+    keyword arguments; ``affinities`` is one prediction file or a directory of ``*.hdf``
+    files, otherwise ``<basedir>/<mode>/processed/<checkpoint>/*.hdf``."""
+    from_cli = not kwargs
+    required = kwargs['check_required'] if 'check_required' in kwargs else True
+    args = vars(get_arguments(check_required=required, argv=None if from_cli else []))
+    if kwargs:
         args = merge_dicts(args, kwargs)
     if 'check_required' in kwargs:
         assert type(args['patchshape']) in [np.ndarray, tuple, list], \
@@ -352,23 +351,22 @@ def main(**kwargs):
         args['context'] = init_cuda()
     os.makedirs(args['result_folder'], exist_ok=True)
 
-    affinities = args['affinities']
-    aff_files = []
-    if affinities is not None:
-        if affinities.endswith(".zarr") or os.path.isfile(affinities):
-            do_all(affinities, **args)
-            return
-        elif os.path.isdir(affinities):
-            aff_files = glob.glob(os.path.join(affinities, "*.hdf"))
-        else:
-            raise RuntimeError("affinities (%s) should be file or dir" % affinities)
+    source = args['affinities']
+    if source is not None and (source.endswith(".zarr") or os.path.isfile(source)):
+        do_all(source, **args)          # (the reference returns here without delete_cuda, :584-586)
+        return
+    if source is not None:
+        if not os.path.isdir(source):
+            raise RuntimeError("affinities (%s) should be file or dir" % source)
+        pattern = os.path.join(source, "*.hdf")
     elif args['mode'] is not None and args['checkpoint'] is not None:
-        aff_files = glob.glob(os.path.join(args['basedir'], args['mode'], "processed",
-                                           args['checkpoint'], "*.hdf"))
+        pattern = os.path.join(args['basedir'], args['mode'], "processed", args['checkpoint'], "*.hdf")
+    else:
+        pattern = None
     if args.get('parallel'):
         raise NotImplementedError
-    for fl in aff_files:
-        do_all(fl, **args)
+    for aff_file in (glob.glob(pattern) if pattern else []):
+        do_all(aff_file, **args)
     delete_cuda(args.get('context'))
 
 

@@ -200,3 +200,47 @@ def test_th05_quotient(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
     out = subprocess.check_output([exe]).decode().split()
     assert int(out[0]) == 201326593 and int(out[1]) == 0
+
+
+def test_blockwise_io_helpers():
+    """load_input / verify_shape / clean_mask / replace / merge_dicts (the helpers the reference
+    package re-exports, vote_instances/__init__.py:2): checked against straightforward NumPy
+    constructions of what they must return."""
+    from scipy import ndimage
+    from patchperpix_amd.vote_instances import stitch_patch_graph as spg
+    from patchperpix_amd.vote_instances.vote_instances import merge_dicts, replace
+    rng = np.random.default_rng(0)
+
+    class IO:
+        def __init__(self, a, channel_order):
+            self.a, self.shape, self.channel_order, self.keys = a, a.shape, channel_order, ["k"]
+
+        def read(self, bb, key):
+            return np.array(self.a[bb])
+
+    vol = rng.random((3, 20, 22, 24))
+    big = np.pad(vol, ((0, 0), (3, 3), (3, 3), (3, 3)))          # margin = context + overlap = 3
+    for off in ([0, 0, 0], [8, 8, 8], [16, 16, 16], [12, 16, 20]):
+        data, margin = spg.load_input(IO(vol, [slice(0, 3)]), "k", off, [1, 1, 1], [2, 2, 2], [8, 8, 8])
+        want = big[(slice(None),) + tuple(slice(o, o + 14) for o in off)]
+        want = want[(slice(None),) + tuple(slice(0, min(14, 3 + s - o + 3)) for o, s in zip(off, vol.shape[1:]))]
+        assert data.shape[0] == 3 and np.array_equal(data[:, :want.shape[1], :want.shape[2], :want.shape[3]], want)
+        assert list(margin) == [0 if o - 3 < 0 else 3 for o in off]
+    data, _ = spg.load_input(IO(vol[0], None), "k", [8, 8, 8], [0, 0, 0], [2, 2, 2], [8, 8, 8], padding=False)
+    assert np.array_equal(data, vol[0][6:18, 6:18, 6:18])
+    out = rng.random((12, 12, 12))                               # 8^3 block with an overlap of 2
+    res, box = spg.verify_shape([1, 8, 8, 8], out, (20, 22, 24), (8, 8, 8))
+    assert res.shape == (1, 12, 12, 12) and box == (slice(1, 2), slice(6, 18), slice(6, 18), slice(6, 18))
+    res, box = spg.verify_shape([0, 0, 0, 0], out, (20, 22, 24), (8, 8, 8))
+    assert res.shape == (1, 10, 10, 10) and box[1:] == (slice(0, 10),) * 3 and np.array_equal(res[0], out[2:, 2:, 2:])
+    mask = rng.random((12, 13, 14)) > 0.7
+    lab, n = ndimage.label(mask, np.ones((3, 3, 3)))
+    sizes = np.bincount(lab.ravel())
+    want = np.isin(lab, [i for i in range(1, n + 1) if sizes[i] > 4])
+    assert np.array_equal(spg.clean_mask(mask, np.ones((3, 3, 3)), 4), want)
+    arr = rng.integers(0, 9, size=(5, 6))
+    got = replace(arr, np.array([1, 3]), np.array([0, 7]))
+    assert np.array_equal(got, np.where(arr == 1, 0, np.where(arr == 3, 7, arr)))
+    a = {"a": 1, "b": {"c": 2, "d": {"e": 3}}, "f": [1]}
+    assert merge_dicts(a, {"b": {"c": 5, "d": {"g": 1}}, "f": {"x": 1}, "h": 2}) == \
+        {"a": 1, "b": {"c": 5, "d": {"e": 3, "g": 1}}, "f": {"x": 1}, "h": 2}
