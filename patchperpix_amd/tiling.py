@@ -861,6 +861,10 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
     if kw.get("chunksize") is not None and kw.get("blockwise", False):
         n_slabs = max(1, int(np.ceil((bb[0].stop - bb[0].start) / kw["chunksize"][0])))
     kw["blockwise"] = False
+    # the reference's blockwise driver sets return_intermediates for its per-block calls
+    # (default.toml:159, stitch_patch_graph.py:131-133); here the boxed volume is assembled as a
+    # whole and the driver wants the instance map
+    kw["return_intermediates"] = False
     fg_bb = np.ascontiguousarray(foreground[bb])
     inst_bb, _ = to_instance_seg_tiled(
         np.ascontiguousarray(affinities[sub]), fg_bb, fg_bb.copy(),

@@ -105,6 +105,8 @@ def test_decode_then_vote_without_leaving_hbm():
     fg = dec.foreground_from_numinst(numinst, 0.5)
     logits = dec.decode_volume(d, code, fg, batch_size=512, device="cuda", out_dtype=torch.float32)
     assert logits.is_cuda and tuple(logits.shape) == (125,) + shape
+    sel = torch.as_tensor(fg, device="cuda").bool().expand_as(logits)
+    logits = logits - logits[sel].median()      # (random weights: centre the logits so that both classes occur)
     pred = torch.sigmoid(logits)                # loadAffinities applies expit to logits (:249-250)
     pred = pred * torch.as_tensor(fg, device="cuda").float()   # nothing decoded outside the foreground
     pred16 = pred.to(torch.float16)             # decode writes float16 (decode.py:104-109)
