@@ -462,6 +462,7 @@ def rank_vm_available(P):
         return False
     Pv = P.copy()
     Pv.cons_layout = CONS_VOXEL_MAJOR
+    Pv.cons_box = Box(0, 0, 0, P.Z, P.Y, P.X)     # (the question is about the configuration, not a tile)
     return int(lib().ppp_rank_workspace_bytes(None, ctypes.byref(Pv))) > 0
 
 

@@ -41,11 +41,15 @@ static constexpr int V2_WAVES = 4;
 #define PPP_S1_MINWAVES(PX) ((PX) <= 7 ? 3 : 2)   // waves per SIMD the register budget must allow
 #endif
 
-template <int PX>
+// FLAT: the 64 base voxels of a wave are consecutive in the FLATTENED (y, x) order of a z-slice of
+// the consensus box, so a run may continue on the next line (two segments A / B, each with its
+// own PX-1 halo of centres).  Without it the last run of every line carries idle lanes: 140
+// columns = 64 + 64 + 12, 27 % of all lanes at the 140^3 benchmark volume.
+template <int PX, bool FLAT>
 struct V2 {
     static constexpr int RX = PX / 2;
-    static constexpr int NC = 64 + PX - 1;       // centres per x-run
-    static constexpr int NT = 64 + 2 * (PX - 1); // target pixels per x-run
+    static constexpr int NC = 64 + (FLAT ? 2 : 1) * (PX - 1);   // centres per run (both segments)
+    static constexpr int NT = 64 + (FLAT ? 4 : 2) * (PX - 1);   // target pixels per run
     static constexpr int NACC = 2 * PX - 1;
     static constexpr int IMG = 2 * PX * NC;      // floats of LDS image per wave
 };
@@ -104,12 +108,11 @@ __device__ __forceinline__ void vote(const double th2, const double den, const d
 // all votes of one (kz, ky): kx descending (raster order of the centre), every partner column.
 // ROW0: offset row (dz, dy) == (0, 0), where only dx > 0 exists.  Returns "some fast-path
 // result was ambiguous" (never when EXACT).
-template <int PX, int VAL, bool ROW0, bool EXACT, bool TH05>
+template <int PX, int NC, int VAL, bool ROW0, bool EXACT, bool TH05>
 __device__ __forceinline__ bool tile_votes(const float *ia, const float *ib, const bool u_ok,
                                            const double th2, const double den,
                                            const double inv_den, float (&acc)[2 * PX - 1],
                                            unsigned (&cnt)[2 * PX - 1]) {
-    constexpr int NC = 64 + PX - 1;
     unsigned amb_min = 0xFFFFFFFFu;
 #pragma unroll
     for (int kx = PX - 1; kx >= 0; --kx) {
@@ -136,12 +139,12 @@ __device__ __forceinline__ float ldf_at(const T *base, unsigned byte_off) {
     return ldf(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off), 0);
 }
 
-template <typename T, int PX, int VAL, bool TH05>
+template <typename T, int PX, int VAL, bool TH05, bool FLAT>
 __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
     consensus_v2_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
                         float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
                         const int n_rows, const int runs_per_line, const long long n_waves) {
-    using K = V2<PX>;
+    using K = V2<PX, FLAT>;
     constexpr int NE = (K::IMG + 63) / 64;           // staged elements per lane and tile
     constexpr int NEA = (PX * K::NC + 63) / 64;      // ... of which may belong to the "about u" rows
     __shared__ float lds[V2_WAVES][K::IMG];
@@ -164,16 +167,35 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
     int dz, dy;
     if (row < G.py) { dz = 0; dy = row; }
     else { const int t = row - G.py; dz = 1 + t / G.wy; dy = t % G.wy - (G.py - 1); }
-    // x-run -> base voxels (box coordinates -> global)
+    // run -> base voxels (box coordinates -> global).  `runs_per_line` = runs per line, or per
+    // z-slice when FLAT.  Segment A: nA lanes from (uy, ux0) on; segment B (FLAT): the other
+    // lanes from the start of the next line.
     const int xr = (int)(run % runs_per_line);
     run /= runs_per_line;
-    const int uy = G.by0 + (int)(run % G.bY);
-    const int uz = G.bz0 + (int)(run / G.bY);
-    const int ux0 = G.bx0 + xr * 64;
-    const int ux = ux0 + lane;
-    const bool lane_ok = ux < G.bx0 + G.bX;
-    const int wz = uz + dz, wy = uy + dy;
-    const bool w_row_ok = wz < G.Z && wy >= 0 && wy < G.Y;
+    int uy, uz, ux0, nA;
+    if (FLAT) {
+        const int flat0 = xr * 64;
+        uy = G.by0 + flat0 / G.bX;
+        uz = G.bz0 + (int)run;
+        ux0 = G.bx0 + flat0 % G.bX;
+        nA = min(64, G.bX - flat0 % G.bX);
+    } else {
+        uy = G.by0 + (int)(run % G.bY);
+        uz = G.bz0 + (int)(run / G.bY);
+        ux0 = G.bx0 + xr * 64;
+        nA = 64;
+    }
+    const bool in_b = FLAT && lane >= nA;                          // this lane sits on line B
+    const bool have_b = FLAT && nA < 64 && uy + 1 < G.by0 + G.bY;  // (wave-uniform)
+    const int ux = in_b ? G.bx0 + (lane - nA) : ux0 + lane;
+    const int uy_l = in_b ? uy + 1 : uy;
+    const bool lane_ok = in_b ? have_b : ux < G.bx0 + G.bX;
+    // image column of this lane's own centre (kx = PX-1); segment B starts after A's halo
+    const int pos_l = lane + (PX - 1) + (in_b ? PX - 1 : 0);
+    const int wz = uz + dz, wy = uy + dy;                          // (line A; line B: wy + 1)
+    const bool w_ok_a = wz < G.Z && wy >= 0 && wy < G.Y;
+    const bool w_ok_b = have_b && wz < G.Z && wy + 1 >= 0 && wy + 1 < G.Y;
+    const bool w_row_ok = w_ok_a || w_ok_b;
     const bool row0 = dz == 0 && dy == 0;
 
     float acc[K::NACC];
@@ -184,16 +206,19 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
     const T *mid = pred + (long long)G.mid * G.V;
     float *img = lds[wave];
     uint8_t *uval = lds_valid[wave][0], *wval = lds_valid[wave][1];
-    // validity (foreground && !overlap) of the target pixels on the u row and on the w row,
-    // x in [ux0 - (PX-1), ux0 + 63 + (PX-1)]
+    // validity (foreground && !overlap) of the target pixels on the u row and on the w row:
+    // per segment x in [first - (PX-1), first + n - 1 + (PX-1)]; segment B follows A in the arrays
+    const int ntA = nA + 2 * (PX - 1);
     for (int i = lane; i < K::NT; i += 64) {
-        const int x = ux0 - (PX - 1) + i;
+        const bool sb = FLAT && i >= ntA;
+        const int x = sb ? G.bx0 - (PX - 1) + (i - ntA) : ux0 - (PX - 1) + i;
+        const int yy = sb ? uy + 1 : uy, wyy = sb ? wy + 1 : wy;
         bool vu = false, vw = false;
-        if (x >= 0 && x < G.X) {
-            const long long lu = vox(G, uz, uy, x);
+        if (x >= 0 && x < G.X && (!sb || have_b)) {
+            const long long lu = vox(G, uz, yy, x);
             vu = ldf(mid, lu) > G.th_gt && (!G.use_overlap || ov[lu] == 0);
-            if (w_row_ok) {
-                const long long lw = vox(G, wz, wy, x);
+            if (sb ? w_ok_b : w_ok_a) {
+                const long long lw = vox(G, wz, wyy, x);
                 vw = ldf(mid, lw) > G.th_gt && (!G.use_overlap || ov[lw] == 0);
             }
         }
@@ -201,33 +226,38 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const bool u_ok = lane_ok && uval[lane + PX - 1];
+    const bool u_ok = lane_ok && uval[(in_b ? ntA + (lane - nA) : lane) + PX - 1];
     const double inv_den = 1.0 / G.den;
 
     // Per-lane description of the NE image elements this lane stages for every tile
     // (element e = it*64 + lane  ->  row half, column j, centre i): constant over the tiles.
     //   ok_bits  bit it : the pixel the value talks about is valid and the centre is inside
-    //                     the x-interior (centre foreground is tile dependent, tested later)
-    //   el_off[it]      : j * V + clamped centre x  (added to the tile's row base)
+    //                     the x-interior (centre row / foreground are tile dependent, tested later)
+    //   seg_bits bit it : the centre belongs to segment B (next line)
+    //   el_off[it]      : j * V + (line) * X + clamped centre x  (added to the tile's row base)
     // (32-bit BYTE offsets from a scalar row base: one VGPR per element and the
     // saddr + voffset addressing form; the launcher checks that they fit)
-    unsigned ok_bits = 0;
+    unsigned ok_bits = 0, seg_bits = 0;
     unsigned el_off[NE];
     unsigned el_cx[NE];
+    const int ncA = nA + (PX - 1);                    // centres of segment A
 #pragma unroll
     for (int it = 0; it < NE; ++it) {
         const int e = it * 64 + lane;
         const int i = e % K::NC;
         const int j = (e / K::NC) % PX;
         const bool is_b = e >= PX * K::NC;
-        const int cx = ux0 - (PX - 1) + K::RX + i;
-        bool ok = e < K::IMG && cx >= K::RX && cx < G.X - K::RX;
+        const bool sb = FLAT && i >= ncA;
+        const int iseg = sb ? i - ncA : i;
+        const int cx = (sb ? G.bx0 : ux0) - (PX - 1) + K::RX + iseg;
+        bool ok = e < K::IMG && cx >= K::RX && cx < G.X - K::RX && (!sb || have_b);
         if (ok) {
-            const int ti = cx + j - K::RX - (ux0 - (PX - 1));
+            const int ti = (sb ? ntA : 0) + iseg + j;        // target pixel = centre + j - RX
             ok = is_b ? wval[ti] : uval[ti];
         }
         ok_bits |= (ok ? 1u : 0u) << it;
-        const int cxc = min(max(cx, 0), G.X - 1);
+        seg_bits |= (sb ? 1u : 0u) << it;
+        const int cxc = min(max(cx, 0), G.X - 1) + (sb ? G.X : 0);
         el_cx[it] = (unsigned)cxc * (unsigned)sizeof(T);
         el_off[it] = (unsigned)(((long long)j * G.V + cxc) * (long long)sizeof(T));
     }
@@ -237,17 +267,25 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
         const int ky_hi = min(G.py - 1, G.py - 1 - dy), ky_lo = max(0, -dy);
         // tiles (kz, ky) in descending order, skipping centre rows outside the interior
         int kz = kz_hi, ky = ky_hi + 1;
+        bool row_a_ok = true, row_b_ok = false;   // centre row of the tile inside the interior, per segment
         auto next_tile = [&](int &z, int &y) -> bool {
             while (true) {
                 if (--y < ky_lo) { y = ky_hi; --z; }
                 if (z < kz_lo) return false;
                 const int cz = uz - z + G.rz, cy = uy - y + G.ry;
-                if (cz >= G.rz && cz < G.Z - G.rz && cy >= G.ry && cy < G.Y - G.ry) return true;
+                if (!(cz >= G.rz && cz < G.Z - G.rz)) continue;
+                row_a_ok = cy >= G.ry && cy < G.Y - G.ry;
+                row_b_ok = have_b && cy + 1 >= G.ry && cy + 1 < G.Y - G.ry;
+                if (row_a_ok || row_b_ok) return true;
             }
         };
         float raw[NE], cmid[NEA];
         // issue the (independent, unconditional) loads of one tile into registers
         auto load_tile = [&](int z, int y) {
+            // (FLAT: a tile is kept when the centre row of EITHER line is interior; the other
+            // line's elements are masked but still loaded -- harmless: with ry >= 1, "row cy + 1
+            // interior" implies cy >= 0 and "row cy interior" implies cy + 1 <= Y - 1, so both rows
+            // are inside the slice)
             const long long crow = vox(G, uz - z + G.rz, uy - y + G.ry, 0);
             const long long ra0 = (long long)((z * G.py + y) * PX) * G.V + crow;
             const long long rb0 = (long long)(((z + dz) * G.py + (y + dy)) * PX) * G.V + crow;
@@ -273,6 +311,7 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
             for (int it = 0; it < NE; ++it) {
                 const int e = it * 64 + lane;
                 bool ok = (ok_bits >> it) & 1u;
+                if (FLAT) ok = ok && (((seg_bits >> it) & 1u) ? row_b_ok : row_a_ok);   // centre row interior
                 if (it < NEA) ok = ok && (e >= PX * K::NC || cmid[it] > G.th_gt);  // centre fg
                 const float v = raw[it];
                 const float t = v > G.th_gt ? v : (v < G.bg_lt ? -(1.0f - v) : 0.0f);
@@ -286,30 +325,30 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
             if (PREFETCH && have) load_tile(kz, ky);
             // ---- votes (fast path; redo the tile with true divisions if any lane saw an
             //      ambiguous rounding -- probability ~2^-26 per vote)
-            const float *ia = img + lane + (PX - 1);
-            const float *ib = img + PX * K::NC + lane + (PX - 1);
+            const float *ia = img + pos_l;
+            const float *ib = img + PX * K::NC + pos_l;
             if constexpr (TH05 && VAL == PPP_VAL_NORM_PROB_PRODUCT) {
                 // float-only quotient; a tile with an out-of-range operand (never for
                 // probabilities) takes the double divisions
                 if (__ballot(big) == 0ull) {
-                    if (row0) tile_votes<PX, VAL, true, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
-                    else tile_votes<PX, VAL, false, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    if (row0) tile_votes<PX, K::NC, VAL, true, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes<PX, K::NC, VAL, false, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
                 } else {
-                    if (row0) tile_votes<PX, VAL, true, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
-                    else tile_votes<PX, VAL, false, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    if (row0) tile_votes<PX, K::NC, VAL, true, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes<PX, K::NC, VAL, false, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
                 }
             } else {
                 float acc0[K::NACC];
                 unsigned cnt0[K::NACC];
 #pragma unroll
                 for (int i = 0; i < K::NACC; ++i) { acc0[i] = acc[i]; cnt0[i] = cnt[i]; }
-                const bool amb = row0 ? tile_votes<PX, VAL, true, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt)
-                                      : tile_votes<PX, VAL, false, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                const bool amb = row0 ? tile_votes<PX, K::NC, VAL, true, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt)
+                                      : tile_votes<PX, K::NC, VAL, false, false, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
                 if (VAL == PPP_VAL_NORM_PROB_PRODUCT && __ballot(amb) != 0ull) {
 #pragma unroll
                     for (int i = 0; i < K::NACC; ++i) { acc[i] = acc0[i]; cnt[i] = cnt0[i]; }
-                    if (row0) tile_votes<PX, VAL, true, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
-                    else tile_votes<PX, VAL, false, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    if (row0) tile_votes<PX, K::NC, VAL, true, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes<PX, K::NC, VAL, false, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -321,39 +360,54 @@ __global__ void __launch_bounds__(64 * V2_WAVES, PPP_S1_MINWAVES(PX))
     for (int i = 0; i < K::NACC; ++i) {
         const int dx = i - (PX - 1);
         if (dz == 0 && dy == 0 && dx <= 0) continue;
-        const long long o = cons_at(G, dz, dy, dx, uz, uy, ux);
+        const long long o = cons_at(G, dz, dy, dx, uz, uy_l, ux);
         const float c = (float)cnt[i];
         if (cons) cons[o] = (G.normalise && cnt[i] != 0u) ? acc[i] / c : acc[i];
         if (cnt_out) cnt_out[o] = c;
     }
 }
 
-template <typename T, int PX>
-static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float *cnt,
-                            const Geo &G, hipStream_t s) {
+template <typename T, int PX, bool FLAT>
+static hipError_t launch_v2f(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                             const Geo &G, hipStream_t s) {
     const int n_rows = (G.pz - 1) * G.wy + G.py;
-    const int runs_per_line = (G.bX + 63) / 64;
-    const long long n_waves = (long long)runs_per_line * G.bY * G.bZ * n_rows;
+    // FLAT: runs of 64 over the flattened (y, x) slice of the box; else runs per line
+    const int runs_per_line = FLAT ? (int)(((long long)G.bX * G.bY + 63) / 64) : (G.bX + 63) / 64;
+    const long long n_waves = (long long)runs_per_line * (FLAT ? 1 : G.bY) * G.bZ * n_rows;
     const long long n_blocks = (n_waves + V2_WAVES - 1) / V2_WAVES;
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
     PPP_GRID_CHECK(n_blocks, 64 * V2_WAVES);
-    // per-lane element offsets are 32-bit byte offsets within PX channel volumes
-    if (((long long)(PX - 1) * G.V + G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
+    // per-lane element offsets are 32-bit byte offsets within PX channel volumes (+ one line)
+    if (((long long)(PX - 1) * G.V + 2ll * G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
     const dim3 grid((unsigned)n_blocks), block(64 * V2_WAVES);
     if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
         G.bg_lt <= 0.5f && !getenv("PPP_S1_NO_TH05"))
-        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, true><<<grid, block, 0, s>>>(
+        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, true, FLAT><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     else if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT)
-        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, false><<<grid, block, 0, s>>>(
+        consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, false, FLAT><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     else if (G.value_rule == PPP_VAL_PROB_PRODUCT)
-        consensus_v2_kernel<T, PX, PPP_VAL_PROB_PRODUCT, false><<<grid, block, 0, s>>>(
+        consensus_v2_kernel<T, PX, PPP_VAL_PROB_PRODUCT, false, FLAT><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     else
-        consensus_v2_kernel<T, PX, PPP_VAL_COUNT, false><<<grid, block, 0, s>>>(
+        consensus_v2_kernel<T, PX, PPP_VAL_COUNT, false, FLAT><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     return hipGetLastError();
+}
+
+template <typename T, int PX>
+static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                            const Geo &G, hipStream_t s) {
+    // Flattened runs pay when the lines leave idle lanes (bX not a multiple of 64); they need
+    // lines of at least 64 base voxels (a run then touches two lines at most), a patch with
+    // py >= 3 (see load_tile) and more than one line.  PPP_S1_FLAT=0 / 1 overrides.
+    const char *e = getenv("PPP_S1_FLAT");
+    bool flat = G.bX >= 64 && G.bX % 64 != 0 && G.py >= 3 && G.bY > 1;
+    if (e && e[0] == '0') flat = false;
+    if (e && e[0] == '1' && G.bX >= 64 && G.py >= 3) flat = true;
+    return flat ? launch_v2f<T, PX, true>(pred, ov, cons, cnt, G, s)
+                : launch_v2f<T, PX, false>(pred, ov, cons, cnt, G, s);
 }
 
 // returns hipErrorNotSupported when the shape has no specialised kernel

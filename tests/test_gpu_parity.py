@@ -587,3 +587,29 @@ def test_rank_voxel_major_tiles_and_boxes(ps, shape, cell, torch_cuda):
     got_t = backend.rank_patches(pred, vm_t, ov, Pvt, score_box=sb).cpu().numpy()
     sl = tuple(slice(sb[i], sb[i + 3]) for i in range(3))
     assert np.array_equal(got_t[sl].view(np.uint32), want[sl].view(np.uint32))
+
+
+@pytest.mark.parametrize("ps,shape", [((7, 7, 7), (10, 12, 150)), ((5, 5, 5), (8, 11, 97)), ((9, 9, 9), (11, 12, 131)),
+                                      ((1, 5, 5), (1, 30, 90))])
+def test_consensus_flat_runs_equal_line_runs(ps, shape, torch_cuda, monkeypatch):
+    """S1 with waves running over the flattened (y, x) order of the consensus box (a run may
+    continue on the next line) == S1 with one run per line: whole volume and a sub-box whose
+    lines start and end inside the volume; values and counts."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    c = synth.make_case(shape, ps, seed=95, cell=[6, 6, 9], overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    boxes = [None, (min(1, shape[0] - 1), 2, 9, shape[0], shape[1] - 1, shape[2] - 7)]
+    for box in boxes:
+        P = backend.make_params(shape, ps, cons_box=box, **kw)
+        out = {}
+        for flat in ("0", "1"):
+            monkeypatch.setenv("PPP_S1_FLAT", flat)
+            cons, cnt = backend.consensus(pred, ov, P, want_count=True)
+            out[flat] = (cons.cpu().numpy(), cnt.cpu().numpy())
+        assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+        assert np.array_equal(out["0"][1], out["1"][1])
+        assert np.count_nonzero(out["0"][0]) > 1000
