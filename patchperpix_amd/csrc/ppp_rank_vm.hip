@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
     __shared__ float accs[NT];
     constexpr int UB = (TZ + 2 * R) * (TY + 2 * R) * (TX + 2 * R);
     __shared__ uint32_t act_bits[(NT + 31) / 32];      // centre of the tile takes part
+    __shared__ uint32_t spread[256];                   // byte -> 8 nibbles, nibble i = bit i
     __shared__ uint32_t uvalid_bits[(UB + 63) / 64 * 2];   // voxel of the grown tile can be a first pixel
     const int lane = threadIdx.x;
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
@@ -120,6 +121,11 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
     auto sb_index = [&](int lz, int ly, int lx) -> long long {
         return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
     };
+    for (int e = lane; e < 256; e += 64) {
+        uint32_t v = 0;
+        for (int i = 0; i < 8; ++i) v |= ((e >> i) & 1u) << (4 * i);
+        spread[e] = v;
+    }
     bool any_active = false;
     static_assert(NT % 64 == 0, "tile size must be a multiple of the wave size");
     for (int cl = lane; cl < NT; cl += 64) {
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int e = lane + i * 64;
-            if (e < W) rowbuf[RV_PAD + e] = src[e];
+            if (e < W) rowbuf[RV_PAD + e] = src[e] * 16.0f;
         }
     }
     __syncthreads();
@@ -219,26 +225,38 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
                         const uint32_t neg = nw[w];
                         const bool any_pos = __ballot(pos != 0u) != 0, any_neg = __ballot(neg != 0u) != 0;
                         if (!any_pos && !any_neg) continue;
+                        // The staged row holds 16 * S (exact).  A term is fma(16 S, c, acc) with
+                        // c = +1/16 (b in P, b > a), -1/16 (b in N) or 0: the product is exactly
+                        // +-S or 0, so the fma rounds once, like the reference's acc += / -= S.
                         if (!any_neg) {
+                            // only foreground partners in this word: c from one mask bit
 #pragma unroll
                             for (int bb = 0; bb < 32; ++bb) {
                                 const int b = w * 32 + bb;
                                 if (b < C) {
                                     const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
                                     const int m = ((int)(pos << (31 - bb))) >> 31;
-                                    acc += __int_as_float(__float_as_int(row[off]) & m);
+                                    acc = __builtin_fmaf(row[off], __int_as_float(m & 0x3D800000), acc);   // 1/16
                                 }
                             }
                         } else {
+                            // signed coefficients: 8 at a time as nibbles (+1 -> 0x1, -1 -> 0xF) through
+                            // the byte-spread table, decoded by v_cvt_off_f32_i4 (nibble / 16)
 #pragma unroll
-                            for (int bb = 0; bb < 32; ++bb) {
-                                const int b = w * 32 + bb;
-                                if (b < C) {
-                                    const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
-                                    const int v = __float_as_int(row[off]);
-                                    const int mp = ((int)(pos << (31 - bb))) >> 31, mn = ((int)(neg << (31 - bb))) >> 31;
-                                    acc += __int_as_float(v & mp);
-                                    acc -= __int_as_float(v & mn);
+                            for (int g = 0; g < 4; ++g) {
+                                if (w * 32 + g * 8 < C) {
+                                    const uint32_t sp = spread[(pos >> (8 * g)) & 0xFFu], sn = spread[(neg >> (8 * g)) & 0xFFu];
+                                    const uint32_t code = sp + (sn << 4) - sn;
+                                    if (__ballot(code != 0u) == 0) continue;
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) {
+                                        const int b = w * 32 + g * 8 + i;
+                                        if (b < C) {
+                                            const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
+                                            const float cf = __builtin_amdgcn_cvt_off_f32_i4((code >> (4 * i)) & 15u);
+                                            acc = __builtin_fmaf(row[off], cf, acc);
+                                        }
+                                    }
                                 }
                             }
                         }
@@ -251,7 +269,7 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
 #pragma unroll
                     for (int i = 0; i < NST; ++i) {
                         const int e = lane + i * 64;
-                        if (e < W) rowbuf[RV_PAD + e] = st[i];
+                        if (e < W) rowbuf[RV_PAD + e] = st[i] * 16.0f;
                     }
                 }
                 __syncthreads();
@@ -305,24 +323,26 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     rank_masks_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, Pb, Nb, info, score, G);
     // tile of centres per wave: 8 x 8 x 8 by default; PPP_RANK_TILE=8x8x16 doubles it along x
     // (fewer row stagings per centre and fuller waves, half as many tiles to spread over the CUs)
-    static int long_tiles = -1;
-    if (long_tiles < 0) {
-        const char *e = getenv("PPP_RANK_TILE");
-        long_tiles = (e && strcmp(e, "8x8x16") == 0) ? 1 : 0;
-    }
-    const int TZ = 8, TY = 8, TX = long_tiles ? 16 : 8;
+    // Tile of centres per wave.  One wave per tile, ~4 waves per SIMD resident: 4096 tiles run at
+    // a time, so a volume of few tiles is cut finer (4 x 8 x 8: 140^3 -> 10.7 k tiles, 2.6 rounds
+    // instead of 1.3 rounds of which the second is a third full: 95 -> 86 ms), a large one coarser
+    // (8 x 8 x 8: 5.4 instead of 7.7 row stagings per centre).  PPP_RANK_TILE overrides.
+    int tile_kind = ((long long)((sZ + 7) / 8) * ((sY + 7) / 8) * ((sX + 7) / 8) < 3 * 4096) ? 2 : 0;
+    if (const char *e = getenv("PPP_RANK_TILE"))
+        tile_kind = strcmp(e, "8x8x16") == 0 ? 1 : (strcmp(e, "4x8x8") == 0 ? 2 : (strcmp(e, "8x8x8") == 0 ? 0 : tile_kind));
+    const int TZ = tile_kind == 2 ? 4 : 8, TY = 8, TX = tile_kind == 1 ? 16 : 8;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64);
+#define PPP_RV_LAUNCH(P, A, B, C_)                                                                     \
+    rank_vm_kernel<P, A, B, C_><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                         \
+        S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x)
 #define PPP_RV_CASE(P)                                                                                 \
     case P:                                                                                            \
-        if (long_tiles)                                                                                \
-            rank_vm_kernel<P, 8, 8, 16><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                 \
-                S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x);                               \
-        else                                                                                           \
-            rank_vm_kernel<P, 8, 8, 8><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                  \
-                S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x);                               \
+        if (tile_kind == 1) PPP_RV_LAUNCH(P, 8, 8, 16);                                                \
+        else if (tile_kind == 2) PPP_RV_LAUNCH(P, 4, 8, 8);                                            \
+        else PPP_RV_LAUNCH(P, 8, 8, 8);                                                                \
         break;
     switch (G.px) {
         PPP_RV_CASE(3)
@@ -332,6 +352,7 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     default:
         return hipErrorNotSupported;
     }
+#undef PPP_RV_LAUNCH
 #undef PPP_RV_CASE
     return hipGetLastError();
 }
