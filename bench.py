@@ -173,6 +173,7 @@ def main():
                     help="N > 1: weak = the volume grows with N (N x taller), strong = the "
                          "1-GPU volume is split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU oracle and exit")
     ap.add_argument("--no-north-star", action="store_true",
                     help="skip the S1 pass over the 512^3 / 9^3 volume (about half a minute)")
     ap.add_argument("--no-variants", action="store_true")
@@ -187,6 +188,10 @@ def main():
     from patchperpix_amd import flags as flagsets
     from patchperpix_amd.vote_instances import vote_instances as vi
 
+    if args.cpu_baseline_only:
+        shape, ps, cell = WORKLOADS[args.workload]
+        print(json.dumps(cpu_baseline(ps, cell, dict(flagsets.FLAG_SETS[args.flags]))))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -412,7 +417,7 @@ def cpu_baseline(ps, cell, kw):
     from oracle import ppp_oracle as orc
     from patchperpix_amd import synth
     orc.lib()
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cores()
     out = {"unit": "Mvoxels/s", "kind": "port",
            "what": "oracle/ppp_oracle.c (gcc -O3 -fopenmp; S1 in gather form over offset planes, "
                    "S2 over centres, S5 over pair rows) + host stages (ppp_host_* C++, one thread)"}
@@ -425,19 +430,41 @@ def cpu_baseline(ps, cell, kw):
         pred = synth.pred_from_labels(lab, ps, seed=0)
         fg = lab != 0
         orc.set_threads(threads)
+        CPU_STAGE_SECONDS.clear()
         t0 = time.perf_counter()
         inst = cpu_pipeline(orc, pred, fg, ps, kw)
         dt = time.perf_counter() - t0
         runs.append({"threads": threads, "sample": "x".join(map(str, sshape)), "seconds": dt,
                      "value": float(np.prod(sshape)) / dt / 1e6,
-                     "instances_found": int(len(np.unique(inst)) - 1)})
+                     "instances_found": int(len(np.unique(inst)) - 1),
+                     "stage_seconds": {k: round(v, 3) for k, v in CPU_STAGE_SECONDS.items()}})
     orc.set_threads(0)
     out["single_thread"], out["all_cores"] = runs
     # the headline of this object: all cores (the stronger baseline)
-    out.update(value=runs[1]["value"], cores=runs[1]["threads"],
+    out.update(value=runs[1]["value"], cores=runs[1]["threads"], cores_note=cores_note,
                sample="%s sub-volume of the same generator, %s patch, flags as timed, full pipeline"
                       % (runs[1]["sample"], "x".join(map(str, ps))))
     return out
+
+
+CPU_STAGE_SECONDS = {}
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut down to the cgroup CPU
+    quota when there is one (the GPU boxes expose 256 hardware threads under a quota of 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = "%d hardware threads in the affinity mask" % n
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                note += ", cgroup cpu.max quota = %d" % q
+                n = q
+    except (OSError, ValueError):
+        pass
+    return n, note
 
 
 def cpu_pipeline(orc, pred, fg, ps, kw):
@@ -450,9 +477,20 @@ def cpu_pipeline(orc, pred, fg, ps, kw):
     numinst = fg.astype(np.uint8)
     ov = 1 * (numinst > 1)
     mask = fg.copy()
+    t_stage = time.perf_counter()
+
+    def lap(name):
+        nonlocal t_stage
+        now = time.perf_counter()
+        CPU_STAGE_SECONDS[name] = CPU_STAGE_SECONDS.get(name, 0.0) + now - t_stage
+        t_stage = now
+
     cons = orc.consensus_planes(pred, ov, ps, **kw)
+    lap("s1_consensus")
     score = orc.rank(pred, cons, ov, ps, **kw)
+    lap("s2_rank")
     lin = backend.host_rank_order(score, fg, ps)
+    lap("sort")
     if len(lin) == 0:
         return np.zeros(shape, np.uint16)
     C = int(np.prod(ps))
@@ -466,6 +504,7 @@ def cpu_pipeline(orc, pred, fg, ps, kw):
         return out
 
     bits = bits_of(lin)
+    lap("patch_bits")
     running, _owner = backend.padded_mask(mask)
     selected = np.zeros(len(lin), dtype=np.uint8)
     radslice = tuple(slice(r, s - r) for r, s in zip(rad, shape))
@@ -473,16 +512,20 @@ def cpu_pipeline(orc, pred, fg, ps, kw):
     backend.host_cover_pass(running, np.ascontiguousarray(ov > 0).astype(np.uint8), ps, lin,
                             score.reshape(-1)[lin], bits, 0, None, selected, remaining)
     sel = np.flatnonzero(selected)
+    lap("s3_cover")
     if not kw.get("skipThinCover") and len(sel):
         keep = backend.host_thin_cover(mask.astype(np.uint8), ps, lin[sel], bits[sel])
         sel = sel[keep]
+    lap("s4_thin")
     sel_lin = lin[sel]
     coords = np.stack(np.unravel_index(sel_lin, shape), axis=1).astype(np.int32)
     _, pairs = backend.host_patch_pairs(coords, ps, kw.get("max_total_patch_distance_in_ps_multiples", 2),
                                         kw["includeSinglePatchCCS"])
+    lap("pairs")
     if pairs is None:
         return np.zeros(shape, np.uint16)
     aff = orc.patch_graph(pred, cons, pairs, ps, **kw)
+    lap("s5_patch_graph")
     if kw.get("mws"):
         nodes, labels, _ = backend.host_mws(pairs, aff, shape)
     else:
@@ -506,6 +549,7 @@ def cpu_pipeline(orc, pred, fg, ps, kw):
         win = tuple(slice(int(v) - r, int(v) + r + 1) for v, r in zip(c, rad))
         patch = pred[(slice(None),) + tuple(int(v) for v in c)].reshape(ps)
         inst[win][patch > th] = lab
+    lap("s6_label_paint")
     return inst
 
 
