@@ -127,19 +127,47 @@ __global__ void __launch_bounds__(256)
         unsigned long long win = b[0] | ((unsigned long long)(words > 1 ? b[1] : 0u) << 32);
         int have = 64, next = 2, hits = 0;
         // only "more than pix_th" matters: stop at the first plane of rows that settles it
-        // (with pix_th = 0 a surviving patch is usually done after the first plane)
+        // (with pix_th = 0 a surviving patch is usually done after the first plane).  The mask
+        // words of a whole plane are loaded before any of them is used: a patch about to be
+        // rejected walks all pz * py rows, and with the exit test after every row each load
+        // waited for the previous one (59 us per launch, most of it that chain).
+        constexpr int MAXPY = 9;
         for (int dz = 0; dz < G.pz && hits <= pix_th; ++dz) {
             const uint32_t *row = mbits + ((long long)(cz + dz - G.rz) * G.Y + (cy - G.ry)) * XW + wi;
-            for (int dy = 0; dy < G.py; ++dy, row += XW) {
-                unsigned long long mw = row[0];
-                if (two) mw |= (unsigned long long)row[1] << 32;
-                hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
-                win >>= G.px;
-                have -= G.px;
-                if (have <= 32) {
-                    win |= (unsigned long long)(next < words ? b[next] : 0u) << have;
-                    ++next;
-                    have += 32;
+            if (G.py <= MAXPY) {
+                uint32_t lo[MAXPY], hi[MAXPY];
+#pragma unroll
+                for (int dy = 0; dy < MAXPY; ++dy) {
+                    const bool in_p = dy < G.py;
+                    lo[dy] = in_p ? row[(long long)dy * XW] : 0u;
+                    hi[dy] = (in_p && two) ? row[(long long)dy * XW + 1] : 0u;
+                }
+#pragma unroll
+                for (int dy = 0; dy < MAXPY; ++dy) {
+                    if (dy < G.py) {
+                        const unsigned long long mw = lo[dy] | ((unsigned long long)hi[dy] << 32);
+                        hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                        win >>= G.px;
+                        have -= G.px;
+                        if (have <= 32) {
+                            win |= (unsigned long long)(next < words ? b[next] : 0u) << have;
+                            ++next;
+                            have += 32;
+                        }
+                    }
+                }
+            } else {
+                for (int dy = 0; dy < G.py; ++dy, row += XW) {
+                    unsigned long long mw = row[0];
+                    if (two) mw |= (unsigned long long)row[1] << 32;
+                    hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                    win >>= G.px;
+                    have -= G.px;
+                    if (have <= 32) {
+                        win |= (unsigned long long)(next < words ? b[next] : 0u) << have;
+                        ++next;
+                        have += 32;
+                    }
                 }
             }
         }
@@ -213,20 +241,32 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// the three passes (x+y fused, then z) : in -> tmp -> out
+// x and y passes of the neighbourhood minimum: in -> out (scratch: the x pass when the fused
+// kernel's tile does not fit LDS).  The z pass is NOT a sweep of its own: only the few voxels that
+// hold an undecided patch need the 3-d minimum, and the select kernels take it over the 2 pz - 1
+// slices themselves (one volume write + read and one launch less per round).
 template <typename T>
-static void minfilter_3d(const T *in, T *tmp, T *out, const Geo &G, hipStream_t s) {
+static void minfilter_xy(const T *in, T *scratch, T *out, const Geo &G, hipStream_t s) {
     const int rx = G.px - 1, ry = G.py - 1;
     const dim3 grid((unsigned)((G.X + MF_TX - 1) / MF_TX), (unsigned)((G.Y + MF_TY - 1) / MF_TY), (unsigned)G.Z);
     const size_t lds = (size_t)((MF_TY + 2 * ry) * (MF_TX + 2 * rx) + (MF_TY + 2 * ry) * MF_TX) * sizeof(T);
     const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
     if (lds <= 48 * 1024 && G.Y <= 65535 * MF_TY && G.Z <= 65535) {
-        cover_minfilter_xy_kernel<T><<<grid, block, lds, s>>>(in, tmp, G, rx, ry);
+        cover_minfilter_xy_kernel<T><<<grid, block, lds, s>>>(in, out, G, rx, ry);
     } else {
-        cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(in, out, G.V, G.X, 1, rx);
-        cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(out, tmp, G.V, G.Y, G.X, ry);
+        cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(in, scratch, G.V, G.X, 1, rx);
+        cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(scratch, out, G.V, G.Y, G.X, ry);
     }
-    cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(tmp, out, G.V, G.Z, (long long)G.X * G.Y, G.pz - 1);
+}
+// minimum over the slices z - (pz-1) .. z + (pz-1) of the xy-filtered volume at voxel v
+template <typename T>
+__device__ __forceinline__ T zmin_at(const T *__restrict__ xy, long long v, const Geo &G) {
+    const long long plane = (long long)G.X * G.Y;
+    const int z = (int)(v / plane);
+    T m = FilterNone<T>::value;
+    for (int d = -(G.pz - 1); d <= G.pz - 1; ++d)
+        if (z + d >= 0 && z + d < G.Z) m = min(m, xy[v + (long long)d * plane]);
+    return m;
 }
 
 // Thread per voxel: the best ranked undecided patch of its neighbourhood selects itself; its
@@ -241,7 +281,7 @@ __global__ void __launch_bounds__(256)
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int k = v < G.V ? rank_vol[v] : RANK_NONE;
-    bool ready = k != RANK_NONE && nbr_min[v] == k;
+    bool ready = k != RANK_NONE && zmin_at<int32_t>(nbr_min, v, G) == k;   // nbr_min: xy-filtered ranks
     if (loc_vol && ready) { k = loc_vol[v]; ready = k >= 0; }   // own centres only; local index
     unsigned long long todo = __ballot(ready);
     const int words = (G.C + 31) / 32, XW = row_words(G);
@@ -334,7 +374,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
             cover_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
                                                        W.counters + r, nullptr, G);
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
-            minfilter_3d<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
+            minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
                                                         W.dirty, nullptr, G.Z + G.oz, G);
         }
@@ -511,7 +551,7 @@ __global__ void __launch_bounds__(256)
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const long long key = v < G.V ? key_vol[v] : THIN_NONE;
-    const bool ready = key != THIN_NONE && nbr_min[v] == key;
+    const bool ready = key != THIN_NONE && zmin_at<long long>(nbr_min, v, G) == key;   // (xy-filtered keys)
     unsigned long long todo = __ballot(ready);
     const int words = (G.C + 31) / 32, XW = row_words(G);
     const int k = (int)(key & 0xFFFFFFFFll);
@@ -584,7 +624,7 @@ hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long 
         for (int r = 0; r < COVER_BATCH; ++r) {
             thin_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, W.state, W.key_vol,
                                                       W.counters + r, G);
-            minfilter_3d<long long>(W.key_vol, W.tmp, W.nbr_min, G, s);
+            minfilter_xy<long long>(W.key_vol, W.tmp, W.nbr_min, G, s);
             thin_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, W.state, W.key_vol,
                                                        W.sel_count, W.cleared, W.dirty, G);
         }
@@ -671,7 +711,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
 
 hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s) {
     CoverWork W = carve(work, G);
-    minfilter_3d<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
+    minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
     return hipGetLastError();
 }
 
