@@ -58,14 +58,14 @@ template <int PX> struct PaCfg {
     // so PX >= 7 takes one row buffer.
     static constexpr int ROW_BUFS = PX >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
     // waves per SIMD the register budget must allow
-    static constexpr int MIN_WAVES = PX <= 7 ? PPP_PA_MINWAVES7 : (THREADS == 512 ? 4 : (ROW_BUFS == 1 ? 3 : 2));
+    static constexpr int MIN_WAVES = PX <= 7 ? PPP_PA_MINWAVES7 : (PX >= 25 ? 1 : (THREADS == 512 ? 4 : (ROW_BUFS == 1 ? 3 : 2)));
     // Small workgroups for lists with few rows per patch (after set-cover thinning a patch has
     // ~60 dispatched rows at 7^3): with 256 threads three of four waves only stage and wait
     // (29 % of the issued instructions on the thinned 140^3 volume), and the 11 KB of B-patch
     // bits they reserve cap the CU at 8 workgroups.  One or two waves: 11.6 KB -> 13 per CU, and
     // a register budget without spills.
-    static constexpr int THREADS_SMALL = PX >= 9 ? 128 : 64;
-    static constexpr int MIN_WAVES_SMALL = PX >= 9 ? 2 : 4;
+    static constexpr int THREADS_SMALL = PX >= 25 ? 64 : (PX >= 9 ? 128 : 64);
+    static constexpr int MIN_WAVES_SMALL = PX >= 25 ? 1 : (PX >= 9 ? 2 : 4);
 };
 static constexpr int PA_PAD = 8;       // floats of slack either side of the staged row (a masked row read overshoots by < PX)
 
@@ -271,9 +271,14 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
 
     int prev_z1o = -1, prev_y1o = -1;
     AxisMasks mz = axis_masks(dz, 0, G.pz), my = axis_masks(dy, 0, G.py);
-    u64 EYf[NCH], EYbk[NCH], EYpos[NCH], EYzero[NCH], EYst[NCH], EYin[NCH];
+    // expanded y masks per chunk: cached across the pixels of a row of A while a plane has few
+    // chunks (3-d patches: 1-2); a 25-wide 2-d patch has 13 chunks of two rows -- 156 registers
+    // of masks -- and expands them inside the chunk instead (a dozen instructions per chunk)
+    constexpr bool EY_CACHED = NCH <= 2;
+    constexpr int NEY = EY_CACHED ? NCH : 1;
+    u64 EYf[NEY], EYbk[NEY], EYpos[NEY], EYzero[NEY], EYst[NEY], EYin[NEY];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) EYf[c] = EYbk[c] = EYpos[c] = EYzero[c] = EYst[c] = EYin[c] = 0ull;
+    for (int c = 0; c < NEY; ++c) EYf[c] = EYbk[c] = EYpos[c] = EYzero[c] = EYst[c] = EYin[c] = 0ull;
     for (int k = 0; k < n_u; ++k) {
         const int r1 = r_next;
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
@@ -299,10 +304,12 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
             if (y1o != prev_y1o) {
                 my = axis_masks(dy, y1o, G.py);   // (bits >= py are clear: the masks stop at py)
                 prev_y1o = y1o;
+                if constexpr (EY_CACHED) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    EYf[c] = expand_y(my.f, c); EYbk[c] = expand_y(my.bk, c); EYpos[c] = expand_y(my.pos, c);
-                    EYzero[c] = expand_y(my.zero, c); EYst[c] = expand_y(my.st, c); EYin[c] = expand_y(my.in, c);
+                    for (int c = 0; c < NCH; ++c) {
+                        EYf[c] = expand_y(my.f, c); EYbk[c] = expand_y(my.bk, c); EYpos[c] = expand_y(my.pos, c);
+                        EYzero[c] = expand_y(my.zero, c); EYst[c] = expand_y(my.st, c); EYin[c] = expand_y(my.in, c);
+                    }
                 }
             }
             const int q0x = dx - x1o;
@@ -332,12 +339,18 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                     if (ya > yb) return;
                     // forward orientation (pixel z1 before z2 in raster order <=> q >= 0
                     // lexicographically) and the position of q == 0 (never stored)
-                    const M fwd = z_pos ? (M)~(M)0 : (z_zero ? (M)((M)EYpos[c] | ((M)EYzero[c] & (M)RXnn)) : (M)0);
-                    const M range = (z_f ? (M)((M)EYf[c] & (M)RXf & fwd) : (M)0) |
-                                    (z_bk ? (M)((M)EYbk[c] & (M)RXbk & (M)~fwd) : (M)0);
-                    const M inter = z_in ? (M)((M)EYin[c] & (M)RXin) : (M)0;
-                    M stored = z_st ? (M)((M)EYst[c] & (M)RXst & range) : (M)0;
-                    if (z_zero) stored &= (M) ~((M)EYzero[c] & (M)RXzero);
+                    const u64 eyf = EY_CACHED ? EYf[EY_CACHED ? c : 0] : expand_y(my.f, c);
+                    const u64 eybk = EY_CACHED ? EYbk[EY_CACHED ? c : 0] : expand_y(my.bk, c);
+                    const u64 eypos = EY_CACHED ? EYpos[EY_CACHED ? c : 0] : expand_y(my.pos, c);
+                    const u64 eyzero = EY_CACHED ? EYzero[EY_CACHED ? c : 0] : expand_y(my.zero, c);
+                    const u64 eyst = EY_CACHED ? EYst[EY_CACHED ? c : 0] : expand_y(my.st, c);
+                    const u64 eyin = EY_CACHED ? EYin[EY_CACHED ? c : 0] : expand_y(my.in, c);
+                    const M fwd = z_pos ? (M)~(M)0 : (z_zero ? (M)((M)eypos | ((M)eyzero & (M)RXnn)) : (M)0);
+                    const M range = (z_f ? (M)((M)eyf & (M)RXf & fwd) : (M)0) |
+                                    (z_bk ? (M)((M)eybk & (M)RXbk & (M)~fwd) : (M)0);
+                    const M inter = z_in ? (M)((M)eyin & (M)RXin) : (M)0;
+                    M stored = z_st ? (M)((M)eyst & (M)RXst & range) : (M)0;
+                    if (z_zero) stored &= (M) ~((M)eyzero & (M)RXzero);
                     if (__ballot((M)(range | inter) != (M)0) == 0ull) return;
                     PA_STAT(1, lane == 0 ? 1 : 0);
                     // foreground bits of patch B on these candidate rows
@@ -397,10 +410,16 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                 };
                 // the last chunk of the 9-row planes holds (PX - (NCH-1) RPC) rows
                 constexpr bool LAST32 = NCH > 1 && (PX - (NCH - 1) * RPC) * PX <= 32;
+                if constexpr (NCH <= 2) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (LAST32 && c == NCH - 1) chunk(uint32_t{}, c);
-                    else chunk(u64{}, c);
+                    for (int c = 0; c < NCH; ++c) {
+                        if (LAST32 && c == NCH - 1) chunk(uint32_t{}, c);
+                        else chunk(u64{}, c);
+                    }
+                } else {
+                    // many chunks per plane (wide 2-d patches): a real loop, one chunk body
+#pragma unroll 1
+                    for (int c = 0; c < NCH; ++c) chunk(u64{}, c);
                 }
             }
         }
@@ -436,6 +455,7 @@ int patch_graph_pa_chunk(const Geo &G, bool small) {
     case 5: return small ? PaCfg<5>::THREADS_SMALL : PaCfg<5>::THREADS;
     case 7: return small ? PaCfg<7>::THREADS_SMALL : PaCfg<7>::THREADS;
     case 9: return small ? PaCfg<9>::THREADS_SMALL : PaCfg<9>::THREADS;
+    case 25: return G.pz == 1 ? (small ? PaCfg<25>::THREADS_SMALL : PaCfg<25>::THREADS) : 0;   // 2-d only
     }
     return 0;
 }
@@ -488,6 +508,7 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
         PPP_PA_CASE(5)
         PPP_PA_CASE(7)
         PPP_PA_CASE(9)
+        PPP_PA_CASE(25)
     default:
         return hipErrorNotSupported;
     }

@@ -86,19 +86,19 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- main kernel ---------------------------------------------------------------------------------
-template <int PS, int TZ, int TY, int TX>
-__global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
+template <int PZ, int PY, int PX, int TZ, int TY, int TX>
+__global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
     rank_vm_kernel(const float *__restrict__ S, const uint32_t *__restrict__ Pb,
                    const uint32_t *__restrict__ Nb, const uint32_t *__restrict__ info,
                    const uint8_t *__restrict__ valid, float *__restrict__ score, const ppp_box sb,
                    const Geo G, const int tiles_y, const int tiles_x) {
-    constexpr int C = PS * PS * PS, WORDS = (C + 31) / 32, R = PS / 2;
-    constexpr int WX = 2 * PS - 1, W = WX * WX * WX, LC = (W - 1) / 2;
+    constexpr int C = PZ * PY * PX, WORDS = (C + 31) / 32, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
+    constexpr int WZ = 2 * PZ - 1, WY = 2 * PY - 1, WX = 2 * PX - 1, W = WZ * WY * WX, LC = (W - 1) / 2;
     constexpr int NST = (W + 63) / 64;
     constexpr int NT = TZ * TY * TX;
     __shared__ float rowbuf[W + 2 * RV_PAD];
     __shared__ float accs[NT];
-    constexpr int UB = (TZ + 2 * R) * (TY + 2 * R) * (TX + 2 * R);
+    constexpr int UB = (TZ + 2 * RZ) * (TY + 2 * RY) * (TX + 2 * RX);
     __shared__ uint32_t act_bits[(NT + 31) / 32];      // centre of the tile takes part
     __shared__ uint32_t spread[256];                   // byte -> 8 nibbles, nibble i = bit i
     __shared__ uint32_t uvalid_bits[(UB + 63) / 64 * 2];   // voxel of the grown tile can be a first pixel
@@ -142,9 +142,9 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
     const long long rsY = G.bX, rsZ = (long long)G.bX * G.bY;
     // voxels of the tile grown by the radius, clipped to the consensus box (rows outside it are
     // rows of voxels outside the volume: no centre of the interior has them in its window)
-    const int uz0 = max(c0z - R, G.bz0), uz1 = min(c0z + tz - 1 + R, G.bz0 + G.bZ - 1);
-    const int uy0 = max(c0y - R, G.by0), uy1 = min(c0y + ty - 1 + R, G.by0 + G.bY - 1);
-    const int ux0 = max(c0x - R, G.bx0), ux1 = min(c0x + tx - 1 + R, G.bx0 + G.bX - 1);
+    const int uz0 = max(c0z - RZ, G.bz0), uz1 = min(c0z + tz - 1 + RZ, G.bz0 + G.bZ - 1);
+    const int uy0 = max(c0y - RY, G.by0), uy1 = min(c0y + ty - 1 + RY, G.by0 + G.bY - 1);
+    const int ux0 = max(c0x - RX, G.bx0), ux1 = min(c0x + tx - 1 + RX, G.bx0 + G.bX - 1);
     const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
     for (int k0 = 0; k0 < nu; k0 += 64) {
         const int k = k0 + lane;
@@ -191,9 +191,9 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
                     }
                 }
                 // pixels a of this voxel whose centre c = u + R - a lies in the tile
-                const int az0 = max(0, uz + R - (c0z + tz - 1)), az1 = min(PS - 1, uz + R - c0z);
-                const int ay0 = max(0, uy + R - (c0y + ty - 1)), ay1 = min(PS - 1, uy + R - c0y);
-                const int ax0 = max(0, ux + R - (c0x + tx - 1)), ax1 = min(PS - 1, ux + R - c0x);
+                const int az0 = max(0, uz + RZ - (c0z + tz - 1)), az1 = min(PZ - 1, uz + RZ - c0z);
+                const int ay0 = max(0, uy + RY - (c0y + ty - 1)), ay1 = min(PY - 1, uy + RY - c0y);
+                const int ax0 = max(0, ux + RX - (c0x + tx - 1)), ax1 = min(PX - 1, ux + RX - c0x);
                 const int nz = az1 - az0 + 1, ny = ay1 - ay0 + 1, nx = ax1 - ax0 + 1;
                 const int n_box = (nz <= 0 || ny <= 0 || nx <= 0) ? 0 : nz * ny * nx;
                 for (int i0 = 0; i0 < n_box; i0 += 64) {
@@ -201,9 +201,9 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
                     const bool in = i < n_box;
                     const int ii = in ? i : 0;
                     const int ax = ax0 + ii % nx, ay = ay0 + (ii / nx) % ny, az = az0 + ii / (nx * ny);
-                    const int lz = uz + R - az - c0z, ly = uy + R - ay - c0y, lx = ux + R - ax - c0x;
+                    const int lz = uz + RZ - az - c0z, ly = uy + RY - ay - c0y, lx = ux + RX - ax - c0x;
                     const int cl = (lz * TY + ly) * TX + lx;
-                    const int a = (az * PS + ay) * PS + ax;
+                    const int a = (az * PY + ay) * PX + ax;
                     const long long t = sb_index(lz, ly, lx);
                     bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
                     if (active) active = ((Pb[(long long)(a >> 5) * sbV + t] >> (a & 31)) & 1u) != 0;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
                         nw[w] = active ? Nb[(long long)w * sbV + t] : 0u;
                     }
                     float acc = active ? accs[cl] : 0.0f;
-                    const float *row = rowbuf + RV_PAD + LC - ((az * WX + ay) * WX + ax);
+                    const float *row = rowbuf + RV_PAD + LC - ((az * WY + ay) * WX + ax);
                     const int aw = a >> 5;
                     const uint32_t above = ~((2u << (a & 31)) - 1u);   // bits of a's word above a
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
                             for (int bb = 0; bb < 32; ++bb) {
                                 const int b = w * 32 + bb;
                                 if (b < C) {
-                                    const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
+                                    const int off = ((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX;
                                     const int m = ((int)(pos << (31 - bb))) >> 31;
                                     acc = __builtin_fmaf(row[off], __int_as_float(m & 0x3D800000), acc);   // 1/16
                                 }
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
                                     for (int i = 0; i < 8; ++i) {
                                         const int b = w * 32 + g * 8 + i;
                                         if (b < C) {
-                                            const int off = ((b / (PS * PS)) * WX + (b / PS) % PS) * WX + b % PS;
+                                            const int off = ((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX;
                                             const float cf = __builtin_amdgcn_cvt_off_f32_i4((code >> (4 * i)) & 15u);
                                             acc = __builtin_fmaf(row[off], cf, acc);
                                         }
@@ -288,9 +288,14 @@ __global__ void __launch_bounds__(64, PS <= 7 ? 4 : 2)
 
 static size_t up256r(size_t v) { return (v + 255) / 256 * 256; }
 
+// 0 = no kernel; else an id of the instantiated patch shape
+static int rank_vm_shape(const Geo &G) {
+    if (G.pz == G.py && G.py == G.px && (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9)) return G.px;
+    if (G.pz == 1 && G.py == G.px && (G.px == 5 || G.px == 7 || G.px == 9 || G.px == 25)) return 100 + G.px;
+    return 0;
+}
 bool rank_vm_supported(const Geo &G) {
-    return G.pz == G.py && G.py == G.px && (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9) &&
-           !G.count_pos_neg && G.layout == PPP_CONS_VOXEL_MAJOR;
+    return rank_vm_shape(G) != 0 && !G.count_pos_neg && G.layout == PPP_CONS_VOXEL_MAJOR;
 }
 
 size_t rank_vm_workspace_bytes(const ppp_box &sb, const Geo &G) {
@@ -326,33 +331,45 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     // Tile of centres per wave.  One wave per tile, ~4 waves per SIMD resident: 4096 tiles run at
     // a time, so a volume of few tiles is cut finer (4 x 8 x 8: 140^3 -> 10.7 k tiles, 2.6 rounds
     // instead of 1.3 rounds of which the second is a third full: 95 -> 86 ms), a large one coarser
-    // (8 x 8 x 8: 5.4 instead of 7.7 row stagings per centre).  PPP_RANK_TILE overrides.
+    // (8 x 8 x 8: 5.4 instead of 7.7 row stagings per centre).  PPP_RANK_TILE overrides.  2-d
+    // patches (pz = 1): 1 x 8 x 8.
+    const int shape_id = rank_vm_shape(G);
     int tile_kind = ((long long)((sZ + 7) / 8) * ((sY + 7) / 8) * ((sX + 7) / 8) < 3 * 4096) ? 2 : 0;
     if (const char *e = getenv("PPP_RANK_TILE"))
         tile_kind = strcmp(e, "8x8x16") == 0 ? 1 : (strcmp(e, "4x8x8") == 0 ? 2 : (strcmp(e, "8x8x8") == 0 ? 0 : tile_kind));
-    const int TZ = tile_kind == 2 ? 4 : 8, TY = 8, TX = tile_kind == 1 ? 16 : 8;
+    if (shape_id > 100) tile_kind = 3;
+    const int TZ = tile_kind == 3 ? 1 : (tile_kind == 2 ? 4 : 8), TY = 8, TX = tile_kind == 1 ? 16 : 8;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64);
-#define PPP_RV_LAUNCH(P, A, B, C_)                                                                     \
-    rank_vm_kernel<P, A, B, C_><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(                         \
+#define PPP_RV_LAUNCH(A_, B_, C_, D_, E_, F_)                                                          \
+    rank_vm_kernel<A_, B_, C_, D_, E_, F_><<<dim3((unsigned)n_blocks), dim3(64), 0, s>>>(              \
         S, Pb, Nb, info, valid, score, sb, G, tiles_y, tiles_x)
 #define PPP_RV_CASE(P)                                                                                 \
     case P:                                                                                            \
-        if (tile_kind == 1) PPP_RV_LAUNCH(P, 8, 8, 16);                                                \
-        else if (tile_kind == 2) PPP_RV_LAUNCH(P, 4, 8, 8);                                            \
-        else PPP_RV_LAUNCH(P, 8, 8, 8);                                                                \
+        if (tile_kind == 1) PPP_RV_LAUNCH(P, P, P, 8, 8, 16);                                          \
+        else if (tile_kind == 2) PPP_RV_LAUNCH(P, P, P, 4, 8, 8);                                      \
+        else PPP_RV_LAUNCH(P, P, P, 8, 8, 8);                                                          \
         break;
-    switch (G.px) {
+#define PPP_RV_CASE2D(P)                                                                               \
+    case 100 + P:                                                                                      \
+        PPP_RV_LAUNCH(1, P, P, 1, 8, 8);                                                               \
+        break;
+    switch (shape_id) {
         PPP_RV_CASE(3)
         PPP_RV_CASE(5)
         PPP_RV_CASE(7)
         PPP_RV_CASE(9)
+        PPP_RV_CASE2D(5)
+        PPP_RV_CASE2D(7)
+        PPP_RV_CASE2D(9)
+        PPP_RV_CASE2D(25)
     default:
         return hipErrorNotSupported;
     }
 #undef PPP_RV_LAUNCH
+#undef PPP_RV_CASE2D
 #undef PPP_RV_CASE
     return hipGetLastError();
 }

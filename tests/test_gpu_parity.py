@@ -53,7 +53,7 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
         vm, Pv = backend.cons_to_voxel_major(cons, P)                             # re-layout
         aff3 = backend.patch_graph(pred, vm, pd, Pv, order=order).cpu().numpy()
         assert np.array_equal(out["aff"].view(np.uint32), aff3.view(np.uint32))
-        if P.px in (3, 5, 7, 9):                                                  # per-patch kernel
+        if P.px in (3, 5, 7, 9) or (P.px == 25 and P.pz == 1):                    # per-patch kernel
             aff4 = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
             assert np.array_equal(out["aff"].view(np.uint32), aff4.view(np.uint32))
     return out
