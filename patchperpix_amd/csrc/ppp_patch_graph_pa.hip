@@ -392,6 +392,42 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                     if (__ballot(add != (M)0) == 0ull) return;
                     // this lane's offset into the staged row for candidate (y2o = 0, x2o = 0)
                     const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + q0x;
+// (measured and rejected: 73 -> 79 ms on the thinned list, 540 -> 640 ms on the dense one --
+// the extra PX registers cost spills at the 64 / 128-VGPR budgets and every row is read)
+#ifndef PPP_PA_ROW_PIPELINE
+#define PPP_PA_ROW_PIPELINE 0
+#endif
+                    if constexpr (PPP_PA_ROW_PIPELINE && PX <= 9) {
+                        // The PX values of a row feed a chain of PX dependent adds; with the LDS
+                        // reads issued right in front of them a wave waits out the LDS latency
+                        // once per row (45 % of the wave-cycles parked at 3-4 waves per SIMD).
+                        // So the reads run ONE ROW AHEAD of the adds: row y2o + 1 is in flight
+                        // while row y2o is summed.  A row nobody needs is still read (lanes
+                        // without work point at slot 0): LDS bandwidth is not what is short.
+                        float nx[PX];
+                        auto fetch = [&](int y2o, float (&dst)[PX]) {
+                            const uint32_t rbn = (uint32_t)(add >> (PX * (y2o - c_first))) & RM;
+                            const float *rowq = cur + (rbn != 0u ? idx0 + y2o * G.wx : 0);
+#pragma unroll
+                            for (int t = 0; t < PX; ++t) dst[t] = rowq[t];
+                        };
+                        fetch(ya, nx);
+                        for (int y2o = ya; y2o <= yb; ++y2o) {
+                            float cv[PX];
+#pragma unroll
+                            for (int t = 0; t < PX; ++t) cv[t] = nx[t];
+                            if (y2o < yb) fetch(y2o + 1, nx);
+                            const uint32_t rb = (uint32_t)(add >> (PX * (y2o - c_first))) & RM;
+                            if (__ballot(rb != 0u) == 0ull) continue;
+                            PA_STAT(2, lane == 0 ? 1 : 0);
+                            PA_STAT(3, __popc(rb));
+#pragma unroll
+                            for (int t = 0; t < PX; ++t) {
+                                const int sel = ((int)(rb << (31 - t))) >> 31;
+                                acc += __int_as_float(__float_as_int(cv[t]) & sel);
+                            }
+                        }
+                    } else {
                     for (int y2o = ya; y2o <= yb; ++y2o) {
                         const uint32_t rb = (uint32_t)(add >> (PX * (y2o - c_first))) & RM;
                         if (__ballot(rb != 0u) == 0ull) continue;
@@ -406,6 +442,7 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                             const int sel = ((int)(rb << (31 - t))) >> 31;
                             acc += __int_as_float(__float_as_int(rowq[t]) & sel);
                         }
+                    }
                     }
                 };
                 // the last chunk of the 9-row planes holds (PX - (NCH-1) RPC) rows
