@@ -871,12 +871,21 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
         np.ascontiguousarray(numinst[bb]), patchshape, n_slabs, **kw)
     instances = np.zeros(shape, dtype=np.uint16)
     instances[bb] = inst_bb
+    # post-steps of the reference driver (stitch_patch_graph.py:831-894)
+    from . import postprocess
+    if kw.get("remove_small_comps", 0) > 0:
+        instances = postprocess.relabel(
+            postprocess.remove_small_components(instances, kw["remove_small_comps"]))
     masked = instances.copy()
     masked[foreground == 0] = 0
     os.makedirs(result_folder, exist_ok=True)
     fn = os.path.splitext(os.path.basename(pred_file.rstrip("/")))[0]
     res_key = kw.get("res_key", "vote_instances")
-    write_result(os.path.join(result_folder, fn + ".hdf"),
-                 {res_key: instances, "vote_foreground": foreground.astype(np.uint8),
-                  res_key + "_masked": masked})
+    datasets = {res_key: instances.astype(np.uint16), "vote_foreground": foreground.astype(np.uint16),
+                res_key + "_masked": masked.astype(np.uint16)}
+    if kw.get("dilate_instances", False):
+        dil = postprocess.dilate_instances(instances)
+        datasets[res_key + "_dil_1"] = dil.astype(np.uint16)
+        datasets[res_key + "_masked_dil_1"] = np.where(foreground == 0, 0, dil).astype(np.uint16)
+    write_result(os.path.join(result_folder, fn + ".hdf"), datasets)
     return instances

@@ -244,3 +244,32 @@ def test_blockwise_io_helpers():
     a = {"a": 1, "b": {"c": 2, "d": {"e": 3}}, "f": [1]}
     assert merge_dicts(a, {"b": {"c": 5, "d": {"g": 1}}, "f": {"x": 1}, "h": 2}) == \
         {"a": 1, "b": {"c": 5, "d": {"e": 3, "g": 1}}, "f": {"x": 1}, "h": 2}
+
+
+def test_post_steps():
+    """remove_small_components / relabel / dilate_instances against literal loops over the labels
+    (PatchPerPix/util/postprocess.py:24-52, stitch_patch_graph.py:871-880)."""
+    from scipy import ndimage
+    from patchperpix_amd import postprocess as pp
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 12, size=(9, 10, 11)).astype(np.uint16) * (rng.random((9, 10, 11)) < 0.3)
+    a = a.astype(np.uint16)
+    want = a.copy()
+    for lab in np.unique(a):
+        if np.count_nonzero(a == lab) <= 20:
+            want[a == lab] = 0
+    got = pp.remove_small_components(a, 20)
+    assert np.array_equal(got, want)
+    rl = pp.relabel(got)
+    labs = [l for l in np.unique(got) if l != 0]
+    want_rl = np.zeros_like(got)
+    for i, l in enumerate(labs):
+        want_rl[got == l] = i + 1
+    assert np.array_equal(rl, want_rl)
+    assert np.array_equal(pp.relabel(got, start=5), np.where(want_rl > 0, want_rl + 4, 0))
+    d = pp.dilate_instances(rl)
+    ref = rl.copy()
+    for l in np.unique(rl):
+        if l:
+            ref[ndimage.binary_dilation(ref == l, iterations=1)] = l
+    assert np.array_equal(d, ref)
