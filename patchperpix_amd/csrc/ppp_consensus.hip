@@ -107,6 +107,9 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     // specialised kernel for px in {3,5,7,9}; PPP_CONSENSUS_GENERIC=1 forces the generic one
     static const bool force_generic = getenv("PPP_CONSENSUS_GENERIC") != nullptr;
     if (!force_generic) {
+        // packed two-slice kernel (TH = 0.5, normalised product), else the general v2
+        const hipError_t e3 = launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
+        if (e3 != hipErrorNotSupported) return e3;
         const hipError_t e2 = launch_consensus_v2(pred, dtype, ov, cons, cnt, G, s);
         if (e2 != hipErrorNotSupported) return e2;
     }

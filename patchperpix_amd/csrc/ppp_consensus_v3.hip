@@ -1,0 +1,500 @@
+// ppp_consensus_v3.hip -- S1, third generation: TWO z-slices per lane, packed f32 arithmetic.
+//
+// Same sums, same summation order, bit-identical output as ppp_consensus_v2.hip (whose header
+// describes the work decomposition: wave = 64 base voxels x one offset row (dz, dy), lane = one
+// base voxel with the 2*PX-1 accumulators of all dx, loops over the patch rows (kz, ky), kx and
+// the partner column unrolled).  What is new:
+//
+//   * a lane owns the base voxels (uz, uy, ux) AND (uz + 1, uy, ux).  Every quantity of the vote
+//     chain is a float2 {slice 0, slice 1} in an aligned register pair, the LDS images hold the
+//     two slices interleaved (one ds_read_b64 per operand pair, conflict free), and the chain is
+//     executed with v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: 9 vector instructions per PAIR
+//     of votes instead of 11 per vote.  (Pairing two votes of ONE voxel is not possible: the
+//     accumulator pair (i, i+1) and the LDS pair would need opposite alignments for odd / even
+//     kx.)  The x / y geometry (flattened runs, segments) is shared by the two slices.
+//   * no compares / selects in the chain.  With TH = 0.5 a classified operand is t = v (> 0.5),
+//     t = v - 1 (< -0.5) or 0, x = ta*tb, and the vote is valid iff x != 0 and not both
+//     operands negative.  Per kx the lane forms ga = [ta > 0] as a float; then
+//         dp = clamp01(x*ga - 0.25)      (positive votes; 0 for x <= 0 and for ta < 0)
+//         dn = clamp01(-x - 0.25)        (negative votes; 0 for x >= 0, i.e. also for (neg, neg))
+//         d  = dp - dn                   = x -/+ 0.25 exactly, or +0 for an invalid pair
+//     followed by the verified float-only quotient of v2 (q0, r, y) and acc += y (y = +0 for an
+//     invalid pair).  clamp01 is the VOP3P clamp bit (inline asm).  Needs |x| <= 1.25: any value
+//     of the tile outside [0, 1] (never for probabilities) sends the tile down the exact path
+//     (compares + double division, as v2).
+//   * counts: operand codes {0, 1 (pos), 256 (neg)} as 16-bit integers, one v_pk_mad_u16 per
+//     vote pair: pos*pos adds 1 to the low byte, pos*neg / neg*pos add 1 to the high byte and
+//     neg*neg = 65536 vanishes mod 2^16.  The two bytes are folded into the running counts
+//     before they can overflow.
+//   * masks by construction instead of per element: everything that depends on the CENTRE
+//     (foreground, interior in x / y / z, segment exists) is one float factor cf[centre][slice]
+//     multiplied into the "about u" operands; everything that depends on the TARGET pixels
+//     (u and w = u + d valid foreground) is constant per accumulator and applied once, when the
+//     accumulators are written.
+#include <stdlib.h>
+
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+static constexpr int V3_WAVES = 4;
+#ifndef PPP_S1V3_PREFETCH
+#define PPP_S1V3_PREFETCH(PX) ((PX) >= 9)
+#endif
+#ifndef PPP_S1V3_MINWAVES
+#define PPP_S1V3_MINWAVES(PX) ((PX) <= 7 ? 3 : 2)
+#endif
+
+template <int PX, bool FLAT>
+struct V3 {
+    static constexpr int RX = PX / 2;
+    static constexpr int NC = 64 + (FLAT ? 2 : 1) * (PX - 1);   // centres per run (both segments)
+    static constexpr int NT = 64 + (FLAT ? 4 : 2) * (PX - 1);   // target pixels per run
+    static constexpr int NACC = 2 * PX - 1;
+    static constexpr int NEL = PX * NC;                         // elements of one operand image
+    static constexpr int NIT = (NEL + 63) / 64;                 // staging iterations per image
+    static constexpr int NELP = NIT * 64;
+    static constexpr int FOLD = 255 / PX;                       // tiles between two count folds
+};
+
+// ---- packed helpers -----------------------------------------------------------------------
+__device__ __forceinline__ v2f pk_mul_clamp(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_fma_clamp(v2f a, v2f b, v2f c) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// clamp01(-a + c)
+__device__ __forceinline__ v2f pk_nadd_clamp(v2f a, v2f c) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
+// codes {0, 1, 256} of a pair of indicator pairs -> two 16-bit integers in one register
+__device__ __forceinline__ uint32_t pack_codes(v2f pos, v2f neg) {
+    const v2f c = pk_fma(neg, splat(256.0f), pos);
+    return (uint32_t)c.x | ((uint32_t)c.y << 16);
+}
+
+// all votes of one (kz, ky) for both slices: kx descending (raster order of the centre), every
+// partner column.  ROW0: offset row (dz, dy) == (0, 0), where only dx > 0 exists.
+template <int PX, int NC, bool ROW0, bool EXACT>
+__device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *bt, const uint32_t *bi,
+                                            const double th2, const double den,
+                                            v2f (&acc)[2 * PX - 1], uint32_t (&tc)[2 * PX - 1]) {
+    const v2f kq = splat(-0.25f), c43 = splat(0x1.555556p+0f), kn75 = splat(-0.75f);
+#pragma unroll
+    for (int kx = PX - 1; kx >= 0; --kx) {
+        const v2f ta = at[kx * NC - kx];
+        v2f ga, na;
+        if constexpr (!EXACT) {
+            ga = pk_mul_clamp(ta, splat(4.0f));            // [ta > 0]  (|ta| > 0.5 when classified)
+            na = pk_mul_clamp(ta, splat(-4.0f));           // [ta < 0]
+        } else {
+            ga = (v2f){ta.x > 0.0f ? 1.0f : 0.0f, ta.y > 0.0f ? 1.0f : 0.0f};
+            na = (v2f){ta.x < 0.0f ? 1.0f : 0.0f, ta.y < 0.0f ? 1.0f : 0.0f};
+        }
+        const uint32_t ca = pack_codes(ga, na);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            if (ROW0 && j <= kx) continue;   // offsets must be lexicographically positive
+            const int i = j - kx + PX - 1;
+            const v2f tb = bt[j * NC - kx];
+            const uint32_t cb = bi[j * NC - kx];
+            const v2f x = ta * tb;
+            if constexpr (!EXACT) {
+                const v2f dp = pk_fma_clamp(x, ga, kq);
+                const v2f dn = pk_nadd_clamp(x, kq);
+                const v2f d = dp - dn;
+                const v2f q0 = d * c43;
+                const v2f r = pk_fma(q0, kn75, d);
+                const v2f y = pk_fma(r, c43, q0);
+                acc[i] = acc[i] + y;
+            } else {
+                v2f y;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float a = s ? ta.y : ta.x, b = s ? tb.y : tb.x, xs = s ? x.y : x.x;
+                    const bool valid = a != 0.0f && b != 0.0f && !(a < 0.0f && b < 0.0f);
+                    const double xd = (double)xs;
+                    const float ys = (float)((xd - __builtin_copysign(th2, xd)) / den);
+                    if (s) y.y = valid ? ys : 0.0f; else y.x = valid ? ys : 0.0f;
+                }
+                acc[i] = acc[i] + y;
+            }
+            tc[i] = pk_mad_u16(ca, cb, tc[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ float ldf_at3(const T *base, unsigned byte_off) {
+    return ldf(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off), 0);
+}
+
+template <typename T, int PX, bool FLAT>
+__global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
+    consensus_v3_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
+                        float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
+                        const int n_rows, const int runs_per_line, const int bZ2,
+                        const long long n_waves) {
+    using K = V3<PX, FLAT>;
+    constexpr int NIT = K::NIT;
+    __shared__ v2f lds_at[V3_WAVES][K::NELP];
+    __shared__ v2f lds_bt[V3_WAVES][K::NELP];
+    __shared__ uint32_t lds_bi[V3_WAVES][K::NELP];
+    __shared__ v2f lds_cf[V3_WAVES][128];
+    __shared__ uint8_t lds_valid[V3_WAVES][2][2][K::NT + 2];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // XCD-aware order (as v2): each XCD gets a contiguous range of (x-run, row) work
+    long long bid = blockIdx.x;
+    {
+        const long long nb = gridDim.x, per = nb / 8, main = per * 8;
+        if (bid < main) bid = (bid % 8) * per + bid / 8;
+    }
+    const long long wid = bid * V3_WAVES + wave;
+    if (wid >= n_waves) return;
+    const int row = (int)(wid % n_rows);
+    long long run = wid / n_rows;
+    int dz, dy;
+    if (row < G.py) { dz = 0; dy = row; }
+    else { const int t = row - G.py; dz = 1 + t / G.wy; dy = t % G.wy - (G.py - 1); }
+    // run -> base voxels of slice 0 (slice 1 = one slice further).  `runs_per_line` = runs per
+    // line, or per z-slice when FLAT; bZ2 = pairs of slices.
+    const int xr = (int)(run % runs_per_line);
+    run /= runs_per_line;
+    int uy, uz, ux0, nA;
+    if (FLAT) {
+        const int flat0 = xr * 64;
+        uy = G.by0 + flat0 / G.bX;
+        uz = G.bz0 + 2 * (int)run;
+        ux0 = G.bx0 + flat0 % G.bX;
+        nA = min(64, G.bX - flat0 % G.bX);
+    } else {
+        uy = G.by0 + (int)(run % G.bY);
+        uz = G.bz0 + 2 * (int)(run / G.bY);
+        ux0 = G.bx0 + xr * 64;
+        nA = 64;
+    }
+    const bool have_s1 = uz + 1 < G.bz0 + G.bZ;                    // slice 1 exists (wave-uniform)
+    const bool in_b = FLAT && lane >= nA;                          // this lane sits on line B
+    const bool have_b = FLAT && nA < 64 && uy + 1 < G.by0 + G.bY;  // (wave-uniform)
+    const int ux = in_b ? G.bx0 + (lane - nA) : ux0 + lane;
+    const int uy_l = in_b ? uy + 1 : uy;
+    const bool lane_ok = in_b ? have_b : ux < G.bx0 + G.bX;
+    const int pos_l = lane + (PX - 1) + (in_b ? PX - 1 : 0);       // image column of the lane's centre at kx = PX-1
+    const int wy = uy + dy;                                        // (line A; line B: wy + 1)
+    const bool wy_ok_a = wy >= 0 && wy < G.Y;
+    const bool wy_ok_b = have_b && wy + 1 >= 0 && wy + 1 < G.Y;
+    const bool wz_ok0 = uz + dz < G.Z, wz_ok1 = have_s1 && uz + 1 + dz < G.Z;
+    const bool w_row_ok = (wy_ok_a || wy_ok_b) && (wz_ok0 || wz_ok1);
+    const bool row0 = dz == 0 && dy == 0;
+
+    v2f acc[K::NACC];
+    uint32_t tc[K::NACC], cnt[K::NACC];
+#pragma unroll
+    for (int i = 0; i < K::NACC; ++i) { acc[i] = splat(0.0f); tc[i] = 0u; cnt[i] = 0u; }
+
+    const T *mid = pred + (long long)G.mid * G.V;
+    // validity (foreground && !overlap) of the target pixels on the u row and on the w row of
+    // both slices; applied when the accumulators are written
+    const int ntA = nA + 2 * (PX - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint8_t *uval = lds_valid[wave][s][0], *wval = lds_valid[wave][s][1];
+        const bool s_ok = s == 0 || have_s1;
+        const bool wz_ok = s ? wz_ok1 : wz_ok0;
+        for (int i = lane; i < K::NT; i += 64) {
+            const bool sb = FLAT && i >= ntA;
+            const int x = sb ? G.bx0 - (PX - 1) + (i - ntA) : ux0 - (PX - 1) + i;
+            const int yy = sb ? uy + 1 : uy, wyy = sb ? wy + 1 : wy;
+            bool vu = false, vw = false;
+            if (s_ok && x >= 0 && x < G.X && (!sb || have_b)) {
+                const long long lu = vox(G, uz + s, yy, x);
+                vu = ldf(mid, lu) > G.th_gt && (!G.use_overlap || ov[lu] == 0);
+                if (wz_ok && (sb ? wy_ok_b : wy_ok_a)) {
+                    const long long lw = vox(G, uz + s + dz, wyy, x);
+                    vw = ldf(mid, lw) > G.th_gt && (!G.use_overlap || ov[lw] == 0);
+                }
+            }
+            uval[i] = vu; wval[i] = vw;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // Per-lane description of the NIT elements of an operand image this lane stages for every
+    // tile (element e = it*64 + lane -> channel column j, centre i); the same for both images
+    // and both slices:
+    //   el_off[it] : byte offset j * V + (line) * X + clamped centre x from the tile's row base
+    //   cf_idx[it] : centre index i (for the centre factor of the "about u" image)
+    // and of the (up to two) centres whose factor this lane computes:
+    //   cf_off[c]  : byte offset (line) * X + clamped centre x from the centre row of `mid`
+    //   cf_st bit c: centre inside the x-interior and its segment exists;  cf_sb bit c: segment B
+    unsigned el_off[NIT];
+    unsigned cf_idx[NIT];
+    const int ncA = nA + (PX - 1);                    // centres of segment A
+    auto centre_x = [&](int i, bool &sb, bool &ok) -> int {
+        sb = FLAT && i >= ncA;
+        const int iseg = sb ? i - ncA : i;
+        const int cx = (sb ? G.bx0 : ux0) - (PX - 1) + K::RX + iseg;
+        ok = cx >= K::RX && cx < G.X - K::RX && (!sb || have_b);
+        return min(max(cx, 0), G.X - 1) + (sb ? G.X : 0);
+    };
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = it * 64 + lane;
+        const int i = e % K::NC;
+        const int j = min(e / K::NC, PX - 1);         // (padding elements repeat the last column)
+        bool sb, ok;
+        const int cxc = centre_x(i, sb, ok);
+        cf_idx[it] = (unsigned)i;
+        el_off[it] = (unsigned)(((long long)j * G.V + cxc) * (long long)sizeof(T));
+    }
+    unsigned cf_off[2];
+    unsigned cf_st = 0, cf_sb = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int i = min(lane + 64 * c, K::NC - 1);
+        bool sb, ok;
+        const int cxc = centre_x(i, sb, ok);
+        cf_off[c] = (unsigned)cxc * (unsigned)sizeof(T);
+        cf_st |= ((ok && lane + 64 * c < K::NC) ? 1u : 0u) << c;
+        cf_sb |= (sb ? 1u : 0u) << c;
+    }
+
+    v2f *at = lds_at[wave], *bt = lds_bt[wave], *cf = lds_cf[wave];
+    uint32_t *bi = lds_bi[wave];
+
+    if (w_row_ok) {
+        const int kz_hi = min(G.pz - 1, G.pz - 1 - dz), kz_lo = max(0, -dz);
+        const int ky_hi = min(G.py - 1, G.py - 1 - dy), ky_lo = max(0, -dy);
+        const long long slice = (long long)G.Y * G.X;
+        // tiles (kz, ky) in descending order, skipping tiles without an interior centre row
+        int kz = kz_hi, ky = ky_hi + 1;
+        bool row_a_ok = true, row_b_ok = false;   // centre row inside the y-interior, per segment
+        bool z_ok0 = true, z_ok1 = false;         // centre slice inside the z-interior, per slice
+        auto next_tile = [&](int &z, int &y) -> bool {
+            while (true) {
+                if (--y < ky_lo) { y = ky_hi; --z; }
+                if (z < kz_lo) return false;
+                const int cz = uz - z + G.rz, cy = uy - y + G.ry;
+                z_ok0 = cz >= G.rz && cz < G.Z - G.rz;
+                z_ok1 = have_s1 && cz + 1 >= G.rz && cz + 1 < G.Z - G.rz;
+                if (!(z_ok0 || z_ok1)) continue;
+                row_a_ok = cy >= G.ry && cy < G.Y - G.ry;
+                row_b_ok = have_b && cy + 1 >= G.ry && cy + 1 < G.Y - G.ry;
+                if (row_a_ok || row_b_ok) return true;
+            }
+        };
+        float ra[2][NIT], rb[2][NIT], rc[2][2];
+        bool lz0 = true, lz1 = false, la = true, lb = false;   // flags of the LOADED tile
+        // issue the (independent, unconditional) loads of one tile into registers.  A slice whose
+        // centre slice is not interior reads the other slice's rows (in bounds; its centre
+        // factors are 0).  FLAT: both lines are inside the z-slice (see v2).
+        auto load_tile = [&](int z, int y) {
+            lz0 = z_ok0; lz1 = z_ok1; la = row_a_ok; lb = row_b_ok;
+            const int cz = uz - z + G.rz;
+            const long long crow0 = vox(G, z_ok0 ? cz : cz + 1, uy - y + G.ry, 0);
+            const long long crow1 = z_ok1 ? crow0 + (z_ok0 ? slice : 0) : crow0;
+            const long long cha = (long long)((z * G.py + y) * PX) * G.V;
+            const long long chb = (long long)(((z + dz) * G.py + (y + dy)) * PX) * G.V;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                ra[0][it] = ldf_at3(pred + cha + crow0, el_off[it]);
+                ra[1][it] = ldf_at3(pred + cha + crow1, el_off[it]);
+                rb[0][it] = ldf_at3(pred + chb + crow0, el_off[it]);
+                rb[1][it] = ldf_at3(pred + chb + crow1, el_off[it]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                rc[0][c] = ldf_at3(mid + crow0, cf_off[c]);
+                rc[1][c] = ldf_at3(mid + crow1, cf_off[c]);
+            }
+        };
+        constexpr bool PREFETCH = PPP_S1V3_PREFETCH(PX);
+        const v2f big26 = splat(0x1p26f), nbig26 = splat(-0x1p26f), hb = splat(0x1p25f),
+                  nhb = splat(-0x1p25f);
+        int n_fold = 0;
+        bool have = next_tile(kz, ky);
+        if (PREFETCH && have) load_tile(kz, ky);
+        while (have) {
+            if (!PREFETCH) load_tile(kz, ky);
+            // ---- centre factors: foreground && interior (x, y, z) && segment exists
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool st = (cf_st >> c) & 1u, sb = (cf_sb >> c) & 1u;
+                const bool rok = st && (sb ? lb : la);
+                v2f f;
+                f.x = (rok && lz0 && rc[0][c] > G.th_gt) ? 1.0f : 0.0f;
+                f.y = (rok && lz1 && rc[1][c] > G.th_gt) ? 1.0f : 0.0f;
+                if (c == 0 || lane + 64 < K::NC) cf[lane + 64 * c] = f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- classify both images of both slices into LDS
+            //      t = v (v > 0.5), v - 1 (v < 0.5), 0 (v == 0.5):  g = [v > 0.5], h = [v < 0.5]
+            //      from clamp01((v - 0.5) * 2^26) / clamp01((0.5 - v) * 2^26), t = v*(g + h) - h
+            unsigned bigmax = 0u;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = it * 64 + lane;
+                {
+                    const v2f v = {ra[0][it], ra[1][it]};
+                    bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
+                    const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
+                    v2f t = pk_fma(v, g + h, -h);
+                    t = t * cf[cf_idx[it]];
+                    at[e] = t;
+                }
+                {
+                    const v2f v = {rb[0][it], rb[1][it]};
+                    bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
+                    const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
+                    bt[e] = pk_fma(v, g + h, -h);
+                    bi[e] = pack_codes(g, h);
+                }
+            }
+            // a value outside [0, 1] (as an unsigned bit pattern: > 1.0f, negative, inf, nan) sends
+            // the tile down the exact path: classification by compares (nan -> unclassified, no
+            // 0 * inf), votes with compares and the double division
+            const bool any_big = __ballot(bigmax > 0x3F800000u) != 0ull;
+            if (any_big) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int e = it * 64 + lane;
+                    const v2f f = cf[cf_idx[it]];
+                    v2f ta, tb;
+                    unsigned code = 0u;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const float va = ra[s][it], vb = rb[s][it];
+                        float xa = va > G.th_gt ? va : (va < G.bg_lt ? va - 1.0f : 0.0f);
+                        const float xb = vb > G.th_gt ? vb : (vb < G.bg_lt ? vb - 1.0f : 0.0f);
+                        if ((s ? f.y : f.x) == 0.0f) xa = 0.0f;
+                        if (s) { ta.y = xa; tb.y = xb; } else { ta.x = xa; tb.x = xb; }
+                        code |= (xb > 0.0f ? 1u : (xb < 0.0f ? 256u : 0u)) << (16 * s);
+                    }
+                    at[e] = ta; bt[e] = tb; bi[e] = code;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- prefetch the next tile; its latency hides behind this tile's votes
+            have = next_tile(kz, ky);
+            if (PREFETCH && have) load_tile(kz, ky);
+            // ---- votes
+            const v2f *ia = at + pos_l;
+            const v2f *ib = bt + pos_l;
+            const uint32_t *ic = bi + pos_l;
+            if (!any_big) {
+                if (row0) tile_votes3<PX, K::NC, true, false>(ia, ib, ic, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, false>(ia, ib, ic, G.th2, G.den, acc, tc);
+            } else {
+                if (row0) tile_votes3<PX, K::NC, true, true>(ia, ib, ic, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, true>(ia, ib, ic, G.th2, G.den, acc, tc);
+            }
+            if (++n_fold == K::FOLD) {
+                n_fold = 0;
+#pragma unroll
+                for (int i = 0; i < K::NACC; ++i) {
+                    cnt[i] += (tc[i] & 0x00FF00FFu) + ((tc[i] >> 8) & 0x00FF00FFu);
+                    tc[i] = 0u;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!lane_ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ti_u = (in_b ? ntA + (lane - nA) : lane) + PX - 1;   // index of u in the validity rows
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s == 1 && !have_s1) break;
+        const uint8_t *uval = lds_valid[wave][s][0], *wval = lds_valid[wave][s][1];
+        const bool u_ok = uval[ti_u] != 0;
+#pragma unroll
+        for (int i = 0; i < K::NACC; ++i) {
+            const int dx = i - (PX - 1);
+            if (dz == 0 && dy == 0 && dx <= 0) continue;
+            const unsigned total = cnt[i] + (tc[i] & 0x00FF00FFu) + ((tc[i] >> 8) & 0x00FF00FFu);
+            const bool ok = u_ok && wval[ti_u + dx] != 0;
+            const unsigned n = ok ? ((s ? total >> 16 : total) & 0xFFFFu) : 0u;
+            const float a = ok ? (s ? acc[i].y : acc[i].x) : 0.0f;
+            const long long o = cons_at(G, dz, dy, dx, uz + s, uy_l, ux);
+            const float c = (float)n;
+            if (cons) cons[o] = (G.normalise && n != 0u) ? a / c : a;
+            if (cnt_out) cnt_out[o] = c;
+        }
+    }
+}
+
+template <typename T, int PX, bool FLAT>
+static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                             const Geo &G, hipStream_t s) {
+    const int n_rows = (G.pz - 1) * G.wy + G.py;
+    const int runs_per_line = FLAT ? (int)(((long long)G.bX * G.bY + 63) / 64) : (G.bX + 63) / 64;
+    const int bZ2 = (G.bZ + 1) / 2;
+    const long long n_waves = (long long)runs_per_line * (FLAT ? 1 : G.bY) * bZ2 * n_rows;
+    const long long n_blocks = (n_waves + V3_WAVES - 1) / V3_WAVES;
+    if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
+    PPP_GRID_CHECK(n_blocks, 64 * V3_WAVES);
+    if (((long long)(PX - 1) * G.V + 2ll * G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
+    consensus_v3_kernel<T, PX, FLAT><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), 0, s>>>(
+        pred, ov, cons, cnt, G, n_rows, runs_per_line, bZ2, n_waves);
+    return hipGetLastError();
+}
+
+template <typename T, int PX>
+static hipError_t launch_v3(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                            const Geo &G, hipStream_t s) {
+    const char *e = getenv("PPP_S1_FLAT");     // same rule as v2
+    bool flat = G.bX >= 64 && G.bX % 64 != 0 && G.py >= 3 && G.bY > 1;
+    if (e && e[0] == '0') flat = false;
+    if (e && e[0] == '1' && G.bX >= 64 && G.py >= 3) flat = true;
+    return flat ? launch_v3f<T, PX, true>(pred, ov, cons, cnt, G, s)
+                : launch_v3f<T, PX, false>(pred, ov, cons, cnt, G, s);
+}
+
+// TH = 0.5, normalised probability product, px in {3,5,7,9}; hipErrorNotSupported otherwise
+// (the caller falls back to v2).  PPP_S1_V3=0 switches it off.
+hipError_t launch_consensus_v3(const void *pred, int dtype, const uint8_t *ov, float *cons,
+                               float *cnt, const Geo &G, hipStream_t s) {
+    const char *e = getenv("PPP_S1_V3");
+    if (e && e[0] == '0') return hipErrorNotSupported;
+    if (!(G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
+          G.th_gt == 0.5f && G.bg_lt == 0.5f))
+        return hipErrorNotSupported;
+#define PPP_V3_CASE(P)                                                                          \
+    case P:                                                                                     \
+        return dtype == PPP_F16                                                                 \
+                   ? launch_v3<__half, P>((const __half *)pred, ov, cons, cnt, G, s)            \
+                   : launch_v3<float, P>((const float *)pred, ov, cons, cnt, G, s);
+    switch (G.px) {
+        PPP_V3_CASE(3)
+        PPP_V3_CASE(5)
+        PPP_V3_CASE(7)
+        PPP_V3_CASE(9)
+    default:
+        return hipErrorNotSupported;
+    }
+#undef PPP_V3_CASE
+}
+
+}  // namespace ppp

@@ -8,6 +8,8 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
                             float *cnt, const Geo &G, hipStream_t s);
 hipError_t launch_consensus_v2(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s);
+hipError_t launch_consensus_v3(const void *pred, int dtype, const uint8_t *ov, float *cons,
+                               float *cnt, const Geo &G, hipStream_t s);
 hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uint8_t *ov,
                        float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
 hipError_t launch_rank_v2(const void *pred, int dtype, const float *cons, const uint8_t *ov,

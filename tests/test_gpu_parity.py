@@ -613,3 +613,32 @@ def test_consensus_flat_runs_equal_line_runs(ps, shape, torch_cuda, monkeypatch)
         assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
         assert np.array_equal(out["0"][1], out["1"][1])
         assert np.count_nonzero(out["0"][0]) > 1000
+
+
+@pytest.mark.parametrize("ps,shape", [((7, 7, 7), (11, 12, 150)), ((5, 5, 5), (9, 11, 97)), ((9, 9, 9), (12, 13, 131)),
+                                      ((3, 3, 3), (7, 9, 70)), ((1, 5, 5), (1, 30, 90)), ((7, 7, 7), (16, 20, 40))])
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_consensus_two_slice_packed_kernel_equals_v2(ps, shape, dtype, torch_cuda, monkeypatch):
+    """S1 v3 (two z-slices per lane, packed f32 chain, 16-bit count codes, masks applied per
+    centre / per accumulator) == S1 v2, values and counts, bit for bit: whole volume (odd and even
+    numbers of slices), a sub-box, flattened and per-line runs."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    c = synth.make_case(shape, ps, seed=96, cell=[6, 6, 9], overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    pred = torch.from_numpy(c["pred"].astype(np.float16 if dtype == "f16" else np.float32)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    boxes = [None, (min(1, shape[0] - 1), 2, 9, shape[0], shape[1] - 1, shape[2] - 7)]
+    for box in boxes:
+        P = backend.make_params(shape, ps, cons_box=box, **kw)
+        for flat in ("0", "1"):
+            monkeypatch.setenv("PPP_S1_FLAT", flat)
+            out = {}
+            for v3 in ("0", "1"):
+                monkeypatch.setenv("PPP_S1_V3", v3)
+                cons, cnt = backend.consensus(pred, ov, P, want_count=True)
+                out[v3] = (cons.cpu().numpy(), cnt.cpu().numpy())
+            assert np.array_equal(out["0"][1], out["1"][1]), (box, flat, "counts")
+            assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32)), (box, flat)
+            assert np.count_nonzero(out["0"][0]) > 1000
