@@ -114,7 +114,8 @@ def s1_roofline(ev_ms, base_voxels, C, kernel="consensus_v2_kernel"):
             "avg_ms": total_ms / len(ev_ms),
             "pair_votes_per_s_upper": C * (C - 1) / 2.0 * base_voxels / (total_ms * 1e-3),
             "note": "the kernel is bound by vector-instruction issue, not by HBM: C(C-1)/2 pair "
-                    "votes per foreground voxel at ~11 VALU instructions each (DESIGN.md section 4)"}
+                    "votes per foreground voxel at ~4.5 (v3: packed, two slices per lane) or ~11 (v2) "
+                    "VALU instructions each (DESIGN.md section 4)"}
 
 
 def north_star_s1(torch, backend, kw):
@@ -151,7 +152,7 @@ def north_star_s1(torch, backend, kw):
         del cons
     del pred, ov
     torch.cuda.empty_cache()
-    r = s1_roofline(times, voxels, C)
+    r = s1_roofline(times, voxels, C, kernel=backend.NOTES.get("s1_kernel", "consensus_v3_kernel"))
     r.update({"workload": "synth512_p9 (BASELINE configs[2]): one S1 pass over all base voxels",
               "volume": list(shape), "patchshape": list(ps), "foreground_fraction": fg_frac,
               "slab_thickness": T, "total_ms": float(np.sum(times)),
@@ -288,10 +289,11 @@ def main():
     value = float(np.prod(gshape)) * args.steps / dt / 1e6
     roofline = None
     if ev.get("consensus"):
-        roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C)
+        s1_kernel = notes.get("s1_kernel", "consensus_v3_kernel")
+        roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C, kernel=s1_kernel)
         roofline["workload"] = args.workload
         if rank == 0 and args.workload == "flylight140_p7" and world == 1 and not args.slabs:
-            roofline.update(pmc_traffic("consensus_v2_kernel"))
+            roofline.update(pmc_traffic(s1_kernel))
     # Secondary figures for the other two big kernels.  S2 (ranking): the consensus it sums +
     # the prediction block once, 4 * planes + 2 * C bytes per voxel.  S5 (patch graph): both
     # patches' channel vectors per dispatched pair row, SURVEY 8(d)'s bound without `visited`.

@@ -97,6 +97,9 @@ typedef struct ppp_params {
 /* --- library / device ------------------------------------------------------------- */
 int ppp_abi_version(void);
 const char *ppp_last_error(void);
+/* name of the kernel the last ppp_consensus call launched (which generation / specialisation
+ * served the shape): "consensus_v3_kernel", "consensus_v2_kernel" or "consensus_gather_kernel" */
+const char *ppp_consensus_kernel_name(void);
 /* number of HIP devices visible; 0 if none (never fails) */
 int ppp_device_count(void);
 

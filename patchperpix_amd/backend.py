@@ -62,6 +62,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "ppp_abi_version": (ctypes.c_int, []),
     "ppp_last_error": (ctypes.c_char_p, []),
+    "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
     "ppp_device_count": (ctypes.c_int, []),
     "ppp_cons_planes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
     "ppp_cons_elems": (ctypes.c_int64, [ctypes.POINTER(Params)]),
@@ -360,8 +361,8 @@ NOTES = {}
 
 
 def note(key, value):
-    """Record a workload statistic (number of selected patches, pairs, ...)."""
-    NOTES[key] = int(value)
+    """Record a workload statistic (number of selected patches, pairs, ...) or a name."""
+    NOTES[key] = value if isinstance(value, str) else int(value)
 
 
 def note_add(key, value):
@@ -415,6 +416,7 @@ def consensus(pred, overlap, P, want_count=False):
     with _timed("consensus"):
         check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
                               _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
+    note("s1_kernel", L.ppp_consensus_kernel_name().decode())
     return (cons, cnt) if want_count else cons
 
 

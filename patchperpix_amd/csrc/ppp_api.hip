@@ -120,6 +120,7 @@ extern "C" {
 
 int ppp_abi_version(void) { return PPP_ABI_VERSION; }
 const char *ppp_last_error(void) { return g_err; }
+const char *ppp_consensus_kernel_name(void) { return ppp::last_consensus_kernel(); }
 
 int ppp_device_count(void) {
     int n = 0;

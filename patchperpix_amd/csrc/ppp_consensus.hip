@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(256)
     if (cnt_out) cnt_out[o] = cnt;
 }
 
+static const char *g_s1_kernel = "none";
+const char *last_consensus_kernel() { return g_s1_kernel; }
+
 hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, float *cons,
                             float *cnt, const Geo &G, hipStream_t s) {
     const dim3 block(256);
@@ -109,10 +112,11 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     if (!force_generic) {
         // packed two-slice kernel (TH = 0.5, normalised product), else the general v2
         const hipError_t e3 = launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
-        if (e3 != hipErrorNotSupported) return e3;
+        if (e3 != hipErrorNotSupported) { g_s1_kernel = "consensus_v3_kernel"; return e3; }
         const hipError_t e2 = launch_consensus_v2(pred, dtype, ov, cons, cnt, G, s);
-        if (e2 != hipErrorNotSupported) return e2;
+        if (e2 != hipErrorNotSupported) { g_s1_kernel = "consensus_v2_kernel"; return e2; }
     }
+    g_s1_kernel = "consensus_gather_kernel";
     if (dtype == PPP_F16)
         consensus_gather_kernel<__half><<<grid, block, 0, s>>>((const __half *)pred, ov, cons, cnt, G);
     else

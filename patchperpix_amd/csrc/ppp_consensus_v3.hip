@@ -18,8 +18,8 @@
 //         dp = clamp01(x*ga - 0.25)      (positive votes; 0 for x <= 0 and for ta < 0)
 //         dn = clamp01(-x - 0.25)        (negative votes; 0 for x >= 0, i.e. also for (neg, neg))
 //         d  = dp - dn                   = x -/+ 0.25 exactly, or +0 for an invalid pair
-//     followed by the verified float-only quotient of v2 (q0, r, y) and acc += y (y = +0 for an
-//     invalid pair).  clamp01 is the VOP3P clamp bit (inline asm).  Needs |x| <= 1.25: any value
+//     followed by a two-operation correctly rounded quotient y = fma(d, fl(4/3), d * lo(4/3)) and
+//     acc += y (y = +0 for an invalid pair).  clamp01 is the VOP3P clamp bit (inline asm).  Needs |x| <= 1.25: any value
 //     of the tile outside [0, 1] (never for probabilities) sends the tile down the exact path
 //     (compares + double division, as v2).
 //   * counts: operand codes {0, 1 (pos), 256 (neg)} as 16-bit integers, one v_pk_mad_u16 per
@@ -38,8 +38,19 @@
 namespace ppp {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// (explicit LDS address space: a volatile access through a generic pointer stays a flat load)
+typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f_cvp;
 
-static constexpr int V3_WAVES = 4;
+// waves per workgroup: LDS (16 / 20 KB per wave at 7^3 / 9^3) decides how many waves a CU holds;
+// small workgroups waste less of it
+#ifndef PPP_S1V3_WAVES
+#define PPP_S1V3_WAVES(PX) 1
+#endif
+// votes whose chains are interleaved (dependent packed operations issue back to back otherwise)
+#ifndef PPP_S1V3_GROUP
+#define PPP_S1V3_GROUP 3
+#endif
 #ifndef PPP_S1V3_PREFETCH
 #define PPP_S1V3_PREFETCH(PX) ((PX) >= 9)
 #endif
@@ -91,51 +102,94 @@ __device__ __forceinline__ uint32_t pack_codes(v2f pos, v2f neg) {
 
 // all votes of one (kz, ky) for both slices: kx descending (raster order of the centre), every
 // partner column.  ROW0: offset row (dz, dy) == (0, 0), where only dx > 0 exists.
+// The "about w" image holds 16-byte elements {t slice 0, t slice 1, codes, -}: one ds_read_b128
+// per vote pair (volatile: the compiler would narrow it to a slower 12-byte read).  Votes are
+// processed in groups of GS whose chains are interleaved stage by stage; the LDS reads of the
+// next group are issued before the arithmetic of the current one.
 template <int PX, int NC, bool ROW0, bool EXACT>
-__device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *bt, const uint32_t *bi,
+__device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt,
                                             const double th2, const double den,
                                             v2f (&acc)[2 * PX - 1], uint32_t (&tc)[2 * PX - 1]) {
-    const v2f kq = splat(-0.25f), c43 = splat(0x1.555556p+0f), kn75 = splat(-0.75f);
+    // fl(4/3) and fl(4/3 - fl(4/3)): y = fma(d, c43, d * c43lo) is the correctly rounded d / 0.75
+    // (= the reference's float(double(d) / 0.75)) for every float d = |x| - 0.25, x in [0.25, 2^22]
+    // -- 4d/3 is never closer than 1/6 ulp to a rounding boundary; checked exhaustively by
+    // tests/csrc/th05_quotient.c
+    const v2f kq = splat(-0.25f), c43 = splat(0x1.555556p+0f), c43lo = splat(-0x1.555556p-25f);
+    constexpr int GS = PPP_S1V3_GROUP;
+    constexpr int NJG = (PX + GS - 1) / GS;     // groups per kx
+    constexpr int NG = PX * NJG;                // groups per tile, n -> kx = PX-1 - n / NJG
+    v4f bcur[GS], bnxt[GS];
+    v2f ta, ta_nxt, ga, na;
+    uint32_t ca = 0u;
+    auto used = [](int kx, int j) { return j < PX && !(ROW0 && j <= kx); };
+    auto load_group = [&](int n, v4f (&b)[GS], v2f &t) {
+        const int kx = PX - 1 - n / NJG, jg = (n % NJG) * GS;
+        if (jg == 0) t = at[kx * NC - kx];
 #pragma unroll
-    for (int kx = PX - 1; kx >= 0; --kx) {
-        const v2f ta = at[kx * NC - kx];
-        v2f ga, na;
-        if constexpr (!EXACT) {
-            ga = pk_mul_clamp(ta, splat(4.0f));            // [ta > 0]  (|ta| > 0.5 when classified)
-            na = pk_mul_clamp(ta, splat(-4.0f));           // [ta < 0]
-        } else {
-            ga = (v2f){ta.x > 0.0f ? 1.0f : 0.0f, ta.y > 0.0f ? 1.0f : 0.0f};
-            na = (v2f){ta.x < 0.0f ? 1.0f : 0.0f, ta.y < 0.0f ? 1.0f : 0.0f};
-        }
-        const uint32_t ca = pack_codes(ga, na);
+        for (int g = 0; g < GS; ++g)
+            if (used(kx, jg + g)) b[g] = bt[(jg + g) * NC - kx];
+    };
+    load_group(0, bcur, ta);
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            if (ROW0 && j <= kx) continue;   // offsets must be lexicographically positive
-            const int i = j - kx + PX - 1;
-            const v2f tb = bt[j * NC - kx];
-            const uint32_t cb = bi[j * NC - kx];
-            const v2f x = ta * tb;
+    for (int n = 0; n < NG; ++n) {
+        const int kx = PX - 1 - n / NJG, jg = (n % NJG) * GS;
+        if (n + 1 < NG) load_group(n + 1, bnxt, ta_nxt);
+        if (jg == 0) {
             if constexpr (!EXACT) {
-                const v2f dp = pk_fma_clamp(x, ga, kq);
-                const v2f dn = pk_nadd_clamp(x, kq);
-                const v2f d = dp - dn;
-                const v2f q0 = d * c43;
-                const v2f r = pk_fma(q0, kn75, d);
-                const v2f y = pk_fma(r, c43, q0);
-                acc[i] = acc[i] + y;
+                ga = pk_mul_clamp(ta, splat(4.0f));            // [ta > 0]  (|ta| > 0.5 when classified)
+                na = pk_mul_clamp(ta, splat(-4.0f));           // [ta < 0]
             } else {
-                v2f y;
+                ga = (v2f){ta.x > 0.0f ? 1.0f : 0.0f, ta.y > 0.0f ? 1.0f : 0.0f};
+                na = (v2f){ta.x < 0.0f ? 1.0f : 0.0f, ta.y < 0.0f ? 1.0f : 0.0f};
+            }
+            ca = pack_codes(ga, na);
+        }
+        v2f tb[GS], x[GS], y[GS];
+        uint32_t cb[GS];
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            if (!used(kx, jg + g)) continue;
+            tb[g] = (v2f){bcur[g].x, bcur[g].y};
+            cb[g] = __float_as_uint(bcur[g].z);
+            x[g] = ta * tb[g];
+        }
+        if constexpr (!EXACT) {
+            v2f dp[GS], dn[GS], d[GS], q0[GS];
+#pragma unroll
+            for (int g = 0; g < GS; ++g) if (used(kx, jg + g)) dp[g] = pk_fma_clamp(x[g], ga, kq);
+#pragma unroll
+            for (int g = 0; g < GS; ++g) if (used(kx, jg + g)) dn[g] = pk_nadd_clamp(x[g], kq);
+#pragma unroll
+            for (int g = 0; g < GS; ++g) if (used(kx, jg + g)) d[g] = dp[g] - dn[g];
+#pragma unroll
+            for (int g = 0; g < GS; ++g) if (used(kx, jg + g)) q0[g] = d[g] * c43lo;
+#pragma unroll
+            for (int g = 0; g < GS; ++g) if (used(kx, jg + g)) y[g] = pk_fma(d[g], c43, q0[g]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < GS; ++g) {
+                if (!used(kx, jg + g)) continue;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const float a = s ? ta.y : ta.x, b = s ? tb.y : tb.x, xs = s ? x.y : x.x;
+                    const float a = s ? ta.y : ta.x, b = s ? tb[g].y : tb[g].x, xs = s ? x[g].y : x[g].x;
                     const bool valid = a != 0.0f && b != 0.0f && !(a < 0.0f && b < 0.0f);
                     const double xd = (double)xs;
                     const float ys = (float)((xd - __builtin_copysign(th2, xd)) / den);
-                    if (s) y.y = valid ? ys : 0.0f; else y.x = valid ? ys : 0.0f;
+                    if (s) y[g].y = valid ? ys : 0.0f; else y[g].x = valid ? ys : 0.0f;
                 }
-                acc[i] = acc[i] + y;
             }
-            tc[i] = pk_mad_u16(ca, cb, tc[i]);
+        }
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+            if (!used(kx, jg + g)) continue;
+            const int i = jg + g - kx + PX - 1;
+            acc[i] = acc[i] + y[g];
+            tc[i] = pk_mad_u16(ca, cb[g], tc[i]);
+        }
+        if (n + 1 < NG) {
+#pragma unroll
+            for (int g = 0; g < GS; ++g) bcur[g] = bnxt[g];
+            if ((n + 1) % NJG == 0) ta = ta_nxt;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -143,21 +197,24 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *bt, const 
 
 template <typename T>
 __device__ __forceinline__ float ldf_at3(const T *base, unsigned byte_off) {
+    // (keeps the zero extension of the offset next to the load: hoisted out of the tile loop it
+    // would turn every load into a 64-bit VGPR address computation instead of saddr + voffset)
+    asm volatile("" : "+v"(byte_off));
     return ldf(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off), 0);
 }
 
 template <typename T, int PX, bool FLAT>
-__global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
+__global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX))
     consensus_v3_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
                         float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
                         const int n_rows, const int runs_per_line, const int bZ2,
                         const long long n_waves) {
     using K = V3<PX, FLAT>;
     constexpr int NIT = K::NIT;
+    constexpr int V3_WAVES = PPP_S1V3_WAVES(PX);
+    __shared__ v4f lds_bt[V3_WAVES][K::NELP];
     __shared__ v2f lds_at[V3_WAVES][K::NELP];
-    __shared__ v2f lds_bt[V3_WAVES][K::NELP];
-    __shared__ uint32_t lds_bi[V3_WAVES][K::NELP];
-    __shared__ v2f lds_cf[V3_WAVES][128];
+    __shared__ v2f lds_cf[V3_WAVES][K::NC];
     __shared__ uint8_t lds_valid[V3_WAVES][2][2][K::NT + 2];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // XCD-aware order (as v2): each XCD gets a contiguous range of (x-run, row) work
@@ -277,8 +334,8 @@ __global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
         cf_sb |= (sb ? 1u : 0u) << c;
     }
 
-    v2f *at = lds_at[wave], *bt = lds_bt[wave], *cf = lds_cf[wave];
-    uint32_t *bi = lds_bi[wave];
+    v2f *at = lds_at[wave], *cf = lds_cf[wave];
+    v4f *bt = lds_bt[wave];
 
     if (w_row_ok) {
         const int kz_hi = min(G.pz - 1, G.pz - 1 - dz), kz_lo = max(0, -dz);
@@ -342,7 +399,7 @@ __global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
                 v2f f;
                 f.x = (rok && lz0 && rc[0][c] > G.th_gt) ? 1.0f : 0.0f;
                 f.y = (rok && lz1 && rc[1][c] > G.th_gt) ? 1.0f : 0.0f;
-                if (c == 0 || lane + 64 < K::NC) cf[lane + 64 * c] = f;
+                if (lane + 64 * c < K::NC) cf[lane + 64 * c] = f;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -350,23 +407,26 @@ __global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
             //      t = v (v > 0.5), v - 1 (v < 0.5), 0 (v == 0.5):  g = [v > 0.5], h = [v < 0.5]
             //      from clamp01((v - 0.5) * 2^26) / clamp01((0.5 - v) * 2^26), t = v*(g + h) - h
             unsigned bigmax = 0u;
+            v2f cf_cur = cf[cf_idx[0]], cf_nxt = cf_cur;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int e = it * 64 + lane;
+                if (it + 1 < NIT) cf_nxt = cf[cf_idx[it + 1]];
                 {
                     const v2f v = {ra[0][it], ra[1][it]};
                     bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
                     const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
                     v2f t = pk_fma(v, g + h, -h);
-                    t = t * cf[cf_idx[it]];
+                    t = t * cf_cur;
                     at[e] = t;
+                    cf_cur = cf_nxt;
                 }
                 {
                     const v2f v = {rb[0][it], rb[1][it]};
                     bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
                     const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
-                    bt[e] = pk_fma(v, g + h, -h);
-                    bi[e] = pack_codes(g, h);
+                    const v2f t = pk_fma(v, g + h, -h);
+                    bt[e] = (v4f){t.x, t.y, __uint_as_float(pack_codes(g, h)), 0.0f};
                 }
             }
             // a value outside [0, 1] (as an unsigned bit pattern: > 1.0f, negative, inf, nan) sends
@@ -389,7 +449,8 @@ __global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
                         if (s) { ta.y = xa; tb.y = xb; } else { ta.x = xa; tb.x = xb; }
                         code |= (xb > 0.0f ? 1u : (xb < 0.0f ? 256u : 0u)) << (16 * s);
                     }
-                    at[e] = ta; bt[e] = tb; bi[e] = code;
+                    at[e] = ta;
+                    bt[e] = (v4f){tb.x, tb.y, __uint_as_float(code), 0.0f};
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -399,14 +460,13 @@ __global__ void __launch_bounds__(64 * V3_WAVES, PPP_S1V3_MINWAVES(PX))
             if (PREFETCH && have) load_tile(kz, ky);
             // ---- votes
             const v2f *ia = at + pos_l;
-            const v2f *ib = bt + pos_l;
-            const uint32_t *ic = bi + pos_l;
+            lds_v4f_cvp ib = (lds_v4f_cvp)(bt + pos_l);
             if (!any_big) {
-                if (row0) tile_votes3<PX, K::NC, true, false>(ia, ib, ic, G.th2, G.den, acc, tc);
-                else tile_votes3<PX, K::NC, false, false>(ia, ib, ic, G.th2, G.den, acc, tc);
+                if (row0) tile_votes3<PX, K::NC, true, false>(ia, ib, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, false>(ia, ib, G.th2, G.den, acc, tc);
             } else {
-                if (row0) tile_votes3<PX, K::NC, true, true>(ia, ib, ic, G.th2, G.den, acc, tc);
-                else tile_votes3<PX, K::NC, false, true>(ia, ib, ic, G.th2, G.den, acc, tc);
+                if (row0) tile_votes3<PX, K::NC, true, true>(ia, ib, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, true>(ia, ib, G.th2, G.den, acc, tc);
             }
             if (++n_fold == K::FOLD) {
                 n_fold = 0;
@@ -452,6 +512,7 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
     const int runs_per_line = FLAT ? (int)(((long long)G.bX * G.bY + 63) / 64) : (G.bX + 63) / 64;
     const int bZ2 = (G.bZ + 1) / 2;
     const long long n_waves = (long long)runs_per_line * (FLAT ? 1 : G.bY) * bZ2 * n_rows;
+    constexpr int V3_WAVES = PPP_S1V3_WAVES(PX);
     const long long n_blocks = (n_waves + V3_WAVES - 1) / V3_WAVES;
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
     PPP_GRID_CHECK(n_blocks, 64 * V3_WAVES);
