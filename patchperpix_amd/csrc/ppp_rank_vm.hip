@@ -26,6 +26,9 @@
 namespace ppp {
 
 static constexpr int RV_PAD = 8;
+// row reads through a volatile LDS pointer: one ds_read_b32 with a 16-bit immediate offset each.
+// (Merged into ds_read2_b32 -- 8-bit offsets -- the compiler needs an address add for most pairs.)
+typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp;
 
 // ---- pre-pass: per-centre masks, pair counts, border / background scores ---------------------
 // thread per centre of the score box; masks are stored word-major over the box so that the main
@@ -100,7 +103,9 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
     __shared__ float accs[NT];
     constexpr int UB = (TZ + 2 * RZ) * (TY + 2 * RY) * (TX + 2 * RX);
     __shared__ uint32_t act_bits[(NT + 31) / 32];      // centre of the tile takes part
-    __shared__ uint32_t spread[256];                   // byte -> 8 nibbles, nibble i = bit i
+    // byte of mask bits -> 8 coefficient bytes (byte i = bit i ? code : 0); code 0x3D / 0xBD is
+    // the top byte of +-1/32 as a float (all lower bits zero)
+    __shared__ uint2 coefP[256], coefN[256];
     __shared__ uint32_t uvalid_bits[(UB + 63) / 64 * 2];   // voxel of the grown tile can be a first pixel
     const int lane = threadIdx.x;
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
@@ -122,9 +127,13 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
         return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
     };
     for (int e = lane; e < 256; e += 64) {
-        uint32_t v = 0;
-        for (int i = 0; i < 8; ++i) v |= ((e >> i) & 1u) << (4 * i);
-        spread[e] = v;
+        uint32_t lo = 0, hi = 0;
+        for (int i = 0; i < 4; ++i) {
+            lo |= ((e >> i) & 1u) << (8 * i);
+            hi |= ((e >> (4 + i)) & 1u) << (8 * i);
+        }
+        coefP[e] = make_uint2(lo * 0x3Du, hi * 0x3Du);
+        coefN[e] = make_uint2(lo * 0xBDu, hi * 0xBDu);
     }
     bool any_active = false;
     static_assert(NT % 64 == 0, "tile size must be a multiple of the wave size");
@@ -175,7 +184,7 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int e = lane + i * 64;
-            if (e < W) rowbuf[RV_PAD + e] = src[e] * 16.0f;
+            if (e < W) rowbuf[RV_PAD + e] = src[e] * 32.0f;
         }
     }
     __syncthreads();
@@ -205,6 +214,8 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
                     const int cl = (lz * TY + ly) * TX + lx;
                     const int a = (az * PY + ay) * PX + ax;
                     const long long t = sb_index(lz, ly, lx);
+                    // (prefetching the next chunk's mask words -- for every item, before it is known
+                    // whether a is in P -- was measured slower: 73 -> 80 ms at 140^3 / 7^3)
                     bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
                     if (active) active = ((Pb[(long long)(a >> 5) * sbV + t] >> (a & 31)) & 1u) != 0;
                     if (__ballot(active) == 0) continue;
@@ -215,7 +226,7 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
                         nw[w] = active ? Nb[(long long)w * sbV + t] : 0u;
                     }
                     float acc = active ? accs[cl] : 0.0f;
-                    const float *row = rowbuf + RV_PAD + LC - ((az * WY + ay) * WX + ax);
+                    lds_f32_cvp row = (lds_f32_cvp)(rowbuf + RV_PAD + LC - ((az * WY + ay) * WX + ax));
                     const int aw = a >> 5;
                     const uint32_t above = ~((2u << (a & 31)) - 1u);   // bits of a's word above a
 #pragma unroll
@@ -223,39 +234,43 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
                         // b in P counts only for b > a
                         const uint32_t pos = pw[w] & (w < aw ? 0u : (w > aw ? 0xFFFFFFFFu : above));
                         const uint32_t neg = nw[w];
-                        const bool any_pos = __ballot(pos != 0u) != 0, any_neg = __ballot(neg != 0u) != 0;
-                        if (!any_pos && !any_neg) continue;
-                        // The staged row holds 16 * S (exact).  A term is fma(16 S, c, acc) with
-                        // c = +1/16 (b in P, b > a), -1/16 (b in N) or 0: the product is exactly
+                        if (__ballot((pos | neg) != 0u) == 0) continue;
+                        // The staged row holds 32 * S (exact).  A term is fma(32 S, c, acc) with
+                        // c = +1/32 (b in P, b > a), -1/32 (b in N) or 0: the product is exactly
                         // +-S or 0, so the fma rounds once, like the reference's acc += / -= S.
-                        if (!any_neg) {
-                            // only foreground partners in this word: c from one mask bit
+                        // The coefficients of 8 partners come as bytes from two table reads; a
+                        // byte moved to the top of a register IS the float (v_perm_b32).
+                        // all table reads of the word first, then the groups of 8 partners with the
+                        // row values of the next group already in flight
+                        uint32_t c_lo[4], c_hi[4];
 #pragma unroll
-                            for (int bb = 0; bb < 32; ++bb) {
-                                const int b = w * 32 + bb;
-                                if (b < C) {
-                                    const int off = ((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX;
-                                    const int m = ((int)(pos << (31 - bb))) >> 31;
-                                    acc = __builtin_fmaf(row[off], __int_as_float(m & 0x3D800000), acc);   // 1/16
-                                }
+                        for (int g = 0; g < 4; ++g) {
+                            if (w * 32 + g * 8 < C) {
+                                const uint2 cp = coefP[(pos >> (8 * g)) & 0xFFu], cn = coefN[(neg >> (8 * g)) & 0xFFu];
+                                c_lo[g] = cp.x | cn.x;
+                                c_hi[g] = cp.y | cn.y;
                             }
-                        } else {
-                            // signed coefficients: 8 at a time as nibbles (+1 -> 0x1, -1 -> 0xF) through
-                            // the byte-spread table, decoded by v_cvt_off_f32_i4 (nibble / 16)
+                        }
+                        float rv[2][8];
+                        auto load_rows = [&](int g, float (&r)[8]) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                if (w * 32 + g * 8 < C) {
-                                    const uint32_t sp = spread[(pos >> (8 * g)) & 0xFFu], sn = spread[(neg >> (8 * g)) & 0xFFu];
-                                    const uint32_t code = sp + (sn << 4) - sn;
-                                    if (__ballot(code != 0u) == 0) continue;
+                            for (int i = 0; i < 8; ++i) {
+                                const int b = w * 32 + g * 8 + i;
+                                if (b < C) r[i] = row[((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX];
+                            }
+                        };
+                        load_rows(0, rv[0]);
 #pragma unroll
-                                    for (int i = 0; i < 8; ++i) {
-                                        const int b = w * 32 + g * 8 + i;
-                                        if (b < C) {
-                                            const int off = ((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX;
-                                            const float cf = __builtin_amdgcn_cvt_off_f32_i4((code >> (4 * i)) & 15u);
-                                            acc = __builtin_fmaf(row[off], cf, acc);
-                                        }
+                        for (int g = 0; g < 4; ++g) {
+                            if (w * 32 + g * 8 < C) {
+                                if (g + 1 < 4 && w * 32 + (g + 1) * 8 < C) load_rows(g + 1, rv[(g + 1) & 1]);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const int b = w * 32 + g * 8 + i;
+                                    if (b < C) {
+                                        const uint32_t c = __builtin_amdgcn_perm(0u, i < 4 ? c_lo[g] : c_hi[g],
+                                                                                 0x000C0C0Cu | ((uint32_t)(i & 3) << 24));
+                                        acc = __builtin_fmaf(rv[g & 1][i], __uint_as_float(c), acc);
                                     }
                                 }
                             }
@@ -269,7 +284,7 @@ __global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
 #pragma unroll
                     for (int i = 0; i < NST; ++i) {
                         const int e = lane + i * 64;
-                        if (e < W) rowbuf[RV_PAD + e] = st[i] * 16.0f;
+                        if (e < W) rowbuf[RV_PAD + e] = st[i] * 32.0f;
                     }
                 }
                 __syncthreads();
