@@ -31,7 +31,8 @@
  *                     These are exactly the planes the reference ever writes.
  *  PPP_CONS_VOXEL_MAJOR [bz][by][bx][W] float32, W = (2pz-1)(2py-1)(2px-1): for every base
  *                     voxel v the consensus between v and v+q for ALL signed offsets q
- *                     (index Lc + (qz*(2py-1)+qy)*(2px-1)+qx, Lc = (W-1)/2); made from a
+ *                     (index Lc + (qz*(2py-1)+qy)*(2px-1)+qx, Lc = (W-1)/2); written directly by
+ *                     ppp_consensus where ppp_consensus_writes_voxel_major() says so, else made from a
  *                     COMPACT array by ppp_cons_to_voxel_major; the layout ppp_patch_graph
  *                     is fastest on (every lane sweeps contiguous memory).
  *  PPP_CONS_REFERENCE [NSZ][NSY][NSX][Z][Y][X] float32, index o = d + p - 1,
@@ -118,6 +119,10 @@ int64_t ppp_cons_elems(const ppp_params *p);
  * d_overlap: uint8 (Z,Y,X) or NULL when !use_overlap                                   */
 int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
                   float *d_count, const ppp_params *p, void *stream);
+/* 1 when ppp_consensus can write p->cons_layout = PPP_CONS_VOXEL_MAJOR directly for these
+ * parameters (then no COMPACT array and no ppp_cons_to_voxel_major are needed); 0 otherwise
+ * (write COMPACT, then convert).  d_count must be NULL for that layout. */
+int ppp_consensus_writes_voxel_major(const ppp_params *p);
 
 /* --- S2: patch ranking ---------------------------------------------------------------
  * replaces rank_patches_cuda (ranked_patches.py:33-74) + kernel rankPatches

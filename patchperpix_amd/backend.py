@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ppp_abi_version": (ctypes.c_int, []),
     "ppp_last_error": (ctypes.c_char_p, []),
     "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
+    "ppp_consensus_writes_voxel_major": (ctypes.c_int, [ctypes.POINTER(Params)]),
     "ppp_device_count": (ctypes.c_int, []),
     "ppp_cons_planes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
     "ppp_cons_elems": (ctypes.c_int64, [ctypes.POINTER(Params)]),
@@ -408,6 +409,8 @@ def consensus(pred, overlap, P, want_count=False):
     L = lib()
     if P.cons_layout == CONS_REFERENCE:
         shape = (2 * P.pz if P.pz > 1 else 1, 2 * P.py, 2 * P.px, P.Z, P.Y, P.X)
+    elif P.cons_layout == CONS_VOXEL_MAJOR:
+        shape = P.cons_box.shape() + (int(L.ppp_cons_planes(ctypes.byref(P))),)
     else:
         shape = (int(L.ppp_cons_planes(ctypes.byref(P))),) + P.cons_box.shape()
     cons = _big_empty(shape, pred.device)
@@ -701,6 +704,20 @@ def paint_instances(pred, nodes, labels, instances, P):
                                         _dev_ptr(labels), int(nodes.shape[0]),
                                         _dev_ptr(instances), ctypes.byref(P), _stream()))
     return instances
+
+
+def consensus_voxel_major(pred, overlap, P):
+    """S1 straight into the symmetric voxel-major layout when the library can do that for these
+    parameters (ppp_consensus_writes_voxel_major), else COMPACT + ppp_cons_to_voxel_major.
+    Returns (tensor [bz, by, bx, W], params with cons_layout = VOXEL_MAJOR)."""
+    Pv = P.copy()
+    Pv.cons_layout = CONS_VOXEL_MAJOR
+    if os.environ.get("PPP_S1_DIRECT_VM", "1") != "0" and lib().ppp_consensus_writes_voxel_major(ctypes.byref(Pv)):
+        return consensus(pred, overlap, Pv), Pv
+    Pc = P.copy()
+    Pc.cons_layout = CONS_COMPACT
+    cons = consensus(pred, overlap, Pc)
+    return cons_to_voxel_major(cons, Pc)
 
 
 def cons_to_reference(cons_compact, P):

@@ -149,10 +149,18 @@ int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, 
     PPP_TRY(check_dtype(pred_dtype));
     if (!d_pred || (!d_cons && !d_count)) return fail(PPP_ERR_INVALID_ARG, "NULL pred / outputs");
     if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
-    if (G.layout == PPP_CONS_VOXEL_MAJOR) return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus writes COMPACT or REFERENCE layout");
+    if (G.layout == PPP_CONS_VOXEL_MAJOR && (!ppp::consensus_v3_supported(G) || d_count || !d_cons))
+        return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus writes VOXEL_MAJOR only with the packed kernel (TH = 0.5, normalised "
+                                         "product, px in {3,5,7,9}; no counts): see ppp_consensus_writes_voxel_major");
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, d_count, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus");
+}
+
+int ppp_consensus_writes_voxel_major(const ppp_params *p) {
+    ppp::Geo G;
+    if (!p || make_geo(p, &G) != PPP_OK) return 0;
+    return ppp::consensus_v3_supported(G) ? 1 : 0;
 }
 
 int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,

@@ -97,6 +97,12 @@ const char *last_consensus_kernel() { return g_s1_kernel; }
 
 hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, float *cons,
                             float *cnt, const Geo &G, hipStream_t s) {
+    if (G.layout == PPP_CONS_VOXEL_MAJOR) {
+        // only the packed two-slice kernel writes the voxel-major rows directly
+        if (!consensus_v3_supported(G)) return hipErrorNotSupported;
+        g_s1_kernel = "consensus_v3_kernel";
+        return launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
+    }
     const dim3 block(256);
     PPP_GRID_CHECK((G.BV + 255) / 256, 256);
     const dim3 grid((unsigned)((G.BV + 255) / 256), (unsigned)G.n_planes);

@@ -489,19 +489,82 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
         if (s == 1 && !have_s1) break;
         const uint8_t *uval = lds_valid[wave][s][0], *wval = lds_valid[wave][s][1];
         const bool u_ok = uval[ti_u] != 0;
+        float val[K::NACC];
 #pragma unroll
         for (int i = 0; i < K::NACC; ++i) {
             const int dx = i - (PX - 1);
+            val[i] = 0.0f;
             if (dz == 0 && dy == 0 && dx <= 0) continue;
             const unsigned total = cnt[i] + (tc[i] & 0x00FF00FFu) + ((tc[i] >> 8) & 0x00FF00FFu);
             const bool ok = u_ok && wval[ti_u + dx] != 0;
             const unsigned n = ok ? ((s ? total >> 16 : total) & 0xFFFFu) : 0u;
             const float a = ok ? (s ? acc[i].y : acc[i].x) : 0.0f;
-            const long long o = cons_at(G, dz, dy, dx, uz + s, uy_l, ux);
             const float c = (float)n;
-            if (cons) cons[o] = (G.normalise && n != 0u) ? a / c : a;
-            if (cnt_out) cnt_out[o] = c;
+            val[i] = (G.normalise && n != 0u) ? a / c : a;
+            if (G.layout != PPP_CONS_VOXEL_MAJOR) {
+                const long long o = cons_at(G, dz, dy, dx, uz + s, uy_l, ux);
+                if (cons) cons[o] = val[i];
+                if (cnt_out) cnt_out[o] = c;
+            }
         }
+        if (G.layout == PPP_CONS_VOXEL_MAJOR) {
+            // symmetric voxel-major rows written directly (no compact planes, no transpose):
+            // S[u][Lc + L(d)] -- the 2 PX - 1 entries of this offset row are contiguous, stored
+            // four at a time -- and, when w = u + d lies in the box, the mirror S[w][Lc - L(d)].
+            // Entries whose source voxel lies outside the box (and L = Lc) are zeroed by
+            // vm_zero_kernel.
+            const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
+            const int L0 = (dz * G.wy + dy) * G.wx;
+            const long long vu = ((long long)(uz + s - G.bz0) * G.bY + (uy_l - G.by0)) * G.bX + (ux - G.bx0);
+            float *pos = cons + vu * W + Lc + L0 - (PX - 1);     // entry of dx = -(PX-1)
+            if (row0) {
+#pragma unroll
+                for (int i = PX; i < K::NACC; ++i) pos[i] = val[i];
+            } else {
+                typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+                for (int i = 0; i + 4 <= K::NACC; i += 4)
+                    *reinterpret_cast<f4u *>(pos + i) = (f4u){val[i], val[i + 1], val[i + 2], val[i + 3]};
+#pragma unroll
+                for (int i = K::NACC / 4 * 4; i < K::NACC; ++i) pos[i] = val[i];
+            }
+            const int wz = uz + s + dz, wy2 = uy_l + dy;
+            if (wz < G.bz0 + G.bZ && wy2 >= G.by0 && wy2 < G.by0 + G.bY) {
+                const long long vw0 = vu + ((long long)dz * G.bY + dy) * G.bX;
+#pragma unroll
+                for (int i = 0; i < K::NACC; ++i) {
+                    const int dx = i - (PX - 1);
+                    if (row0 && dx <= 0) continue;
+                    const int wx2 = ux + dx;
+                    if (wx2 >= G.bx0 && wx2 < G.bx0 + G.bX) cons[(vw0 + dx) * W + Lc - L0 - dx] = val[i];
+                }
+            }
+        }
+    }
+}
+
+// Voxel-major output: the entries S1 never writes -- L = Lc (offset 0) and the mirrored entries
+// S[w][Lc - L(d)] whose source voxel w - d lies outside the consensus box -- are zero.
+// Thread per (box voxel, offset row (dz, dy)).
+__global__ void __launch_bounds__(256)
+    vm_zero_kernel(float *__restrict__ S, const Geo G, const int n_rows) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G.BV * n_rows) return;
+    const int row = (int)(t % n_rows);
+    const long long v = t / n_rows;
+    const int bx = (int)(v % G.bX), by = (int)((v / G.bX) % G.bY), bz = (int)(v / ((long long)G.bX * G.bY));
+    int dz, dy;
+    if (row < G.py) { dz = 0; dy = row; }
+    else { const int q = row - G.py; dz = 1 + q / G.wy; dy = q % G.wy - (G.py - 1); }
+    const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
+    float *Sv = S + v * W;
+    if (row == 0) Sv[Lc] = 0.0f;
+    const bool line_out = bz - dz < 0 || by - dy < 0 || by - dy >= G.bY;
+    const int L0 = (dz * G.wy + dy) * G.wx;
+    for (int dx = -(G.px - 1); dx <= G.px - 1; ++dx) {
+        if (row == 0 && dx <= 0) continue;
+        const int sx = bx - dx;
+        if (line_out || sx < 0 || sx >= G.bX) Sv[Lc - L0 - dx] = 0.0f;
     }
 }
 
@@ -517,6 +580,11 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
     PPP_GRID_CHECK(n_blocks, 64 * V3_WAVES);
     if (((long long)(PX - 1) * G.V + 2ll * G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
+    if (G.layout == PPP_CONS_VOXEL_MAJOR) {
+        const long long nt = G.BV * n_rows;
+        PPP_GRID_CHECK((nt + 255) / 256, 256);
+        vm_zero_kernel<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s>>>(cons, G, n_rows);
+    }
     consensus_v3_kernel<T, PX, FLAT><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), 0, s>>>(
         pred, ov, cons, cnt, G, n_rows, runs_per_line, bZ2, n_waves);
     return hipGetLastError();
@@ -533,15 +601,20 @@ static hipError_t launch_v3(const T *pred, const uint8_t *ov, float *cons, float
                 : launch_v3f<T, PX, false>(pred, ov, cons, cnt, G, s);
 }
 
+// the shapes / rules the packed kernel serves (and with them the direct voxel-major output)
+bool consensus_v3_supported(const Geo &G) {
+    const char *e = getenv("PPP_S1_V3");
+    if (e && e[0] == '0') return false;
+    return G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
+           G.th_gt == 0.5f && G.bg_lt == 0.5f && (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9);
+}
+
 // TH = 0.5, normalised probability product, px in {3,5,7,9}; hipErrorNotSupported otherwise
 // (the caller falls back to v2).  PPP_S1_V3=0 switches it off.
 hipError_t launch_consensus_v3(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s) {
-    const char *e = getenv("PPP_S1_V3");
-    if (e && e[0] == '0') return hipErrorNotSupported;
-    if (!(G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
-          G.th_gt == 0.5f && G.bg_lt == 0.5f))
-        return hipErrorNotSupported;
+    if (!consensus_v3_supported(G)) return hipErrorNotSupported;
+    if (G.layout == PPP_CONS_VOXEL_MAJOR && (cnt || !cons)) return hipErrorInvalidValue;
 #define PPP_V3_CASE(P)                                                                          \
     case P:                                                                                     \
         return dtype == PPP_F16                                                                 \

@@ -9,6 +9,7 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
 hipError_t launch_consensus_v2(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s);
 const char *last_consensus_kernel();
+bool consensus_v3_supported(const Geo &G);
 hipError_t launch_consensus_v3(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s);
 hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uint8_t *ov,

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256)
 
 // ---- main kernel ---------------------------------------------------------------------------------
 template <int PZ, int PY, int PX, int TZ, int TY, int TX>
-__global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 4 : 2)
+__global__ void __launch_bounds__(64, PZ * PY * PX <= 343 ? 3 : 2)
     rank_vm_kernel(const float *__restrict__ S, const uint32_t *__restrict__ Pb,
                    const uint32_t *__restrict__ Nb, const uint32_t *__restrict__ info,
                    const uint8_t *__restrict__ valid, float *__restrict__ score, const ppp_box sb,

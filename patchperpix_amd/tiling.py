@@ -188,6 +188,9 @@ class DeviceOps:
     def to_voxel_major(self, cons, P):
         return backend.cons_to_voxel_major(cons, P)
 
+    def consensus_voxel_major(self, pred, ov, P):
+        return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P)
+
     def patch_bits(self, pred, centres, thresh, P):
         return backend.patch_bits(pred, centres, thresh, P)
 
@@ -452,16 +455,14 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     for t in my_tiles:
         z0, z1, y0, y1, x0, x1 = t
         P = params(bases_for_pairs(t) if keep_cons else bases_for_scores(t))
-        with backend.host_timer("s1_consensus"):
-            cons = ops.consensus(pred_local, ov_local, P)
-        if hasattr(ops, "to_voxel_major") and ops.rank_on_voxel_major(P):
-            # ranking and patch graph both read the voxel-major re-layout: make it once, drop
-            # the compact planes
-            with backend.host_timer("s1b_voxel_major"):
-                vm, P = ops.to_voxel_major(cons, P)
-            del cons
-            cons = vm
-            del vm
+        if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
+            # ranking and patch graph both read the voxel-major layout: S1 writes it directly
+            # where the library can (else compact planes + one re-layout, planes dropped)
+            with backend.host_timer("s1_consensus"):
+                cons, P = ops.consensus_voxel_major(pred_local, ov_local, P)
+        else:
+            with backend.host_timer("s1_consensus"):
+                cons = ops.consensus(pred_local, ov_local, P)
         with backend.host_timer("s2_rank"):
             sc = ops.rank_patches(pred_local, cons, ov_local, P,
                                   (z0 - lo, y0, x0, z1 - lo, y1, x1))
@@ -630,7 +631,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                         cons, P = kept.pop(t)
                     else:
                         P = params(bases_for_pairs(t))
-                        cons = ops.consensus(pred_local, ov_local, P)
+                        if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
+                            cons, P = ops.consensus_voxel_major(pred_local, ov_local, P)
+                        else:
+                            cons = ops.consensus(pred_local, ov_local, P)
                 with backend.host_timer("s5c_patch_graph"):
                     a = ops.patch_graph(pred_local, cons, rows_l, P)
                 with backend.host_timer("s6_label_paint"):
@@ -680,7 +684,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                     cons, P = kept.pop(t)
                 else:
                     P = params(bases_for_pairs(t))
-                    cons = ops.consensus(pred_local, ov_local, P)
+                    if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
+                        cons, P = ops.consensus_voxel_major(pred_local, ov_local, P)
+                    else:
+                        cons = ops.consensus(pred_local, ov_local, P)
             with backend.host_timer("s5c_patch_graph"):
                 a = ops.patch_graph(pred_local, cons, rows_l, P)
             with backend.host_timer("s5d_scatter"):
@@ -747,13 +754,14 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     return instances, foreground.astype(np.uint8)
 
 
-def slabs_needed(shape, patchshape, free_bytes, safety=0.6):
-    """Smallest number of z-slabs whose consensus working set (compact planes + the voxel-major
-    copy the patch-graph kernel reads = 3x the compact size, on a box of own thickness + 4*rz
-    slices) fits into `free_bytes` of device memory."""
+def slabs_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
+    """Smallest number of z-slabs whose consensus working set (`copies` x the compact size: 3 =
+    compact planes + the voxel-major copy ranking and patch graph read, 2 = voxel-major written
+    directly by S1; on a box of own thickness + 4*rz slices) fits into `free_bytes` of device
+    memory."""
     pz, py, px = [int(p) for p in patchshape]
     planes = ((2 * pz - 1) * (2 * py - 1) * (2 * px - 1) - 1) // 2
-    per_slice = 3.0 * planes * 4 * int(shape[1]) * int(shape[2])
+    per_slice = float(copies) * planes * 4 * int(shape[1]) * int(shape[2])
     extra = 4 * (pz // 2)
     budget = safety * free_bytes
     Z = int(shape[0])
@@ -764,10 +772,10 @@ def slabs_needed(shape, patchshape, free_bytes, safety=0.6):
     return Z
 
 
-def tiles_needed(shape, patchshape, free_bytes, safety=0.6):
+def tiles_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
     """(n_slabs, ny, nx): z-slabs first (slabs_needed); when even thin slabs do not fit, the
-    longest tile edge among y / x is halved until the working set of one tile (3x the compact
-    consensus on the tile grown by the pairs halo) fits `free_bytes`."""
+    longest tile edge among y / x is halved until the working set of one tile (`copies` x the
+    compact consensus on the tile grown by the pairs halo) fits `free_bytes`."""
     pz, py, px = [int(p) for p in patchshape]
     planes = ((2 * pz - 1) * (2 * py - 1) * (2 * px - 1) - 1) // 2
     Z, Y, X = [int(v) for v in shape]
@@ -777,21 +785,31 @@ def tiles_needed(shape, patchshape, free_bytes, safety=0.6):
         bz = min(Z, tz + 2 * (pz // 2) + pz - 1)
         by = min(Y, ty + 2 * (py // 2) + 2 * (py - 1))
         bx = min(X, tx + 2 * (px // 2) + 2 * (px - 1))
-        return 3.0 * planes * 4 * bz * by * bx <= budget
+        return float(copies) * planes * 4 * bz * by * bx <= budget
 
-    n = slabs_needed(shape, patchshape, free_bytes, safety)
-    ny = nx = 1
-    # thin slabs waste most of their work on halos: keep the slab at least ~4 radii thick
-    min_tz = min(Z, max(8 * (pz // 2), 8))
-    while (-(-Z // n) < min_tz or not fits(-(-Z // n), -(-Y // ny), -(-X // nx))) and (ny < Y or nx < X):
-        n = min(n, max(1, Z // min_tz))
-        if fits(-(-Z // n), -(-Y // ny), -(-X // nx)):
-            break
-        if -(-Y // ny) >= -(-X // nx) and ny < Y:
-            ny *= 2
-        else:
-            nx *= 2
-    return n, min(ny, Y), min(nx, X)
+    n0 = slabs_needed(shape, patchshape, free_bytes, safety, copies)
+    if n0 == 1 or fits(-(-Z // n0), Y, X):
+        return n0, 1, 1
+    # Even thin slabs do not fit: choose the grid (n, ny, nx) of fitting tiles with the least
+    # consensus work, i.e. the smallest total volume of the tiles grown by their halos (cube-like
+    # tiles: thin slabs spend most of their work on the z halo).
+    hz, hy, hx = 2 * (pz // 2) + pz - 1, 2 * (py // 2) + 2 * (py - 1), 2 * (px // 2) + 2 * (px - 1)
+    best = None
+    for n in range(1, max(1, Z // max(1, pz // 2)) + 1):
+        tz = -(-Z // n)
+        for ny in range(1, min(Y, 64) + 1):
+            ty = -(-Y // ny)
+            # smallest nx that fits (more cuts only add halo)
+            nx = next((k for k in range(1, min(X, 64) + 1) if fits(tz, ty, -(-X // k))), None)
+            if nx is None:
+                continue
+            tx = -(-X // nx)
+            work = float(n * ny * nx) * min(Z, tz + hz) * min(Y, ty + hy) * min(X, tx + hx)
+            if best is None or work < best[0] - 1e-9:
+                best = (work, n, ny, nx)
+    if best is None:
+        return Z, min(Y, 64), min(X, 64)
+    return best[1], best[2], best[3]
 
 
 def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,

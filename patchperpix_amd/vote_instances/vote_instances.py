@@ -143,7 +143,13 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         # free HBM + what the caching allocator holds but has not handed out
         avail = torch.cuda.mem_get_info()[0] + \
             (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
-        n_slabs, ny_t, nx_t = tiling.tiles_needed(shape, patchshape, avail)
+        # working set per tile: voxel-major rows only when S1 can write them directly
+        Pq = backend.params_from_kwargs(shape, patchshape, kwargs)
+        Pq.cons_layout = backend.CONS_VOXEL_MAJOR
+        direct = os.environ.get("PPP_S1_DIRECT_VM", "1") != "0" and \
+            backend.lib().ppp_consensus_writes_voxel_major(Pq) == 1
+        n_slabs, ny_t, nx_t = tiling.tiles_needed(shape, patchshape, avail,
+                                                  copies=2.0 if direct else 3.0)
         if yx_tiles is None and (ny_t > 1 or nx_t > 1):
             yx_tiles = (ny_t, nx_t)
     # With nothing to store or load between the stages, the single-slab case takes the same

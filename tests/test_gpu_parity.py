@@ -642,3 +642,32 @@ def test_consensus_two_slice_packed_kernel_equals_v2(ps, shape, dtype, torch_cud
             assert np.array_equal(out["0"][1], out["1"][1]), (box, flat, "counts")
             assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32)), (box, flat)
             assert np.count_nonzero(out["0"][0]) > 1000
+
+
+@pytest.mark.parametrize("ps,shape", [((7, 7, 7), (11, 12, 150)), ((5, 5, 5), (9, 11, 97)), ((9, 9, 9), (12, 13, 131)),
+                                      ((1, 5, 5), (1, 30, 90)), ((7, 7, 7), (16, 20, 40))])
+def test_consensus_written_voxel_major_directly(ps, shape, torch_cuda, monkeypatch):
+    """S1 writing the symmetric voxel-major rows itself (positive entry, mirrored entry, zero fill
+    of the entries without a source voxel in the box) == compact planes + ppp_cons_to_voxel_major,
+    bit for bit: whole volume and a sub-box, flattened and per-line runs."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    c = synth.make_case(shape, ps, seed=97, cell=[6, 6, 9], overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    boxes = [None, (min(1, shape[0] - 1), 2, 9, shape[0], shape[1] - 1, shape[2] - 7)]
+    for box in boxes:
+        P = backend.make_params(shape, ps, cons_box=box, **kw)
+        assert backend.lib().ppp_consensus_writes_voxel_major(P) == 1
+        for flat in ("0", "1"):
+            monkeypatch.setenv("PPP_S1_FLAT", flat)
+            monkeypatch.setenv("PPP_S1_DIRECT_VM", "0")
+            want, _ = backend.consensus_voxel_major(pred, ov, P)
+            monkeypatch.setenv("PPP_S1_DIRECT_VM", "1")
+            got, Pv = backend.consensus_voxel_major(pred, ov, P)
+            assert Pv.cons_layout == backend.CONS_VOXEL_MAJOR and got.shape == want.shape
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (box, flat)
+            assert int(torch.count_nonzero(want)) > 1000
+            del got, want
