@@ -33,6 +33,8 @@
 //     accumulators are written.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ppp_kernels.hpp"
 
 namespace ppp {
@@ -511,13 +513,13 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             // symmetric voxel-major rows written directly (no compact planes, no transpose):
             // S[u][Lc + L(d)] -- the 2 PX - 1 entries of this offset row are contiguous, stored
             // four at a time -- and, when w = u + d lies in the box, the mirror S[w][Lc - L(d)].
-            // Entries whose source voxel lies outside the box (and L = Lc) are zeroed by
-            // vm_zero_kernel.
+            // Entries whose source voxel lies outside the box are zeroed by vm_zero_kernel.
             const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
             const int L0 = (dz * G.wy + dy) * G.wx;
             const long long vu = ((long long)(uz + s - G.bz0) * G.bY + (uy_l - G.by0)) * G.bX + (ux - G.bx0);
             float *pos = cons + vu * W + Lc + L0 - (PX - 1);     // entry of dx = -(PX-1)
             if (row0) {
+                pos[PX - 1] = 0.0f;                              // offset 0
 #pragma unroll
                 for (int i = PX; i < K::NACC; ++i) pos[i] = val[i];
             } else {
@@ -543,22 +545,30 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
     }
 }
 
-// Voxel-major output: the entries S1 never writes -- L = Lc (offset 0) and the mirrored entries
-// S[w][Lc - L(d)] whose source voxel w - d lies outside the consensus box -- are zero.
-// Thread per (box voxel, offset row (dz, dy)).
+// Voxel-major output: the mirrored entries S[w][Lc - L(d)] whose source voxel w - d lies outside
+// the consensus box have no wave that writes them; they are zero.  Only voxels within p - 1 of
+// the low-z, low / high-y and low / high-x faces have such entries: thread per (face voxel,
+// offset row (dz, dy)); the five face slabs may overlap (the same zero is then stored twice).
+// (L = Lc, offset 0, is written by the waves of offset row 0.)
+struct VmFaces { long long start[6]; int lo[5][3], ext[5][3]; };
 __global__ void __launch_bounds__(256)
-    vm_zero_kernel(float *__restrict__ S, const Geo G, const int n_rows) {
+    vm_zero_kernel(float *__restrict__ S, const Geo G, const int n_rows, const VmFaces F) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= G.BV * n_rows) return;
+    if (t >= F.start[5] * n_rows) return;
     const int row = (int)(t % n_rows);
-    const long long v = t / n_rows;
-    const int bx = (int)(v % G.bX), by = (int)((v / G.bX) % G.bY), bz = (int)(v / ((long long)G.bX * G.bY));
+    const long long fv = t / n_rows;
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) f += fv >= F.start[k] ? 1 : 0;
+    const long long r = fv - F.start[f];
+    const int ex = F.ext[f][2], ey = F.ext[f][1];
+    const int bx = F.lo[f][2] + (int)(r % ex), by = F.lo[f][1] + (int)((r / ex) % ey),
+              bz = F.lo[f][0] + (int)(r / ((long long)ex * ey));
     int dz, dy;
     if (row < G.py) { dz = 0; dy = row; }
     else { const int q = row - G.py; dz = 1 + q / G.wy; dy = q % G.wy - (G.py - 1); }
     const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
-    float *Sv = S + v * W;
-    if (row == 0) Sv[Lc] = 0.0f;
+    float *Sv = S + (((long long)bz * G.bY + by) * G.bX + bx) * W;
     const bool line_out = bz - dz < 0 || by - dy < 0 || by - dy >= G.bY;
     const int L0 = (dz * G.wy + dy) * G.wx;
     for (int dx = -(G.px - 1); dx <= G.px - 1; ++dx) {
@@ -566,6 +576,26 @@ __global__ void __launch_bounds__(256)
         const int sx = bx - dx;
         if (line_out || sx < 0 || sx >= G.bX) Sv[Lc - L0 - dx] = 0.0f;
     }
+}
+
+static hipError_t launch_vm_zero(float *S, const Geo &G, int n_rows, hipStream_t s) {
+    VmFaces F{};
+    const int gz = std::min(G.pz - 1, G.bZ), gy = std::min(G.py - 1, G.bY), gx = std::min(G.px - 1, G.bX);
+    const int lo[5][3] = {{0, 0, 0}, {0, 0, 0}, {0, G.bY - gy, 0}, {0, 0, 0}, {0, 0, G.bX - gx}};
+    const int ext[5][3] = {{gz, G.bY, G.bX}, {G.bZ, gy, G.bX}, {G.bZ, gy, G.bX}, {G.bZ, G.bY, gx}, {G.bZ, G.bY, gx}};
+    long long acc = 0;
+    for (int f = 0; f < 5; ++f) {
+        F.start[f] = acc;
+        for (int a = 0; a < 3; ++a) { F.lo[f][a] = lo[f][a]; F.ext[f][a] = std::max(ext[f][a], 1); }
+        acc += (long long)ext[f][0] * ext[f][1] * ext[f][2];
+        // (a face of extent 0 -- patch size 1 on that axis -- contributes no voxels)
+    }
+    F.start[5] = acc;
+    const long long nt = acc * n_rows;
+    if (nt == 0) return hipSuccess;
+    PPP_GRID_CHECK((nt + 255) / 256, 256);
+    vm_zero_kernel<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s>>>(S, G, n_rows, F);
+    return hipGetLastError();
 }
 
 template <typename T, int PX, bool FLAT>
@@ -581,9 +611,8 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
     PPP_GRID_CHECK(n_blocks, 64 * V3_WAVES);
     if (((long long)(PX - 1) * G.V + 2ll * G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
     if (G.layout == PPP_CONS_VOXEL_MAJOR) {
-        const long long nt = G.BV * n_rows;
-        PPP_GRID_CHECK((nt + 255) / 256, 256);
-        vm_zero_kernel<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s>>>(cons, G, n_rows);
+        const hipError_t ez = launch_vm_zero(cons, G, n_rows, s);
+        if (ez != hipSuccess) return ez;
     }
     consensus_v3_kernel<T, PX, FLAT><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), 0, s>>>(
         pred, ov, cons, cnt, G, n_rows, runs_per_line, bZ2, n_waves);
