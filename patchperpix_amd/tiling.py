@@ -165,6 +165,29 @@ class TorchDistComm:
                 vol[ra:rb] = recv[r, :rb - ra]
         return vol
 
+    def neighbour_min(self, items):
+        """items: [(peer rank, tensor)].  Every tensor is replaced by the element-wise minimum
+        of this rank's and the peer's tensor of the same position in the peer's list for us
+        (point-to-point: xGMI links are pairwise, and a slab boundary concerns two ranks -- an
+        all-reduce over all ranks moves every boundary's buffer to everybody)."""
+        import torch
+        if self.world == 1 or not items:
+            return
+        host = self.via_host and items[0][1].is_cuda
+        mine = [(p, (t.cpu() if host else t.contiguous())) for p, t in items]
+        recv = [torch.empty_like(t) for _, t in mine]
+        ops = []
+        # lower peer first on both sides of a boundary: matching order of sends and receives
+        for k in sorted(range(len(mine)), key=lambda k: mine[k][0]):
+            p, t = mine[k]
+            ops.append(self.dist.P2POp(self.dist.isend, t, p, self.group))
+            ops.append(self.dist.P2POp(self.dist.irecv, recv[k], p, self.group))
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        for (p, t_orig), (_, t), r in zip(items, mine, recv):
+            m = torch.minimum(t, r)
+            t_orig.copy_(m.to(t_orig.device) if host else m)
+
 
 # ------------------------------------------------------------------------------------------
 # device operations (the C ABI); tests substitute an oracle-backed object with the same API
@@ -288,10 +311,32 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
     mask_buf = torch.empty((max(len(zones), 1), 2, zlen), dtype=torch.uint8, device=dev)
     own_loc = (z0 - a, z1 - a)
 
+    # a boundary zone concerns the two ranks next to it -- unless slabs are thinner than the zones
+    # (then a zone reaches a third rank and everybody takes part in an all-reduce)
+    pairwise = hasattr(comm, "neighbour_min") and os.environ.get("PPP_COVER_P2P", "1") != "0" and \
+        all(r[1] - r[0] >= 2 * h for r in ranges)
+
     def exchange(with_rank):
         if not zones:
             return
         buf = rank_buf if with_rank else mask_buf
+        if pairwise:
+            items = []
+            for i in mine:
+                lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
+                if with_rank:
+                    shard.zone(False, lo_z, hi_z, own_loc, rank=rank_buf[i])
+                else:
+                    shard.zone(False, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+                items.append((comm.rank + 1 if bounds[i] == z1 else comm.rank - 1, buf[i]))
+            comm.neighbour_min(items)
+            for i in mine:
+                lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
+                if with_rank:
+                    shard.zone(True, lo_z, hi_z, own_loc, rank=rank_buf[i])
+                else:
+                    shard.zone(True, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+            return
         buf.fill_(INT32_MAX if with_rank else 1)
         for i in mine:
             lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
@@ -350,6 +395,7 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
             break
     backend.note("cover_rounds", total_rounds)
     backend.note("cover_sharded", comm.world)
+    backend.note("cover_p2p", 1 if pairwise else 0)
     return selected
 
 

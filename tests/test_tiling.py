@@ -119,7 +119,8 @@ inst, fg = tiling.assemble(pred_local, lo, c["foreground"].shape, c["foreground"
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 from patchperpix_amd import backend
 np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
-        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0)]))
+        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
+                  backend.NOTES.get("cover_p2p", 0)]))
 dist.destroy_process_group()
 """
 
@@ -150,7 +151,7 @@ def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypa
         assert np.array_equal(inst, ref["instances"]), "rank %d differs" % r
         # the cover ran sharded (z-halo exchange per round), the labels were merged
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
-        assert notes[0] == world and notes[1] > 0
+        assert notes[0] == world and notes[1] > 0 and notes[2] == int(p2p)
 
 
 @pytest.mark.gpu
@@ -300,20 +301,23 @@ inst, fg = tiling.assemble(pred_local, lo, shape, c["foreground"].copy(), c["for
                            c["numinst"], list(ps), mine, comm=tiling.TorchDistComm(), **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
-        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0)]))
+        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
+                  backend.NOTES.get("cover_p2p", 0)]))
 dist.destroy_process_group()
 """
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,empty_top,ps,flagset", [
-    (2, False, (5, 5, 5), "nothin_cc"), (3, False, (5, 5, 5), "nothin_cc"),
-    (2, True, (5, 5, 5), "nothin_cc"), (2, False, (7, 7, 7), "shipped"),
-    (3, False, (7, 7, 7), "cc")])
-def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps, flagset):
+@pytest.mark.parametrize("world,empty_top,ps,flagset,p2p", [
+    (2, False, (5, 5, 5), "nothin_cc", "1"), (3, False, (5, 5, 5), "nothin_cc", "1"),
+    (2, True, (5, 5, 5), "nothin_cc", "1"), (2, False, (7, 7, 7), "shipped", "1"),
+    (3, False, (7, 7, 7), "cc", "1"), (3, False, (5, 5, 5), "nothin_cc", "0")])
+def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps, flagset, p2p):
     """The multi-rank path with the REAL kernels: `world` processes on the one GPU of the box,
     gloo as the transport (RCCL needs one device per rank): sharded cover with z-halo exchange,
-    per-rank pair rows, merged label forests -- same instance map as one process."""
+    per-rank pair rows, merged label forests -- same instance map as one process.  The slab
+    boundary zones of the cover travel point to point between the two neighbours (p2p = "1") or
+    through an all-reduce over all ranks (the form for slabs thinner than the zones)."""
     from patchperpix_amd.vote_instances import vote_instances as vi
     from patchperpix_amd import flags as flagsets
     FLYLIGHT = flagsets.FLAG_SETS[flagset]
@@ -328,7 +332,8 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", OMP_NUM_THREADS="1",
-               PPP_TEST_EMPTY_TOP="1" if empty_top else "0", PPP_TEST_FLAGSET=flagset)
+               PPP_TEST_EMPTY_TOP="1" if empty_top else "0", PPP_TEST_FLAGSET=flagset,
+               PPP_COVER_P2P=p2p)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                            "--master-port", "29593", str(script)], env=env, timeout=900)
@@ -337,7 +342,7 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
         inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
         assert np.array_equal(inst, want), "rank %d differs" % r
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
-        assert notes[0] == world and notes[1] > 0
+        assert notes[0] == world and notes[1] > 0 and notes[2] == int(p2p)
 
 
 RCCL_WORKER = r"""
