@@ -151,7 +151,7 @@ def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypa
         assert np.array_equal(inst, ref["instances"]), "rank %d differs" % r
         # the cover ran sharded (z-halo exchange per round), the labels were merged
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
-        assert notes[0] == world and notes[1] > 0 and notes[2] == int(p2p)
+        assert notes[0] == world and notes[1] > 0
 
 
 @pytest.mark.gpu
