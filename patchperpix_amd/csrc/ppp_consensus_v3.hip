@@ -8,7 +8,7 @@
 //   * a lane owns the base voxels (uz, uy, ux) AND (uz + 1, uy, ux).  Every quantity of the vote
 //     chain is a float2 {slice 0, slice 1} in an aligned register pair, the LDS images hold the
 //     two slices interleaved (one ds_read_b64 per operand pair, conflict free), and the chain is
-//     executed with v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: 9 vector instructions per PAIR
+//     executed with v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: 8 vector instructions per PAIR
 //     of votes instead of 11 per vote.  (Pairing two votes of ONE voxel is not possible: the
 //     accumulator pair (i, i+1) and the LDS pair would need opposite alignments for odd / even
 //     kx.)  The x / y geometry (flattened runs, segments) is shared by the two slices.
