@@ -402,9 +402,12 @@ def to_device_pred(pred, device="cuda", keep_f16=True):
 # ----------------------------------------------------------------------------------------
 # device stages
 # ----------------------------------------------------------------------------------------
-def consensus(pred, overlap, P, want_count=False):
+def consensus(pred, overlap, P, want_count=False, out=None):
     """S1.  Returns cons (and count) as device float32 tensors shaped
-    [planes, bz, by, bx] (compact) or [NSZ, NSY, NSX, Z, Y, X] (reference layout)."""
+    [planes, bz, by, bx] (compact), [bz, by, bx, W] (voxel-major) or [NSZ, NSY, NSX, Z, Y, X]
+    (reference layout).  out: a flat float32 device tensor to carve the result from (the tiled
+    path keeps ONE buffer for all its tiles: tens of GB allocated and freed per tile fragment the
+    caching allocator until a tile that fits on paper no longer does)."""
     torch = _torch()
     L = lib()
     if P.cons_layout == CONS_REFERENCE:
@@ -413,7 +416,11 @@ def consensus(pred, overlap, P, want_count=False):
         shape = P.cons_box.shape() + (int(L.ppp_cons_planes(ctypes.byref(P))),)
     else:
         shape = (int(L.ppp_cons_planes(ctypes.byref(P))),) + P.cons_box.shape()
-    cons = _big_empty(shape, pred.device)
+    n_el = int(np.prod(shape))
+    if out is not None and out.numel() >= n_el:
+        cons = out[:n_el].view(shape)
+    else:
+        cons = _big_empty(shape, pred.device)
     cnt = torch.empty(shape, dtype=torch.float32, device=pred.device) if want_count else None
     note_add("s1_base_voxels", int(np.prod(P.cons_box.shape())))
     with _timed("consensus"):
@@ -706,14 +713,22 @@ def paint_instances(pred, nodes, labels, instances, P):
     return instances
 
 
-def consensus_voxel_major(pred, overlap, P):
-    """S1 straight into the symmetric voxel-major layout when the library can do that for these
-    parameters (ppp_consensus_writes_voxel_major), else COMPACT + ppp_cons_to_voxel_major.
-    Returns (tensor [bz, by, bx, W], params with cons_layout = VOXEL_MAJOR)."""
+def direct_voxel_major(P):
+    """S1 can write the voxel-major layout itself for these parameters."""
     Pv = P.copy()
     Pv.cons_layout = CONS_VOXEL_MAJOR
-    if os.environ.get("PPP_S1_DIRECT_VM", "1") != "0" and lib().ppp_consensus_writes_voxel_major(ctypes.byref(Pv)):
-        return consensus(pred, overlap, Pv), Pv
+    return os.environ.get("PPP_S1_DIRECT_VM", "1") != "0" and \
+        lib().ppp_consensus_writes_voxel_major(ctypes.byref(Pv)) == 1
+
+
+def consensus_voxel_major(pred, overlap, P, out=None):
+    """S1 straight into the symmetric voxel-major layout when the library can do that for these
+    parameters (ppp_consensus_writes_voxel_major), else COMPACT + ppp_cons_to_voxel_major.
+    Returns (tensor [bz, by, bx, W], params with cons_layout = VOXEL_MAJOR).  out: see consensus."""
+    Pv = P.copy()
+    Pv.cons_layout = CONS_VOXEL_MAJOR
+    if direct_voxel_major(P):
+        return consensus(pred, overlap, Pv, out=out), Pv
     Pc = P.copy()
     Pc.cons_layout = CONS_COMPACT
     cons = consensus(pred, overlap, Pc)

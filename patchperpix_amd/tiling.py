@@ -211,8 +211,16 @@ class DeviceOps:
     def to_voxel_major(self, cons, P):
         return backend.cons_to_voxel_major(cons, P)
 
-    def consensus_voxel_major(self, pred, ov, P):
-        return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P)
+    def consensus_voxel_major(self, pred, ov, P, out=None):
+        return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P, out=out)
+
+    def voxel_major_pool(self, P, n_voxels):
+        """One flat buffer for the voxel-major consensus of every tile (both passes) when S1
+        writes that layout directly; None otherwise."""
+        if not backend.direct_voxel_major(P):
+            return None
+        W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
+        return backend._big_empty((int(n_voxels) * W,), self.device)
 
     def patch_bits(self, pred, centres, thresh, P):
         return backend.patch_bits(pred, centres, thresh, P)
@@ -497,6 +505,15 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         return tuple(b)
 
     # ---- stage A: consensus + scores per slab --------------------------------------------
+    # several tiles: ONE consensus buffer, sized for the largest box of either pass, serves all
+    # of them (allocated first, while the allocator's address space is still unfragmented)
+    pool = None
+    if not keep_cons and my_tiles and hasattr(ops, "voxel_major_pool"):
+        biggest = max(int(np.prod([b[2 * a + 1] - b[2 * a] for a in range(3)]))
+                      for b in (bases_for_pairs(t) for t in my_tiles))
+        P0 = params(bases_for_pairs(my_tiles[0]))
+        if ops.rank_on_voxel_major(P0):
+            pool = ops.voxel_major_pool(P0, biggest)
     score_dev = torch.zeros(shape, dtype=torch.float32, device=dev)
     for t in my_tiles:
         z0, z1, y0, y1, x0, x1 = t
@@ -505,7 +522,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             # ranking and patch graph both read the voxel-major layout: S1 writes it directly
             # where the library can (else compact planes + one re-layout, planes dropped)
             with backend.host_timer("s1_consensus"):
-                cons, P = ops.consensus_voxel_major(pred_local, ov_local, P)
+                cons, P = ops.consensus_voxel_major(pred_local, ov_local, P, **({"out": pool} if pool is not None else {}))
         else:
             with backend.host_timer("s1_consensus"):
                 cons = ops.consensus(pred_local, ov_local, P)
@@ -520,6 +537,20 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         comm.all_gather_slabs(score_dev, rank_ranges)
     else:
         comm.all_reduce_sum(score_dev)
+    # the global stage needs the room (dense patch bits, ranked lists): the buffer comes back for
+    # the patch-graph pass
+    pool_voxels = None
+    if pool is not None:
+        pool_voxels, pool_P = biggest, P0
+        del pool
+        pool = None
+        torch.cuda.empty_cache()
+
+    def pool_again():
+        if pool_voxels is None:
+            return None
+        torch.cuda.empty_cache()
+        return ops.voxel_major_pool(pool_P, pool_voxels)
 
     # ---- stage B: ranking, greedy cover, thinning (global; identical on every rank) -------
     # The ranked list stays on the device (it has one entry per foreground voxel of the GLOBAL
@@ -664,6 +695,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         backend.note("n_selected", len(nodes))
         backend.note("n_pairs", n_rows)
         state = ops.label_state(nodes_dev, Pg)
+        pool = pool_again()
         with backend.host_timer("s5_patch_graph"):
             for t, subset in zip(my_tiles, subsets):
                 with backend.host_timer("s5a_select_rows"):
@@ -678,7 +710,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                     else:
                         P = params(bases_for_pairs(t))
                         if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
-                            cons, P = ops.consensus_voxel_major(pred_local, ov_local, P)
+                            cons, P = ops.consensus_voxel_major(pred_local, ov_local, P,
+                                                                **({"out": pool} if pool is not None else {}))
                         else:
                             cons = ops.consensus(pred_local, ov_local, P)
                 with backend.host_timer("s5c_patch_graph"):
@@ -687,6 +720,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                     state.add(rows_t, a, gid_t)
                 del cons, rows_l, rows_t, gid_t, a
         kept.clear()
+        pool = None
         del counts, goffsets, subsets
         if comm.world > 1:
             # boundary-label merge: every rank's forest (node -> parent) is gathered and united
@@ -712,6 +746,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     # ---- stage C (materialised list: intermediates wanted, injected pairs, mutex watershed):
     # pair affinities, each pair on the rank / tile that owns patch A
     aff = None if state is not None else torch.zeros((n_rows,), dtype=torch.float32, device=dev)
+    if state is None:
+        pool = pool_again()
     with backend.host_timer("s5_patch_graph"):
         for t in (my_tiles if state is None else []):
             z0, z1, y0, y1, x0, x1 = t
@@ -731,7 +767,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 else:
                     P = params(bases_for_pairs(t))
                     if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
-                        cons, P = ops.consensus_voxel_major(pred_local, ov_local, P)
+                        cons, P = ops.consensus_voxel_major(pred_local, ov_local, P,
+                                                            **({"out": pool} if pool is not None else {}))
                     else:
                         cons = ops.consensus(pred_local, ov_local, P)
             with backend.host_timer("s5c_patch_graph"):
@@ -740,6 +777,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 aff[idx] = a
             del cons, rows_l, idx, a
     kept.clear()
+    pool = None
     if state is None:
         comm.all_reduce_sum(aff)
     if want_inter:
