@@ -294,6 +294,14 @@ def main():
         roofline["workload"] = args.workload
         if rank == 0 and args.workload == "flylight140_p7" and world == 1 and not args.slabs:
             roofline.update(pmc_traffic(s1_kernel))
+        if notes.get("s1_output_bytes"):
+            # the algorithmic figure counts the INPUT; the launch also writes the whole
+            # consensus -- most of the measured traffic
+            roofline["output_bytes_per_launch"] = notes["s1_output_bytes"] / max(1, len(ev["consensus"]))
+            roofline["traffic_reading"] = (
+                "writes = the consensus output (symmetric voxel-major rows, 2x the stored planes; the "
+                "4-byte mirrored stores are counted ~1.6x); reads = the f16 prediction (re-read ~4x across "
+                "the offset rows of a run) + the read-for-ownership of the partially written lines")
     # Secondary figures for the other two big kernels.  S2 (ranking): the consensus it sums +
     # the prediction block once, 4 * planes + 2 * C bytes per voxel.  S5 (patch graph): both
     # patches' channel vectors per dispatched pair row, SURVEY 8(d)'s bound without `visited`.
@@ -335,7 +343,7 @@ def main():
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
             "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
                               for k, v in (host_times or {}).items()},
-            "workload_stats": {k: (v // args.steps if k in ("s1_base_voxels", "s5_rows_dispatched") else v)
+            "workload_stats": {k: (v // args.steps if k in ("s1_base_voxels", "s5_rows_dispatched", "s1_output_bytes") else v)
                                for k, v in notes.items()},
         }
     if world == 1:

@@ -423,6 +423,7 @@ def consensus(pred, overlap, P, want_count=False, out=None):
         cons = _big_empty(shape, pred.device)
     cnt = torch.empty(shape, dtype=torch.float32, device=pred.device) if want_count else None
     note_add("s1_base_voxels", int(np.prod(P.cons_box.shape())))
+    note_add("s1_output_bytes", 4 * n_el)
     with _timed("consensus"):
         check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
                               _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
