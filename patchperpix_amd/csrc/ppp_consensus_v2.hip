@@ -31,6 +31,10 @@
 
 #include "ppp_kernels.hpp"
 
+// (the 25-wide kernel's vote loops exceed the full-unroll size limit in its rarely used rule
+// variants; partial unrolling is fine there -- and measurably better than forcing it: 88 vs 104 ms)
+#pragma clang diagnostic ignored "-Wpass-failed"
+
 namespace ppp {
 
 static constexpr int V2_WAVES = 4;
@@ -410,6 +414,224 @@ static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float
                 : launch_v2f<T, PX, false>(pred, ov, cons, cnt, G, s);
 }
 
+// ---- wide patches (px = 25: the 2-d configuration) ---------------------------------------------
+// Same decomposition, but a lane cannot hold 2*PX-1 = 49 accumulator pairs and the per-lane
+// staging descriptors of a 2*PX*NC image: a wave takes a WINDOW of NW consecutive dx (the offset
+// row is split over ceil((2 PX - 1) / NW) waves, each staging the full images again), and the
+// images are staged by a rolled loop that derives every element's address on the fly.
+template <int PX>
+struct V2W {
+    static constexpr int RX = PX / 2;
+    static constexpr int NC = 64 + (PX - 1);     // centres per run
+    static constexpr int NT = 64 + 2 * (PX - 1); // target pixels per run
+    static constexpr int NACC = 2 * PX - 1;
+#ifndef PPP_S1W_NW
+#define PPP_S1W_NW 25
+#endif
+    static constexpr int NW = PPP_S1W_NW;        // accumulators per wave
+    static constexpr int NWIN = (NACC + NW - 1) / NW;
+    static constexpr int IMG = 2 * PX * NC;
+};
+
+template <int PX, int WIN, int VAL, bool ROW0, bool EXACT, bool TH05>
+__device__ __forceinline__ bool tile_votes_w(const float *ia, const float *ib, const bool u_ok,
+                                             const double th2, const double den, const double inv_den,
+                                             float (&acc)[V2W<PX>::NW], unsigned (&cnt)[V2W<PX>::NW]) {
+    using K = V2W<PX>;
+    constexpr int I0 = WIN * K::NW;
+    unsigned amb_min = 0xFFFFFFFFu;
+#pragma unroll
+    for (int kx = PX - 1; kx >= 0; --kx) {
+        // partner columns of this kx inside the window: i = j - kx + PX - 1 in [I0, I0 + NW)
+        const int j_lo = max(ROW0 ? kx + 1 : 0, I0 + kx - (PX - 1));
+        const int j_hi = min(PX - 1, I0 + K::NW - 1 + kx - (PX - 1));
+        if (j_lo > j_hi) continue;
+        const float ta = u_ok ? ia[kx * K::NC - kx] : 0.0f;
+        int lim = ta < 0.0f ? 0 : (int)0x80000000;
+        asm volatile("" : "+v"(lim));
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            if (j < j_lo || j > j_hi) continue;
+            vote<VAL, EXACT, TH05>(th2, den, inv_den, ta, lim, ib[j * K::NC - kx], acc[j - kx + PX - 1 - I0],
+                                   cnt[j - kx + PX - 1 - I0], amb_min);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return amb_min <= 8u;
+}
+
+template <typename T, int PX, int WIN, int VAL, bool TH05>
+__global__ void __launch_bounds__(64, 2)
+    consensus_wide_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
+                          float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
+                          const int n_rows, const int runs_per_line, const long long n_waves) {
+    using K = V2W<PX>;
+    __shared__ float img[K::IMG];
+    __shared__ uint8_t lds_valid[2][K::NT + 2];
+    const int lane = threadIdx.x;
+    const long long wid = blockIdx.x;
+    if (wid >= n_waves) return;
+    const int row = (int)(wid % n_rows);
+    long long run = wid / n_rows;
+    int dz, dy;
+    if (row < G.py) { dz = 0; dy = row; }
+    else { const int t = row - G.py; dz = 1 + t / G.wy; dy = t % G.wy - (G.py - 1); }
+    const int xr = (int)(run % runs_per_line);
+    run /= runs_per_line;
+    const int uy = G.by0 + (int)(run % G.bY), uz = G.bz0 + (int)(run / G.bY), ux0 = G.bx0 + xr * 64;
+    const int ux = ux0 + lane;
+    const bool lane_ok = ux < G.bx0 + G.bX;
+    const int wz = uz + dz, wy = uy + dy;
+    const bool w_row_ok = wz < G.Z && wy >= 0 && wy < G.Y;
+    const bool row0 = dz == 0 && dy == 0;
+    constexpr int I0 = WIN * K::NW;
+
+    float acc[K::NW];
+    unsigned cnt[K::NW];
+#pragma unroll
+    for (int i = 0; i < K::NW; ++i) { acc[i] = 0.0f; cnt[i] = 0u; }
+    const T *mid = pred + (long long)G.mid * G.V;
+    uint8_t *uval = lds_valid[0], *wval = lds_valid[1];
+    for (int i = lane; i < K::NT; i += 64) {
+        const int x = ux0 - (PX - 1) + i;
+        bool vu = false, vw = false;
+        if (x >= 0 && x < G.X) {
+            const long long lu = vox(G, uz, uy, x);
+            vu = ldf(mid, lu) > G.th_gt && (!G.use_overlap || ov[lu] == 0);
+            if (w_row_ok) {
+                const long long lw = vox(G, wz, wy, x);
+                vw = ldf(mid, lw) > G.th_gt && (!G.use_overlap || ov[lw] == 0);
+            }
+        }
+        uval[i] = vu; wval[i] = vw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool u_ok = lane_ok && uval[lane + PX - 1];
+    const double inv_den = 1.0 / G.den;
+    const int pos_l = lane + (PX - 1);
+
+    if (w_row_ok) {
+        const int kz_hi = min(G.pz - 1, G.pz - 1 - dz), kz_lo = max(0, -dz);
+        const int ky_hi = min(G.py - 1, G.py - 1 - dy), ky_lo = max(0, -dy);
+        for (int kz = kz_hi; kz >= kz_lo; --kz) {
+            const int cz = uz - kz + G.rz;
+            if (!(cz >= G.rz && cz < G.Z - G.rz)) continue;
+            for (int ky = ky_hi; ky >= ky_lo; --ky) {
+                const int cy = uy - ky + G.ry;
+                if (!(cy >= G.ry && cy < G.Y - G.ry)) continue;
+                // ---- stage + classify both images (rolled: element e -> half, column j, centre i)
+                const long long crow = vox(G, cz, cy, 0);
+                const long long cha = (long long)((kz * G.py + ky) * PX) * G.V + crow;
+                const long long chb = (long long)(((kz + dz) * G.py + (ky + dy)) * PX) * G.V + crow;
+                bool big = false;
+                // U elements at a time: all their (independent) loads first, then the
+                // classification -- one element per iteration waits a full memory latency each
+#ifndef PPP_S1W_U
+#define PPP_S1W_U 8
+#endif
+                constexpr int U = PPP_S1W_U;
+                int i = lane, j = 0;                       // element e = j * NC + i (+ PX*NC for "about w")
+                static_assert(K::NC >= 64, "one wrap per step of 64");
+                for (int e0 = lane; e0 < K::IMG; e0 += 64 * U) {
+                    float v[U], m[U];
+                    bool okx[U];
+                    int ti[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool in = e0 + 64 * u < K::IMG;
+                        const int ju = in ? j : 0, iu = in ? i : 0;
+                        const bool is_b = ju >= PX;
+                        const int jj = is_b ? ju - PX : ju;
+                        const int cx = ux0 - (PX - 1) + K::RX + iu;
+                        okx[u] = in && cx >= K::RX && cx < G.X - K::RX;
+                        const int cxc = min(max(cx, 0), G.X - 1);
+                        v[u] = ldf(pred, (is_b ? chb : cha) + (long long)jj * G.V + cxc);
+                        m[u] = is_b ? 1.0f : ldf(mid, crow + cxc);
+                        ti[u] = (is_b ? K::NT + 2 : 0) + iu + jj;        // index into uval / wval (contiguous arrays)
+                        i += 64;
+                        if (i >= K::NC) { i -= K::NC; ++j; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int e = e0 + 64 * u;
+                        if (e < K::IMG) {
+                            const bool ok = okx[u] && lds_valid[0][ti[u]] != 0 && (m[u] > G.th_gt || ti[u] >= K::NT + 2);
+                            const float t = v[u] > G.th_gt ? v[u] : (v[u] < G.bg_lt ? -(1.0f - v[u]) : 0.0f);
+                            if (TH05) big = big || !(fabsf(t) <= 1024.0f);
+                            img[e] = ok ? t : 0.0f;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *ia = img + pos_l;
+                const float *ib = img + PX * K::NC + pos_l;
+                if constexpr (TH05 && VAL == PPP_VAL_NORM_PROB_PRODUCT) {
+                    if (__ballot(big) == 0ull) {
+                        if (row0) tile_votes_w<PX, WIN, VAL, true, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                        else tile_votes_w<PX, WIN, VAL, false, false, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    } else {
+                        if (row0) tile_votes_w<PX, WIN, VAL, true, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                        else tile_votes_w<PX, WIN, VAL, false, true, true>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    }
+                } else {
+                    // general rules: the exact form (double division where the rule has one)
+                    if (row0) tile_votes_w<PX, WIN, VAL, true, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                    else tile_votes_w<PX, WIN, VAL, false, true, false>(ia, ib, u_ok, G.th2, G.den, inv_den, acc, cnt);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (!lane_ok) return;
+#pragma unroll
+    for (int k = 0; k < K::NW; ++k) {
+        const int i = I0 + k;
+        if (i >= K::NACC) continue;
+        const int dx = i - (PX - 1);
+        if (dz == 0 && dy == 0 && dx <= 0) continue;
+        const long long o = cons_at(G, dz, dy, dx, uz, uy, ux);
+        const float c = (float)cnt[k];
+        if (cons) cons[o] = (G.normalise && cnt[k] != 0u) ? acc[k] / c : acc[k];
+        if (cnt_out) cnt_out[o] = c;
+    }
+}
+
+template <typename T, int PX, int VAL, bool TH05>
+static hipError_t launch_wide_rule(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                                   const Geo &G, hipStream_t s) {
+    using K = V2W<PX>;
+    static_assert(K::NWIN <= 4, "launcher written for up to four windows");
+    const int n_rows = (G.pz - 1) * G.wy + G.py;
+    const int runs_per_line = (G.bX + 63) / 64;
+    const long long n_waves = (long long)runs_per_line * G.bY * G.bZ * n_rows;
+    if (n_waves >= (1ll << 31)) return hipErrorInvalidValue;
+    PPP_GRID_CHECK(n_waves, 64);
+    const dim3 grid((unsigned)n_waves), block(64);
+    consensus_wide_kernel<T, PX, 0, VAL, TH05><<<grid, block, 0, s>>>(pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    if constexpr (K::NWIN > 1)
+        consensus_wide_kernel<T, PX, 1, VAL, TH05><<<grid, block, 0, s>>>(pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    if constexpr (K::NWIN > 2)
+        consensus_wide_kernel<T, PX, 2, VAL, TH05><<<grid, block, 0, s>>>(pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    if constexpr (K::NWIN > 3)
+        consensus_wide_kernel<T, PX, 3, VAL, TH05><<<grid, block, 0, s>>>(pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
+    return hipGetLastError();
+}
+
+template <typename T, int PX>
+static hipError_t launch_wide(const T *pred, const uint8_t *ov, float *cons, float *cnt,
+                              const Geo &G, hipStream_t s) {
+    if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 && G.bg_lt <= 0.5f)
+        return launch_wide_rule<T, PX, PPP_VAL_NORM_PROB_PRODUCT, true>(pred, ov, cons, cnt, G, s);
+    if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT)
+        return launch_wide_rule<T, PX, PPP_VAL_NORM_PROB_PRODUCT, false>(pred, ov, cons, cnt, G, s);
+    if (G.value_rule == PPP_VAL_PROB_PRODUCT)
+        return launch_wide_rule<T, PX, PPP_VAL_PROB_PRODUCT, false>(pred, ov, cons, cnt, G, s);
+    return launch_wide_rule<T, PX, PPP_VAL_COUNT, false>(pred, ov, cons, cnt, G, s);
+}
+
 // returns hipErrorNotSupported when the shape has no specialised kernel
 hipError_t launch_consensus_v2(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s) {
@@ -423,6 +645,11 @@ hipError_t launch_consensus_v2(const void *pred, int dtype, const uint8_t *ov, f
         PPP_V2_CASE(5)
         PPP_V2_CASE(7)
         PPP_V2_CASE(9)
+    case 25:
+        // (2-d patches only: a 25-wide 3-d patch has 15 625 channels)
+        if (G.pz != 1 || (getenv("PPP_S1_WIDE") && getenv("PPP_S1_WIDE")[0] == '0')) return hipErrorNotSupported;
+        return dtype == PPP_F16 ? launch_wide<__half, 25>((const __half *)pred, ov, cons, cnt, G, s)
+                                : launch_wide<float, 25>((const float *)pred, ov, cons, cnt, G, s);
     default:
         return hipErrorNotSupported;
     }

@@ -671,3 +671,35 @@ def test_consensus_written_voxel_major_directly(ps, shape, torch_cuda, monkeypat
             assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (box, flat)
             assert int(torch.count_nonzero(want)) > 1000
             del got, want
+
+
+@pytest.mark.parametrize("rule", ["flylight", "probprod", "count", "th07"])
+def test_consensus_wide_patch_kernel_equals_generic(rule, torch_cuda, monkeypatch):
+    """S1 for 25-wide 2-d patches (accumulator windows, rolled staging; ppp_consensus_v2.hip)
+    == the generic gather kernel: values and counts, whole image and a sub-box, for the value /
+    threshold rules the wide kernel instantiates."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    shape, ps = (1, 70, 150), (1, 25, 25)
+    c = synth.make_case(shape, ps, seed=99, cell=[1, 30, 30], overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    if rule == "probprod":
+        kw.update(consensus_norm_prob_product=False, consensus_prob_product=True)
+    elif rule == "count":
+        kw.update(consensus_norm_prob_product=False)
+    elif rule == "th07":
+        kw.update(patch_threshold=0.7)
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    for box in (None, (0, 3, 9, 1, shape[1] - 2, shape[2] - 7)):
+        P = backend.make_params(shape, ps, cons_box=box, **kw)
+        out = {}
+        for wide in ("0", "1"):
+            monkeypatch.setenv("PPP_S1_WIDE", wide)
+            cons, cnt = backend.consensus(pred, ov, P, want_count=True)
+            out[wide] = (cons.cpu().numpy(), cnt.cpu().numpy(), backend.NOTES.get("s1_kernel"))
+        assert out["0"][2] == "consensus_gather_kernel" and out["1"][2] == "consensus_v2_kernel"
+        assert np.array_equal(out["0"][1], out["1"][1]), (box, "counts")
+        assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32)), box
+        assert np.count_nonzero(out["0"][0]) > 1000
