@@ -98,24 +98,52 @@ __global__ void __launch_bounds__(256)
     if (k < n && state[k] == 0) rank_vol[lin[k]] = k;
 }
 
-// Thread per voxel: an undecided patch centred here whose neighbourhood changed is recounted
-// (per row of the window: mask bits AND patch bits, popcount) and rejected when it can cover
-// <= pix_th voxels.  Consumes the dirty marks; flags whether any patch is still undecided.
-__global__ void __launch_bounds__(256)
+// Count step.  Thread per voxel; a workgroup of 1024 voxels first COMPACTS its undecided patches
+// whose neighbourhood changed into a list in LDS (and consumes the dirty marks; "any patch still
+// undecided" is flagged), then its first lanes recount them (per row of the window: mask bits AND
+// patch bits, popcount) and reject those that can cover <= pix_th voxels.  Recounting inside the
+// per-voxel sweep left one or two lanes of almost every wave walking the 49-row window while the
+// others idled -- a few per cent of the voxels are dirty candidates, scattered.  (A global list
+// costs a same-address atomic per wave: 4x slower than no compaction at all.)
+static constexpr int COUNT_THREADS = 1024;
+__global__ void __launch_bounds__(COUNT_THREADS)
     cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                        uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
                        const int32_t *__restrict__ loc_vol, const Geo G) {
-    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const bool in = v < G.V;
-    int k = in ? rank_vol[v] : RANK_NONE;
-    // sharded: rank_vol holds GLOBAL ranks (also of the neighbour's patches in the halo);
-    // only the own centres are worked on, through their local table index
-    if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
-    bool alive = k != RANK_NONE;
-    const bool marked = in && dirty[v] != 0;
-    if (marked) dirty[v] = 0;
-    if (alive && marked) {
+    __shared__ uint16_t s_list[COUNT_THREADS];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const long long v0 = blockIdx.x * (long long)blockDim.x;
+    {
+        const long long v = v0 + threadIdx.x;
+        const bool in = v < G.V;
+        int k = in ? rank_vol[v] : RANK_NONE;
+        // sharded: rank_vol holds GLOBAL ranks (also of the neighbour's patches in the halo);
+        // only the own centres are worked on, through their local table index
+        if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
+        const bool alive = k != RANK_NONE;
+        const bool marked = in && dirty[v] != 0;
+        if (marked) dirty[v] = 0;
+        const unsigned long long m = __ballot(alive && marked);
+        if (m != 0ull) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
+            base = __shfl(base, 0);
+            if (alive && marked) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        }
+        // "is any patch still undecided": a plain store of the same value from every wave that
+        // has one (same-address atomics from ~V/64 waves would dominate the kernel)
+        if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const long long v = v0 + s_list[t];
+        int k = rank_vol[v];
+        if (loc_vol) k = loc_vol[v];
         const int words = (G.C + 31) / 32, XW = row_words(G);
         int cz, cy, cx;
         centre_of(G, v, cz, cy, cx);
@@ -128,9 +156,7 @@ __global__ void __launch_bounds__(256)
         int have = 64, next = 2, hits = 0;
         // only "more than pix_th" matters: stop at the first plane of rows that settles it
         // (with pix_th = 0 a surviving patch is usually done after the first plane).  The mask
-        // words of a whole plane are loaded before any of them is used: a patch about to be
-        // rejected walks all pz * py rows, and with the exit test after every row each load
-        // waited for the previous one (59 us per launch, most of it that chain).
+        // words of a whole plane are loaded before any of them is used.
         constexpr int MAXPY = 9;
         for (int dz = 0; dz < G.pz && hits <= pix_th; ++dz) {
             const uint32_t *row = mbits + ((long long)(cz + dz - G.rz) * G.Y + (cy - G.ry)) * XW + wi;
@@ -172,14 +198,10 @@ __global__ void __launch_bounds__(256)
             }
         }
         if (hits <= pix_th) {
-            alive = false;
             state[k] = 2;
             rank_vol[v] = RANK_NONE;
         }
     }
-    // "is any patch still undecided": a plain store of the same value from every wave that
-    // has one (same-address atomics from ~V/64 waves would dominate the kernel)
-    if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
 }
 
 // "no patch here" of a filter volume: the largest value of the element type's byte pattern 0x7F..
@@ -370,8 +392,9 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
     int32_t n_alive = 1;
     while (n_alive > 0) {
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
+        const dim3 cgrid((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), cblock(COUNT_THREADS);
         for (int r = 0; r < COVER_BATCH; ++r) {
-            cover_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
+            cover_count_kernel<<<cgrid, cblock, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
                                                        W.counters + r, nullptr, G);
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
             minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
@@ -704,7 +727,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
     CoverWork W = carve(work, G);
     hipError_t e;
     if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
-    cover_count_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
+    cover_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
         W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, G);
     return hipGetLastError();
 }
