@@ -272,10 +272,13 @@ def main():
         # per-stage wall clock (adds a device sync around every stage)
         backend.HOST_TIMES = host_times = {}
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         inst = step()
+        step_ends.append(time.perf_counter())     # (the step ends with a device -> host copy)
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [1e3 * (b - a) for a, b in zip([t0] + step_ends[:-1], step_ends)]
     if dist is not None:
         t = torch.tensor([dt], device="cpu" if one_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -340,6 +343,9 @@ def main():
                        "z-slabs x%d, yx tiles %dx%d" % ((args.slabs or 1,) + tuple(args.yx))},
             "roofline": roofline,
             "roofline_other_kernels": roofline_other,
+            "step_ms": [round(v, 1) for v in step_ms],
+            **({"stage_lists_ms": {k: [1e3 * x for x in v] for k, v in (host_times or {}).items()}}
+               if os.environ.get("PPP_BENCH_DUMP_STAGES") else {}),
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
             "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
                               for k, v in (host_times or {}).items()},
