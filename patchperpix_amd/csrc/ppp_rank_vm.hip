@@ -350,10 +350,15 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     // patches (pz = 1): 1 x 8 x 8.
     const int shape_id = rank_vm_shape(G);
     int tile_kind = ((long long)((sZ + 7) / 8) * ((sY + 7) / 8) * ((sX + 7) / 8) < 3 * 4096) ? 2 : 0;
+    // 7^3: five slices of centres instead of four -- an inner voxel then serves 5 * 49 = 245
+    // (centre, a) items = 3.8 chunks of 64 lanes instead of 196 = 3.06 (the fourth chunk 6 % full)
+    if (tile_kind == 2 && shape_id == 7) tile_kind = 4;
     if (const char *e = getenv("PPP_RANK_TILE"))
-        tile_kind = strcmp(e, "8x8x16") == 0 ? 1 : (strcmp(e, "4x8x8") == 0 ? 2 : (strcmp(e, "8x8x8") == 0 ? 0 : tile_kind));
+        tile_kind = strcmp(e, "8x8x16") == 0 ? 1 : (strcmp(e, "4x8x8") == 0 ? 2 : (strcmp(e, "8x8x8") == 0 ? 0 :
+                    (strcmp(e, "5x8x8") == 0 ? 4 : (strcmp(e, "7x8x8") == 0 ? 5 : tile_kind))));
     if (shape_id > 100) tile_kind = 3;
-    const int TZ = tile_kind == 3 ? 1 : (tile_kind == 2 ? 4 : 8), TY = 8, TX = tile_kind == 1 ? 16 : 8;
+    const int TZ = tile_kind == 3 ? 1 : (tile_kind == 2 ? 4 : (tile_kind == 4 ? 5 : (tile_kind == 5 ? 7 : 8))), TY = 8,
+              TX = tile_kind == 1 ? 16 : 8;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
@@ -365,6 +370,8 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     case P:                                                                                            \
         if (tile_kind == 1) PPP_RV_LAUNCH(P, P, P, 8, 8, 16);                                          \
         else if (tile_kind == 2) PPP_RV_LAUNCH(P, P, P, 4, 8, 8);                                      \
+        else if (tile_kind == 4) PPP_RV_LAUNCH(P, P, P, 5, 8, 8);                                      \
+        else if (tile_kind == 5) PPP_RV_LAUNCH(P, P, P, 7, 8, 8);                                      \
         else PPP_RV_LAUNCH(P, P, P, 8, 8, 8);                                                          \
         break;
 #define PPP_RV_CASE2D(P)                                                                               \
