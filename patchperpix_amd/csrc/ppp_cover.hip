@@ -134,9 +134,10 @@ __global__ void __launch_bounds__(COUNT_THREADS)
             base = __shfl(base, 0);
             if (alive && marked) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
         }
-        // "is any patch still undecided": a plain store of the same value from every wave that
-        // has one (same-address atomics from ~V/64 waves would dominate the kernel)
-        if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+        // "is any patch still undecided" AFTER this step: a plain store of the same value from
+        // every wave that has one that is not recounted now (same-address atomics from ~V/64
+        // waves would dominate the kernel); the recounted ones report below if they survive
+        if (__ballot(alive && !marked) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
     }
     __syncthreads();
     const int n = s_n;
@@ -200,6 +201,8 @@ __global__ void __launch_bounds__(COUNT_THREADS)
         if (hits <= pix_th) {
             state[k] = 2;
             rank_vol[v] = RANK_NONE;
+        } else {
+            *n_alive = 1;
         }
     }
 }
@@ -514,20 +517,40 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// Thread per voxel: an undecided patch centred here whose neighbourhood changed is recounted in
-// full; a patch that covers nothing any more is retired.
-__global__ void __launch_bounds__(256)
+// Thread per voxel: the undecided patches of a workgroup whose neighbourhood changed are compacted
+// in LDS (as in cover_count_kernel), then recounted in full; a patch that covers nothing any more
+// is retired.
+__global__ void __launch_bounds__(COUNT_THREADS)
     thin_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                       uint8_t *__restrict__ dirty, int32_t *__restrict__ state,
                       long long *__restrict__ key_vol, int32_t *__restrict__ n_alive, const Geo G) {
-    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const bool in = v < G.V;
-    const long long key = in ? key_vol[v] : THIN_NONE;
-    bool alive = key != THIN_NONE;
-    const bool marked = in && dirty[v] != 0;
-    if (marked) dirty[v] = 0;
-    if (alive && marked) {
-        const int k = (int)(key & 0xFFFFFFFFll);
+    __shared__ uint16_t s_list[COUNT_THREADS];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const long long v0 = blockIdx.x * (long long)blockDim.x;
+    {
+        const long long v = v0 + threadIdx.x;
+        const bool in = v < G.V;
+        const bool alive = in && key_vol[v] != THIN_NONE;
+        const bool marked = in && dirty[v] != 0;
+        if (marked) dirty[v] = 0;
+        const unsigned long long m = __ballot(alive && marked);
+        if (m != 0ull) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
+            base = __shfl(base, 0);
+            if (alive && marked) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        }
+        // undecided after this step: those not recounted now; recounted survivors report below
+        if (__ballot(alive && !marked) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const long long v = v0 + s_list[t];
+        const int k = (int)(key_vol[v] & 0xFFFFFFFFll);
         const int words = (G.C + 31) / 32, XW = row_words(G);
         int cz, cy, cx;
         centre_of(G, v, cz, cy, cx);
@@ -553,14 +576,13 @@ __global__ void __launch_bounds__(256)
             }
         }
         if (hits == 0) {
-            alive = false;
             state[k] = 2;
             key_vol[v] = THIN_NONE;
         } else {
             key_vol[v] = ((THIN_MAXC - (long long)hits) << 32) | (long long)k;
+            *n_alive = 1;
         }
     }
-    if (__ballot(alive) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
 }
 
 // Thread per voxel: the patch with the best key of its neighbourhood keeps itself; its wave
@@ -645,8 +667,8 @@ hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long 
     while (n_alive > 0) {
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
         for (int r = 0; r < COVER_BATCH; ++r) {
-            thin_count_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.dirty, W.state, W.key_vol,
-                                                      W.counters + r, G);
+            thin_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
+                W.mbits, bits, W.dirty, W.state, W.key_vol, W.counters + r, G);
             minfilter_xy<long long>(W.key_vol, W.tmp, W.nbr_min, G, s);
             thin_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, W.state, W.key_vol,
                                                        W.sel_count, W.cleared, W.dirty, G);
