@@ -184,6 +184,18 @@ def main():
                     help="cut every z-slab into NY x NX tiles (single-GPU tiled path)")
     args = ap.parse_args()
 
+    # Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
+    # a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
+    # unmapped again on every call by glibc (~5 ms per step of page faults).  Same effect as
+    # MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment; PPP_BENCH_MALLOPT=0 skips it.
+    if os.environ.get("PPP_BENCH_MALLOPT", "1") != "0":
+        try:
+            import ctypes
+            libc = ctypes.CDLL("libc.so.6")
+            libc.mallopt(-1, 1 << 30)      # M_TRIM_THRESHOLD
+            libc.mallopt(-3, 1 << 30)      # M_MMAP_THRESHOLD
+        except OSError:
+            pass
     import torch
     from patchperpix_amd import backend
     from patchperpix_amd import flags as flagsets

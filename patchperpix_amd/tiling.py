@@ -446,13 +446,15 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     Zl = int(pred_local.shape[1])
     hi = lo + Zl
     radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
-    overlap_mask = 1 * (numinst > 1)
-    mask_to_cover[overlap_mask > 0] = 0
-    instances0 = np.zeros(shape, dtype=np.uint16)
+    # (a boolean, not the reference's `1 * (numinst > 1)`: the int64 copy is 8 bytes per voxel of
+    # host memory allocated, first-touched and freed every call -- at 140^3 a 22 MB temporary whose
+    # page faults showed up as sporadic +25 ms calls)
+    overlap_mask = np.asarray(numinst) > 1
+    mask_to_cover[overlap_mask] = 0
     want_inter = kw.get("return_intermediates", False)
 
     def early():
-        return (None, None) if want_inter else (instances0, foreground.astype(np.uint8))
+        return (None, None) if want_inter else (np.zeros(shape, dtype=np.uint16), foreground.astype(np.uint8))
 
     if np.count_nonzero(mask_to_cover[radslice]) == 0 or \
             np.count_nonzero(foreground[radslice]) == 0:
@@ -483,7 +485,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
             rank_ranges = rr
     ov_local = torch.from_numpy(
-        np.ascontiguousarray((overlap_mask[lo:hi] > 0).astype(np.uint8))).to(dev)
+        np.ascontiguousarray(overlap_mask[lo:hi].astype(np.uint8))).to(dev)
     keep_cons = len(my_tiles) == 1 and kw.get("_keep_cons", True)
     kept = {}
     dims = (Z, Y, X)
@@ -605,7 +607,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             # overlap voxel; everything from the first score below score_threshold on
             never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
             if overlap_mask.any():
-                ov_g = torch.from_numpy(np.ascontiguousarray(overlap_mask.reshape(-1) > 0)).to(dev)
+                ov_g = torch.from_numpy(np.ascontiguousarray(overlap_mask.reshape(-1))).to(dev)
                 never |= ov_g[lin_t]
                 del ov_g
             thr = kw.get("score_threshold", False)
