@@ -453,15 +453,19 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     mask_to_cover[overlap_mask] = 0
     want_inter = kw.get("return_intermediates", False)
 
+    id_dtype = np.dtype(kw.get("_instances_dtype") or np.uint16)
+    if id_dtype not in (np.dtype(np.uint16), np.dtype(np.uint32)):
+        raise ValueError("_instances_dtype must be uint16 or uint32")
+
     def early():
-        return (None, None) if want_inter else (np.zeros(shape, dtype=np.uint16), foreground.astype(np.uint8))
+        return (None, None) if want_inter else (np.zeros(shape, dtype=id_dtype), foreground.astype(np.uint8))
 
     if np.count_nonzero(mask_to_cover[radslice]) == 0 or \
             np.count_nonzero(foreground[radslice]) == 0:
         return early()
 
     flags = {k: v for k, v in kw.items()
-             if k not in ("cons_box", "cons_layout", "origin", "_yx_tiles")}
+             if k not in ("cons_box", "cons_layout", "origin", "_yx_tiles", "_instances_dtype")}
     ny_t, nx_t = kw.get("_yx_tiles") or (1, 1)
     # tiles of patch centres (z0, z1, y0, y1, x0, x1): the rank's z-slabs, each cut in y / x
     my_tiles = [(z0, z1) + t for (z0, z1) in my_slabs for t in plan_yx(Y, X, ny_t, nx_t)]
@@ -813,8 +817,13 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             labels = (inverse + 1).to(torch.int32)
             n_labels = int(uniq.numel())
             del keys, valid, uniq, inverse
-        if n_labels > np.iinfo(np.uint16).max:
-            raise OverflowError("%d instances do not fit uint16" % n_labels)
+        # ids are uint16 in the whole-volume entry (vote_instances.py:230; its np.seterr(over=
+        # 'raise') makes an id above 65 535 an error) and uint32 in the blockwise / stitched one
+        # (stitch_patch_graph.py:120), which the caller asks for with _instances_dtype
+        if n_labels > np.iinfo(id_dtype).max:
+            raise OverflowError("%d instance ids do not fit %s (the blockwise entry, "
+                                "stitch_patch_graph.main, carries uint32 ids)" % (n_labels, id_dtype.name))
+        backend.note("ids_issued", n_labels)
         inst_dev = torch.zeros(shape, dtype=torch.int32, device=dev)
         Pl = params()
         for (z0, z1) in my_slabs:
@@ -827,16 +836,23 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             ops.paint(pred_local, loc.contiguous(), labels[near].contiguous(), inst_l, Pl)
             inst_dev[z0:z1] = inst_l[z0 - lo:z1 - lo]
             del inst_l
-        # ids fit 16 bits (checked above): half the bytes on the wire and to the host
-        inst16 = inst_dev.to(torch.int16)
-        del inst_dev
-        if rank_ranges is not None:
-            comm.all_gather_slabs(inst16, rank_ranges)
+        if id_dtype == np.uint32:
+            if rank_ranges is not None:
+                comm.all_gather_slabs(inst_dev, rank_ranges)
+            else:
+                comm.all_reduce_sum(inst_dev)
+            instances = inst_dev.cpu().numpy().view(np.uint32)
         else:
-            inst32 = inst16.to(torch.int32) & 0xFFFF
-            comm.all_reduce_sum(inst32)
-            inst16 = inst32.to(torch.int16)
-        instances = inst16.cpu().numpy().view(np.uint16)
+            # ids fit 16 bits (checked above): half the bytes on the wire and to the host
+            inst16 = inst_dev.to(torch.int16)
+            del inst_dev
+            if rank_ranges is not None:
+                comm.all_gather_slabs(inst16, rank_ranges)
+            else:
+                inst32 = inst16.to(torch.int32) & 0xFFFF
+                comm.all_reduce_sum(inst32)
+                inst16 = inst32.to(torch.int16)
+            instances = inst16.cpu().numpy().view(np.uint16)
     return instances, foreground.astype(np.uint8)
 
 
@@ -970,16 +986,27 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
     # whole and the driver wants the instance map
     kw["return_intermediates"] = False
     fg_bb = np.ascontiguousarray(foreground[bb])
+    # the stitched volume carries uint32 ids (stitch_patch_graph.py:120): with the shipped
+    # mws = true + includeSinglePatchCCS = true every selected patch is issued an id
+    # (graph_mws.py:34-41), far more than 65 535 on a large volume
+    kw["_instances_dtype"] = np.uint32
     inst_bb, _ = to_instance_seg_tiled(
         np.ascontiguousarray(affinities[sub]), fg_bb, fg_bb.copy(),
         np.ascontiguousarray(numinst[bb]), patchshape, n_slabs, **kw)
-    instances = np.zeros(shape, dtype=np.uint16)
+    instances = np.zeros(shape, dtype=np.uint32)
     instances[bb] = inst_bb
-    # post-steps of the reference driver (stitch_patch_graph.py:831-894)
+    # post-steps of the reference driver (stitch_patch_graph.py:831-894): small components
+    # removed and the ids compacted -- on the uint32 map -- when remove_small_comps asks for it;
+    # every dataset is then written as uint16 (the reference's astype: ids above 65 535 that
+    # survive wrap, :852-870)
     from . import postprocess
     if kw.get("remove_small_comps", 0) > 0:
         instances = postprocess.relabel(
             postprocess.remove_small_components(instances, kw["remove_small_comps"]))
+    if int(instances.max(initial=0)) > np.iinfo(np.uint16).max:
+        logger.warning("instance ids up to %d are written as uint16 like the reference does "
+                       "(stitch_patch_graph.py:852-856): set remove_small_comps > 0 to compact "
+                       "them first", int(instances.max()))
     masked = instances.copy()
     masked[foreground == 0] = 0
     os.makedirs(result_folder, exist_ok=True)

@@ -173,7 +173,10 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     overlap_mask = 1 * (numinst > 1)
 
     mask_to_cover[overlap_mask > 0] = 0
-    instances = np.zeros(shape, dtype=np.uint16)
+    # uint16 ids (vote_instances.py:230); the blockwise driver carries uint32
+    # (stitch_patch_graph.py:120) and asks for it with _instances_dtype
+    id_dtype = np.dtype(kwargs.get("_instances_dtype") or np.uint16)
+    instances = np.zeros(shape, dtype=id_dtype)
 
     def unpadded(inst, fg):
         if kwargs.get("pad_with_ps", False):
@@ -186,7 +189,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         if kwargs.get('return_intermediates', False):
             return None, None
         inst, fg = unpadded(instances, foreground)
-        return inst.astype(np.uint16), fg.astype(np.uint8)
+        return inst.astype(id_dtype), fg.astype(np.uint8)
 
     neighshape = patchshape.copy()
     if neighshape[0] > 1:
@@ -206,7 +209,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         logger.info("no patches found, returning...")
         if kwargs.get('return_intermediates', False):
             return None, None
-        return instances.astype(np.uint16), foreground.astype(np.uint8)
+        return instances.astype(id_dtype), foreground.astype(np.uint8)
 
     # (1) consensus
     if not kwargs.get('skipConsensus'):
@@ -264,7 +267,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         if selected_patch_pairsIDs is None:
             if kwargs.get('return_intermediates', False):
                 return None, None
-            return instances.astype(np.uint16), foreground.astype(np.uint8)
+            return instances.astype(id_dtype), foreground.astype(np.uint8)
         if kwargs.get('termAfterThinCover'):
             raise SystemExit(0)
 
