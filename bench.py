@@ -8,18 +8,24 @@ JSON line ("Measurement").
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--flags SET]
 
-The timed workload runs the flag set named by --flags; the default, ``shipped``, is the
-reference's flylight default.toml [vote_instances] (mutex watershed and thinning on; exact
-entries in the JSON's config.flags).  At N = 1 the same line also carries
-  * ``variants``: ms per step of the other flag sets (mws off; mws and thinning off),
-  * ``roofline`` for the scoring kernel S1 on the timed workload (HIP events of this run),
-  * ``roofline_north_star``: the same kernel on BASELINE configs[2] (512^3 volume, 9^3 patch,
-    float16 prediction resident), one pass over all base voxels, measured in this run,
+Default workload: ``synth512_p9`` = BASELINE.json configs[2] (512^3 volume, 9^3 patch, dense
+foreground, float16 prediction resident: 196 GB), the configuration the north star's target is
+stated on, with the reference's SHIPPED flylight flag set (``--flags shipped``: mutex watershed
+and thinning on; exact entries in the JSON's config.flags) and the uint32 instance ids of the
+reference's blockwise entry.  A step of that volume takes the better part of a minute; so that a
+default run always ends inside the driver's window, the first warm-up step is timed and, if
+(W + K) steps would exceed PPP_BENCH_BUDGET_S (default 1400 s), the timed loop falls back to
+``flylight140_p7`` (configs[1]) and the one 512^3 step is reported as ``config2_end_to_end``.
+
+At N = 1 the same line also carries
+  * ``roofline`` for the scoring kernel S1 on the timed workload (HIP events of this run; for
+    flylight140_p7 additionally ``roofline_north_star``: the kernel over the 512^3 / 9^3 volume),
+  * ``variants`` (flylight140_p7 only): ms per step of the other flag sets,
   * ``cpu_baseline``: the CPU oracle (C, -O3) on host cores -- one thread and all threads.
 
 N > 1 is launched by torch.distributed.run, one rank per GPU: ONE volume, split into z-slabs
-with patch-radius halos (patchperpix_amd/tiling.py); --scaling weak (default) makes it N times
-taller than the 1-GPU workload, --scaling strong keeps the 1-GPU volume.
+with patch-radius halos (patchperpix_amd/tiling.py); --scaling strong (default): the 1-GPU
+volume split over the ranks; --scaling weak: a volume N times taller.
 """
 import argparse
 import hashlib
@@ -58,6 +64,8 @@ WORKLOADS = {
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
 }
+DEFAULT_WORKLOAD = "synth512_p9"      # BASELINE.json configs[2]
+FALLBACK_WORKLOAD = "flylight140_p7"  # BASELINE.json configs[1]
 NORTH_STAR = ((512, 512, 512), (9, 9, 9), (24, 24, 24))   # BASELINE.json configs[2]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -88,6 +96,13 @@ def device_labels(torch, shape, cell, seed, z_offset=0):
     lab = (h % 65000) + 1
     lab = torch.where(((h >> 16) % 16) == 0, torch.zeros_like(lab), lab)
     return lab.to(torch.int32).contiguous()
+
+
+def count_instances(torch, inst):
+    """Distinct non-zero ids of the instance map (on the device: np.unique sorts 134 M voxels on
+    one host core for half a minute at 512^3)."""
+    u = torch.unique(torch.from_numpy(np.ascontiguousarray(inst).astype(np.int64)).cuda())
+    return int(u.numel()) - int((u == 0).any().item())
 
 
 def source_sha16():
@@ -160,23 +175,113 @@ def north_star_s1(torch, backend, kw):
     return r
 
 
+def set_host_allocator():
+    """Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
+    a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
+    unmapped again on every call by glibc (~5 ms per step of page faults at 140^3).  Same effect
+    as MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment; PPP_BENCH_MALLOPT=0
+    skips it.  Returns what was done (reported in the JSON)."""
+    if os.environ.get("PPP_BENCH_MALLOPT", "1") == "0":
+        return "off"
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        ok = libc.mallopt(-1, 1 << 30) and libc.mallopt(-3, 1 << 30)   # M_TRIM_ / M_MMAP_THRESHOLD
+        return "trim/mmap thresholds 1 GiB" if ok else "mallopt refused"
+    except OSError:
+        return "no libc"
+
+
+class Workload:
+    """One synthetic volume set up for timing: the float16 prediction and the per-voxel fields
+    (foreground, numinst) resident in HBM, and ``step(flags)`` = one pass of the hot path."""
+
+    def __init__(self, torch, name, kw, args, world, rank, comm=None):
+        from patchperpix_amd import backend, tiling
+        from patchperpix_amd.vote_instances import vote_instances as vi
+        self.name = name
+        shape, ps, cell = WORKLOADS[name]
+        self.shape, self.ps, self.cell = shape, ps, cell
+        self.kw = kw
+        big = int(np.prod(shape)) >= 256 ** 3
+        extra = {}
+        if big:
+            # large volumes carry uint32 ids like the reference's blockwise entry
+            # (stitch_patch_graph.py:120): the shipped mws + includeSinglePatchCCS issue one id
+            # per selected patch (454 029 at 512^3)
+            extra["_instances_dtype"] = np.uint32
+        self.ids = "uint32" if big else "uint16"
+        if world == 1:
+            self.gshape = shape
+            P = backend.make_params(shape, ps, **kw)
+            labels = device_labels(torch, shape, cell, seed=0)
+            self.pred = backend.synth_pred(labels, P, seed=0, f16=True)       # resident in HBM
+            fg = (labels != 0).to(torch.uint8)
+            del labels
+            if args.slabs:
+                extra["_n_slabs"] = args.slabs
+            if args.yx:
+                extra["_yx_tiles"] = tuple(args.yx)
+                extra.setdefault("_n_slabs", 1)
+
+            def step(flag_kw=kw):
+                # foreground / mask / numinst are inputs like the prediction: resident in HBM
+                # (the mask is the pipeline's scratch: a fresh copy per call, on the device)
+                inst, _ = vi.to_instance_seg(self.pred, fg, fg.clone(), fg, ps, **dict(flag_kw, **extra))
+                return inst
+        else:
+            # ONE volume split into z-slabs: rank r holds the prediction of its slab + halo only
+            gshape = (shape[0] * world, shape[1], shape[2]) if args.scaling == "weak" else shape
+            self.gshape = gshape
+            slabs = tiling.plan_slabs(gshape[0], world)
+            mine = tiling.slabs_of_rank(slabs, rank, world)
+            if not mine:
+                raise SystemExit("more ranks than z-slabs")
+            lo, hi = tiling.local_range(mine, gshape[0], ps)
+            # generate rz extra slices on both sides so that every channel of the kept range sees
+            # its true neighbours, then keep [lo, hi)
+            glo, ghi = max(0, lo - ps[0] // 2), min(gshape[0], hi + ps[0] // 2)
+            eshape = (ghi - glo, shape[1], shape[2])
+            Pe = backend.make_params(eshape, ps, **kw)
+            labels_e = device_labels(torch, eshape, cell, seed=0, z_offset=glo)
+            pred = backend.synth_pred(labels_e, Pe, seed=0, f16=True,
+                                      voxel_offset=glo * shape[1] * shape[2])
+            self.pred = pred[:, lo - glo:hi - glo].contiguous()
+            del labels_e, pred
+            fg = (device_labels(torch, gshape, cell, seed=0) != 0).to(torch.uint8)
+
+            def step(flag_kw=kw):
+                inst, _ = tiling.assemble(self.pred, lo, gshape, fg, fg.clone(), fg, ps, mine,
+                                          comm=comm, **dict(flag_kw, **extra))
+                return inst
+        self.step = step
+        self.fg_fraction = float(fg.float().mean().item())
+
+    def free(self, torch):
+        self.pred = None
+        self.step = None
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="flylight140_p7", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: %s (BASELINE configs[2]) with a fall-back to %s when the run would "
+                         "not fit the time budget" % (DEFAULT_WORKLOAD, FALLBACK_WORKLOAD))
     ap.add_argument("--flags", default="shipped", choices=["shipped", "cc", "nothin_cc"],
                     help="flag set (patchperpix_amd/flags.py): shipped = default.toml "
                          "[vote_instances] (mws + thinning), cc = mws off, nothin_cc = "
                          "kernels-only pipeline")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = the volume grows with N (N x taller), strong = the "
-                         "1-GPU volume is split over the ranks")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = the 1-GPU volume is split over the ranks, weak = the volume "
+                         "grows with N (N x taller)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU oracle and exit")
     ap.add_argument("--no-north-star", action="store_true",
-                    help="skip the S1 pass over the 512^3 / 9^3 volume (about half a minute)")
+                    help="flylight140_p7: skip the S1 pass over the 512^3 / 9^3 volume (half a minute)")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--slabs", type=int, default=None,
                     help="force the number of z-slabs of the single-GPU tiled path")
@@ -184,26 +289,15 @@ def main():
                     help="cut every z-slab into NY x NX tiles (single-GPU tiled path)")
     args = ap.parse_args()
 
-    # Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
-    # a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
-    # unmapped again on every call by glibc (~5 ms per step of page faults).  Same effect as
-    # MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment; PPP_BENCH_MALLOPT=0 skips it.
-    if os.environ.get("PPP_BENCH_MALLOPT", "1") != "0":
-        try:
-            import ctypes
-            libc = ctypes.CDLL("libc.so.6")
-            libc.mallopt(-1, 1 << 30)      # M_TRIM_THRESHOLD
-            libc.mallopt(-3, 1 << 30)      # M_MMAP_THRESHOLD
-        except OSError:
-            pass
+    allocator = set_host_allocator()
     import torch
     from patchperpix_amd import backend
     from patchperpix_amd import flags as flagsets
-    from patchperpix_amd.vote_instances import vote_instances as vi
 
+    kw = dict(flagsets.FLAG_SETS[args.flags])
     if args.cpu_baseline_only:
-        shape, ps, cell = WORKLOADS[args.workload]
-        print(json.dumps(cpu_baseline(ps, cell, dict(flagsets.FLAG_SETS[args.flags]))))
+        shape, ps, cell = WORKLOADS[args.workload or DEFAULT_WORKLOAD]
+        print(json.dumps(cpu_baseline(ps, cell, kw)))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -213,68 +307,67 @@ def main():
     # gloo as the transport -- numbers from such a run mean nothing
     one_gpu = os.environ.get("PPP_BENCH_ONE_GPU", "0") == "1"
     torch.cuda.set_device(0 if one_gpu else local_rank)
-    dist = None
+    dist = comm = None
     if world > 1:
         import torch.distributed as dist
+        from patchperpix_amd import tiling
         dist.init_process_group("gloo" if one_gpu else "nccl")  # "nccl" = RCCL
-    n_gpus = max(args.gpus, world)
-
-    shape, ps, cell = WORKLOADS[args.workload]
-    kw = dict(flagsets.FLAG_SETS[args.flags])
-    from patchperpix_amd import tiling
-    if world == 1:
-        P = backend.make_params(shape, ps, **kw)
-        labels = device_labels(torch, shape, cell, seed=0)
-        pred = backend.synth_pred(labels, P, seed=0, f16=True)       # resident in HBM
-        fg_host = (labels != 0).cpu().numpy()
-        numinst = fg_host.astype(np.uint8)
-        gshape = shape
-        del labels
-        tile_kw = {}
-        if args.slabs:
-            tile_kw["_n_slabs"] = args.slabs
-        if args.yx:
-            tile_kw["_yx_tiles"] = tuple(args.yx)
-            tile_kw.setdefault("_n_slabs", 1)
-
-        def step(flag_kw=kw):
-            inst, _ = vi.to_instance_seg(pred, fg_host.copy(), fg_host.copy(), numinst, ps,
-                                         **dict(flag_kw, **tile_kw))
-            return inst
-    else:
-        # ONE volume split into z-slabs: rank r holds the prediction of its slab + halo only
-        gshape = (shape[0] * world, shape[1], shape[2]) if args.scaling == "weak" else shape
-        slabs = tiling.plan_slabs(gshape[0], world)
-        mine = tiling.slabs_of_rank(slabs, rank, world)
-        lo, hi = tiling.local_range(mine, gshape[0], ps)
-        # generate rz extra slices on both sides so that every channel of the kept range sees
-        # its true neighbours, then keep [lo, hi)
-        glo, ghi = max(0, lo - ps[0] // 2), min(gshape[0], hi + ps[0] // 2)
-        eshape = (ghi - glo, shape[1], shape[2])
-        Pe = backend.make_params(eshape, ps, **kw)
-        labels_e = device_labels(torch, eshape, cell, seed=0, z_offset=glo)
-        pred = backend.synth_pred(labels_e, Pe, seed=0, f16=True,
-                                  voxel_offset=glo * shape[1] * shape[2])
-        pred = pred[:, lo - glo:hi - glo].contiguous()
-        del labels_e
-        fg_host = (device_labels(torch, gshape, cell, seed=0) != 0).cpu().numpy()
-        numinst = fg_host.astype(np.uint8)
         comm = tiling.TorchDistComm()
-
-        def step(flag_kw=kw):
-            inst, _ = tiling.assemble(pred, lo, gshape, fg_host.copy(), fg_host.copy(), numinst,
-                                      ps, mine, comm=comm, **flag_kw)
-            return inst
-    torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        inst = step()
+    n_gpus = max(args.gpus, world)
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def agree_max(x):
+        """the same number on every rank: the maximum"""
+        if dist is None:
+            return float(x)
+        t = torch.tensor([float(x)], device="cpu" if one_gpu else "cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    budget_s = float(os.environ.get("PPP_BENCH_BUDGET_S", "1400"))
+    auto = args.workload is None
+    wl = Workload(torch, args.workload or DEFAULT_WORKLOAD, kw, args, world, rank, comm)
+    barrier()
+    warm_done = 0
+    config2 = None
+    if auto:
+        # the first step of the default workload is timed (it also serves as the first warm-up
+        # step): would W + K steps fit the budget?
+        backend.NOTES.clear()
+        backend.HOST_TIMES = {}
+        t0 = time.perf_counter()
+        inst = wl.step()
+        barrier()
+        t_first = agree_max(time.perf_counter() - t0)
+        stages = {k: float(np.sum(v) * 1e3) for k, v in backend.HOST_TIMES.items()}
+        backend.HOST_TIMES = None
+        warm_done = 1
+        planned = t_first * (args.steps + args.warmup)
+        if planned > budget_s:
+            config2 = {
+                "workload": wl.name, "volume": list(wl.gshape), "patchshape": list(wl.ps),
+                "flag_set": args.flags, "ids": wl.ids, "steps": 1, "warmup": 0,
+                "ms_per_step": t_first * 1e3, "value": float(np.prod(wl.gshape)) / t_first / 1e6,
+                "unit": "Mvoxels/s", "instances_found": count_instances(torch, inst),
+                "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
+                "stage_wall_ms": stages, "workload_stats": dict(backend.NOTES),
+                "why_not_timed": "%d steps of %.1f s = %.0f s exceed the budget of %.0f s "
+                                 "(PPP_BENCH_BUDGET_S)" % (args.steps + args.warmup, t_first, planned, budget_s)}
+            del inst
+            wl.free(torch)
+            wl = Workload(torch, FALLBACK_WORKLOAD, kw, args, world, rank, comm)
+            warm_done = 0
+            barrier()
+    shape, ps, cell, gshape = wl.shape, wl.ps, wl.cell, wl.gshape
+    step = wl.step
+
+    for _ in range(max(0, args.warmup - warm_done)):
+        inst = step()
 
     backend.EVENTS = {}
     backend.NOTES.clear()
@@ -291,10 +384,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step_ms = [1e3 * (b - a) for a, b in zip([t0] + step_ends[:-1], step_ends)]
-    if dist is not None:
-        t = torch.tensor([dt], device="cpu" if one_gpu else "cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = agree_max(dt)
     ev = backend.event_times_ms()
     notes = dict(backend.NOTES)
     backend.EVENTS = None
@@ -306,29 +396,31 @@ def main():
     if ev.get("consensus"):
         s1_kernel = notes.get("s1_kernel", "consensus_v3_kernel")
         roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C, kernel=s1_kernel)
-        roofline["workload"] = args.workload
-        if rank == 0 and args.workload == "flylight140_p7" and world == 1 and not args.slabs:
-            roofline.update(pmc_traffic(s1_kernel))
+        roofline["workload"] = wl.name
+        if rank == 0 and world == 1 and not args.slabs and not args.yx:
+            roofline.update(pmc_traffic(s1_kernel, wl.name))
         if notes.get("s1_output_bytes"):
             # the algorithmic figure counts the INPUT; the launch also writes the whole
             # consensus -- most of the measured traffic
             roofline["output_bytes_per_launch"] = notes["s1_output_bytes"] / max(1, len(ev["consensus"]))
             roofline["traffic_reading"] = (
-                "writes = the consensus output (symmetric voxel-major rows, 2x the stored planes; the "
-                "4-byte mirrored stores are counted ~1.6x); reads = the f16 prediction (re-read ~4x across "
-                "the offset rows of a run) + the read-for-ownership of the partially written lines")
-    # Secondary figures for the other two big kernels.  S2 (ranking): the consensus it sums +
-    # the prediction block once, 4 * planes + 2 * C bytes per voxel.  S5 (patch graph): both
-    # patches' channel vectors per dispatched pair row, SURVEY 8(d)'s bound without `visited`.
+                "writes = the consensus output (symmetric voxel-major rows, 2x the stored planes); "
+                "reads = the f16 prediction (re-read across the offset rows of a run) + the "
+                "read-for-ownership of partially written lines")
+    # Secondary figures for the other two big kernels.  S2 (ranking): the voxel-major consensus
+    # rows it reads once + the prediction block once: 4 (2p-1)^3 + 2 C bytes per base voxel.
+    # S5 (patch graph): both patches' channel vectors per dispatched pair row, SURVEY 8(d)'s
+    # bound without `visited`.
     roofline_other = {}
     if ev.get("rank_patches"):
-        planes = ((2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1) - 1) // 2
+        W_vm = (2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1)
         ms = float(np.sum(ev["rank_patches"]))
-        b = (4.0 * planes + 2.0 * C) * notes.get("s1_base_voxels", 0)
+        b = (4.0 * W_vm + 2.0 * C) * notes.get("s2_base_voxels", notes.get("s1_base_voxels", 0))
         roofline_other["rank_patches"] = {
             "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["rank_patches"]),
-            "launches": len(ev["rank_patches"])}
+            "launches": len(ev["rank_patches"]),
+            "bytes": "voxel-major consensus rows of the launch's box once + the prediction block once"}
     if ev.get("patch_graph") and notes.get("n_pairs"):
         ms = float(np.sum(ev["patch_graph"]))
         rows = float(notes.get("s5_rows_dispatched", notes["n_pairs"] * args.steps))
@@ -340,19 +432,22 @@ def main():
             "pair_rows_in_list_per_step": notes["n_pairs"]}
     out = None
     if rank == 0:
+        per_step = ("s1_base_voxels", "s2_base_voxels", "s5_rows_dispatched", "s1_output_bytes")
         out = {
             "metric": "Mvoxels/sec assembled (vote_instances)", "value": value,
             "unit": "Mvoxels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f16 in, f32 accumulate", "data": "synthetic",
-            "config": {"workload": args.workload, "volume": list(shape), "patchshape": list(ps),
+            "config": {"workload": wl.name, "volume": list(shape), "patchshape": list(ps),
                        "pred_dtype": "f16 resident, widened to f32 in registers",
                        "flag_set": args.flags, "flags": flagsets.describe(kw),
-                       "instances_found": int(len(np.unique(inst)) - 1),
+                       "instance_ids": wl.ids, "foreground_fraction": wl.fg_fraction,
+                       "instances_found": count_instances(torch, inst),
                        "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
                        "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus if not args.yx else
-                       "z-slabs x%d, yx tiles %dx%d" % ((args.slabs or 1,) + tuple(args.yx))},
+                       "z-slabs x%d, yx tiles %dx%d" % ((args.slabs or 1,) + tuple(args.yx)),
+                       "host_allocator": allocator},
             "roofline": roofline,
             "roofline_other_kernels": roofline_other,
             "step_ms": [round(v, 1) for v in step_ms],
@@ -361,12 +456,14 @@ def main():
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
             "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
                               for k, v in (host_times or {}).items()},
-            "workload_stats": {k: (v // args.steps if k in ("s1_base_voxels", "s5_rows_dispatched", "s1_output_bytes") else v)
-                               for k, v in notes.items()},
+            "workload_stats": {k: (v // args.steps if k in per_step else v) for k, v in notes.items()},
         }
+        if config2 is not None:
+            out["config2_end_to_end"] = config2
     if world == 1:
-        # ---- the other flag sets on the same volume (a few steps each)
-        if not args.no_variants:
+        small = wl.name == FALLBACK_WORKLOAD
+        # ---- the other flag sets on the same volume (a few steps each; small volume only)
+        if not args.no_variants and small:
             variants = {}
             for name in ("shipped", "cc", "nothin_cc"):
                 if name == args.flags:
@@ -381,12 +478,13 @@ def main():
                 torch.cuda.synchronize()
                 vdt = (time.perf_counter() - t1) / n_v
                 variants[name] = {"ms_per_step": vdt * 1e3, "value": float(np.prod(gshape)) / vdt / 1e6,
-                                  "instances_found": int(len(np.unique(vinst)) - 1),
+                                  "instances_found": count_instances(torch, vinst),
                                   "differs_in": {k: vkw[k] for k in ("mws", "skipThinCover")}}
             out["variants"] = variants
-        del pred
-        # ---- the north-star shape of the scoring kernel, in this run
-        if not args.no_north_star and args.workload == "flylight140_p7":
+        wl.free(torch)
+        # ---- the north-star shape of the scoring kernel, in this run (when the timed workload is
+        # not that shape itself)
+        if not args.no_north_star and small and config2 is None:
             out["roofline_north_star"] = north_star_s1(torch, backend, kw)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ps, cell, kw)
@@ -396,25 +494,36 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel):
-    """HBM traffic of `kernel` per launch from the newest committed rocprofv3 PMC passes
-    (profiles/*_pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE, separate --pmc passes, KiB) --
-    only when that profile was taken from the kernel sources of THIS tree (its .meta.json holds
-    their fingerprint); otherwise traffic stays null.  Calibration (MI355X_MICROARCH.md: counters
-    are exact for some access widths, halved for 16 B / lane streaming reads, uncalibrated
-    otherwise): the transpose kernel of the same profile moves a known byte count with this
-    kernel's access width; its counter / true-bytes ratios are reported next to the raw values."""
+def pmc_traffic(kernel, workload):
+    """HBM traffic of `kernel` per launch from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/*_pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE, separate --pmc passes, KiB,
+    per-dispatch means) -- only from a profile taken from the kernel sources of THIS tree (its
+    .meta.json holds their fingerprint and the workload); otherwise traffic stays null.  Among
+    several matching profiles the last tag in name order is taken (not file times: they are
+    arbitrary after a checkout).  Calibration (MI355X_MICROARCH.md: counters are exact for some
+    access widths, halved for 16 B / lane streaming reads, uncalibrated otherwise): when the
+    profile holds the transpose kernel, which moves a known byte count with this kernel's access
+    width, its counter / true-bytes ratios are reported next to the raw values."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write.txt")),
-                   key=os.path.getmtime)
-    if not files:
-        return {"traffic": None, "traffic_note": "no PMC profile committed"}
-    f = files[-1]
-    meta_f = f.replace("_pmc_fetch_write.txt", ".meta.json")
-    meta = json.load(open(meta_f)) if os.path.exists(meta_f) else {}
-    if meta.get("src_sha16") != source_sha16():
-        return {"traffic": None, "traffic_note": "newest PMC profile (%s) was taken from other kernel "
-                "sources: rerun tools/profile_round.sh" % os.path.relpath(f, ROOT)}
+    sha = source_sha16()
+    match, stale = [], 0
+    for meta_f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*.meta.json"))):
+        try:
+            meta = json.load(open(meta_f))
+        except ValueError:
+            continue
+        f = meta_f.replace(".meta.json", "_pmc_fetch_write.txt")
+        if meta.get("workload", FALLBACK_WORKLOAD) != workload or not os.path.exists(f):
+            continue
+        if meta.get("src_sha16") == sha:
+            match.append((f, meta))
+        else:
+            stale += 1
+    if not match:
+        return {"traffic": None,
+                "traffic_note": "no PMC profile of %s from these kernel sources is committed (%d from "
+                                "other sources): rerun tools/profile_round.sh" % (workload, stale)}
+    f, meta = match[-1]
     vals, calib = {}, {}
     for ln in open(f):
         parts = ln.split()
@@ -429,7 +538,7 @@ def pmc_traffic(kernel):
         return {"traffic": None, "traffic_note": "kernel not in %s" % os.path.relpath(f, ROOT)}
     out = {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "traffic_read": vals["FETCH_SIZE"],
            "traffic_write": vals["WRITE_SIZE"],
-           "traffic_source": os.path.relpath(f, ROOT) + " (raw counters, per launch)"}
+           "traffic_source": os.path.relpath(f, ROOT) + " (raw counters, mean per launch)"}
     if len(calib) == 2 and meta.get("transpose_true_read_bytes"):
         out["counter_over_true_bytes"] = {
             "read": calib["FETCH_SIZE"] / meta["transpose_true_read_bytes"],
@@ -450,7 +559,10 @@ def cpu_baseline(ps, cell, kw):
            "what": "oracle/ppp_oracle.c (gcc -O3 -fopenmp; S1 in gather form over offset planes, "
                    "S2 over centres, S5 over pair rows) + host stages (ppp_host_* C++, one thread)"}
     runs = []
-    for threads, sshape in ((1, (32, 32, 32)), (cores, (64, 64, 64))):
+    # bounded samples (10-30 s each): the per-voxel work grows with C^2 (4.5x from 7^3 to 9^3)
+    samples = ((1, (24, 24, 24)), (cores, (48, 48, 48))) if int(np.prod(ps)) > 343 else \
+        ((1, (32, 32, 32)), (cores, (64, 64, 64)))
+    for threads, sshape in samples:
         sshape = tuple(min(s, 64) if p > 1 else 1 for s, p in zip(sshape, ps))
         if ps[0] == 1:
             sshape = (1, 96, 96) if threads == 1 else (1, 192, 192)

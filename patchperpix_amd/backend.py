@@ -456,6 +456,13 @@ def rank_patches(pred, cons, overlap, P, score_box=None, out=None):
         if nbytes == 0:
             raise RuntimeError("libppp_mi355x: no voxel-major ranking kernel for this configuration")
         work = torch.empty(nbytes, dtype=torch.uint8, device=pred.device)
+        # voxels whose consensus row the launch reads: the score box grown by the patch radius
+        sb = (0, 0, 0) + tuple(P.shape) if score_box is None else tuple(int(v) for v in score_box)
+        cb = P.cons_box
+        rad = (P.pz // 2, P.py // 2, P.px // 2)
+        lo3 = [max(sb[a] - rad[a], (cb.z0, cb.y0, cb.x0)[a]) for a in range(3)]
+        hi3 = [min(sb[3 + a] + rad[a], (cb.z1, cb.y1, cb.x1)[a]) for a in range(3)]
+        note_add("s2_base_voxels", int(np.prod([max(0, h - l) for l, h in zip(lo3, hi3)])))
         with _timed("rank_patches"):
             check(lib().ppp_rank_patches_vm(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons),
                                             _dev_ptr(overlap), _dev_ptr(out), box, _dev_ptr(work),
@@ -989,8 +996,12 @@ def rank_order_device(score, foreground, patchshape, to_host=True):
     P.th = P.thi = 0.5
     P.bg_rule, P.value_rule = BG_LESS_THAN_TH, VAL_COUNT
     P.cons_box = Box(0, 0, 0, Z, Y, X)
-    fg = torch.from_numpy(np.ascontiguousarray(np.asarray(foreground) != 0).astype(np.uint8)
-                          ).to(score.device).reshape(-1)
+    if torch.is_tensor(foreground):
+        fg = foreground.to(score.device)
+        fg = (fg if fg.dtype == torch.uint8 else (fg != 0).to(torch.uint8)).contiguous().reshape(-1)
+    else:
+        fg = torch.from_numpy(np.ascontiguousarray(np.asarray(foreground) != 0).astype(np.uint8)
+                              ).to(score.device).reshape(-1)
     V = Z * Y * X
     nbytes = int(lib().ppp_rank_order_workspace_bytes(ctypes.byref(P)))
     check(min(nbytes, 0))

@@ -22,6 +22,10 @@ bool rank_vm_supported(const Geo &G);
 size_t rank_vm_workspace_bytes(const ppp_box &sb, const Geo &G);
 hipError_t launch_rank_vm(const void *pred, int dtype, const float *S, const uint8_t *ov, float *score,
                           const ppp_box &sb, void *work, const Geo &G, hipStream_t s);
+bool rank_wg_supported(const Geo &G);
+size_t rank_wg_workspace_bytes(const ppp_box &sb, const Geo &G);
+hipError_t launch_rank_wg(const void *pred, int dtype, const float *S, const uint8_t *ov, float *score,
+                          const ppp_box &sb, void *work, const Geo &G, hipStream_t s);
 hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
                               const uint32_t *pairs, const uint32_t *order, uint64_t n,
                               float *aff, const Geo &G, hipStream_t s);

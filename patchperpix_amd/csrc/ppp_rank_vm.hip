@@ -316,7 +316,10 @@ bool rank_vm_supported(const Geo &G) {
 size_t rank_vm_workspace_bytes(const ppp_box &sb, const Geo &G) {
     const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
     const size_t words = (size_t)(G.C + 31) / 32;
-    return 2 * up256r(words * sbV * 4) + up256r(sbV * 4) + up256r((size_t)G.V);
+    const size_t one_wave = 2 * up256r(words * sbV * 4) + up256r(sbV * 4) + up256r((size_t)G.V);
+    // (either kernel may serve the call: ppp_rank_wg.hip takes the cubic 5 / 7 / 9 patches)
+    const size_t wg = rank_wg_supported(G) ? rank_wg_workspace_bytes(sb, G) : 0;
+    return one_wave > wg ? one_wave : wg;
 }
 
 template <typename T>
@@ -399,6 +402,7 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
 hipError_t launch_rank_vm(const void *pred, int dtype, const float *S, const uint8_t *ov, float *score,
                           const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
     if (!rank_vm_supported(G)) return hipErrorNotSupported;
+    if (rank_wg_supported(G)) return launch_rank_wg(pred, dtype, S, ov, score, sb, work, G, s);
     return dtype == PPP_F16 ? launch_rv<__half>((const __half *)pred, S, ov, score, sb, work, G, s)
                             : launch_rv<float>((const float *)pred, S, ov, score, sb, work, G, s);
 }

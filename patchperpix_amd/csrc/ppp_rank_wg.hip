@@ -1,0 +1,404 @@
+// ppp_rank_wg.hip -- S2 (patch ranking) on the VOXEL-MAJOR consensus, row-stationary, one
+// WORKGROUP (four waves) per tile of centres.
+//
+// Reference: cuda/rankPatches.cu:28-147; same sums in the same order as ppp_rank_vm.hip (whose
+// header states the decomposition: walk the voxels u of the tile grown by the patch radius in
+// raster order, stage the consensus row S[u][.] in LDS, every centre of the tile whose window
+// holds u takes its step a = u - c + rad; lane = (centre, a); accumulators live in LDS between
+// the steps of a centre).  What differs from the one-wave kernel:
+//
+//   * four waves share ONE row image, ONE coefficient table and a tile of 8 x 16 x 16 (or
+//     8 x 8 x 16) centres: the one-wave kernel needs 26 KB of LDS per wave at 9^3 (6 waves per
+//     CU, 1.5 per SIMD -- an LDS read then runs at a fraction of its rate and nothing hides
+//     the dependent fma chain); here a workgroup needs 30 KB for four waves (16 waves per CU at
+//     <= 128 VGPRs).  The items of a row are dealt to the waves in chunks of 64, the wave that
+//     takes the odd chunk rotates from row to row.
+//   * a row is staged (tz + 2 rz)(ty + 2 ry)(tx + 2 rx) / (tz ty tx) = 4.5 times per centre at
+//     9^3 instead of 8 times (HBM fetches of the launch: 0.45 of the one-wave kernel's).
+//   * a term is ONE instruction: v_fma_mix_f32 takes its coefficient +-1/32 / 0 as a float16 from
+//     either half of a register (no v_perm_b32 to build a float32 coefficient).  fma(32 S, c, acc)
+//     with c = +-2^-5 has an exact product and rounds once, like the reference's acc += / -= S.
+//   * the P / N masks of a centre are stored interleaved by the pre-pass -- byte j of word k holds
+//     the P bits (low nibble) and the N bits (high nibble) of the four partners 16 k + 4 j .. + 3 --
+//     so that ONE byte indexes ONE 256-entry table of four float16 coefficients (2 KB; 8-byte
+//     reads): 0.25 table reads and 0.25 address operations per term instead of 0.25 + 0.6.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "ppp_kernels.hpp"
+
+namespace ppp {
+
+static constexpr int RW_PAD = 8;
+static constexpr int RW_WAVES = 4;
+typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp2;
+
+__device__ __forceinline__ float fma_mix_lo(float r, uint32_t c, float acc) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(r), "v"(c));
+    return acc;
+}
+__device__ __forceinline__ float fma_mix_hi(float r, uint32_t c, float acc) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(r), "v"(c));
+    return acc;
+}
+
+template <int I, int END>
+struct StaticFor {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, I>{});
+        StaticFor<I + 1, END>::run(f);
+    }
+};
+template <int END>
+struct StaticFor<END, END> {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+// 16 P bits and 16 N bits -> one word: byte j = P nibble j | N nibble j << 4
+__host__ __device__ __forceinline__ uint32_t interleave16(uint32_t p, uint32_t n) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        out |= (((p >> (4 * j)) & 0xFu) | (((n >> (4 * j)) & 0xFu) << 4)) << (8 * j);
+    return out;
+}
+
+// ---- pre-pass: interleaved masks, pair counts, border / background scores ------------------
+// thread per centre of the score box; masks word-major over the box (lanes = neighbouring
+// centres coalesce in the main kernel)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rank_masks_il_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, const ppp_box sb,
+                         uint32_t *__restrict__ M, uint32_t *__restrict__ info,
+                         float *__restrict__ score, const Geo G) {
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const long long sbV = (long long)sX * sY * sZ;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sbV) return;
+    const int cx = sb.x0 + (int)(t % sX), cy = sb.y0 + (int)((t / sX) % sY), cz = sb.z0 + (int)(t / ((long long)sX * sY));
+    const long long lc = vox(G, cz, cy, cx);
+    const T *mid = pred + (long long)G.mid * G.V;
+    uint32_t inf = 0;
+    if (!interior(G, cz, cy, cx)) {
+        score[lc] = G.norm_rank ? -1.0f : -9999999.0f;
+    } else if (!(ldf(mid, lc) > G.th_gt)) {
+        score[lc] = 0.0f;   // the reference leaves the allocation's zero
+    } else {
+        const int words16 = (G.C + 15) / 16;
+        unsigned nP = 0, nV = 0;
+        int r = 0;
+        for (int w = 0; w < words16; ++w) {
+            uint32_t p = 0, n = 0;
+            for (int b = 0; b < 16 && r < G.C; ++b, ++r) {
+                const int z = cz + r / (G.py * G.px) - G.rz, y = cy + (r / G.px) % G.py - G.ry,
+                          x = cx + r % G.px - G.rx;
+                const long long lz = vox(G, z, y, x);
+                const bool valid = ldf(mid, lz) > G.th_gt && (!G.use_overlap || ov[lz] == 0);
+                const float val = ldf(pred, (long long)r * G.V + lc);
+                if (valid) ++nV;
+                if (valid && val > G.th_gt) p |= 1u << b;
+                if (valid && val < G.bg_lt) n |= 1u << b;
+            }
+            M[(long long)w * sbV + t] = interleave16(p, n);
+            nP += __popc(p);
+        }
+        // fgCnt = |P| (|V| - 1) - |P| (|P| - 1) / 2   (rankPatches.cu:139, see ppp_rank_v2.hip)
+        const unsigned fg_cnt = nP ? nP * (nV - 1u) - nP * (nP - 1u) / 2u : 0u;
+        inf = 0x80000000u | fg_cnt;
+        if (nP == 0) score[lc] = 0.0f;   // no first pixel: acc = 0, 0 / max(1, 0)
+    }
+    info[t] = inf;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rank_valid2_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, uint8_t *__restrict__ valid,
+                       const Geo G) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    valid[v] = (ldf(pred, (long long)G.mid * G.V + v) > G.th_gt && (!G.use_overlap || ov[v] == 0)) ? 1 : 0;
+}
+
+// ---- main kernel ---------------------------------------------------------------------------
+template <int PZ, int PY, int PX, int TZ, int TY, int TX>
+__global__ void __launch_bounds__(64 * RW_WAVES, 4)
+    rank_wg_kernel(const float *__restrict__ S, const uint32_t *__restrict__ M,
+                   const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
+                   float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
+                   const int tiles_x, const int n_tiles) {
+    constexpr int C = PZ * PY * PX, W16 = (C + 15) / 16, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
+    constexpr int WZ = 2 * PZ - 1, WY = 2 * PY - 1, WX = 2 * PX - 1, W = WZ * WY * WX, LC = (W - 1) / 2;
+    constexpr int NTHR = 64 * RW_WAVES;
+    constexpr int NST = (W + NTHR - 1) / NTHR;
+    constexpr int NT = TZ * TY * TX;
+    constexpr int UB = (TZ + 2 * RZ) * (TY + 2 * RY) * (TX + 2 * RX);
+    __shared__ float rowbuf[W + 2 * RW_PAD];
+    __shared__ float accs[NT];
+    __shared__ uint32_t act_bits[(NT + 31) / 32];
+    __shared__ uint2 coefT[256];
+    __shared__ uint32_t uvalid_bits[(UB + 63) / 64 * 2];
+    __shared__ int any_act;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const long long sbV = (long long)sX * sY * sZ;
+    // XCD-aware order: consecutive blocks go to different XCDs; give each XCD a contiguous range
+    // of tiles so that x-neighbours (which share a third of their rows) meet in one L2
+    const int n_blocks = gridDim.x;
+    const int per_xcd = (n_blocks + 7) / 8;
+    const int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (bid >= n_tiles) return;
+    const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
+    const int c0z = sb.z0 + tz_i * TZ, c0y = sb.y0 + ty_i * TY, c0x = sb.x0 + tx_i * TX;
+    const int tz = min(TZ, sb.z1 - c0z), ty = min(TY, sb.y1 - c0y), tx = min(TX, sb.x1 - c0x);
+    if (tz <= 0 || ty <= 0 || tx <= 0) return;
+
+    auto sb_index = [&](int lz, int ly, int lx) -> long long {
+        return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
+    };
+    // coefficient table: entry e -> four float16 {+2^-5 (P bit), -2^-5 (N bit), 0}
+    {
+        const int e = tid;   // NTHR == 256
+        uint32_t h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = ((e >> i) & 1) ? 0x2800u : (((e >> (4 + i)) & 1) ? 0xA800u : 0u);
+        coefT[e] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    }
+    if (tid == 0) any_act = 0;
+    __syncthreads();
+    static_assert(NT % 64 == 0, "tile size must be a multiple of the wave size");
+    for (int cl = tid; cl < NT; cl += NTHR) {
+        const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
+        uint32_t v = 0;
+        if (lz < tz && ly < ty && lx < tx) v = info[sb_index(lz, ly, lx)];
+        const unsigned long long m = __ballot((v >> 31) != 0);
+        if (lane == 0) {
+            act_bits[cl >> 5] = (uint32_t)m; act_bits[(cl >> 5) + 1] = (uint32_t)(m >> 32);
+            if (m) any_act = 1;
+        }
+        accs[cl] = 0.0f;
+    }
+    __syncthreads();
+    if (!any_act) return;
+
+    const long long rsY = G.bX, rsZ = (long long)G.bX * G.bY;
+    const int uz0 = max(c0z - RZ, G.bz0), uz1 = min(c0z + tz - 1 + RZ, G.bz0 + G.bZ - 1);
+    const int uy0 = max(c0y - RY, G.by0), uy1 = min(c0y + ty - 1 + RY, G.by0 + G.bY - 1);
+    const int ux0 = max(c0x - RX, G.bx0), ux1 = min(c0x + tx - 1 + RX, G.bx0 + G.bX - 1);
+    const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
+    for (int k0 = 64 * wave; k0 < nu; k0 += NTHR) {
+        const int k = k0 + lane;
+        const bool ok = k < nu && valid[vox(G, uz0 + k / (nuy * nux), uy0 + (k / nux) % nuy, ux0 + k % nux)] != 0;
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) { uvalid_bits[k0 >> 5] = (uint32_t)m; uvalid_bits[(k0 >> 5) + 1] = (uint32_t)(m >> 32); }
+    }
+    __syncthreads();
+    auto next_valid = [&](int k) -> int {
+        while (k < nu) {
+            const uint32_t wbits = uvalid_bits[k >> 5] >> (k & 31);
+            if (wbits) return k + __builtin_ctz(wbits);
+            k = (k | 31) + 1;
+        }
+        return nu;
+    };
+    auto row_src = [&](int k) -> const float * {
+        const int uz = uz0 + k / (nuy * nux), uy = uy0 + (k / nux) % nuy, ux = ux0 + k % nux;
+        return S + (((long long)(uz - G.bz0) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
+    };
+    float st[NST];
+    int uk = __builtin_amdgcn_readfirstlane(next_valid(0));
+    if (uk < nu) {
+        const float *src = row_src(uk);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = tid + i * NTHR;
+            if (e < W) rowbuf[RW_PAD + e] = src[e] * 32.0f;
+        }
+    }
+    __syncthreads();
+    int turn = 0;   // rotates the wave that takes the first chunk of a row
+    while (uk < nu) {
+        const int uz = uz0 + uk / (nuy * nux), uy = uy0 + (uk / nux) % nuy, ux = ux0 + uk % nux;
+        const int uk_next = __builtin_amdgcn_readfirstlane(next_valid(uk + 1));
+        if (uk_next < nu) {
+            const float *src = row_src(uk_next);
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int e = tid + i * NTHR;
+                st[i] = e < W ? src[e] : 0.0f;
+            }
+        }
+        // pixels a of this voxel whose centre c = u + R - a lies in the tile
+        const int az0 = max(0, uz + RZ - (c0z + tz - 1)), az1 = min(PZ - 1, uz + RZ - c0z);
+        const int ay0 = max(0, uy + RY - (c0y + ty - 1)), ay1 = min(PY - 1, uy + RY - c0y);
+        const int ax0 = max(0, ux + RX - (c0x + tx - 1)), ax1 = min(PX - 1, ux + RX - c0x);
+        const int nz = az1 - az0 + 1, ny = ay1 - ay0 + 1, nx = ax1 - ax0 + 1;
+        const int n_box = (nz <= 0 || ny <= 0 || nx <= 0) ? 0 : nz * ny * nx;
+        const int first = (wave + RW_WAVES - turn) & (RW_WAVES - 1);
+        turn = (turn + ((n_box + 63) >> 6)) & (RW_WAVES - 1);
+        for (int i0 = 64 * first; i0 < n_box; i0 += NTHR) {
+            const int i = i0 + lane;
+            const bool in = i < n_box;
+            const int ii = in ? i : 0;
+            const int ax = ax0 + ii % nx, ay = ay0 + (ii / nx) % ny, az = az0 + ii / (nx * ny);
+            const int lz = uz + RZ - az - c0z, ly = uy + RY - ay - c0y, lx = ux + RX - ax - c0x;
+            const int cl = (lz * TY + ly) * TX + lx;
+            const int a = (az * PY + ay) * PX + ax;
+            const long long t = sb_index(lz, ly, lx);
+            bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
+            // is a in P?  P bit of partner s: bit 8 (s >> 2 & 3) + (s & 3) of word s >> 4
+            if (active) active = ((M[(long long)(a >> 4) * sbV + t] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
+            if (__ballot(active) == 0) continue;
+            uint32_t mw[W16];
+#pragma unroll
+            for (int w = 0; w < W16; ++w) mw[w] = active ? M[(long long)w * sbV + t] : 0u;
+            float acc = active ? accs[cl] : 0.0f;
+            lds_f32_cvp2 row = (lds_f32_cvp2)(rowbuf + RW_PAD + LC - ((az * WY + ay) * WX + ax));
+            const int aw = a >> 4;
+            // b in P counts only for b > a: P bits of the partners <= a go (N bits stay)
+            const uint32_t above16 = ~((2u << (a & 15)) - 1u) & 0xFFFFu;
+            const uint32_t keep_a = interleave16(above16, 0xFFFFu);
+            // (a compile-time recursion, not a loop: at 9^3 the 46 x 16 terms exceed the size up to
+            // which the compiler honours an unroll pragma, and a rolled loop computes every LDS
+            // offset at run time)
+            StaticFor<0, W16>::run([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                const uint32_t m = mw[w] & (w < aw ? 0xF0F0F0F0u : (w > aw ? 0xFFFFFFFFu : keep_a));
+                if (__ballot(m != 0u) == 0) return;
+                // table reads of the word first; then the four groups of four partners, the row
+                // values of the next group in flight while the current chain runs
+                uint2 cf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (w * 16 + j * 4 < C) cf[j] = coefT[(m >> (8 * j)) & 0xFFu];
+                float rv[2][4];
+                auto load_rows = [&](int j, float (&r)[4]) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) {
+                        const int b = w * 16 + j * 4 + i2;
+                        if (b < C) r[i2] = row[((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX];
+                    }
+                };
+                load_rows(0, rv[0]);
+                if (w * 16 + 4 < C) load_rows(1, rv[1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (w * 16 + j * 4 < C) {
+                        float r0[4];
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) r0[i2] = rv[j & 1][i2];
+                        if (j + 2 < 4 && w * 16 + (j + 2) * 4 < C) load_rows(j + 2, rv[j & 1]);
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2) {
+                            const int b = w * 16 + j * 4 + i2;
+                            if (b < C) {
+                                const uint32_t c2 = i2 < 2 ? cf[j].x : cf[j].y;
+                                acc = (i2 & 1) ? fma_mix_hi(r0[i2], c2, acc) : fma_mix_lo(r0[i2], c2, acc);
+                            }
+                        }
+                    }
+                }
+            });
+            if (active) accs[cl] = acc;
+        }
+        // ---- publish the next row
+        __syncthreads();
+        if (uk_next < nu) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int e = tid + i * NTHR;
+                if (e < W) rowbuf[RW_PAD + e] = st[i] * 32.0f;
+            }
+        }
+        __syncthreads();
+        uk = uk_next;
+    }
+    // ---- scores of the tile
+    for (int cl = tid; cl < NT; cl += NTHR) {
+        const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
+        if (lz < tz && ly < ty && lx < tx && ((act_bits[cl >> 5] >> (cl & 31)) & 1u)) {
+            const unsigned fg_cnt = info[sb_index(lz, ly, lx)] & 0x7FFFFFFFu;
+            const float acc = accs[cl];
+            score[vox(G, c0z + lz, c0y + ly, c0x + lx)] = G.norm_rank ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
+        }
+    }
+}
+
+static size_t up256w(size_t v) { return (v + 255) / 256 * 256; }
+
+bool rank_wg_supported(const Geo &G) {
+    if (const char *e = getenv("PPP_RANK_WG"))
+        if (e[0] == '0') return false;
+    return G.pz == G.py && G.py == G.px && (G.px == 5 || G.px == 7 || G.px == 9) && !G.count_pos_neg &&
+           G.layout == PPP_CONS_VOXEL_MAJOR;
+}
+
+size_t rank_wg_workspace_bytes(const ppp_box &sb, const Geo &G) {
+    const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
+    const size_t words16 = (size_t)(G.C + 15) / 16;
+    return up256w(words16 * sbV * 4) + up256w(sbV * 4) + up256w((size_t)G.V);
+}
+
+template <typename T>
+static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, float *score,
+                             const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const size_t sbV = (size_t)sX * sY * sZ;
+    const size_t words16 = (size_t)(G.C + 15) / 16;
+    char *p = (char *)work;
+    uint32_t *M = (uint32_t *)p;    p += up256w(words16 * sbV * 4);
+    uint32_t *info = (uint32_t *)p; p += up256w(sbV * 4);
+    uint8_t *valid = (uint8_t *)p;
+    if (G.bz0 > (sb.z0 - G.rz > 0 ? sb.z0 - G.rz : 0) || G.by0 > (sb.y0 - G.ry > 0 ? sb.y0 - G.ry : 0) ||
+        G.bx0 > (sb.x0 - G.rx > 0 ? sb.x0 - G.rx : 0) ||
+        G.bz0 + G.bZ < (sb.z1 + G.rz < G.Z ? sb.z1 + G.rz : G.Z) ||
+        G.by0 + G.bY < (sb.y1 + G.ry < G.Y ? sb.y1 + G.ry : G.Y) ||
+        G.bx0 + G.bX < (sb.x1 + G.rx < G.X ? sb.x1 + G.rx : G.X))
+        return hipErrorInvalidValue;
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
+    PPP_GRID_CHECK((sbV + 255) / 256, 256);
+    rank_valid2_kernel<T><<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(pred, ov, valid, G);
+    rank_masks_il_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, M, info, score, G);
+    // Tile of centres per workgroup: 8 x 16 x 16 when that still gives every CU four workgroups
+    // (a row is then staged 4.5 times per centre at 9^3), else 8 x 8 x 16 (6 times).
+    // PPP_RANK_WG_TILE=8x8x16 | 8x16x16 overrides.
+    const long long big_tiles = (long long)((sZ + 7) / 8) * ((sY + 15) / 16) * ((sX + 15) / 16);
+    bool big = big_tiles >= 4 * 256;
+    if (const char *e = getenv("PPP_RANK_WG_TILE")) big = strcmp(e, "8x16x16") == 0 ? true : (strcmp(e, "8x8x16") == 0 ? false : big);
+    const int TZ = 8, TY = big ? 16 : 8, TX = 16;
+    const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
+    const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
+    const long long n_blocks = (n_tiles + 7) / 8 * 8;
+    PPP_GRID_CHECK(n_blocks, 64 * RW_WAVES);
+#define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
+    rank_wg_kernel<A_, A_, A_, D_, E_, F_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>(         \
+        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles)
+#define PPP_RW_CASE(P)                                                                                      \
+    case P:                                                                                                 \
+        if (big) PPP_RW_LAUNCH(P, 8, 16, 16);                                                               \
+        else PPP_RW_LAUNCH(P, 8, 8, 16);                                                                    \
+        break;
+    switch (G.px) {
+        PPP_RW_CASE(5)
+        PPP_RW_CASE(7)
+        PPP_RW_CASE(9)
+    default:
+        return hipErrorNotSupported;
+    }
+#undef PPP_RW_LAUNCH
+#undef PPP_RW_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_wg(const void *pred, int dtype, const float *S, const uint8_t *ov, float *score,
+                          const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
+    if (!rank_wg_supported(G)) return hipErrorNotSupported;
+    return dtype == PPP_F16 ? launch_rwg<__half>((const __half *)pred, S, ov, score, sb, work, G, s)
+                            : launch_rwg<float>((const float *)pred, S, ov, score, sb, work, G, s);
+}
+
+}  // namespace ppp

@@ -248,22 +248,20 @@ class DeviceOps:
         return backend.CoverShard(mask_local, lin_local, rank_id, bits, P_local, global_z)
 
     def rank_order(self, score_dev, foreground, ps):
-        """(lin int64, scores float32) of the ranked list, device tensors."""
+        """(lin int64, scores float32) of the ranked list, device tensors.  foreground: uint8
+        0 / 1 device tensor (Z, Y, X)."""
         return backend.rank_order_device(score_dev, foreground, ps, to_host=False)
 
     def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw):
-        """Greedy cover of the global mask (replicated: every rank runs the same rounds on
-        its own device).  Returns a bool tensor over the ranked list."""
+        """Greedy cover of the global mask (uint8 0 / 1 device tensor, not modified; replicated:
+        every rank runs the same rounds on its own device).  Returns a bool tensor over the
+        ranked list."""
         from .vote_instances import foreground_cover as fc
-        mask = self.torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
-                                     .astype(np.uint8)).to(self.device)
-        sel, _ = fc.greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P)
+        sel, _ = fc.greedy_cover_device(mask_to_cover.clone(), bits, lin, never, pix_ths, radslice, P)
         return sel
 
     def thin_cover(self, mask_to_cover, bits, lin, P):
-        mask = self.torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover) != 0)
-                                     .astype(np.uint8)).to(self.device)
-        return backend.thin_cover_device(mask, bits, lin, P)
+        return backend.thin_cover_device(mask_to_cover, bits, lin, P)
 
     def mws_labels(self, rows, aff, nodes, P):
         return backend.mws_labels_device(rows, aff, nodes, P)
@@ -306,8 +304,7 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
     cz = torch.div(lin_t, plane, rounding_mode="floor")
     own_idx = torch.nonzero((cz >= z0) & (cz < z1)).reshape(-1)          # ascending = rank order
     del cz
-    mask_loc = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_to_cover[a:b]) != 0)
-                                .astype(np.uint8)).to(dev)
+    mask_loc = mask_to_cover[a:b].clone()        # uint8 0 / 1 device tensor; cleared by the rounds
     shard = ops.cover_shard(mask_loc, (lin_t[own_idx] - a * plane).contiguous(),
                             own_idx.to(torch.int32), own_bits(own_idx), make_local_params(a, b), Z)
     # zones around the internal slab boundaries (global slices), and which of them touch me
@@ -360,7 +357,7 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
             else:
                 shard.zone(True, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
 
-    remaining = int(np.count_nonzero(np.asarray(mask_to_cover)[tuple(radslice)]))
+    remaining = int(torch.count_nonzero(mask_to_cover[tuple(radslice)]).item())
     selected = torch.zeros(n, dtype=torch.bool, device=dev)
     total_rounds = 0
     for pix_th in pix_ths:
@@ -410,6 +407,22 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
 # ------------------------------------------------------------------------------------------
 # the slab pipeline
 # ------------------------------------------------------------------------------------------
+def _plain(a):
+    """bool arrays as uint8 (torch.from_numpy has no bool view of NumPy's bool on every version)"""
+    a = np.asarray(a)
+    return a.view(np.uint8) if a.dtype == np.bool_ and a.flags.c_contiguous else \
+        (a.astype(np.uint8) if a.dtype == np.bool_ else a)
+
+
+def _field_u8(a, dev, torch):
+    """A (Z, Y, X) field (NumPy array or tensor, any integer / bool type) as a uint8 0 / 1
+    tensor on `dev`."""
+    t = a.to(dev) if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(_plain(a))).to(dev)
+    if t.dtype == torch.uint8 and not torch.is_tensor(a) and np.asarray(a).dtype == np.bool_:
+        return t.contiguous()
+    return (t != 0).to(torch.uint8).contiguous()
+
+
 def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchshape, my_slabs,
              comm=None, ops=None, **kw):
     """vote_instances on a z-slab decomposition.
@@ -446,22 +459,37 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     Zl = int(pred_local.shape[1])
     hi = lo + Zl
     radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
-    # (a boolean, not the reference's `1 * (numinst > 1)`: the int64 copy is 8 bytes per voxel of
-    # host memory allocated, first-touched and freed every call -- at 140^3 a 22 MB temporary whose
-    # page faults showed up as sporadic +25 ms calls)
-    overlap_mask = np.asarray(numinst) > 1
-    mask_to_cover[overlap_mask] = 0
+    # The per-voxel fields go to the device once (or already are device tensors) and stay there:
+    # every later use -- early-outs, overlap mask of the kernels, ranking, cover, thinning -- is
+    # a device operation.  (Host NumPy passes over a 512^3 volume cost 0.1-0.3 s each, and the
+    # reference's `1 * (numinst > 1)` is an int64 temporary of 8 bytes per voxel.)
+    fg_d = _field_u8(foreground, dev, torch)
+    ni_d = numinst.to(dev) if torch.is_tensor(numinst) else \
+        torch.from_numpy(np.ascontiguousarray(_plain(numinst))).to(dev)
+    ov_d = (ni_d > 1).to(torch.uint8)
+    del ni_d
+    any_overlap = bool(ov_d.any().item())
+    mask_d = _field_u8(mask_to_cover, dev, torch)
+    if any_overlap:
+        mask_d &= 1 - ov_d
+        if not torch.is_tensor(mask_to_cover):
+            # vote_instances.py:226 clears the caller's array as well
+            mask_to_cover[ov_d.cpu().numpy().astype(bool)] = 0
     want_inter = kw.get("return_intermediates", False)
+
+    def fg_out():
+        return fg_d.cpu().numpy() if torch.is_tensor(foreground) else \
+            np.asarray(foreground).astype(np.uint8)
 
     id_dtype = np.dtype(kw.get("_instances_dtype") or np.uint16)
     if id_dtype not in (np.dtype(np.uint16), np.dtype(np.uint32)):
         raise ValueError("_instances_dtype must be uint16 or uint32")
 
     def early():
-        return (None, None) if want_inter else (np.zeros(shape, dtype=id_dtype), foreground.astype(np.uint8))
+        return (None, None) if want_inter else (np.zeros(shape, dtype=id_dtype), fg_out())
 
-    if np.count_nonzero(mask_to_cover[radslice]) == 0 or \
-            np.count_nonzero(foreground[radslice]) == 0:
+    if int(torch.count_nonzero(mask_d[radslice]).item()) == 0 or \
+            int(torch.count_nonzero(fg_d[radslice]).item()) == 0:
         return early()
 
     flags = {k: v for k, v in kw.items()
@@ -488,8 +516,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         rr = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
         if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
             rank_ranges = rr
-    ov_local = torch.from_numpy(
-        np.ascontiguousarray(overlap_mask[lo:hi].astype(np.uint8))).to(dev)
+    ov_local = ov_d[lo:hi].contiguous()
     keep_cons = len(my_tiles) == 1 and kw.get("_keep_cons", True)
     kept = {}
     dims = (Z, Y, X)
@@ -585,7 +612,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         import zlib
         backend.note("crc_scores", zlib.crc32(score_dev.cpu().numpy().tobytes()))
     with backend.host_timer("sort"):
-        lin_t, rscores_t = ops.rank_order(score_dev, foreground, ps)
+        lin_t, rscores_t = ops.rank_order(score_dev, fg_d, ps)
     if debug_crc:
         backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
     del score_dev
@@ -610,10 +637,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             # patches the loop never looks at (foreground_cover.py:136-141): centre on an
             # overlap voxel; everything from the first score below score_threshold on
             never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
-            if overlap_mask.any():
-                ov_g = torch.from_numpy(np.ascontiguousarray(overlap_mask.reshape(-1))).to(dev)
-                never |= ov_g[lin_t]
-                del ov_g
+            if any_overlap:
+                never |= ov_d.reshape(-1)[lin_t] != 0
             thr = kw.get("score_threshold", False)
             if isinstance(thr, float):
                 below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
@@ -629,11 +654,11 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                     return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
 
                 selected = sharded_cover(ops, comm, shape, ps, ranges[comm.rank], ranges,
-                                         mask_to_cover, lin_t, never, fc._pix_thresholds(ps, kw),
+                                         mask_d, lin_t, never, fc._pix_thresholds(ps, kw),
                                          radslice, own_bits, local_params)
             else:
                 bits = gathered_bits(coords_t, kw["fc_threshold"])
-                selected = ops.greedy_cover(mask_to_cover, bits, lin_t, rscores_t, never,
+                selected = ops.greedy_cover(mask_d, bits, lin_t, rscores_t, never,
                                             fc._pix_thresholds(ps, kw), radslice, Pg, kw)
                 del bits
             del never
@@ -652,10 +677,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             if hasattr(ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
                     and ps[2] <= 32:
                 # replicated: every rank thins the same global list on its own device
-                keep = ops.thin_cover(mask_to_cover, bits, torch.from_numpy(sel_lin).to(dev), Pg)
+                keep = ops.thin_cover(mask_d, bits, torch.from_numpy(sel_lin).to(dev), Pg)
                 keep = keep.cpu().numpy()
             else:
-                keep = backend.host_thin_cover(np.ascontiguousarray(mask_to_cover).astype(np.uint8),
+                keep = backend.host_thin_cover(np.ascontiguousarray(mask_d.cpu().numpy()),
                                                ps, np.ascontiguousarray(sel_lin),
                                                bits.cpu().numpy().view(np.uint32))
             sel_coords = sel_coords[keep]
@@ -853,7 +878,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 comm.all_reduce_sum(inst32)
                 inst16 = inst32.to(torch.int16)
             instances = inst16.cpu().numpy().view(np.uint16)
-    return instances, foreground.astype(np.uint8)
+    return instances, fg_out()
 
 
 def slabs_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):

@@ -103,6 +103,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     pred_affs     (C,Z,Y,X) float32/float16 ndarray, or an already-resident device tensor
     foreground    (Z,Y,X) bool       mask_to_cover (Z,Y,X) bool, modified in place (:226)
     numinst       (Z,Y,X) integer    patchshape    int[3]
+    (the three fields may also be device tensors, resident like the prediction)
     Returns (instances uint16 (Z,Y,X), foreground uint8) -- or (pairs uint32 [N,6],
     aff float32 [N]) with ``return_intermediates`` -- with the reference's early-outs.
     """
@@ -169,6 +170,13 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
             kw["_yx_tiles"] = tuple(int(v) for v in yx_tiles)
         return tiling.assemble(pred_affs, 0, shape, foreground, mask_to_cover, numinst,
                                patchshape, tiling.plan_slabs(shape[0], n_slabs), **kw)
+    # the stage-by-stage path below keeps the reference's host arrays
+    if torch.is_tensor(foreground):
+        foreground = foreground.cpu().numpy().astype(bool)
+    if torch.is_tensor(mask_to_cover):
+        mask_to_cover = mask_to_cover.cpu().numpy().astype(bool)
+    if torch.is_tensor(numinst):
+        numinst = numinst.cpu().numpy()
     radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
     overlap_mask = 1 * (numinst > 1)
 

@@ -132,7 +132,8 @@ class OracleOps:
 
     def rank_order(self, score_dev, foreground, ps):
         score_host = score_dev.numpy()
-        lin = backend.host_rank_order(score_host, foreground, ps)
+        fg = foreground.numpy() if torch.is_tensor(foreground) else foreground
+        lin = backend.host_rank_order(score_host, fg, ps)
         return torch.from_numpy(lin), torch.from_numpy(np.ascontiguousarray(score_host.reshape(-1)[lin]))
 
     def label_components(self, rows, aff, nodes, P):
@@ -163,6 +164,8 @@ class OracleOps:
         """The sequential loop (native host code of the library, pinned to the reference's
         goldens by tests/test_abi_and_host.py)."""
         lin, scores, never = lin.numpy(), scores.numpy(), never.numpy()
+        if torch.is_tensor(mask_to_cover):
+            mask_to_cover = mask_to_cover.numpy()
         running, _owner = backend.padded_mask(mask_to_cover)
         selected = np.zeros(len(lin), dtype=np.uint8)
         b = bits.numpy().view(np.uint32)
