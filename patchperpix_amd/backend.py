@@ -768,28 +768,40 @@ def cons_to_voxel_major(cons_compact, P):
     return vm, Pv
 
 
-def patch_bits(pred, centres, thresh, P):
+def patch_bits(pred, centres, thresh, P, scratch=None):
     """Bit r of row k = (pred[r][centre k] > float32(thresh)).  centres int32 [n, 3] on the
-    device; returns int32 [n, ceil(C/32)] on the device."""
+    device; returns int32 [n, ceil(C/32)] on the device.  scratch: a flat int32 device buffer the
+    dense path may carve its per-voxel table and the result from (the caller's idle consensus
+    pool: the two are 23 GB at 512^3 / 9^3)."""
     torch = _torch()
     n = int(centres.shape[0])
     words = (P.pz * P.py * P.px + 31) // 32
     V = int(P.Z) * int(P.Y) * int(P.X)
     dense = n * 16 >= V and os.environ.get("PPP_PATCH_BITS", "auto") != "sparse"
+    vol = None
     if dense:
         # many centres (the cover candidates): one coalesced pass over the prediction for all
         # voxels, then a row gather -- instead of one cache line per (centre, channel)
-        try:
-            vol = torch.empty((V, words), dtype=torch.int32, device=pred.device)
-        except RuntimeError:          # no room for the per-voxel table: per-centre gathers
-            dense = False
+        if scratch is not None and scratch.numel() >= V * words:
+            vol = scratch[:V * words].view(V, words)
+            scratch = scratch[V * words:]
+        else:
+            scratch = None
+            try:
+                vol = torch.empty((V, words), dtype=torch.int32, device=pred.device)
+            except RuntimeError:          # no room for the per-voxel table: per-centre gathers
+                dense = False
     if dense:
         with _timed("patch_bits"):
             check(lib().ppp_patch_bits_volume(_dev_ptr(pred), pred_dtype_code(pred), float(thresh),
                                               _dev_ptr(vol), ctypes.byref(P), _stream()))
             c = centres.to(torch.int64)
             lin = (c[:, 0] * int(P.Y) + c[:, 1]) * int(P.X) + c[:, 2]
-            bits = vol[lin]
+            del c
+            if scratch is not None and scratch.numel() >= n * words:
+                bits = torch.index_select(vol, 0, lin, out=scratch[:n * words].view(n, words))
+            else:
+                bits = vol[lin]
         del vol
         return bits
     bits = torch.empty((n, words), dtype=torch.int32, device=pred.device)

@@ -94,6 +94,23 @@ class LocalComm:
         return vol
 
 
+def gather_lists(comm, t):
+    """[t of rank 0, t of rank 1, ...] for 1-d (or [n, k]) tensors whose length differs between
+    the ranks: lengths first, then one all-gather of the tensors padded to the longest."""
+    import torch
+    if comm.world == 1:
+        return [t]
+    n = torch.tensor([int(t.shape[0])], dtype=torch.int64, device=t.device)
+    lens = [int(v) for v in comm.all_gather(n).reshape(-1).cpu()]
+    m = max(lens)
+    if m == 0:
+        return [t[:0] for _ in lens]
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    allp = comm.all_gather(pad)
+    return [allp[r, :lens[r]] for r in range(comm.world)]
+
+
 class TorchDistComm:
     """torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU)."""
 
@@ -201,9 +218,9 @@ class DeviceOps:
     def consensus(self, pred, ov, P):
         return backend.consensus(pred, ov if P.use_overlap else None, P)
 
-    def rank_patches(self, pred, cons, ov, P, score_box):
+    def rank_patches(self, pred, cons, ov, P, score_box, out=None):
         return backend.rank_patches(pred, cons, ov if P.use_overlap else None, P,
-                                    score_box=score_box)
+                                    score_box=score_box, out=out)
 
     def rank_on_voxel_major(self, P):
         return backend.rank_vm_available(P)
@@ -222,8 +239,8 @@ class DeviceOps:
         W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
         return backend._big_empty((int(n_voxels) * W,), self.device)
 
-    def patch_bits(self, pred, centres, thresh, P):
-        return backend.patch_bits(pred, centres, thresh, P)
+    def patch_bits(self, pred, centres, thresh, P, scratch=None):
+        return backend.patch_bits(pred, centres, thresh, P, scratch=scratch)
 
     def patch_pairs(self, sorted_zyx, P, max_ps_dist, include_single):
         return backend.device_patch_pairs(sorted_zyx, P, max_ps_dist=max_ps_dist,
@@ -282,31 +299,59 @@ INT32_MAX = 0x7FFFFFFF
 
 def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, never, pix_ths,
                   radslice, own_bits, make_local_params):
-    """The priority-parallel greedy cover (csrc/ppp_cover.hip) with the volume split by z: every
-    rank runs the rounds on its own slices + a halo of pz-1 slices and decides its OWN patches;
-    twice per round the 2(pz-1) slices around every slab boundary are made consistent by a MIN
-    all-reduce of a small buffer (rank volume after the count step; mask and dirty marks after
-    the select step).  Same result as the replicated / sequential cover: identical on every rank.
-
-    my_range (z0, z1), ranges: every rank's (z0, z1) in rank order (contiguous, ascending);
-    lin_t int64 [n] / never bool [n]: the global ranked list (replicated, on ops.device);
-    own_bits(idx) -> the patch bits of the listed ranked patches (all of them own);
-    make_local_params(a, b) -> ppp_params for the local buffer of global slices [a, b).
-    Returns selected bool [n] (device tensor)."""
+    """The sharded cover on a REPLICATED ranked list (lin_t int64 [n] / never bool [n]: the global
+    ranked list on every rank; mask_to_cover: uint8 0 / 1 device tensor of the whole volume):
+    every rank decides the patches centred in its own z-range (sharded_cover_own) and the
+    decisions are gathered.  own_bits(idx) -> patch bits of the listed ranked patches (all own).
+    Returns selected bool [n] (device tensor), identical on every rank."""
     import torch
     dev = ops.device
     Z, Y, X = [int(v) for v in shape]
     h = int(ps[0]) - 1
     z0, z1 = my_range
     a, b = max(0, z0 - h), min(Z, z1 + h)
-    plane = Y * X
     n = int(lin_t.numel())
-    cz = torch.div(lin_t, plane, rounding_mode="floor")
+    cz = torch.div(lin_t, Y * X, rounding_mode="floor")
     own_idx = torch.nonzero((cz >= z0) & (cz < z1)).reshape(-1)          # ascending = rank order
     del cz
-    mask_loc = mask_to_cover[a:b].clone()        # uint8 0 / 1 device tensor; cleared by the rounds
-    shard = ops.cover_shard(mask_loc, (lin_t[own_idx] - a * plane).contiguous(),
-                            own_idx.to(torch.int32), own_bits(own_idx), make_local_params(a, b), Z)
+    remaining = int(torch.count_nonzero(mask_to_cover[tuple(radslice)]).item())
+    sel_own = sharded_cover_own(ops, comm, shape, ps, my_range, ranges, mask_to_cover[a:b].clone(), a,
+                                remaining, lin_t[own_idx], own_idx.to(torch.int32), never[own_idx],
+                                own_bits(own_idx), pix_ths, make_local_params)
+    selected = torch.zeros(n, dtype=torch.bool, device=dev)
+    for part in gather_lists(comm, own_idx[sel_own]):
+        selected[part] = True
+    return selected
+
+
+def sharded_cover_own(ops, comm, shape, ps, my_range, ranges, mask_ab, a, remaining, lin_own,
+                      rank_id, never_own, bits_own, pix_ths, make_local_params):
+    """The priority-parallel greedy cover (csrc/ppp_cover.hip) with the volume split by z: every
+    rank runs the rounds on its own slices + a halo of pz-1 slices and decides its OWN patches;
+    twice per round the 2(pz-1) slices around every slab boundary are made consistent (rank
+    volume after the count step; mask and dirty marks after the select step) -- point to point
+    between the two neighbours, or by a MIN all-reduce when slabs are thinner than the zones.
+    Same result as the sequential cover.
+
+    my_range (z0, z1), ranges: every rank's (z0, z1) in rank order (contiguous, ascending);
+    mask_ab   uint8 0 / 1 device tensor, the mask on the global slices [a, b) = own +- (pz - 1)
+              (clipped; cleared in place by the rounds);  remaining: interior mask voxels of the
+              WHOLE volume (the loop's stop rule);
+    lin_own   int64 [m] GLOBAL linear indices of the own ranked patches in rank order,
+    rank_id   int32 [m] their positions in the global ranked list, never_own bool [m],
+    bits_own  int32 [m, words] their patch bits;
+    make_local_params(a, b) -> ppp_params for the local buffer of global slices [a, b).
+    Returns selected bool [m] (device tensor)."""
+    import torch
+    dev = ops.device
+    Z, Y, X = [int(v) for v in shape]
+    h = int(ps[0]) - 1
+    z0, z1 = my_range
+    b = a + int(mask_ab.shape[0])
+    plane = Y * X
+    m_own = int(lin_own.numel())
+    shard = ops.cover_shard(mask_ab, (lin_own - a * plane).contiguous(), rank_id.contiguous(), bits_own,
+                            make_local_params(a, b), Z)
     # zones around the internal slab boundaries (global slices), and which of them touch me
     bounds = [int(r[1]) for r in ranges[:-1]]
     zones = [(max(0, zb - h), min(Z, zb + h)) for zb in bounds]
@@ -321,51 +366,36 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
     pairwise = hasattr(comm, "neighbour_min") and os.environ.get("PPP_COVER_P2P", "1") != "0" and \
         all(r[1] - r[0] >= 2 * h for r in ranges)
 
+    def zone_io(imp, i, with_rank):
+        lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
+        if with_rank:
+            shard.zone(imp, lo_z, hi_z, own_loc, rank=rank_buf[i])
+        else:
+            shard.zone(imp, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+
     def exchange(with_rank):
         if not zones:
             return
         buf = rank_buf if with_rank else mask_buf
         if pairwise:
-            items = []
             for i in mine:
-                lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
-                if with_rank:
-                    shard.zone(False, lo_z, hi_z, own_loc, rank=rank_buf[i])
-                else:
-                    shard.zone(False, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
-                items.append((comm.rank + 1 if bounds[i] == z1 else comm.rank - 1, buf[i]))
-            comm.neighbour_min(items)
+                zone_io(False, i, with_rank)
+            comm.neighbour_min([(comm.rank + 1 if bounds[i] == z1 else comm.rank - 1, buf[i]) for i in mine])
+        else:
+            buf.fill_(INT32_MAX if with_rank else 1)
             for i in mine:
-                lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
-                if with_rank:
-                    shard.zone(True, lo_z, hi_z, own_loc, rank=rank_buf[i])
-                else:
-                    shard.zone(True, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
-            return
-        buf.fill_(INT32_MAX if with_rank else 1)
+                zone_io(False, i, with_rank)
+            comm.all_reduce_min(buf)
         for i in mine:
-            lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
-            if with_rank:
-                shard.zone(False, lo_z, hi_z, own_loc, rank=rank_buf[i])
-            else:
-                shard.zone(False, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
-        comm.all_reduce_min(buf)
-        for i in mine:
-            lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
-            if with_rank:
-                shard.zone(True, lo_z, hi_z, own_loc, rank=rank_buf[i])
-            else:
-                shard.zone(True, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+            zone_io(True, i, with_rank)
 
-    remaining = int(torch.count_nonzero(mask_to_cover[tuple(radslice)]).item())
-    selected = torch.zeros(n, dtype=torch.bool, device=dev)
+    selected = torch.zeros(m_own, dtype=torch.bool, device=dev)
     total_rounds = 0
     for pix_th in pix_ths:
         if remaining <= 0:
             break
         # every pass restarts at rank 0 (the reference passes rpidx by value)
-        state_g = torch.where(selected, 1, torch.where(never, 2, 0)).to(torch.int32)
-        shard.open(state_g[own_idx])
+        shard.open(torch.where(selected, 1, torch.where(never_own, 2, 0)).to(torch.int32))
         alive = True
         while alive:
             for _ in range(COVER_BATCH):
@@ -378,24 +408,28 @@ def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, 
             flag = torch.tensor([1 if shard.alive() else 0], dtype=torch.int32, device=dev)
             alive = int(comm.all_reduce_max(flag).item()) > 0
         shard.close()
-        # decisions and cleared-interior counts of all ranks (every entry has one owner)
-        st = torch.zeros(n, dtype=torch.int32, device=dev)
-        cl = torch.zeros(n, dtype=torch.int32, device=dev)
-        if own_idx.numel():
-            st[own_idx] = shard.state[:own_idx.numel()]
-            cl[own_idx] = shard.cleared[:own_idx.numel()]
-        comm.all_reduce_sum(st)
-        comm.all_reduce_sum(cl)
-        idx = torch.nonzero((st == 1) & ~selected).flatten()              # rank order
-        left = remaining - torch.cumsum(cl[idx].long(), 0)
-        done = torch.nonzero(left <= 0).flatten()
-        if done.numel():
-            # the sequential loop ends right after the patch that empties the interior
-            idx = idx[:int(done[0].item()) + 1]
-            remaining = 0
-        elif idx.numel():
-            remaining = int(left[-1].item())
-        selected[idx] = True
+        # The loop's stop rule: it ends right after the patch that empties the interior.  The
+        # patches selected in this pass, in rank order over ALL ranks, with the interior voxels
+        # each cleared: (rank id, cleared) of the own ones are gathered -- a list as long as the
+        # selection, not as the ranked list.
+        new_own = torch.nonzero((shard.state[:m_own] == 1) & ~selected).reshape(-1) if m_own else \
+            torch.zeros((0,), dtype=torch.int64, device=dev)
+        mine_rc = torch.stack([rank_id[new_own].to(torch.int64), shard.cleared[:m_own][new_own].to(torch.int64)], 1) \
+            if m_own else torch.zeros((0, 2), dtype=torch.int64, device=dev)
+        allrc = torch.cat(gather_lists(comm, mine_rc), 0)
+        cut = None
+        if allrc.shape[0]:
+            order = torch.argsort(allrc[:, 0])
+            left = remaining - torch.cumsum(allrc[order, 1], 0)
+            done = torch.nonzero(left <= 0).reshape(-1)
+            if done.numel():
+                cut = int(allrc[order[int(done[0].item())], 0].item())     # last rank id the loop reaches
+                remaining = 0
+            else:
+                remaining = int(left[-1].item())
+        if m_own:
+            keep = new_own if cut is None else new_own[rank_id[new_own].to(torch.int64) <= cut]
+            selected[keep] = True
         if remaining < 1:
             break
     backend.note("cover_rounds", total_rounds)
@@ -423,15 +457,34 @@ def _field_u8(a, dev, torch):
     return (t != 0).to(torch.uint8).contiguous()
 
 
+class _Frame:
+    """A box of the volume with the prediction (and the overlap mask) of exactly that box on the
+    device: what one kernel launch sees.  origin = global coordinate of local voxel (0, 0, 0)."""
+    __slots__ = ("pred", "ov", "origin", "shape")
+
+    def __init__(self, pred, ov, origin, shape):
+        self.pred, self.ov, self.origin, self.shape = pred, ov, tuple(origin), tuple(shape)
+
+
 def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchshape, my_slabs,
              comm=None, ops=None, **kw):
     """vote_instances on a z-slab decomposition.
 
-    pred_local  (C, hi-lo, Y, X) tensor on ops.device: the prediction for global z in [lo, hi)
-    shape       global (Z, Y, X);  foreground / mask_to_cover / numinst: GLOBAL host arrays
-    my_slabs    [(z0, z1), ...] owned by this rank (contiguous, inside [lo, hi) minus halo)
-    Returns (instances uint16 (Z,Y,X) -- complete on every rank --, foreground uint8), or
-    (pairs, aff) with return_intermediates, with the reference's early-outs.
+    pred_local  the prediction this rank can see: a (C, hi-lo, Y, X) tensor on ops.device holding
+                global z in [lo, hi) -- or a PROVIDER, an object with ``pred_box((z0, z1, y0, y1,
+                x0, x1)) -> (C, bz, by, bx) tensor`` that produces (reads, generates) the
+                prediction of a box on demand, so that a rank holds one tile + halo at a time
+                (BASELINE config [3]: a rank's slab + halo of the 1024^3 / 9^3 volume is 263 GB);
+    shape       global (Z, Y, X);
+    foreground / mask_to_cover / numinst: the per-voxel fields, NumPy arrays or tensors, either
+                GLOBAL (Z, Y, X) or LOCAL: the slices [lo, hi) only (hi = lo + their length; a
+                rank needs its own slabs +- halo(patchshape), clipped).  With local fields -- or
+                ``_sharded_global=True`` -- nothing a rank holds or computes is as large as the
+                whole volume: the ranked list, the cover and the sort are sharded by z (stage B2);
+    my_slabs    [(z0, z1), ...] owned by this rank (contiguous, inside [lo, hi) minus halo).
+    Returns (instances (Z,Y,X) -- complete on every rank; uint16, or uint32 with
+    ``_instances_dtype`` --, foreground uint8); with ``_gather_result=False`` the own z-range of
+    both only; or (pairs, aff) with return_intermediates, with the reference's early-outs.
     """
     import torch
     # flags the slab pipeline does not implement are refused, never ignored (the caller --
@@ -453,78 +506,165 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     ops = ops or DeviceOps()
     dev = ops.device
     Z, Y, X = [int(s) for s in shape]
+    dims = (Z, Y, X)
+    plane = Y * X
     ps = [int(p) for p in patchshape]
     rz = ps[0] // 2
     rad = np.array([p // 2 for p in ps])
-    Zl = int(pred_local.shape[1])
-    hi = lo + Zl
-    radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
-    # The per-voxel fields go to the device once (or already are device tensors) and stay there:
-    # every later use -- early-outs, overlap mask of the kernels, ranking, cover, thinning -- is
-    # a device operation.  (Host NumPy passes over a 512^3 volume cost 0.1-0.3 s each, and the
-    # reference's `1 * (numinst > 1)` is an int64 temporary of 8 bytes per voxel.)
+    H = halo(ps)
+    provider = not torch.is_tensor(pred_local)
+    # ---- the per-voxel fields: on the device once (or already device tensors), in the "field
+    # frame" [flo, fhi) -- the whole volume, or the slices this rank was given.  Every later use
+    # (early-outs, overlap mask of the kernels, ranking, cover, thinning) is a device operation:
+    # host NumPy passes over a 512^3 volume cost 0.1-0.3 s each, and the reference's
+    # `1 * (numinst > 1)` is an int64 temporary of 8 bytes per voxel.
+    Zf = int(foreground.shape[0])
+    local_fields = Zf != Z
+    flo = lo if local_fields else 0
+    fhi = flo + Zf
+    if provider:
+        hi = fhi if local_fields else Z
+        lo_p = lo if local_fields else 0
+    else:
+        hi = lo + int(pred_local.shape[1])
+        lo_p = lo
+        if local_fields and Zf != hi - lo:
+            raise ValueError("local fields must cover the slices of pred_local")
+    for f in (mask_to_cover, numinst):
+        if tuple(int(v) for v in f.shape) != (Zf, Y, X):
+            raise ValueError("foreground / mask_to_cover / numinst differ in shape")
+    oz0, oz1 = int(my_slabs[0][0]), int(my_slabs[-1][1])       # hull of the own slabs
+    contiguous = all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
+    need_lo, need_hi = max(0, oz0 - H), min(Z, oz1 + H)
+    if flo > need_lo or fhi < need_hi or lo_p > need_lo or hi < need_hi:
+        raise ValueError("this rank's slabs [%d, %d) need the slices [%d, %d)" % (oz0, oz1, need_lo, need_hi))
     fg_d = _field_u8(foreground, dev, torch)
     ni_d = numinst.to(dev) if torch.is_tensor(numinst) else \
         torch.from_numpy(np.ascontiguousarray(_plain(numinst))).to(dev)
     ov_d = (ni_d > 1).to(torch.uint8)
     del ni_d
-    any_overlap = bool(ov_d.any().item())
     mask_d = _field_u8(mask_to_cover, dev, torch)
+    want_inter = kw.get("return_intermediates", False)
+    gather_result = kw.get("_gather_result", True)
+    id_dtype = np.dtype(kw.get("_instances_dtype") or np.uint16)
+    if id_dtype not in (np.dtype(np.uint16), np.dtype(np.uint32)):
+        raise ValueError("_instances_dtype must be uint16 or uint32")
+
+    def own_sum(t):
+        """the same scalar on every rank: sum over ranks of a per-rank count"""
+        v = torch.tensor([int(t)], dtype=torch.int64, device=dev)
+        return int(comm.all_reduce_sum(v).item()) if comm.world > 1 else int(t)
+
+    def own_z(z0, z1):
+        """field-frame slice of the global slices [z0, z1)"""
+        return slice(z0 - flo, z1 - flo)
+
+    def interior_count(field):
+        """voxels set in `field` (field frame) inside the interior of the WHOLE volume: counted
+        on the own slabs, summed over the ranks"""
+        n = 0
+        for (z0, z1) in my_slabs:
+            a, b = max(z0, rz), min(z1, Z - rz)
+            if a < b:
+                n += int(torch.count_nonzero(field[own_z(a, b), rad[1]:Y - rad[1], rad[2]:X - rad[2]]).item())
+        return own_sum(n)
+
+    any_overlap = own_sum(int(ov_d[own_z(need_lo, need_hi)].any().item())) > 0
     if any_overlap:
         mask_d &= 1 - ov_d
         if not torch.is_tensor(mask_to_cover):
             # vote_instances.py:226 clears the caller's array as well
             mask_to_cover[ov_d.cpu().numpy().astype(bool)] = 0
-    want_inter = kw.get("return_intermediates", False)
 
-    def fg_out():
-        return fg_d.cpu().numpy() if torch.is_tensor(foreground) else \
-            np.asarray(foreground).astype(np.uint8)
+    def fg_out(z0=None, z1=None):
+        sl = slice(None) if z0 is None else own_z(z0, z1)
+        return fg_d[sl].cpu().numpy() if torch.is_tensor(foreground) else \
+            np.asarray(foreground[sl]).astype(np.uint8)
 
-    id_dtype = np.dtype(kw.get("_instances_dtype") or np.uint16)
-    if id_dtype not in (np.dtype(np.uint16), np.dtype(np.uint32)):
-        raise ValueError("_instances_dtype must be uint16 or uint32")
+    def full_fg():
+        if not local_fields:
+            return fg_out()
+        g = torch.zeros(shape, dtype=torch.uint8, device=dev)
+        g[oz0:oz1] = fg_d[own_z(oz0, oz1)]
+        if rank_ranges is not None:
+            comm.all_gather_slabs(g, rank_ranges)
+        else:
+            comm.all_reduce_sum(g)
+        return g.cpu().numpy()
 
     def early():
-        return (None, None) if want_inter else (np.zeros(shape, dtype=id_dtype), fg_out())
-
-    if int(torch.count_nonzero(mask_d[radslice]).item()) == 0 or \
-            int(torch.count_nonzero(fg_d[radslice]).item()) == 0:
-        return early()
+        if want_inter:
+            return None, None
+        if not gather_result:
+            return np.zeros((oz1 - oz0, Y, X), dtype=id_dtype), fg_out(oz0, oz1)
+        return np.zeros(shape, dtype=id_dtype), full_fg()
 
     flags = {k: v for k, v in kw.items()
              if k not in ("cons_box", "cons_layout", "origin", "_yx_tiles", "_instances_dtype")}
     ny_t, nx_t = kw.get("_yx_tiles") or (1, 1)
     # tiles of patch centres (z0, z1, y0, y1, x0, x1): the rank's z-slabs, each cut in y / x
     my_tiles = [(z0, z1) + t for (z0, z1) in my_slabs for t in plan_yx(Y, X, ny_t, nx_t)]
-    local_shape = (Zl, Y, X)
-
-    def params(box=None):
-        """box: global (z0, z1, y0, y1, x0, x1) of consensus base voxels, or None."""
-        if box is not None:
-            box = (box[0] - lo, box[2], box[4], box[1] - lo, box[3], box[5])
-        return backend.make_params(local_shape, ps, cons_box=box, origin=(lo, 0, 0), **flags)
-
-    Pg = backend.make_params(shape, ps, **flags)          # global geometry (pairs, labels)
     # every rank's contiguous z-range (None when a rank's slabs are not contiguous): the owned
     # parts of the score / instance volumes are exchanged by ONE all-gather of slabs
     rank_ranges = None
     if comm.world > 1:
-        contiguous = all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
-        mine_r = torch.tensor([my_slabs[0][0], my_slabs[-1][1] if contiguous else -1],
-                              dtype=torch.int64, device=dev)
+        mine_r = torch.tensor([oz0, oz1 if contiguous else -1], dtype=torch.int64, device=dev)
         rr = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
         if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
             rank_ranges = rr
-    ov_local = ov_d[lo:hi].contiguous()
+    else:
+        rank_ranges = [(oz0, oz1)] if contiguous else None
+    sharded = bool(kw.get("_sharded_global", local_fields))
+    if sharded and (rank_ranges is None or not hasattr(ops, "cover_shard")):
+        raise ValueError("the sharded global stage needs one contiguous z-range per rank")
+    if local_fields and not sharded:
+        raise ValueError("local fields need the sharded global stage")
+
+    if interior_count(mask_d) == 0 or interior_count(fg_d) == 0:
+        return early()
+
+    # ---- frames: what a kernel launch sees.  Resident prediction: ONE frame, the rank's whole
+    # local block.  Provider: a frame per tile and pass, the tile grown by what the pass reads.
+    def grow(t, g):
+        g = [int(v) for v in (g if np.ndim(g) else (g, g, g))]
+        return tuple(v for a in range(3) for v in (max(0, t[2 * a] - g[a]), min(dims[a], t[2 * a + 1] + g[a])))
+
+    def field_box(field, box):
+        z0, z1, y0, y1, x0, x1 = box
+        return field[own_z(z0, z1), y0:y1, x0:x1].contiguous()
+
+    whole = None
+    if not provider:
+        whole = _Frame(pred_local, field_box(ov_d, (lo, hi, 0, Y, 0, X)), (lo, 0, 0), (hi - lo, Y, X))
+
+    def frame_for(box):
+        if whole is not None:
+            return whole
+        z0, z1, y0, y1, x0, x1 = box
+        with backend.host_timer("provider"):
+            pred_t = pred_local.pred_box(box)
+        backend.note_add("provider_voxels", (z1 - z0) * (y1 - y0) * (x1 - x0))
+        return _Frame(pred_t, field_box(ov_d, box), (z0, y0, x0), (z1 - z0, y1 - y0, x1 - x0))
+
+    def params(fr, box=None):
+        """box: global (z0, z1, y0, y1, x0, x1) of consensus base voxels, or None."""
+        o = fr.origin
+        if box is not None:
+            box = (box[0] - o[0], box[2] - o[1], box[4] - o[2], box[1] - o[0], box[3] - o[1], box[5] - o[2])
+        return backend.make_params(fr.shape, ps, cons_box=box, origin=o, **flags)
+
+    def to_local(coords_t, fr, cols=1):
+        """global (z, y, x) [x cols] -> frame coordinates"""
+        sh = torch.tensor(list(fr.origin) * cols, dtype=coords_t.dtype, device=dev)
+        return (coords_t - sh).contiguous()
+
+    Pg = backend.make_params(shape, ps, **flags)          # global geometry (pairs, labels)
     keep_cons = len(my_tiles) == 1 and kw.get("_keep_cons", True)
     kept = {}
-    dims = (Z, Y, X)
 
     def bases_for_scores(t):
         """consensus bases the scores of the centres in tile t read: t grown by the radius"""
-        return tuple(v for a in range(3) for v in
-                     (max(0, t[2 * a] - int(rad[a])), min(dims[a], t[2 * a + 1] + int(rad[a]))))
+        return grow(t, rad)
 
     def bases_for_pairs(t):
         """... the pairs with patch A in t read: the voxel-major rows S[u][q], u in win(A), are
@@ -537,165 +677,253 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                   min(dims[a], t[2 * a + 1] + int(rad[a]) + (g if a > 0 else 0))]
         return tuple(b)
 
-    # ---- stage A: consensus + scores per slab --------------------------------------------
+    words = (int(np.prod(ps)) + 31) // 32
+    can_vm = hasattr(ops, "consensus_voxel_major")
+
+    def consensus_of(fr, P, pool):
+        if can_vm and ops.rank_on_voxel_major(P):
+            # ranking and patch graph both read the voxel-major layout: S1 writes it directly
+            # where the library can (else compact planes + one re-layout, planes dropped)
+            return ops.consensus_voxel_major(fr.pred, fr.ov, P, **({"out": pool} if pool is not None else {}))
+        return ops.consensus(fr.pred, fr.ov, P), P
+
+    # ---- stage A: consensus + scores per tile ----------------------------------------------
     # several tiles: ONE consensus buffer, sized for the largest box of either pass, serves all
     # of them (allocated first, while the allocator's address space is still unfragmented)
     pool = None
     if not keep_cons and my_tiles and hasattr(ops, "voxel_major_pool"):
         biggest = max(int(np.prod([b[2 * a + 1] - b[2 * a] for a in range(3)]))
                       for b in (bases_for_pairs(t) for t in my_tiles))
-        P0 = params(bases_for_pairs(my_tiles[0]))
+        fr0 = whole if whole is not None else _Frame(None, None, (0, 0, 0), (2 * ps[0], 2 * ps[1], 2 * ps[2]))
+        P0 = params(fr0)
         if ops.rank_on_voxel_major(P0):
             pool = ops.voxel_major_pool(P0, biggest)
-    score_dev = torch.zeros(shape, dtype=torch.float32, device=dev)
+    # scores in the field frame; with a provider also the patch bits of every own voxel (the
+    # cover candidates), packed while the tile's prediction exists
+    score_f = torch.zeros((Zf, Y, X), dtype=torch.float32, device=dev)
+    bits_own = None
+    if provider:
+        bits_own = torch.zeros(((oz1 - oz0) * plane, words), dtype=torch.int32, device=dev)
     for t in my_tiles:
         z0, z1, y0, y1, x0, x1 = t
-        P = params(bases_for_pairs(t) if keep_cons else bases_for_scores(t))
-        if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
-            # ranking and patch graph both read the voxel-major layout: S1 writes it directly
-            # where the library can (else compact planes + one re-layout, planes dropped)
-            with backend.host_timer("s1_consensus"):
-                cons, P = ops.consensus_voxel_major(pred_local, ov_local, P, **({"out": pool} if pool is not None else {}))
-        else:
-            with backend.host_timer("s1_consensus"):
-                cons = ops.consensus(pred_local, ov_local, P)
+        cbox = bases_for_pairs(t) if keep_cons else bases_for_scores(t)
+        fr = frame_for(grow(cbox, 2 * rad))
+        o = fr.origin
+        P = params(fr, cbox)
+        with backend.host_timer("s1_consensus"):
+            cons, P = consensus_of(fr, P, pool)
         with backend.host_timer("s2_rank"):
-            sc = ops.rank_patches(pred_local, cons, ov_local, P,
-                                  (z0 - lo, y0, x0, z1 - lo, y1, x1))
-        score_dev[z0:z1, y0:y1, x0:x1] = sc[z0 - lo:z1 - lo, y0:y1, x0:x1]
+            same = fr.shape == (Zf, Y, X) and o == (flo, 0, 0)
+            sc = ops.rank_patches(fr.pred, cons, fr.ov, P, (z0 - o[0], y0 - o[1], x0 - o[2], z1 - o[0], y1 - o[1], x1 - o[2]),
+                                  **({"out": score_f} if same and hasattr(ops, "voxel_major_pool") else {}))
+            if sc is not score_f:
+                score_f[own_z(z0, z1), y0:y1, x0:x1] = sc[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
+        if provider:
+            with backend.host_timer("patch_bits"):
+                zz, yy, xx = torch.meshgrid(torch.arange(z0, z1, device=dev), torch.arange(y0, y1, device=dev),
+                                            torch.arange(x0, x1, device=dev), indexing="ij")
+                cen = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)], 1).to(torch.int32)
+                row = ((zz - oz0) * Y + yy) * X + xx
+                bits_own[row.reshape(-1)] = ops.patch_bits(fr.pred, to_local(cen, fr), kw["fc_threshold"], params(fr))
+                del zz, yy, xx, cen, row
         if keep_cons:
-            kept[t] = (cons, P)
-        del cons, sc
-    if rank_ranges is not None:
-        comm.all_gather_slabs(score_dev, rank_ranges)
-    else:
-        comm.all_reduce_sum(score_dev)
-    # the global stage needs the room (dense patch bits, ranked lists): the buffer comes back for
-    # the patch-graph pass
-    pool_voxels = None
-    if pool is not None:
-        pool_voxels, pool_P = biggest, P0
-        del pool
-        pool = None
-        torch.cuda.empty_cache()
+            kept[t] = (cons, P, fr)
+        del cons, sc, fr
+    if not sharded and comm.world > 1:
+        if rank_ranges is not None:
+            comm.all_gather_slabs(score_f, rank_ranges)
+        else:
+            comm.all_reduce_sum(score_f)
+    # The pooled consensus buffer stays allocated for the whole call (handing tens of GB back to
+    # the driver and asking for them again costs seconds: 2 s + 1.3 s at 512^3); the global stage
+    # carves its big temporaries -- the dense patch-bit table and the gathered candidate bits --
+    # out of it.
+    scratch = pool.view(torch.int32) if pool is not None else None
 
-    def pool_again():
-        if pool_voxels is None:
-            return None
-        torch.cuda.empty_cache()
-        return ops.voxel_major_pool(pool_P, pool_voxels)
-
-    # ---- stage B: ranking, greedy cover, thinning (global; identical on every rank) -------
-    # The ranked list stays on the device (it has one entry per foreground voxel of the GLOBAL
-    # volume); only the selected patches come back to the host.
     def owned(z):
         m = torch.zeros_like(z, dtype=torch.bool)
         for (z0, z1) in my_slabs:
             m |= (z >= z0) & (z < z1)
         return m
 
-    def gathered_bits(coords_t, thresh):
+    def bits_of_own(coords_own, thresh, use_scratch=False):
+        """patch bits of centres in the own slabs (global int32 [n, 3])"""
+        if provider:
+            c = coords_own.to(torch.int64)
+            return bits_own[((c[:, 0] - oz0) * Y + c[:, 1]) * X + c[:, 2]]
+        kw_s = {"scratch": scratch} if use_scratch and scratch is not None and hasattr(ops, "voxel_major_pool") else {}
+        return ops.patch_bits(whole.pred, to_local(coords_own, whole), thresh, params(whole), **kw_s)
+
+    def gathered_bits(coords_t, thresh, use_scratch=False):
         """Patch bits of `coords_t` (global, int32 [n, 3] on the device): each rank packs those
         centred in its own slabs, the sum over ranks is the full table."""
-        words = (int(np.prod(ps)) + 31) // 32
+        if comm.world == 1:
+            return bits_of_own(coords_t, thresh, use_scratch)       # one rank owns everything
         bits = torch.zeros((int(coords_t.shape[0]), words), dtype=torch.int32, device=dev)
         mine = torch.nonzero(owned(coords_t[:, 0])).reshape(-1)
         if mine.numel():
-            loc = coords_t[mine].clone()
-            loc[:, 0] -= lo
-            bits[mine] = ops.patch_bits(pred_local, loc.contiguous(), thresh, params())
+            bits[mine] = bits_of_own(coords_t[mine], thresh)
         comm.all_reduce_sum(bits)
         return bits
 
+    def coords_of(lin_g):
+        return torch.stack([lin_g // plane, (lin_g // X) % Y, lin_g % X], dim=1).to(torch.int32)
+
+    def local_params(a, b):
+        return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
+
+    from .vote_instances import foreground_cover as fc
+    pix_ths = fc._pix_thresholds(ps, kw)
+    thr = kw.get("score_threshold", False)
     debug_crc = os.environ.get("PPP_DEBUG_CRC") == "1"     # development aid (tools/cover_repro.py)
     if debug_crc:
         import zlib
-        backend.note("crc_scores", zlib.crc32(score_dev.cpu().numpy().tobytes()))
-    with backend.host_timer("sort"):
-        lin_t, rscores_t = ops.rank_order(score_dev, fg_d, ps)
-    if debug_crc:
-        backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
-    del score_dev
-    coords_t = torch.stack([lin_t // (Y * X), (lin_t // X) % Y, lin_t % X], dim=1).to(torch.int32)
-    if kw.get("selected_patches") is not None:
+    injected = kw.get("selected_patches") is not None
+    if injected:
         sel_coords = np.array(list(kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
-    elif kw.get("skipSelection", False):
-        sel_coords = coords_t.cpu().numpy()
-    else:
-        # sharded over the ranks when every rank owns one contiguous z-range of at least
-        # 2(pz-1) slices (PPP_COVER_SHARDED=0: every rank runs the whole cover)
-        ranges = None
-        shard_env = os.environ.get("PPP_COVER_SHARDED", "1")     # "force": also with one rank
-        if (comm.world > 1 or shard_env == "force") and hasattr(ops, "cover_shard") and \
-                kw.get("_shard_cover", shard_env != "0"):
-            # (decided from gathered data only, so that every rank takes the same branch)
-            ranges = rank_ranges if comm.world > 1 else [(my_slabs[0][0], my_slabs[-1][1])]
-            if ranges is not None and not all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in ranges):
-                ranges = None
+    elif sharded:
+        # ---- stage B2: ranking and greedy cover SHARDED by z -- no rank holds a list as long as
+        # the volume.  (i) every rank sorts the patches of its own range; (ii) the position of a
+        # patch in the global ranked list = its own position + the number of patches of every
+        # other rank that precede it -- a binary search in that rank's sorted scores (all-gathered:
+        # 4 bytes per foreground voxel); ties keep raster order, i.e. lower ranks first;
+        # (iii) the cover rounds run on the own slices with the global positions as priorities
+        # (sharded_cover_own); (iv) the selected patches -- a short list -- are gathered.
+        with backend.host_timer("sort"):
+            fg_own = torch.zeros_like(fg_d)
+            fg_own[own_z(oz0, oz1)] = fg_d[own_z(oz0, oz1)]
+            lin_l, sc_own = ops.rank_order(score_f, fg_own, ps)       # field-frame indices, sorted
+            del fg_own
+            lin_own = lin_l + flo * plane
+            del lin_l
+            n_own = int(lin_own.numel())
+            rank_id = torch.arange(n_own, dtype=torch.int64, device=dev)
+            neg = -sc_own
+            for r, other in enumerate(gather_lists(comm, neg)):
+                if r != comm.rank and other.numel():
+                    rank_id += torch.searchsorted(other.contiguous(), neg, right=(r < comm.rank))
+            del neg
+            backend.note("ranked_own", n_own)
+        del score_f
         with backend.host_timer("s3_cover"):
-            from .vote_instances import foreground_cover as fc
-            # patches the loop never looks at (foreground_cover.py:136-141): centre on an
-            # overlap voxel; everything from the first score below score_threshold on
-            never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
-            if any_overlap:
-                never |= ov_d.reshape(-1)[lin_t] != 0
-            thr = kw.get("score_threshold", False)
-            if isinstance(thr, float):
-                below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
-                if below.numel():
-                    never[int(below[0].item()):] = True
-            if ranges is not None:
-                def own_bits(idx):
-                    loc = coords_t[idx].clone()
-                    loc[:, 0] -= lo
-                    return ops.patch_bits(pred_local, loc.contiguous(), kw["fc_threshold"], params())
-
-                def local_params(a, b):
-                    return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
-
-                selected = sharded_cover(ops, comm, shape, ps, ranges[comm.rank], ranges,
-                                         mask_d, lin_t, never, fc._pix_thresholds(ps, kw),
-                                         radslice, own_bits, local_params)
+            if kw.get("skipSelection", False):
+                sel_own = torch.ones(n_own, dtype=torch.bool, device=dev)
             else:
-                bits = gathered_bits(coords_t, kw["fc_threshold"])
-                selected = ops.greedy_cover(mask_d, bits, lin_t, rscores_t, never,
-                                            fc._pix_thresholds(ps, kw), radslice, Pg, kw)
-                del bits
-            del never
-            sel_coords = coords_t[selected].cpu().numpy()
-            if debug_crc:
-                backend.note("crc_selected", zlib.crc32(np.ascontiguousarray(sel_coords).tobytes()))
-                if os.environ.get("PPP_STOP_AFTER_COVER") == "1":
-                    return early()
+                never = torch.zeros(n_own, dtype=torch.bool, device=dev)
+                if any_overlap:
+                    never |= ov_d.reshape(-1)[lin_own - flo * plane] != 0
+                if isinstance(thr, float):
+                    never |= sc_own.double() < thr
+                h = ps[0] - 1
+                a, b = max(0, oz0 - h), min(Z, oz1 + h)
+                sel_own = sharded_cover_own(ops, comm, shape, ps, (oz0, oz1), rank_ranges,
+                                            mask_d[own_z(a, b)].clone(), a, interior_count(mask_d),
+                                            lin_own, rank_id.to(torch.int32), never,
+                                            bits_of_own(coords_of(lin_own), kw["fc_threshold"], True),
+                                            pix_ths, local_params)
+                del never
+            mine_sel = torch.stack([rank_id[sel_own], lin_own[sel_own]], 1)
+            allsel = torch.cat(gather_lists(comm, mine_sel), 0)
+            allsel = allsel[torch.argsort(allsel[:, 0])]                  # global rank order
+            sel_coords = coords_of(allsel[:, 1]).cpu().numpy()
+            del mine_sel, allsel, sel_own, lin_own, sc_own, rank_id
+    else:
+        # ---- stage B: ranking, greedy cover (global; identical on every rank) ---------------
+        # The ranked list stays on the device (it has one entry per foreground voxel of the
+        # GLOBAL volume); only the selected patches come back to the host.
+        if debug_crc:
+            backend.note("crc_scores", zlib.crc32(score_f.cpu().numpy().tobytes()))
+        with backend.host_timer("sort"):
+            lin_t, rscores_t = ops.rank_order(score_f, fg_d, ps)
+        if debug_crc:
+            backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
+        del score_f
+        coords_t = coords_of(lin_t)
+        if kw.get("skipSelection", False):
+            sel_coords = coords_t.cpu().numpy()
+        else:
+            # sharded over the ranks when every rank owns one contiguous z-range
+            # (PPP_COVER_SHARDED=0: every rank runs the whole cover; "force": also with one rank)
+            shard_env = os.environ.get("PPP_COVER_SHARDED", "1")
+            use_shard = (comm.world > 1 or shard_env == "force") and hasattr(ops, "cover_shard") and \
+                kw.get("_shard_cover", shard_env != "0") and rank_ranges is not None and \
+                all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in rank_ranges)
+            with backend.host_timer("s3_cover"):
+                # patches the loop never looks at (foreground_cover.py:136-141): centre on an
+                # overlap voxel; everything from the first score below score_threshold on
+                never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
+                if any_overlap:
+                    never |= ov_d.reshape(-1)[lin_t] != 0
+                if isinstance(thr, float):
+                    below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
+                    if below.numel():
+                        never[int(below[0].item()):] = True
+                radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
+                if use_shard:
+                    selected = sharded_cover(ops, comm, shape, ps, rank_ranges[comm.rank], rank_ranges,
+                                             mask_d, lin_t, never, pix_ths, radslice,
+                                             lambda idx: bits_of_own(coords_t[idx], kw["fc_threshold"]),
+                                             local_params)
+                else:
+                    bits = gathered_bits(coords_t, kw["fc_threshold"], True)
+                    selected = ops.greedy_cover(mask_d, bits, lin_t, rscores_t, never, pix_ths, radslice, Pg, kw)
+                    del bits
+                del never
+                sel_coords = coords_t[selected].cpu().numpy()
+        del lin_t, rscores_t, coords_t
+    if debug_crc and not injected:
+        backend.note("crc_selected", zlib.crc32(np.ascontiguousarray(sel_coords).tobytes()))
+        if os.environ.get("PPP_STOP_AFTER_COVER") == "1":
+            return early()
+    backend.note("n_cover", len(sel_coords))
     if not kw.get("skipThinCover") and len(sel_coords) > 0:
         if kw.get("sample", 1.0) < 1.0:
             raise NotImplementedError("sample < 1 uses unseeded random sampling in the reference")
         with backend.host_timer("s4_thin"):
+            # replicated: every rank thins the same (short) global list on its own device; with
+            # local fields the mask of the whole volume is gathered for it (one byte per voxel)
+            if local_fields:
+                mask_g = torch.zeros(shape, dtype=torch.uint8, device=dev)
+                mask_g[oz0:oz1] = mask_d[own_z(oz0, oz1)]
+                comm.all_gather_slabs(mask_g, rank_ranges)
+            else:
+                mask_g = mask_d
             sel_t = torch.from_numpy(np.ascontiguousarray(sel_coords)).to(dev)
             bits = gathered_bits(sel_t, kw["fc_threshold"])
             sel_lin = (sel_coords[:, 0].astype(np.int64) * Y + sel_coords[:, 1]) * X + sel_coords[:, 2]
             if hasattr(ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
                     and ps[2] <= 32:
-                # replicated: every rank thins the same global list on its own device
-                keep = ops.thin_cover(mask_d, bits, torch.from_numpy(sel_lin).to(dev), Pg)
+                keep = ops.thin_cover(mask_g, bits, torch.from_numpy(sel_lin).to(dev), Pg)
                 keep = keep.cpu().numpy()
             else:
-                keep = backend.host_thin_cover(np.ascontiguousarray(mask_d.cpu().numpy()),
+                keep = backend.host_thin_cover(np.ascontiguousarray(mask_g.cpu().numpy()),
                                                ps, np.ascontiguousarray(sel_lin),
                                                bits.cpu().numpy().view(np.uint32))
             sel_coords = sel_coords[keep]
-            del bits, sel_t
-    del lin_t, rscores_t, coords_t
+            del bits, sel_t, mask_g
+    bits_own = None
 
     # ---- pairs (global coordinates; replicated, it is cheap) -------------------------------
     order = np.argsort(sel_coords[:, 2], kind="stable")
     nodes = np.ascontiguousarray(sel_coords[order].astype(np.int32))
     nodes_dev = torch.from_numpy(nodes).to(dev)
     max_ps = kw.get("max_total_patch_distance_in_ps_multiples", 2)
-    shift = torch.tensor([lo, 0, 0, lo, 0, 0], dtype=torch.int32, device=dev)
     streaming = not want_inter and not kw.get("mws") and kw.get("selected_patch_pairs") is None \
         and kw.get("_stream_pairs", os.environ.get("PPP_STREAM_PAIRS", "1") != "0") \
         and hasattr(ops, "label_state")
+
+    def tile_consensus(t):
+        """(frame, cons, P) for the pairs whose patch A lies in tile t"""
+        if keep_cons:
+            cons, P, fr = kept.pop(t)
+            return fr, cons, P
+        cbox = bases_for_pairs(t)
+        # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
+        # to 2 p away) and their windows: the tile grown by the halo
+        fr = frame_for(grow(t, (H, 2 * ps[1] + int(rad[1]), 2 * ps[2] + int(rad[2]))))
+        cons, P = consensus_of(fr, params(fr, cbox), pool)
+        return fr, cons, P
+
     state = None
     if streaming:
         # ---- stage C (streaming): the pair rows of a tile are enumerated, scored and fed to
@@ -726,7 +954,6 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         backend.note("n_selected", len(nodes))
         backend.note("n_pairs", n_rows)
         state = ops.label_state(nodes_dev, Pg)
-        pool = pool_again()
         with backend.host_timer("s5_patch_graph"):
             for t, subset in zip(my_tiles, subsets):
                 with backend.host_timer("s5a_select_rows"):
@@ -734,24 +961,14 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                                                      Pg, max_ps, kw["includeSinglePatchCCS"])
                     if rows_t is None:
                         continue
-                    rows_l = (rows_t - shift).contiguous()
                 with backend.host_timer("s5b_consensus"):
-                    if keep_cons:
-                        cons, P = kept.pop(t)
-                    else:
-                        P = params(bases_for_pairs(t))
-                        if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
-                            cons, P = ops.consensus_voxel_major(pred_local, ov_local, P,
-                                                                **({"out": pool} if pool is not None else {}))
-                        else:
-                            cons = ops.consensus(pred_local, ov_local, P)
+                    fr, cons, P = tile_consensus(t)
                 with backend.host_timer("s5c_patch_graph"):
-                    a = ops.patch_graph(pred_local, cons, rows_l, P)
+                    a = ops.patch_graph(fr.pred, cons, to_local(rows_t, fr, 2), P)
                 with backend.host_timer("s6_label_paint"):
                     state.add(rows_t, a, gid_t)
-                del cons, rows_l, rows_t, gid_t, a
+                del cons, rows_t, gid_t, a, fr
         kept.clear()
-        pool = None
         del counts, goffsets, subsets
         if comm.world > 1:
             # boundary-label merge: every rank's forest (node -> parent) is gathered and united
@@ -777,8 +994,6 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     # ---- stage C (materialised list: intermediates wanted, injected pairs, mutex watershed):
     # pair affinities, each pair on the rank / tile that owns patch A
     aff = None if state is not None else torch.zeros((n_rows,), dtype=torch.float32, device=dev)
-    if state is None:
-        pool = pool_again()
     with backend.host_timer("s5_patch_graph"):
         for t in (my_tiles if state is None else []):
             z0, z1, y0, y1, x0, x1 = t
@@ -791,24 +1006,15 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 del own
                 if idx.numel() == 0:
                     continue
-                rows_l = (rows[idx] - shift).contiguous()
             with backend.host_timer("s5b_consensus"):
-                if keep_cons:
-                    cons, P = kept.pop(t)
-                else:
-                    P = params(bases_for_pairs(t))
-                    if hasattr(ops, "consensus_voxel_major") and ops.rank_on_voxel_major(P):
-                        cons, P = ops.consensus_voxel_major(pred_local, ov_local, P,
-                                                            **({"out": pool} if pool is not None else {}))
-                    else:
-                        cons = ops.consensus(pred_local, ov_local, P)
+                fr, cons, P = tile_consensus(t)
             with backend.host_timer("s5c_patch_graph"):
-                a = ops.patch_graph(pred_local, cons, rows_l, P)
+                a = ops.patch_graph(fr.pred, cons, to_local(rows[idx], fr, 2), P)
             with backend.host_timer("s5d_scatter"):
                 aff[idx] = a
-            del cons, rows_l, idx, a
+            del cons, idx, a, fr
     kept.clear()
-    pool = None
+    pool = scratch = None
     if state is None:
         comm.all_reduce_sum(aff)
     if want_inter:
@@ -842,6 +1048,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             labels = (inverse + 1).to(torch.int32)
             n_labels = int(uniq.numel())
             del keys, valid, uniq, inverse
+        del rows, aff
         # ids are uint16 in the whole-volume entry (vote_instances.py:230; its np.seterr(over=
         # 'raise') makes an id above 65 535 an error) and uint32 in the blockwise / stitched one
         # (stitch_patch_graph.py:120), which the caller asks for with _instances_dtype
@@ -849,36 +1056,58 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             raise OverflowError("%d instance ids do not fit %s (the blockwise entry, "
                                 "stitch_patch_graph.main, carries uint32 ids)" % (n_labels, id_dtype.name))
         backend.note("ids_issued", n_labels)
-        inst_dev = torch.zeros(shape, dtype=torch.int32, device=dev)
-        Pl = params()
-        for (z0, z1) in my_slabs:
-            near = torch.nonzero((lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)).reshape(-1)
-            if near.numel() == 0:
-                continue
-            loc = lab_nodes[near].clone()
-            loc[:, 0] -= lo
-            inst_l = torch.zeros(local_shape, dtype=torch.int32, device=dev)
-            ops.paint(pred_local, loc.contiguous(), labels[near].contiguous(), inst_l, Pl)
-            inst_dev[z0:z1] = inst_l[z0 - lo:z1 - lo]
-            del inst_l
+        # painted on the own slabs only; `inst_g` is the whole map when it is gathered
+        gz0, gz1 = (0, Z) if gather_result else (oz0, oz1)
+        inst_g = torch.zeros((gz1 - gz0, Y, X), dtype=torch.int32, device=dev)
+        if whole is not None:
+            Pl = params(whole)
+            for (z0, z1) in my_slabs:
+                near = torch.nonzero((lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)).reshape(-1)
+                if near.numel() == 0:
+                    continue
+                inst_l = torch.zeros(whole.shape, dtype=torch.int32, device=dev)
+                ops.paint(whole.pred, to_local(lab_nodes[near], whole), labels[near].contiguous(), inst_l, Pl)
+                inst_g[z0 - gz0:z1 - gz0] = inst_l[z0 - lo:z1 - lo]
+                del inst_l
+        else:
+            for t in my_tiles:
+                z0, z1, y0, y1, x0, x1 = t
+                near = (lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)
+                near &= (lab_nodes[:, 1] >= y0 - int(rad[1])) & (lab_nodes[:, 1] < y1 + int(rad[1]))
+                near &= (lab_nodes[:, 2] >= x0 - int(rad[2])) & (lab_nodes[:, 2] < x1 + int(rad[2]))
+                near = torch.nonzero(near).reshape(-1)
+                if near.numel() == 0:
+                    continue
+                fr = frame_for(grow(t, rad))
+                o = fr.origin
+                inst_l = torch.zeros(fr.shape, dtype=torch.int32, device=dev)
+                ops.paint(fr.pred, to_local(lab_nodes[near], fr), labels[near].contiguous(), inst_l, params(fr))
+                inst_g[z0 - gz0:z1 - gz0, y0:y1, x0:x1] = \
+                    inst_l[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
+                del inst_l, fr
+        if not gather_result:
+            instances = inst_g.cpu().numpy().view(np.uint32).astype(id_dtype, copy=False)
+            return instances, fg_out(oz0, oz1)
         if id_dtype == np.uint32:
-            if rank_ranges is not None:
-                comm.all_gather_slabs(inst_dev, rank_ranges)
-            else:
-                comm.all_reduce_sum(inst_dev)
-            instances = inst_dev.cpu().numpy().view(np.uint32)
+            if comm.world > 1:
+                if rank_ranges is not None:
+                    comm.all_gather_slabs(inst_g, rank_ranges)
+                else:
+                    comm.all_reduce_sum(inst_g)
+            instances = inst_g.cpu().numpy().view(np.uint32)
         else:
             # ids fit 16 bits (checked above): half the bytes on the wire and to the host
-            inst16 = inst_dev.to(torch.int16)
-            del inst_dev
-            if rank_ranges is not None:
-                comm.all_gather_slabs(inst16, rank_ranges)
-            else:
-                inst32 = inst16.to(torch.int32) & 0xFFFF
-                comm.all_reduce_sum(inst32)
-                inst16 = inst32.to(torch.int16)
+            inst16 = inst_g.to(torch.int16)
+            del inst_g
+            if comm.world > 1:
+                if rank_ranges is not None:
+                    comm.all_gather_slabs(inst16, rank_ranges)
+                else:
+                    inst32 = inst16.to(torch.int32) & 0xFFFF
+                    comm.all_reduce_sum(inst32)
+                    inst16 = inst32.to(torch.int16)
             instances = inst16.cpu().numpy().view(np.uint16)
-    return instances, fg_out()
+    return instances, full_fg()
 
 
 def slabs_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
@@ -900,38 +1129,45 @@ def slabs_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
 
 
 def tiles_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
-    """(n_slabs, ny, nx): z-slabs first (slabs_needed); when even thin slabs do not fit, the
-    longest tile edge among y / x is halved until the working set of one tile (`copies` x the
-    compact consensus on the tile grown by the pairs halo) fits `free_bytes`."""
+    """(n_slabs, ny, nx): the grid of tiles with the least consensus work among those whose
+    working set -- `copies` x the compact consensus on the tile grown by the pairs halo (3 =
+    compact planes + the voxel-major copy, 2 = voxel-major written directly by S1) -- fits
+    `safety * free_bytes`.  Work = the base voxels of both passes (scores: tile + radius; pairs:
+    tile + radius + p - 1 on the low side in z and on both sides in y / x), clipped to the volume:
+    cube-like tiles win, thin slabs spend most of their work on the halo.  (1, 1, 1) when the
+    whole volume fits."""
     pz, py, px = [int(p) for p in patchshape]
     planes = ((2 * pz - 1) * (2 * py - 1) * (2 * px - 1) - 1) // 2
     Z, Y, X = [int(v) for v in shape]
     budget = safety * free_bytes
+    per_voxel = float(copies) * planes * 4
 
-    def fits(tz, ty, tx):
-        bz = min(Z, tz + 2 * (pz // 2) + pz - 1)
-        by = min(Y, ty + 2 * (py // 2) + 2 * (py - 1))
-        bx = min(X, tx + 2 * (px // 2) + 2 * (px - 1))
-        return float(copies) * planes * 4 * bz * by * bx <= budget
+    def axis(n_vox, n_tiles, p, both):
+        """(largest pairs-box extent, sum of pairs-box extents, sum of scores-box extents) of
+        n_tiles tiles along an axis of n_vox voxels"""
+        r, g = p // 2, p - 1
+        big = s_pairs = s_scores = 0
+        for (a, b) in plan_slabs(n_vox, n_tiles):
+            e = min(n_vox, b + r + (g if both else 0)) - max(0, a - r - g)
+            big = max(big, e)
+            s_pairs += e
+            s_scores += min(n_vox, b + r) - max(0, a - r)
+        return big, s_pairs, s_scores
 
-    n0 = slabs_needed(shape, patchshape, free_bytes, safety, copies)
-    if n0 == 1 or fits(-(-Z // n0), Y, X):
-        return n0, 1, 1
-    # Even thin slabs do not fit: choose the grid (n, ny, nx) of fitting tiles with the least
-    # consensus work, i.e. the smallest total volume of the tiles grown by their halos (cube-like
-    # tiles: thin slabs spend most of their work on the z halo).
-    hz, hy, hx = 2 * (pz // 2) + pz - 1, 2 * (py // 2) + 2 * (py - 1), 2 * (px // 2) + 2 * (px - 1)
+    if per_voxel * Z * Y * X <= budget:
+        return 1, 1, 1
     best = None
-    for n in range(1, max(1, Z // max(1, pz // 2)) + 1):
-        tz = -(-Z // n)
-        for ny in range(1, min(Y, 64) + 1):
-            ty = -(-Y // ny)
+    zs = [axis(Z, n, pz, False) for n in range(1, Z + 1)]
+    ys = [axis(Y, n, py, True) for n in range(1, min(Y, 64) + 1)]
+    xs = [axis(X, n, px, True) for n in range(1, min(X, 64) + 1)]
+    for n, (bz, pz_sum, sz_sum) in enumerate(zs, 1):
+        for ny, (by, py_sum, sy_sum) in enumerate(ys, 1):
             # smallest nx that fits (more cuts only add halo)
-            nx = next((k for k in range(1, min(X, 64) + 1) if fits(tz, ty, -(-X // k))), None)
+            nx = next((k for k, (bx, _, _) in enumerate(xs, 1) if per_voxel * bz * by * bx <= budget), None)
             if nx is None:
                 continue
-            tx = -(-X // nx)
-            work = float(n * ny * nx) * min(Z, tz + hz) * min(Y, ty + hy) * min(X, tx + hx)
+            _, px_sum, sx_sum = xs[nx - 1]
+            work = float(pz_sum) * py_sum * px_sum + float(sz_sum) * sy_sum * sx_sum
             if best is None or work < best[0] - 1e-9:
                 best = (work, n, ny, nx)
     if best is None:

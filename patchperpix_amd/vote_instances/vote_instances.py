@@ -149,7 +149,12 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         Pq.cons_layout = backend.CONS_VOXEL_MAJOR
         direct = os.environ.get("PPP_S1_DIRECT_VM", "1") != "0" and \
             backend.lib().ppp_consensus_writes_voxel_major(Pq) == 1
-        n_slabs, ny_t, nx_t = tiling.tiles_needed(shape, patchshape, avail,
+        # the pooled consensus buffer is held through the global stage, whose other buffers
+        # (ranked lists, cover / sort work space: ~70 bytes per voxel) and the pair rows of the
+        # patch-graph stage must fit next to it
+        reserve = 70.0 * float(np.prod(shape)) + 4e9
+        n_slabs, ny_t, nx_t = tiling.tiles_needed(shape, patchshape, max(avail - reserve, 0.25 * avail),
+                                                  safety=float(os.environ.get("PPP_TILE_SAFETY", "0.92")),
                                                   copies=2.0 if direct else 3.0)
         if yx_tiles is None and (ny_t > 1 or nx_t > 1):
             yx_tiles = (ny_t, nx_t)

@@ -50,7 +50,7 @@ class OracleOps:
         s = orc.rank(pred.numpy().astype(np.float32), full, ov.numpy(), self._ps(P), **self.kw)
         return torch.from_numpy(s)
 
-    def patch_bits(self, pred, centres, thresh, P):
+    def patch_bits(self, pred, centres, thresh, P, scratch=None):
         p = pred.numpy().astype(np.float32)
         c = centres.numpy()
         C = p.shape[0]

@@ -393,3 +393,115 @@ def test_two_ranks_over_rccl(tmp_path):
     assert want.any()
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / ("inst_rank%d.npy" % r)), want), "rank %d differs" % r
+
+
+# ------------------------------------------------------------------------------------------
+# prediction PROVIDER (a rank holds one tile + halo at a time) and the SHARDED global stage
+# (local fields, sharded sort and cover): BASELINE config [3]'s execution mode
+# ------------------------------------------------------------------------------------------
+class ArrayProvider:
+    """pred_box() from a host array: stands in for a reader / generator of prediction tiles"""
+
+    def __init__(self, pred, device="cpu"):
+        self.pred, self.device, self.calls = pred, device, 0
+
+    def pred_box(self, box):
+        import torch
+        z0, z1, y0, y1, x0, x1 = box
+        self.calls += 1
+        return torch.from_numpy(np.ascontiguousarray(self.pred[:, z0:z1, y0:y1, x0:x1])).to(self.device)
+
+
+@pytest.mark.parametrize("n_slabs,yx,thin,mws", [(3, (2, 2), False, False), (2, (1, 2), True, True)])
+def test_provider_and_sharded_stage_equal_whole_volume_cpu(n_slabs, yx, thin, mws):
+    """One process: prediction through a provider (frames per tile), and the sharded global
+    stage (local sort + merge ranks, sharded cover) forced on: same pair rows / instance map."""
+    import torch
+    from oracle_ops import OracleOps
+    c, ps, kw = make_case(seed=63, shape=(24, 17, 19))
+    kw.update(skipThinCover=not thin, mws=mws)
+    ref = whole_volume(c, ps, kw)
+    ops = OracleOps(**kw)
+    slabs = tiling.plan_slabs(c["pred"].shape[1], n_slabs)
+    shape = c["foreground"].shape
+    prov = ArrayProvider(c["pred"])
+    for sharded in (False, True):
+        extra = dict(_yx_tiles=yx, _sharded_global=sharded)
+        pairs, aff = tiling.assemble(prov, 0, shape, c["foreground"].copy(), c["foreground"].copy(),
+                                     c["numinst"], ps, slabs, ops=ops, return_intermediates=True,
+                                     **extra, **kw)
+        assert np.array_equal(pairs, ref["pairs"])
+        assert np.array_equal(aff.view(np.uint32), ref["aff"].view(np.uint32))
+        inst, fg = tiling.assemble(prov, 0, shape, c["foreground"].copy(), c["foreground"].copy(),
+                                   c["numinst"], ps, slabs, ops=ops, **extra, **kw)
+        assert np.array_equal(inst, ref["instances"]) and inst.any()
+    assert prov.calls > 2 * len(slabs) * yx[0] * yx[1]
+
+
+WORKER_SHARDED = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+from patchperpix_amd import tiling, backend
+from test_tiling import make_case, ArrayProvider
+from oracle_ops import OracleOps
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+c, ps, kw = make_case()
+kw.update(json.loads(os.environ.get("PPP_TEST_KW", "{{}}")))
+Z = c["pred"].shape[1]
+slabs = tiling.plan_slabs(Z, world)
+mine = tiling.slabs_of_rank(slabs, rank, world)
+lo, hi = tiling.local_range(mine, Z, ps)
+# the rank sees ONLY its slices of the fields, and the prediction through a provider
+loc = lambda a: np.ascontiguousarray(a[lo:hi])
+gather = os.environ.get("PPP_TEST_GATHER", "1") == "1"
+inst, fg = tiling.assemble(ArrayProvider(c["pred"]), lo, c["foreground"].shape, loc(c["foreground"]),
+                           loc(c["foreground"]).copy(), loc(c["numinst"]), ps, mine,
+                           comm=tiling.TorchDistComm(), ops=OracleOps(**kw), _yx_tiles=(1, 2),
+                           _gather_result=gather, **kw)
+np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+np.save(os.path.join({out!r}, "fg_rank%d.npy" % rank), fg)
+np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
+        np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("ranked_own", 0), mine[0][0], mine[-1][1]]))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,extra,gather", [
+    (2, {}, True), (3, {}, False),
+    (2, {"skipThinCover": False, "mws": True}, False),
+    (2, {"select_patches_for_sparse_data": False, "skipThinCover": False}, True),
+    (2, {"_empty_top": True}, True)])
+def test_ranks_gloo_provider_local_fields(tmp_path, world, extra, gather, monkeypatch):
+    """Two / three processes over gloo, each with its own slices of the fields only and the
+    prediction through a provider: sharded sort (merge ranks from the gathered sorted scores),
+    sharded cover, gathered selection, replicated thinning on the gathered mask -- the own slab
+    of the result (or the gathered whole) equals the whole-volume result of one process."""
+    import json
+    extra = dict(extra)
+    if extra.pop("_empty_top", False):
+        monkeypatch.setenv("PPP_TEST_EMPTY_TOP", "1")
+    c, ps, kw = make_case()
+    kw.update(extra)
+    ref = whole_volume(c, ps, kw)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_SHARDED.format(repo=REPO, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29595", OMP_NUM_THREADS="1",
+               PPP_TEST_KW=json.dumps(extra), PPP_TEST_GATHER="1" if gather else "0")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                           "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                           "--master-port", "29595", str(script)], env=env, timeout=900)
+    assert ref["instances"].any()
+    n_ranked = 0
+    for r in range(world):
+        inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
+        fg = np.load(tmp_path / ("fg_rank%d.npy" % r))
+        notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
+        z0, z1 = int(notes[2]), int(notes[3])
+        want = ref["instances"] if gather else ref["instances"][z0:z1]
+        assert np.array_equal(inst, want), "rank %d differs" % r
+        assert np.array_equal(fg != 0, c["foreground"] if gather else c["foreground"][z0:z1])
+        assert notes[0] == world
+        n_ranked += int(notes[1])
+    assert n_ranked == len(ref["ranked_coords"])       # every patch was ranked by exactly one rank
