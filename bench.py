@@ -63,16 +63,25 @@ WORKLOADS = {
     "synth128_p9": ((128, 128, 128), (9, 9, 9), (24, 24, 24)),
     # BASELINE.json configs[2] (needs the tiled consensus path)
     "synth512_p9": ((512, 512, 512), (9, 9, 9), (24, 24, 24)),
+    # BASELINE.json configs[3]: 1024^3 / 9^3 over the 8 GPUs of a node.  The float16 prediction
+    # is 1.57 TB: it is GENERATED tile by tile (a rank holds one tile + halo, the provider mode of
+    # patchperpix_amd/tiling.py), fields and every list are local to the rank
+    "synth1024_p9": ((1024, 1024, 1024), (9, 9, 9), (24, 24, 24)),
+    # the provider mode on volumes a single development GPU finishes quickly
+    "synth256_p9_provider": ((256, 256, 256), (9, 9, 9), (24, 24, 24)),
+    "synth128_p7_provider": ((128, 128, 128), (7, 7, 7), (18, 18, 18)),
 }
+PROVIDER_WORKLOADS = ("synth1024_p9", "synth256_p9_provider", "synth128_p7_provider")
 DEFAULT_WORKLOAD = "synth512_p9"      # BASELINE.json configs[2]
 FALLBACK_WORKLOAD = "flylight140_p7"  # BASELINE.json configs[1]
 NORTH_STAR = ((512, 512, 512), (9, 9, 9), (24, 24, 24))   # BASELINE.json configs[2]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def device_labels(torch, shape, cell, seed, z_offset=0):
+def device_labels(torch, shape, cell, seed, z_offset=0, y_offset=0, x_offset=0):
     """patchperpix_amd.synth.cell_labels evaluated with torch ops on the device (plumbing
-    for the synthetic input; not part of the measured path)."""
+    for the synthetic input; not part of the measured path).  The offsets place `shape` as a box
+    inside a larger volume."""
     def hash_u32(x):
         m = 0xFFFFFFFF
         x = x & m
@@ -84,8 +93,8 @@ def device_labels(torch, shape, cell, seed, z_offset=0):
         return x
     dev = "cuda"
     zz = torch.arange(shape[0], device=dev, dtype=torch.int64).view(-1, 1, 1) + z_offset
-    yy = torch.arange(shape[1], device=dev, dtype=torch.int64).view(1, -1, 1)
-    xx = torch.arange(shape[2], device=dev, dtype=torch.int64).view(1, 1, -1)
+    yy = torch.arange(shape[1], device=dev, dtype=torch.int64).view(1, -1, 1) + y_offset
+    xx = torch.arange(shape[2], device=dev, dtype=torch.int64).view(1, 1, -1) + x_offset
     cz = zz // cell[0]
     sy = hash_u32(cz * 7919 + seed) % max(1, cell[1])
     cy = (yy + sy) // cell[1]
@@ -192,6 +201,29 @@ def set_host_allocator():
         return "no libc"
 
 
+class SynthProvider:
+    """Prediction provider of the synthetic workloads: pred_box() GENERATES the float16 prediction
+    of a box on the device (ppp_synth_pred_box; labels of the box + patch radius evaluated with
+    torch ops), bit-identical to generating the whole volume.  Stands where a reader of
+    ``volumes/pred_affs`` chunks would stand for real data."""
+
+    def __init__(self, torch, gshape, ps, cell, kw, seed=0):
+        self.torch, self.gshape, self.ps, self.cell, self.kw, self.seed = torch, gshape, ps, cell, kw, seed
+        self.bytes_max = 0
+
+    def pred_box(self, box):
+        from patchperpix_amd import backend
+        z0, z1, y0, y1, x0, x1 = [int(v) for v in box]
+        r = [p // 2 for p in self.ps]
+        lb = (max(0, z0 - r[0]), min(self.gshape[0], z1 + r[0]), max(0, y0 - r[1]),
+              min(self.gshape[1], y1 + r[1]), max(0, x0 - r[2]), min(self.gshape[2], x1 + r[2]))
+        labels = device_labels(self.torch, (lb[1] - lb[0], lb[3] - lb[2], lb[5] - lb[4]), self.cell,
+                               self.seed, z_offset=lb[0], y_offset=lb[2], x_offset=lb[4])
+        pred = backend.synth_pred_box(labels, lb, box, self.gshape, self.ps, self.kw, seed=self.seed)
+        self.bytes_max = max(self.bytes_max, pred.numel() * pred.element_size())
+        return pred
+
+
 class Workload:
     """One synthetic volume set up for timing: the float16 prediction and the per-voxel fields
     (foreground, numinst) resident in HBM, and ``step(flags)`` = one pass of the hot path."""
@@ -211,7 +243,38 @@ class Workload:
             # per selected patch (454 029 at 512^3)
             extra["_instances_dtype"] = np.uint32
         self.ids = "uint32" if big else "uint16"
-        if world == 1:
+        self.mode = "resident"
+        if name in PROVIDER_WORKLOADS:
+            # ---- provider mode: nothing a rank holds is as large as the volume.  The rank's
+            # z-range is cut into tiles whose consensus fits next to one generated tile.
+            self.mode = "provider"
+            gshape = shape
+            self.gshape = gshape
+            extra["_instances_dtype"] = np.uint32
+            self.ids = "uint32"
+            own = tiling.slabs_of_rank(tiling.plan_slabs(gshape[0], world), rank, world)
+            if not own:
+                raise SystemExit("more ranks than z-slabs")
+            oz0, oz1 = own[0][0], own[-1][1]
+            lo, hi = tiling.local_range(own, gshape[0], ps)
+            fg = (device_labels(torch, (hi - lo, shape[1], shape[2]), cell, seed=0, z_offset=lo) != 0).to(torch.uint8)
+            free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+            tile_pred = 2.0 * int(np.prod(ps)) * 180 ** 3                  # one generated tile + halo
+            reserve = 150.0 * (oz1 - oz0 + 44) * shape[1] * shape[2] + tile_pred + 6e9
+            n, ny, nx = tiling.tiles_needed((oz1 - oz0, shape[1], shape[2]), ps, max(free - reserve, 0.25 * free),
+                                            safety=0.92, copies=2.0)
+            mine = [(oz0 + a, oz0 + b) for a, b in tiling.plan_slabs(oz1 - oz0, args.slabs or n)]
+            yx = tuple(args.yx) if args.yx else (ny, nx)
+            self.provider = SynthProvider(torch, gshape, ps, cell, kw)
+            self.tiles = (len(mine), yx[0], yx[1])
+            self.own_range = (oz0, oz1)
+
+            def step(flag_kw=kw):
+                inst, _ = tiling.assemble(self.provider, lo, gshape, fg, fg.clone(), fg, ps, mine, comm=comm,
+                                          _yx_tiles=yx, _gather_result=False, **dict(flag_kw, **extra))
+                return inst
+            self.pred = None
+        elif world == 1:
             self.gshape = shape
             P = backend.make_params(shape, ps, **kw)
             labels = device_labels(torch, shape, cell, seed=0)
@@ -248,14 +311,25 @@ class Workload:
                                       voxel_offset=glo * shape[1] * shape[2])
             self.pred = pred[:, lo - glo:hi - glo].contiguous()
             del labels_e, pred
-            fg = (device_labels(torch, gshape, cell, seed=0) != 0).to(torch.uint8)
+            # the fields of the rank's own slices only: the global stage runs sharded
+            fg = (device_labels(torch, (hi - lo, shape[1], shape[2]), cell, seed=0, z_offset=lo) != 0).to(torch.uint8)
+            # the rank's slab is cut into tiles whose consensus fits next to its prediction
+            free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+            oz0, oz1 = mine[0][0], mine[-1][1]
+            reserve = 150.0 * (hi - lo) * shape[1] * shape[2] + 6e9
+            n, ny, nx = tiling.tiles_needed((oz1 - oz0, shape[1], shape[2]), ps, max(free - reserve, 0.25 * free),
+                                            safety=0.92, copies=2.0)
+            mine = [(oz0 + a, oz0 + b) for a, b in tiling.plan_slabs(oz1 - oz0, args.slabs or n)]
+            yx = tuple(args.yx) if args.yx else (ny, nx)
+            self.tiles = (len(mine), yx[0], yx[1])
 
             def step(flag_kw=kw):
                 inst, _ = tiling.assemble(self.pred, lo, gshape, fg, fg.clone(), fg, ps, mine,
-                                          comm=comm, **dict(flag_kw, **extra))
+                                          comm=comm, _yx_tiles=yx, **dict(flag_kw, **extra))
                 return inst
         self.step = step
         self.fg_fraction = float(fg.float().mean().item())
+        self.world = world
 
     def free(self, torch):
         self.pred = None
@@ -391,6 +465,9 @@ def main():
     backend.HOST_TIMES = None
 
     C = int(np.prod(ps))
+    # per-rank HBM footprint: the allocator's peak (prediction / tile, consensus pool, lists, work
+    # space) -- the maximum over the ranks
+    peak_gb = agree_max(torch.cuda.max_memory_allocated() / 1e9)
     value = float(np.prod(gshape)) * args.steps / dt / 1e6
     roofline = None
     if ev.get("consensus"):
@@ -445,8 +522,15 @@ def main():
                        "instance_ids": wl.ids, "foreground_fraction": wl.fg_fraction,
                        "instances_found": count_instances(torch, inst),
                        "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
-                       "global_volume": list(gshape), "parallelism": "z-slabs x%d" % n_gpus if not args.yx else
-                       "z-slabs x%d, yx tiles %dx%d" % ((args.slabs or 1,) + tuple(args.yx)),
+                       "global_volume": list(gshape),
+                       "parallelism": ("z-ranges x%d ranks" % n_gpus) + (
+                           ", %d x %d x %d tiles per rank" % wl.tiles if getattr(wl, "tiles", None) else
+                           (", yx tiles %dx%d" % tuple(args.yx) if args.yx else "")),
+                       "prediction": "resident in HBM" if wl.mode == "resident" else
+                                     "generated tile by tile (provider): largest tile %.1f GB" % (wl.provider.bytes_max / 1e9),
+                       "result": "whole instance map on every rank" if wl.mode == "resident" else
+                                 "own z-range per rank (instances_found / crc32: rank 0's range %s)" % (list(wl.own_range),),
+                       "per_rank_peak_hbm_gb": peak_gb,
                        "host_allocator": allocator},
             "roofline": roofline,
             "roofline_other_kernels": roofline_other,

@@ -123,6 +123,16 @@ int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, 
  * parameters (then no COMPACT array and no ppp_cons_to_voxel_major are needed); 0 otherwise
  * (write COMPACT, then convert).  d_count must be NULL for that layout. */
 int ppp_consensus_writes_voxel_major(const ppp_params *p);
+/* ppp_consensus for p->cons_layout = PPP_CONS_VOXEL_MAJOR when the rows are only read by
+ * ppp_rank_patches_vm / ppp_patch_graph_by_patch: the entries S[w][-d] whose SOURCE voxel w - d
+ * lies outside cons_box are left UNDEFINED instead of being zeroed.  Those consumers never read
+ * them: a partner pixel of a patch that lies inside the volume is a voxel of the same window, and
+ * the caller's box holds every window it asks about (the tile grown by the radius for the scores,
+ * by radius + p - 1 for the pair rows); on a 144 x 152 x 152 box at 9^3 the zeroing pass is 8.7 GB
+ * of scattered 4-byte stores, 40 ms next to the kernel's 220.  Same interface and errors as
+ * ppp_consensus otherwise (fillConsensusArray.cu:5-218, normConsensusArray.cu:5-43). */
+int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
+                       const ppp_params *p, void *stream);
 
 /* --- S2: patch ranking ---------------------------------------------------------------
  * replaces rank_patches_cuda (ranked_patches.py:33-74) + kernel rankPatches
@@ -436,6 +446,15 @@ int ppp_mws_edges(const uint32_t *d_pairs, const float *d_aff, int64_t n_rows, c
 int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
                    float hi, float lo, float noise, uint64_t voxel_offset, const ppp_params *p,
                    void *stream);
+/* The same generator for a BOX of a larger volume (tile-wise generation, BASELINE config [3]:
+ * a rank of the 1024^3 workload holds one tile + halo of the prediction at a time).
+ * p: Z / Y / X = extent of the prediction box, origin_* = its position in the volume;
+ * d_labels: int32 labels over label_box = {z0, y0, x0, z1, y1, x1} (global), which must hold the
+ * box grown by the patch radius (clipped to global_dims = {Z, Y, X}); the noise counter is the
+ * global voxel's: bit-identical to ppp_synth_pred on the whole volume. */
+int ppp_synth_pred_box(const int32_t *d_labels, const int32_t *label_box, void *d_pred, int pred_dtype,
+                       uint32_t seed, float hi, float lo, float noise, const int32_t *global_dims,
+                       const ppp_params *p, void *stream);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "ppp_consensus": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_consensus_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_rank_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.POINTER(Box), ctypes.POINTER(Params),
@@ -180,6 +182,9 @@ _SIGNATURES = {
                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_uint64, ctypes.POINTER(Params),
                                       ctypes.c_void_p]),
+    "ppp_synth_pred_box": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                          ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_host_mws": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
@@ -402,7 +407,7 @@ def to_device_pred(pred, device="cuda", keep_f16=True):
 # ----------------------------------------------------------------------------------------
 # device stages
 # ----------------------------------------------------------------------------------------
-def consensus(pred, overlap, P, want_count=False, out=None):
+def consensus(pred, overlap, P, want_count=False, out=None, open_rows=False):
     """S1.  Returns cons (and count) as device float32 tensors shaped
     [planes, bz, by, bx] (compact), [bz, by, bx, W] (voxel-major) or [NSZ, NSY, NSX, Z, Y, X]
     (reference layout).  out: a flat float32 device tensor to carve the result from (the tiled
@@ -425,8 +430,13 @@ def consensus(pred, overlap, P, want_count=False, out=None):
     note_add("s1_base_voxels", int(np.prod(P.cons_box.shape())))
     note_add("s1_output_bytes", 4 * n_el)
     with _timed("consensus"):
-        check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
-                              _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
+        if open_rows and P.cons_layout == CONS_VOXEL_MAJOR and cnt is None:
+            # rows for the library's own consumers: no zeroing of entries they never read
+            check(L.ppp_consensus_rows(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
+                                       _dev_ptr(cons), ctypes.byref(P), _stream()))
+        else:
+            check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
+                                  _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
     note("s1_kernel", L.ppp_consensus_kernel_name().decode())
     return (cons, cnt) if want_count else cons
 
@@ -729,14 +739,14 @@ def direct_voxel_major(P):
         lib().ppp_consensus_writes_voxel_major(ctypes.byref(Pv)) == 1
 
 
-def consensus_voxel_major(pred, overlap, P, out=None):
+def consensus_voxel_major(pred, overlap, P, out=None, open_rows=False):
     """S1 straight into the symmetric voxel-major layout when the library can do that for these
     parameters (ppp_consensus_writes_voxel_major), else COMPACT + ppp_cons_to_voxel_major.
     Returns (tensor [bz, by, bx, W], params with cons_layout = VOXEL_MAJOR).  out: see consensus."""
     Pv = P.copy()
     Pv.cons_layout = CONS_VOXEL_MAJOR
     if direct_voxel_major(P):
-        return consensus(pred, overlap, Pv, out=out), Pv
+        return consensus(pred, overlap, Pv, out=out, open_rows=open_rows), Pv
     Pc = P.copy()
     Pc.cons_layout = CONS_COMPACT
     cons = consensus(pred, overlap, Pc)
@@ -909,6 +919,25 @@ def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True, voxel_
     check(lib().ppp_synth_pred(_dev_ptr(labels), _dev_ptr(pred), F16 if f16 else F32,
                                int(seed) & 0xFFFFFFFF, hi, lo, noise, int(voxel_offset),
                                ctypes.byref(P), _stream()))
+    return pred
+
+
+def synth_pred_box(labels, label_box, box, gshape, patchshape, flags, seed=0, hi=0.95, lo=0.05,
+                   noise=0.04, f16=True):
+    """ppp_synth_pred for a box (z0, z1, y0, y1, x0, x1) of a volume of shape gshape.  labels:
+    int32 device tensor over label_box (z0, z1, y0, y1, x0, x1), the box grown by the patch radius
+    (clipped).  Returns (C, bz, by, bx)."""
+    torch = _torch()
+    z0, z1, y0, y1, x0, x1 = [int(v) for v in box]
+    P = make_params((z1 - z0, y1 - y0, x1 - x0), patchshape, origin=(z0, y0, x0), **flags)
+    C = P.pz * P.py * P.px
+    pred = torch.empty((C,) + P.shape, dtype=torch.float16 if f16 else torch.float32, device=labels.device)
+    lb = np.ascontiguousarray([label_box[0], label_box[2], label_box[4], label_box[1], label_box[3],
+                               label_box[5]], dtype=np.int32)
+    gd = np.ascontiguousarray(gshape, dtype=np.int32)
+    check(lib().ppp_synth_pred_box(_dev_ptr(labels.contiguous()), _np_ptr(lb), _dev_ptr(pred),
+                                   F16 if f16 else F32, int(seed) & 0xFFFFFFFF, hi, lo, noise,
+                                   _np_ptr(gd), ctypes.byref(P), _stream()))
     return pred
 
 

@@ -157,6 +157,22 @@ int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, 
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus");
 }
 
+int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
+                       const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_cons) return fail(PPP_ERR_INVALID_ARG, "NULL pred / outputs");
+    if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    if (G.layout != PPP_CONS_VOXEL_MAJOR || !ppp::consensus_v3_supported(G))
+        return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus_rows writes VOXEL_MAJOR rows with the packed kernel only "
+                                         "(see ppp_consensus_writes_voxel_major)");
+    PPP_TRY(need_device());
+    G.vm_open = 1;
+    hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, nullptr, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus_rows");
+}
+
 int ppp_consensus_writes_voxel_major(const ppp_params *p) {
     ppp::Geo G;
     if (!p || make_geo(p, &G) != PPP_OK) return 0;
@@ -517,6 +533,26 @@ int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_synth(d_labels, d_pred, pred_dtype, seed, hi, lo, noise, voxel_offset, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred");
+}
+
+int ppp_synth_pred_box(const int32_t *d_labels, const int32_t *label_box, void *d_pred, int pred_dtype,
+                       uint32_t seed, float hi, float lo, float noise, const int32_t *global_dims,
+                       const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_labels || !d_pred || !label_box || !global_dims) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    const int lo3[3] = {G.oz, G.oy, G.ox}, ext[3] = {G.Z, G.Y, G.X}, rad[3] = {G.rz, G.ry, G.rx};
+    for (int a = 0; a < 3; ++a) {
+        const int need_lo = lo3[a] - rad[a] < 0 ? 0 : lo3[a] - rad[a];
+        const int need_hi = lo3[a] + ext[a] + rad[a] > global_dims[a] ? global_dims[a] : lo3[a] + ext[a] + rad[a];
+        if (lo3[a] < 0 || lo3[a] + ext[a] > global_dims[a] || label_box[a] > need_lo || label_box[3 + a] < need_hi)
+            return fail(PPP_ERR_INVALID_ARG, "label box must hold the prediction box grown by the patch radius");
+    }
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_synth_box(d_labels, label_box, d_pred, pred_dtype, seed, hi, lo, noise, global_dims,
+                                         G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred_box");
 }
 
 int64_t ppp_cover_workspace_bytes(int64_t n, const ppp_params *p) {

@@ -110,6 +110,57 @@ __global__ void __launch_bounds__(256)
     else pred[(long long)r * G.V + v] = __half2float(h);
 }
 
+// The same generator for a BOX of a larger volume (tile-wise generation: a rank of the 1024^3
+// workload never holds more than one tile + halo of the prediction).  pred: (C, bz, by, bx) for
+// the box at G.oz / oy / ox (G.Z / Y / X = box extent); labels: an int32 array over the label box
+// lb = (z0, y0, x0, z1, y1, x1) that holds the box grown by the patch radius (clipped to the
+// volume gdim); the noise counter is that of the GLOBAL voxel: bit-identical to generating the
+// whole volume at once.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    synth_box_kernel(const int32_t *__restrict__ labels, T *__restrict__ pred, uint32_t seed_mix,
+                     float hi, float lo, float noise, const int lz0, const int ly0, const int lx0,
+                     const int lY, const int lX, const int gZ, const int gY, const int gX, const Geo G) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= G.V) return;
+    const int r = blockIdx.y;
+    const int x = (int)(v % G.X) + G.ox;
+    const long long t = v / G.X;
+    const int y = (int)(t % G.Y) + G.oy, z = (int)(t / G.Y) + G.oz;
+    const int nz = z + r / (G.py * G.px) - G.rz;
+    const int ny = y + (r / G.px) % G.py - G.ry;
+    const int nx = x + r % G.px - G.rx;
+    auto lab_at = [&](int gz, int gy, int gx) -> int {
+        return labels[((long long)(gz - lz0) * lY + (gy - ly0)) * lX + (gx - lx0)];
+    };
+    const int lab = lab_at(z, y, x);
+    int nb = -1;
+    if (nz >= 0 && nz < gZ && ny >= 0 && ny < gY && nx >= 0 && nx < gX) nb = lab_at(nz, ny, nx);
+    const float base = (nb == lab && lab != 0) ? hi : lo;
+    const unsigned long long glin = ((unsigned long long)z * gY + y) * gX + x;
+    const uint32_t ctr = (uint32_t)(glin * (unsigned long long)G.C + (unsigned long long)r + (unsigned long long)seed_mix);
+    const float u = (float)(hash_u32(ctr) >> 8) * (1.0f / 16777216.0f);
+    const float val = base + noise * (2.0f * u - 1.0f);
+    const __half h = __float2half_rn(val);
+    if constexpr (sizeof(T) == 2) pred[(long long)r * G.V + v] = h;
+    else pred[(long long)r * G.V + v] = __half2float(h);
+}
+
+hipError_t launch_synth_box(const int32_t *labels, const int *lb, void *pred, int dtype, uint32_t seed,
+                            float hi, float lo, float noise, const int *gdim, const Geo &G, hipStream_t s) {
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
+    const dim3 grid((unsigned)((G.V + 255) / 256), (unsigned)G.C);
+    const uint32_t seed_mix = (uint32_t)(((unsigned long long)seed * 0x9E3779B1ull) & 0xFFFFFFFFull);
+    const int lY = lb[4] - lb[1], lX = lb[5] - lb[2];
+    if (dtype == PPP_F16)
+        synth_box_kernel<__half><<<grid, dim3(256), 0, s>>>(labels, (__half *)pred, seed_mix, hi, lo, noise,
+                                                           lb[0], lb[1], lb[2], lY, lX, gdim[0], gdim[1], gdim[2], G);
+    else
+        synth_box_kernel<float><<<grid, dim3(256), 0, s>>>(labels, (float *)pred, seed_mix, hi, lo, noise,
+                                                          lb[0], lb[1], lb[2], lY, lX, gdim[0], gdim[1], gdim[2], G);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
                         float lo, float noise, unsigned long long voxel_offset, const Geo &G,
                         hipStream_t s) {

@@ -34,6 +34,7 @@ struct Geo {
     int wy, wx;         // 2py-1, 2px-1 (compact plane grid)
     int n_planes;       // compact: ((2pz-1)(2py-1)(2px-1)-1)/2
     int oz, oy, ox;     // global coordinate of local voxel (0,0,0)
+    int vm_open;        // voxel-major output: entries with a source outside the box stay undefined
 };
 
 // A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch

@@ -610,7 +610,7 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
     PPP_GRID_CHECK(n_blocks, 64 * V3_WAVES);
     if (((long long)(PX - 1) * G.V + 2ll * G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
-    if (G.layout == PPP_CONS_VOXEL_MAJOR) {
+    if (G.layout == PPP_CONS_VOXEL_MAJOR && !G.vm_open) {
         const hipError_t ez = launch_vm_zero(cons, G, n_rows, s);
         if (ez != hipSuccess) return ez;
     }

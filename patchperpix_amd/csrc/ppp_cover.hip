@@ -44,6 +44,9 @@ struct CoverWork {
     int32_t *counters;                   // [COVER_BATCH]
     int32_t *loc_vol;                    // [V] sharded cover only: index into the rank's own
                                          // state / cleared / bits tables, -1 off the own centres
+    uint8_t *witness;                    // [V] pix_th == 0: a window row (dz * py + dy) on which
+                                         // the patch centred here still covered a voxel at its
+                                         // last recount; 0xFF = none known
 };
 
 // words per row of the bit mask: one spare word so a window may be read as two words
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
     cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                        uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
-                       const int32_t *__restrict__ loc_vol, const Geo G) {
+                       const int32_t *__restrict__ loc_vol, uint8_t *__restrict__ witness, const Geo G) {
     __shared__ uint16_t s_list[COUNT_THREADS];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
@@ -152,6 +155,23 @@ __global__ void __launch_bounds__(COUNT_THREADS)
         const int start = cx - G.rx, wi = start >> 5, sh = start & 31;
         const bool two = sh + G.px > 32;
         const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
+        // pix_th == 0: "does the patch still cover ANY voxel" -- a patch is recounted every time a
+        // neighbour within p-1 is selected (hundreds of times on a dense volume) and nearly always
+        // survives: first look at the window row that held a hit last time (one row instead of a
+        // plane of rows); only when that row is exhausted is the window scanned again, and the
+        // first row with a hit becomes the new witness.
+        const bool use_wit = pix_th == 0 && witness != nullptr;
+        if (use_wit) {
+            const int wr = witness[v];
+            if (wr != 0xFF) {
+                const uint32_t *row = mbits + ((long long)(cz + wr / G.py - G.rz) * G.Y + (cy + wr % G.py - G.ry)) * XW;
+                if (bit_window(row, start, G.px, XW) & bit_window(b, wr * G.px, G.px, words)) {
+                    *n_alive = 1;
+                    continue;
+                }
+            }
+        }
+        int wit_new = 0xFF;
         // sliding 64-bit window over the patch's bit string
         unsigned long long win = b[0] | ((unsigned long long)(words > 1 ? b[1] : 0u) << 32);
         int have = 64, next = 2, hits = 0;
@@ -173,7 +193,9 @@ __global__ void __launch_bounds__(COUNT_THREADS)
                 for (int dy = 0; dy < MAXPY; ++dy) {
                     if (dy < G.py) {
                         const unsigned long long mw = lo[dy] | ((unsigned long long)hi[dy] << 32);
-                        hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                        const int rh = __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                        if (rh && wit_new == 0xFF) wit_new = dz * G.py + dy;
+                        hits += rh;
                         win >>= G.px;
                         have -= G.px;
                         if (have <= 32) {
@@ -187,7 +209,9 @@ __global__ void __launch_bounds__(COUNT_THREADS)
                 for (int dy = 0; dy < G.py; ++dy, row += XW) {
                     unsigned long long mw = row[0];
                     if (two) mw |= (unsigned long long)row[1] << 32;
-                    hits += __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                    const int rh = __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
+                    if (rh && wit_new == 0xFF) wit_new = dz * G.py + dy;
+                    hits += rh;
                     win >>= G.px;
                     have -= G.px;
                     if (have <= 32) {
@@ -202,6 +226,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
             state[k] = 2;
             rank_vol[v] = RANK_NONE;
         } else {
+            if (use_wit && wit_new < 0xFF) witness[v] = (uint8_t)wit_new;
             *n_alive = 1;
         }
     }
@@ -359,7 +384,7 @@ static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 size_t cover_workspace_bytes(long long n, const Geo &G) {
     (void)n;
-    return 4 * up256((size_t)G.V * 4) + up256((size_t)G.V) +
+    return 4 * up256((size_t)G.V * 4) + 2 * up256((size_t)G.V) +
            up256((size_t)G.Z * G.Y * row_words(G) * 4) + 256;
 }
 
@@ -372,7 +397,8 @@ static CoverWork carve(void *work, const Geo &G) {
     W.dirty = (uint8_t *)p;    p += up256((size_t)G.V);
     W.mbits = (uint32_t *)p;   p += up256((size_t)G.Z * G.Y * row_words(G) * 4);
     W.counters = (int32_t *)p; p += 256;
-    W.loc_vol = (int32_t *)p;
+    W.loc_vol = (int32_t *)p;  p += up256((size_t)G.V * 4);
+    W.witness = (uint8_t *)p;
     return W;
 }
 
@@ -387,6 +413,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
     hipError_t e;
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;   // count everything once
+    if ((e = hipMemsetAsync(W.witness, 0xFF, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
     const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
     const long long n_words = (long long)G.Z * G.Y * row_words(G);
@@ -398,7 +425,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
         const dim3 cgrid((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), cblock(COUNT_THREADS);
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<cgrid, cblock, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
-                                                       W.counters + r, nullptr, G);
+                                                       W.counters + r, nullptr, W.witness, G);
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
             minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
@@ -485,7 +512,17 @@ static ThinWork carve_thin(void *work, long long n, const Geo &G) {
 __global__ void __launch_bounds__(256)
     thin_init_kernel(const long long *__restrict__ lin, int n, long long *__restrict__ key_vol) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) key_vol[lin[k]] = (THIN_MAXC << 32) | (long long)k;   // count not known yet
+    // (count not known yet.)  A centre listed twice -- possible in a list from outside, never in
+    // one made by the greedy cover -- keeps its FIRST index, like the reference's np.argmax: the
+    // later copy has the same voxel set, which is empty once the first is kept.
+    if (k < n) atomicMin(&key_vol[lin[k]], (THIN_MAXC << 32) | (long long)k);
+}
+// ... and the later copies are retired at once
+__global__ void __launch_bounds__(256)
+    thin_dups_kernel(const long long *__restrict__ lin, int n, const long long *__restrict__ key_vol,
+                     int32_t *__restrict__ state) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && (int)(key_vol[lin[k]] & 0xFFFFFFFFll) != k) state[k] = 2;
 }
 
 // set voxels of the bit mask that are interior voxels of the volume (thread per mask word)
@@ -663,6 +700,7 @@ hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long 
     cover_pack_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(mask, W.mbits, G);
     thin_interior_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(W.mbits, W.interior, G);
     thin_init_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(lin, (int)n, W.key_vol);
+    thin_dups_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(lin, (int)n, W.key_vol, W.state);
     int32_t n_alive = 1;
     while (n_alive > 0) {
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
@@ -733,6 +771,7 @@ hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.loc_vol, 0xFFFFFFFF, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.witness, 0xFF, (size_t)G.V, s)) != hipSuccess) return e;
     if (n && (e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
     const dim3 block(256);
@@ -750,7 +789,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
     hipError_t e;
     if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
     cover_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
-        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, G);
+        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, W.witness, G);
     return hipGetLastError();
 }
 

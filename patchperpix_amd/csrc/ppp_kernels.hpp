@@ -16,8 +16,6 @@ hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uin
                        float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
 hipError_t launch_rank_v2(const void *pred, int dtype, const float *cons, const uint8_t *ov,
                           float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
-hipError_t launch_rank_v3(const void *pred, int dtype, const float *cons, const uint8_t *ov,
-                          float *score, const ppp_box &sb, const Geo &G, int kz, hipStream_t s);
 bool rank_vm_supported(const Geo &G);
 size_t rank_vm_workspace_bytes(const ppp_box &sb, const Geo &G);
 hipError_t launch_rank_vm(const void *pred, int dtype, const float *S, const uint8_t *ov, float *score,
@@ -74,6 +72,9 @@ hipError_t launch_patch_bits_volume(const void *pred, int dtype, float thresh, u
 hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t seed, float hi,
                         float lo, float noise, unsigned long long voxel_offset, const Geo &G,
                         hipStream_t s);
+
+hipError_t launch_synth_box(const int32_t *labels, const int *lb, void *pred, int dtype, uint32_t seed,
+                            float hi, float lo, float noise, const int *gdim, const Geo &G, hipStream_t s);
 
 size_t cover_workspace_bytes(long long n, const Geo &G);
 hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,

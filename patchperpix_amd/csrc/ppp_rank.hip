@@ -10,10 +10,6 @@
 
 #include "ppp_kernels.hpp"
 
-#ifndef PPP_RANK_KZ_DEFAULT
-#define PPP_RANK_KZ_DEFAULT 1
-#endif
-
 namespace ppp {
 
 template <typename T>
@@ -88,16 +84,6 @@ hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uin
     // specialised kernel for px in {3,5,7,9}; PPP_RANK_GENERIC=1 forces the generic one
     static const bool force_generic = getenv("PPP_RANK_GENERIC") != nullptr;
     if (!force_generic) {
-        // PPP_RANK_KZ centres stacked along z per lane (ppp_rank_v3.hip; 1 = ppp_rank_v2.hip).
-        // Measured at 140^3 / 7^3: 1 -> 195 ms, 2 -> 216 ms, 3 -> 299 ms: the shared gathers
-        // (0.65x / 0.55x per centre) do not pay for the halved occupancy (the per-centre bit
-        // masks double the LDS per wave: 14 instead of 28 waves per CU); default 1.
-        const char *kz_env = getenv("PPP_RANK_KZ");
-        const int kz = kz_env ? atoi(kz_env) : PPP_RANK_KZ_DEFAULT;
-        if (kz > 1 && sb.z1 - sb.z0 >= kz && G.pz > 1) {
-            const hipError_t e3 = launch_rank_v3(pred, dtype, cons, ov, score, sb, G, kz, s);
-            if (e3 != hipErrorNotSupported) return e3;
-        }
         const hipError_t e2 = launch_rank_v2(pred, dtype, cons, ov, score, sb, G, s);
         if (e2 != hipErrorNotSupported) return e2;
     }

@@ -82,6 +82,7 @@ static RankWork carve_rank(void *work, const Geo &G) {
 hipError_t run_rank_order(const float *score, const uint8_t *fg, long long *lin, float *out_score,
                           long long *n_out, void *work, const Geo &G, hipStream_t s) {
     PPP_GRID_CHECK((G.V + 255) / 256, 256);
+    if (G.V >= (1ll << 31)) return hipErrorInvalidValue;   // voxel indices travel as int32
     RankWork W = carve_rank(work, G);
     const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
     rank_flags_kernel<<<vgrid, block, 0, s>>>(fg, W.flags, G);

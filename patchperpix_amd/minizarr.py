@@ -156,12 +156,14 @@ def blosc_decode(frame, unshuffle=True):
                 _codec_decode(codec, buf, pos, cs, out, dst, neblock)
             pos += cs
             dst += neblock
-        if unshuffle and shuffle and typesize > 1:
+        # c-blosc applies the BIT shuffle whenever its flag is set (also to 1-byte types: masks,
+        # numinst, raw); only the BYTE shuffle is a no-op for typesize 1
+        if unshuffle and (shuffle == "bit" or (shuffle == "byte" and typesize > 1)):
             blk = out[b * blocksize:b * blocksize + bsize]
             blk[:] = bit_unshuffle(blk, typesize) if shuffle == "bit" else byte_unshuffle(blk, typesize)
     if unshuffle:
         return out
-    return out, typesize, blocksize, (shuffle if typesize > 1 else None)
+    return out, typesize, blocksize, (shuffle if (shuffle == "bit" or typesize > 1) else None)
 
 
 def _codec_decode(codec, src, pos, csize, out, dst, nout):
@@ -192,8 +194,8 @@ def blosc_encode(data, typesize, cname="zstd", clevel=3, shuffle="bit", blocksiz
         blocksize = max(typesize, min(nbytes, 1 << 18) // typesize * typesize) if nbytes else typesize
     nblocks = (nbytes + blocksize - 1) // blocksize if nbytes else 0
     flags = BLOSC_DONT_SPLIT | (codec_id << 5)
-    if typesize > 1 and shuffle == "bit":
-        flags |= BLOSC_DOBITSHUFFLE
+    if shuffle == "bit":
+        flags |= BLOSC_DOBITSHUFFLE          # (also for typesize 1, like c-blosc)
     elif typesize > 1 and shuffle == "byte":
         flags |= BLOSC_DOSHUFFLE
     streams = []
@@ -307,7 +309,9 @@ class Array:
         if c is None:
             return arr.tobytes()
         if c["id"] == "blosc":
-            shuffle = {0: None, 1: "byte", 2: "bit", -1: "byte"}[int(c.get("shuffle", 1))]
+            # (-1 = AUTOSHUFFLE: numcodecs takes the bit shuffle for 1-byte types, the byte shuffle otherwise)
+            shuffle = {0: None, 1: "byte", 2: "bit", -1: "bit" if self.dtype.itemsize == 1 else "byte"}[
+                int(c.get("shuffle", 1))]
             return blosc_encode(arr.view(np.uint8).reshape(-1), self.dtype.itemsize,
                                 cname=c.get("cname", "zstd"), clevel=c.get("clevel", 3), shuffle=shuffle,
                                 blocksize=c.get("blocksize") or None)

@@ -229,7 +229,10 @@ class DeviceOps:
         return backend.cons_to_voxel_major(cons, P)
 
     def consensus_voxel_major(self, pred, ov, P, out=None):
-        return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P, out=out)
+        # (rows only read by the ranking and patch-graph kernels of patches inside the volume:
+        # entries beyond the box need no zeroing, ppp_consensus_rows)
+        return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P, out=out,
+                                             open_rows=os.environ.get("PPP_VM_OPEN", "1") != "0")
 
     def voxel_major_pool(self, P, n_voxels):
         """One flat buffer for the voxel-major consensus of every tile (both passes) when S1

@@ -97,6 +97,38 @@ def test_decode_hand_assembled_frames():
     assert np.array_equal(mz.blosc_decode(fr), data)
 
 
+def test_bitshuffled_one_byte_type():
+    """c-blosc applies the bit shuffle to 1-byte types too (masks, numinst, raw).  A
+    frame assembled by hand -- the shuffled block written out with plain loops: plane k holds bit k
+    of every element, element e at bit e % 8 of byte e // 8 -- must decode; and the writer sets the
+    flag for typesize 1 (explicit BITSHUFFLE and AUTOSHUFFLE = -1)."""
+    rng = np.random.default_rng(4)
+    data = rng.integers(0, 256, size=40, dtype=np.uint8)          # 40 elements: a multiple of 8
+    n = len(data)
+    shuffled = np.zeros(n, dtype=np.uint8)
+    for k in range(8):
+        for e in range(n):
+            if (int(data[e]) >> k) & 1:
+                shuffled[k * (n // 8) + e // 8] |= 1 << (e % 8)
+    fr = _frame(1, mz.BLOSC_DONT_SPLIT | mz.BLOSC_DOBITSHUFFLE | (3 << 5), n, n,
+                [[zlib.compress(shuffled.tobytes())]])
+    assert np.array_equal(mz.blosc_decode(fr), data)
+    out, ts, bs, kind = mz.blosc_decode(fr, unshuffle=False)
+    assert kind == "bit" and ts == 1 and np.array_equal(out, shuffled)
+    fr2 = mz.blosc_encode(data, 1, shuffle="bit")
+    assert fr2[2] & mz.BLOSC_DOBITSHUFFLE and np.array_equal(mz.blosc_decode(fr2), data)
+
+
+def test_autoshuffle_one_byte_array(tmp_path):
+    g = mz.open(str(tmp_path / "a.zarr"), "w")
+    a = (np.arange(4 * 6 * 8).reshape(4, 6, 8) % 3).astype(np.uint8)
+    g.create_dataset("volumes/numinst", data=a, chunks=(2, 6, 8),
+                     compressor={"id": "blosc", "cname": "zstd", "clevel": 3, "shuffle": -1, "blocksize": 0})
+    assert np.array_equal(mz.open(str(tmp_path / "a.zarr"), "r")["volumes/numinst"][:], a)
+    raw = open(tmp_path / "a.zarr" / "volumes" / "numinst" / "0.0.0", "rb").read()
+    assert raw[2] & mz.BLOSC_DOBITSHUFFLE
+
+
 def test_bit_shuffle_layout():
     """bitshuffle's layout: plane (byte j, bit k) = j * 8 + k, element e at bit e % 8 of byte e // 8."""
     el = np.zeros(16, dtype=np.uint16)

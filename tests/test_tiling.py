@@ -505,3 +505,84 @@ def test_ranks_gloo_provider_local_fields(tmp_path, world, extra, gather, monkey
         assert notes[0] == world
         n_ranked += int(notes[1])
     assert n_ranked == len(ref["ranked_coords"])       # every patch was ranked by exactly one rank
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ps,shape,cell,n_slabs,yx,flagset", [
+    ((5, 5, 5), (30, 34, 38), 8, 2, (2, 2), "nothin_cc"),
+    ((7, 7, 7), (30, 34, 38), 10, 2, (2, 2), "shipped"),
+    ((9, 9, 9), (40, 30, 34), 11, 2, (1, 2), "shipped"),
+])
+def test_provider_and_sharded_stage_gpu(ps, shape, cell, n_slabs, yx, flagset):
+    """The real kernels through a prediction provider (a frame per tile and pass, origins in all
+    three axes) and with the sharded global stage forced on: same result as the untiled path."""
+    from patchperpix_amd import flags as flagsets
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    c = synth.make_case(shape, ps, seed=73, cell=[cell] * 3, overlap_frac=0.02)
+    kw = dict(flagsets.FLAG_SETS[flagset])
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), list(ps), **dict(kw, _n_slabs=1))
+    assert want.any()
+    slabs = tiling.plan_slabs(shape[0], n_slabs)
+    prov = ArrayProvider(c["pred"].astype(np.float16), device="cuda")
+    for sharded in (False, True):
+        got, _ = tiling.assemble(prov, 0, shape, c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), list(ps), slabs, _yx_tiles=yx,
+                                 _sharded_global=sharded, **kw)
+        assert np.array_equal(got, want), "sharded=%s" % sharded
+
+
+GPU_WORKER_SHARDED = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+from patchperpix_amd import synth, tiling, backend
+from patchperpix_amd import flags as flagsets
+from test_tiling import ArrayProvider
+torch.cuda.set_device(0)                      # every rank on the one GPU of the box
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+shape, ps = {shape!r}, {ps!r}
+c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+kw = dict(flagsets.FLAG_SETS[os.environ.get("PPP_TEST_FLAGSET", "shipped")])
+Z = shape[0]
+slabs = tiling.plan_slabs(Z, world)
+mine = tiling.slabs_of_rank(slabs, rank, world)
+lo, hi = tiling.local_range(mine, Z, ps)
+loc = lambda a: np.ascontiguousarray(a[lo:hi])
+inst, fg = tiling.assemble(ArrayProvider(c["pred"].astype(np.float16), device="cuda"), lo, shape,
+                           loc(c["foreground"]), loc(c["foreground"]).copy(), loc(c["numinst"]),
+                           list(ps), mine, comm=tiling.TorchDistComm(), _yx_tiles=(2, 1),
+                           _gather_result=False, _instances_dtype=np.uint32, **kw)
+np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+np.save(os.path.join({out!r}, "range_rank%d.npy" % rank), np.array([mine[0][0], mine[-1][1]]))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,ps,flagset", [(2, (7, 7, 7), "shipped"), (3, (5, 5, 5), "cc")])
+def test_ranks_provider_local_fields_share_one_gpu(tmp_path, world, ps, flagset):
+    """BASELINE config [3]'s execution mode with the real kernels: `world` processes (sharing the
+    one GPU, gloo transport), each with its own slices of the fields, the prediction through a
+    provider, sharded sort / cover, uint32 ids, own-slab results: stacked, they equal the
+    instance map of one process."""
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    from patchperpix_amd import flags as flagsets
+    shape = (72, 26, 30)
+    c = synth.make_case(shape, ps, seed=66, cell=[9, 9, 9], overlap_frac=0.02)
+    want, _ = vi.to_instance_seg(c["pred"].copy(), c["foreground"].copy(), c["foreground"].copy(),
+                                 c["numinst"].copy(), list(ps),
+                                 **dict(flagsets.FLAG_SETS[flagset], _n_slabs=1))
+    script = tmp_path / "gpu_worker_sharded.py"
+    script.write_text(GPU_WORKER_SHARDED.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29599", OMP_NUM_THREADS="1",
+               PPP_TEST_FLAGSET=flagset)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                           "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                           "--master-port", "29599", str(script)], env=env, timeout=900)
+    assert want.any()
+    for r in range(world):
+        z0, z1 = [int(v) for v in np.load(tmp_path / ("range_rank%d.npy" % r))]
+        inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
+        assert inst.dtype == np.uint32 and np.array_equal(inst, want[z0:z1]), "rank %d differs" % r
