@@ -14,7 +14,7 @@ stated on, with the reference's SHIPPED flylight flag set (``--flags shipped``: 
 and thinning on; exact entries in the JSON's config.flags) and the uint32 instance ids of the
 reference's blockwise entry.  A step of that volume takes the better part of a minute; so that a
 default run always ends inside the driver's window, the first warm-up step is timed and, if
-(W + K) steps would exceed PPP_BENCH_BUDGET_S (default 1400 s), the timed loop falls back to
+(W + K) steps would exceed PPP_BENCH_BUDGET_S (default 1500 s), the timed loop falls back to
 ``flylight140_p7`` (configs[1]) and the one 512^3 step is reported as ``config2_end_to_end``.
 
 At N = 1 the same line also carries
@@ -403,7 +403,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    budget_s = float(os.environ.get("PPP_BENCH_BUDGET_S", "1400"))
+    budget_s = float(os.environ.get("PPP_BENCH_BUDGET_S", "1500"))
     auto = args.workload is None
     wl = Workload(torch, args.workload or DEFAULT_WORKLOAD, kw, args, world, rank, comm)
     barrier()

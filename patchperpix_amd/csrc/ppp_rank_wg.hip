@@ -22,6 +22,18 @@
 //     the P bits (low nibble) and the N bits (high nibble) of the four partners 16 k + 4 j .. + 3 --
 //     so that ONE byte indexes ONE 256-entry table of four float16 coefficients (2 KB; 8-byte
 //     reads): 0.25 table reads and 0.25 address operations per term instead of 0.25 + 0.6.
+//
+// Measured and dropped on a 128^3 / 9^3 launch (this kernel: 204 ms; profiles/r03_e_pmc_s2_wg_*,
+// r03_f_s2_variants_timing.txt; all bit-identical):
+//   * a two-line row image of 8-byte elements {S[q], S[q + one line]} read by ds_read_b64 (256
+//     instead of 128 B per LDS cycle, 12 instead of 16 waves per CU): 227 ms -- fewer LDS cycles
+//     (4.6 vs 6.7 * 10^10) but the LDS is only half busy in either form;
+//   * a slot-stationary form (a centre always meets the same lane, masks and accumulator stay in
+//     registers for the p rows of an x-run: a ninth of the mask loads, which are 60 % of this
+//     kernel's 482 GB of fetches): 402 ms -- one 12-wave workgroup per CU does one chunk per
+//     barrier interval and nothing overlaps the row publication.
+// What holds the kernel back is neither unit alone (VALU 24 %, LDS 54 % busy of which half bank
+// conflicts, 2.35 TB/s of fetches) but the stalls of its dependent chains at 16 waves per CU.
 #include <stdlib.h>
 #include <string.h>
 
@@ -334,238 +346,11 @@ __global__ void __launch_bounds__(64 * RW_WAVES, 4)
     }
 }
 
-// ---- two-line row image: 8-byte LDS elements ------------------------------------------------
-// The b32 kernel above is bound by its row reads: one ds_read_b32 per term moves 128 B per LDS
-// cycle, and the lanes of a half-wave (runs of 8-9 consecutive ax, 17 apart per ay) collide on
-// the 32 banks 2.4-fold at 9^3.  Here the row image holds 8-byte elements
-//     E[q] = { S[u][q], S[u][q + one line] }            (q = (qz, qy, qx), one line = qy + 1)
-// so that ONE ds_read_b64 -- 256 B per LDS cycle, always 8-byte aligned whatever the parity of
-// the lane's offset -- fetches the operands of partner b and of the partner one patch line
-// further (same bz, by + 1, bx); the second value waits in a register for its turn (the fma
-// chain stays in partner order: line by, then line by + 1).  Twice the LDS per row image (39 KB
-// at 9^3: three workgroups = 12 waves per CU), half the LDS cycles per term.
-template <int PZ, int PY, int PX, int TZ, int TY, int TX>
-__global__ void __launch_bounds__(64 * RW_WAVES, 3)
-    rank_wg2_kernel(const float *__restrict__ S, const uint32_t *__restrict__ M,
-                    const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
-                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
-                    const int tiles_x, const int n_tiles) {
-    constexpr int C = PZ * PY * PX, W16 = (C + 15) / 16, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
-    constexpr int WZ = 2 * PZ - 1, WY = 2 * PY - 1, WX = 2 * PX - 1, W = WZ * WY * WX, LC = (W - 1) / 2;
-    constexpr int NTHR = 64 * RW_WAVES;
-    constexpr int NST = (W + NTHR - 1) / NTHR;
-    constexpr int NT = TZ * TY * TX;
-    constexpr int UB = (TZ + 2 * RZ) * (TY + 2 * RY) * (TX + 2 * RX);
-    constexpr int NSEG = PZ * ((PY + 1) / 2);           // line pairs (+ the odd last line) per patch
-    typedef float v2f_t __attribute__((ext_vector_type(2)));
-    __shared__ v2f_t rowimg[W + 2 * RW_PAD];
-    __shared__ float accs[NT];
-    __shared__ uint32_t act_bits[(NT + 31) / 32];
-    __shared__ uint2 coefT[256];
-    __shared__ uint32_t uvalid_bits[(UB + 63) / 64 * 2];
-    __shared__ int any_act;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
-    const long long sbV = (long long)sX * sY * sZ;
-    const int n_blocks = gridDim.x;
-    const int per_xcd = (n_blocks + 7) / 8;
-    const int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (bid >= n_tiles) return;
-    const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
-    const int c0z = sb.z0 + tz_i * TZ, c0y = sb.y0 + ty_i * TY, c0x = sb.x0 + tx_i * TX;
-    const int tz = min(TZ, sb.z1 - c0z), ty = min(TY, sb.y1 - c0y), tx = min(TX, sb.x1 - c0x);
-    if (tz <= 0 || ty <= 0 || tx <= 0) return;
-    auto sb_index = [&](int lz, int ly, int lx) -> long long {
-        return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
-    };
-    {
-        const int e = tid;
-        uint32_t h[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h[i] = ((e >> i) & 1) ? 0x2800u : (((e >> (4 + i)) & 1) ? 0xA800u : 0u);
-        coefT[e] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    }
-    if (tid == 0) any_act = 0;
-    __syncthreads();
-    static_assert(NT % 64 == 0, "tile size must be a multiple of the wave size");
-    for (int cl = tid; cl < NT; cl += NTHR) {
-        const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
-        uint32_t v = 0;
-        if (lz < tz && ly < ty && lx < tx) v = info[sb_index(lz, ly, lx)];
-        const unsigned long long m = __ballot((v >> 31) != 0);
-        if (lane == 0) {
-            act_bits[cl >> 5] = (uint32_t)m; act_bits[(cl >> 5) + 1] = (uint32_t)(m >> 32);
-            if (m) any_act = 1;
-        }
-        accs[cl] = 0.0f;
-    }
-    __syncthreads();
-    if (!any_act) return;
-
-    const long long rsY = G.bX, rsZ = (long long)G.bX * G.bY;
-    const int uz0 = max(c0z - RZ, G.bz0), uz1 = min(c0z + tz - 1 + RZ, G.bz0 + G.bZ - 1);
-    const int uy0 = max(c0y - RY, G.by0), uy1 = min(c0y + ty - 1 + RY, G.by0 + G.bY - 1);
-    const int ux0 = max(c0x - RX, G.bx0), ux1 = min(c0x + tx - 1 + RX, G.bx0 + G.bX - 1);
-    const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
-    for (int k0 = 64 * wave; k0 < nu; k0 += NTHR) {
-        const int k = k0 + lane;
-        const bool ok = k < nu && valid[vox(G, uz0 + k / (nuy * nux), uy0 + (k / nux) % nuy, ux0 + k % nux)] != 0;
-        const unsigned long long m = __ballot(ok);
-        if (lane == 0) { uvalid_bits[k0 >> 5] = (uint32_t)m; uvalid_bits[(k0 >> 5) + 1] = (uint32_t)(m >> 32); }
-    }
-    __syncthreads();
-    auto next_valid = [&](int k) -> int {
-        while (k < nu) {
-            const uint32_t wbits = uvalid_bits[k >> 5] >> (k & 31);
-            if (wbits) return k + __builtin_ctz(wbits);
-            k = (k | 31) + 1;
-        }
-        return nu;
-    };
-    auto row_src = [&](int k) -> const float * {
-        const int uz = uz0 + k / (nuy * nux), uy = uy0 + (k / nux) % nuy, ux = ux0 + k % nux;
-        return S + (((long long)(uz - G.bz0) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
-    };
-    // element e of the staged row is the FIRST value of image element e and the SECOND value of
-    // the element one line (WX) below it -- unless e sits on the first line of its plane
-    // (qy == 0: no partner line reads it as "next line")
-    bool second_ok[NST];
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int e = tid + i * NTHR;
-        second_ok[i] = e < W && (e / WX) % WY != 0;
-    }
-    float *img = reinterpret_cast<float *>(rowimg + RW_PAD);
-    auto publish = [&](const float (&v)[NST]) {
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * NTHR;
-            if (e < W) {
-                const float x = v[i] * 32.0f;
-                img[2 * e] = x;
-                if (second_ok[i]) img[2 * (e - WX) + 1] = x;
-            }
-        }
-    };
-    float st[NST];
-    int uk = __builtin_amdgcn_readfirstlane(next_valid(0));
-    if (uk < nu) {
-        const float *src = row_src(uk);
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + i * NTHR;
-            st[i] = e < W ? src[e] : 0.0f;
-        }
-        publish(st);
-    }
-    __syncthreads();
-    typedef const volatile __attribute__((address_space(3))) v2f_t *lds_v2f_cvp;
-    int turn = 0;
-    while (uk < nu) {
-        const int uz = uz0 + uk / (nuy * nux), uy = uy0 + (uk / nux) % nuy, ux = ux0 + uk % nux;
-        const int uk_next = __builtin_amdgcn_readfirstlane(next_valid(uk + 1));
-        if (uk_next < nu) {
-            const float *src = row_src(uk_next);
-#pragma unroll
-            for (int i = 0; i < NST; ++i) {
-                const int e = tid + i * NTHR;
-                st[i] = e < W ? src[e] : 0.0f;
-            }
-        }
-        const int az0 = max(0, uz + RZ - (c0z + tz - 1)), az1 = min(PZ - 1, uz + RZ - c0z);
-        const int ay0 = max(0, uy + RY - (c0y + ty - 1)), ay1 = min(PY - 1, uy + RY - c0y);
-        const int ax0 = max(0, ux + RX - (c0x + tx - 1)), ax1 = min(PX - 1, ux + RX - c0x);
-        const int nz = az1 - az0 + 1, ny = ay1 - ay0 + 1, nx = ax1 - ax0 + 1;
-        const int n_box = (nz <= 0 || ny <= 0 || nx <= 0) ? 0 : nz * ny * nx;
-        const int first = (wave + RW_WAVES - turn) & (RW_WAVES - 1);
-        turn = (turn + ((n_box + 63) >> 6)) & (RW_WAVES - 1);
-        for (int i0 = 64 * first; i0 < n_box; i0 += NTHR) {
-            const int i = i0 + lane;
-            const bool in = i < n_box;
-            const int ii = in ? i : 0;
-            const int ax = ax0 + ii % nx, ay = ay0 + (ii / nx) % ny, az = az0 + ii / (nx * ny);
-            const int lz = uz + RZ - az - c0z, ly = uy + RY - ay - c0y, lx = ux + RX - ax - c0x;
-            const int cl = (lz * TY + ly) * TX + lx;
-            const int a = (az * PY + ay) * PX + ax;
-            const long long t = sb_index(lz, ly, lx);
-            bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
-            if (active) active = ((M[(long long)(a >> 4) * sbV + t] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
-            if (__ballot(active) == 0) continue;
-            uint32_t mw[W16];
-            const int aw = a >> 4;
-            const uint32_t above16 = ~((2u << (a & 15)) - 1u) & 0xFFFFu;
-            const uint32_t keep_a = interleave16(above16, 0xFFFFu);
-#pragma unroll
-            for (int w = 0; w < W16; ++w) mw[w] = M[(long long)w * sbV + t];   // (unconditional: t is valid on every lane)
-#pragma unroll
-            for (int w = 0; w < W16; ++w) {
-                // b in P counts only for b > a: P bits of the partners <= a go (N bits stay)
-                const uint32_t keep = w < aw ? 0xF0F0F0F0u : (w > aw ? 0xFFFFFFFFu : keep_a);
-                mw[w] &= active ? keep : 0u;
-            }
-            float acc = active ? accs[cl] : 0.0f;
-            lds_v2f_cvp row = (lds_v2f_cvp)(rowimg + RW_PAD + LC - ((az * WY + ay) * WX + ax));
-            // segments: (bz, by) and (bz, by + 1), by even; the last line of a plane is alone
-            StaticFor<0, NSEG>::run([&](auto sc) {
-                constexpr int seg = decltype(sc)::value;
-                constexpr int bz = seg / ((PY + 1) / 2), by = 2 * (seg % ((PY + 1) / 2));
-                constexpr bool pair = by + 1 < PY;
-                constexpr int b0 = (bz * PY + by) * PX, nb = pair ? 2 * PX : PX;   // partners b0 .. b0 + nb - 1
-                constexpr int w0 = b0 >> 4, w1 = (b0 + nb - 1) >> 4;
-                // any coefficient of this segment on any lane?  (bits of partner s: 0x11 << ...)
-                uint32_t any = 0u;
-#pragma unroll
-                for (int w = w0; w <= w1; ++w) {
-                    // partners of word w inside [b0, b0 + nb): mask over the interleaved bits
-                    uint32_t rm = 0u;
-#pragma unroll
-                    for (int sl = 0; sl < 16; ++sl) {
-                        const int b = w * 16 + sl;
-                        if (b >= b0 && b < b0 + nb && b < C) rm |= 0x11u << (8 * (sl >> 2) + (sl & 3));
-                    }
-                    any |= mw[w] & rm;
-                }
-                if (__ballot(any != 0u) == 0) return;
-                // row values: one 8-byte element per bx gives line by (x) and line by + 1 (y)
-                v2f_t rv[PX];
-#pragma unroll
-                for (int bx = 0; bx < PX; ++bx) rv[bx] = row[(bz * WY + by) * WX + bx];
-                constexpr int g0 = b0 >> 2, g1 = (b0 + nb - 1) >> 2;
-                uint2 cf[g1 - g0 + 1];
-#pragma unroll
-                for (int g = g0; g <= g1; ++g) cf[g - g0] = coefT[(mw[g >> 2] >> (8 * (g & 3))) & 0xFFu];
-#pragma unroll
-                for (int k = 0; k < nb; ++k) {
-                    const int b = b0 + k;
-                    const float r = k < PX ? rv[k].x : rv[k - PX].y;
-                    const uint2 c4 = cf[(b >> 2) - g0];
-                    const uint32_t c2 = (b & 3) < 2 ? c4.x : c4.y;
-                    acc = (b & 1) ? fma_mix_hi(r, c2, acc) : fma_mix_lo(r, c2, acc);
-                }
-            });
-            if (active) accs[cl] = acc;
-        }
-        __syncthreads();
-        if (uk_next < nu) publish(st);
-        __syncthreads();
-        uk = uk_next;
-    }
-    for (int cl = tid; cl < NT; cl += NTHR) {
-        const int lx = cl % TX, ly = (cl / TX) % TY, lz = cl / (TX * TY);
-        if (lz < tz && ly < ty && lx < tx && ((act_bits[cl >> 5] >> (cl & 31)) & 1u)) {
-            const unsigned fg_cnt = info[sb_index(lz, ly, lx)] & 0x7FFFFFFFu;
-            const float acc = accs[cl];
-            score[vox(G, c0z + lz, c0y + ly, c0x + lx)] = G.norm_rank ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
-        }
-    }
-}
-
 static size_t up256w(size_t v) { return (v + 255) / 256 * 256; }
 
 bool rank_wg_supported(const Geo &G) {
-    if (const char *e = getenv("PPP_RANK_WG"))
-        if (e[0] == '0') return false;
+    static const bool off = [] { const char *e = getenv("PPP_RANK_WG"); return e && e[0] == '0'; }();
+    if (off) return false;       // (PPP_RANK_WG=0: the one-wave kernel of ppp_rank_vm.hip, read once)
     return G.pz == G.py && G.py == G.px && (G.px == 5 || G.px == 7 || G.px == 9) && !G.count_pos_neg &&
            G.layout == PPP_CONS_VOXEL_MAJOR;
 }
@@ -607,18 +392,9 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64 * RW_WAVES);
-    // PPP_RANK_WG=1: the 4-byte row image (one ds_read_b32 per term); default: the two-line image
-    const char *ev = getenv("PPP_RANK_WG");
-    const bool two_line = !(ev && ev[0] == '1');
 #define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
-    do {                                                                                                    \
-        if (two_line)                                                                                       \
-            rank_wg2_kernel<A_, A_, A_, D_, E_, F_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>( \
-                S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles);                           \
-        else                                                                                                \
-            rank_wg_kernel<A_, A_, A_, D_, E_, F_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>( \
-                S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles);                           \
-    } while (0)
+    rank_wg_kernel<A_, A_, A_, D_, E_, F_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>(         \
+        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles)
 #define PPP_RW_CASE(P)                                                                                      \
     case P:                                                                                                 \
         if (big) PPP_RW_LAUNCH(P, 8, 16, 16);                                                               \
