@@ -456,6 +456,22 @@ int ppp_synth_pred_box(const int32_t *d_labels, const int32_t *label_box, void *
                        uint32_t seed, float hi, float lo, float noise, const int32_t *global_dims,
                        const ppp_params *p, void *stream);
 
+/* --- ppp+dec: tail of the patch decoder, fused with the scatter into the prediction block ------
+ * replaces, for the shipped decoder (default_train_code.toml [model.autoencoder]: num_fmaps
+ * [64, 128], kernel_size 3, num_repetitions 2, resize_conv, patchshape 7^3), the last stage of
+ * Autoencoder.forward (torch_model.py:537-544: up[1] = nearest upsampling x2 + conv 64 -> 1 + ReLU,
+ * up_conv[1] = two 1 -> 1 convolutions without activation, centre crop 8^3 -> 7^3) and the
+ * per-voxel scatter of decode_sample (decode.py:61-65) with its float32 (C, Z, Y, X) array.
+ * d_x   : float32 [n][fmaps = 64][side^3 = 4^3], the output of up_conv[0] for n foreground voxels
+ * d_w1  : float32 [64][27] (= the conv weight [1][64][3][3][3]); d_w2, d_w3: float32 [27]; b*: biases
+ * d_dst : int64 [n] linear voxel index of every decoded voxel in the prediction block
+ * d_pred: the (C = 343, Z, Y, X) block described by p (float16 or float32): pred[r][dst] written
+ * float arithmetic: f32 MFMA over the channels, f32 sums over the taps; checked against the torch
+ * restatement of the same layers within a tolerance (the reference ships no decoder to pin to). */
+int ppp_decode_tail(const float *d_x, int64_t n, int32_t fmaps, int32_t side, const float *d_w1, float b1,
+                    const float *d_w2, float b2, const float *d_w3, float b3, const int64_t *d_dst,
+                    void *d_pred, int pred_dtype, const ppp_params *p, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -486,21 +486,30 @@ def to_instance_seg(pred, foreground, mask_to_cover, numinst, patchshape, **kw):
         return out
     cons = consensus(pred, overlap_mask, patchshape, **kw)
     out["cons"] = cons
-    scores = rank(pred, cons, overlap_mask, patchshape, **kw)
-    out["scores"] = scores
-    ranked_coords, ranked_scores = rank_by_score(coords, scores)
-    out["ranked_coords"], out["ranked_scores"] = ranked_coords, ranked_scores
-    sel = foreground_cover(ranked_coords, ranked_scores, overlap_mask, mask_to_cover,
-                           pred, patchshape, **kw)
-    sel_coords = ranked_coords[sel]
-    out["cover_coords"] = sel_coords
+    if kw.get("selected_patches") is not None:
+        # injected by the blockwise driver (vote_instances.py:369-375; it also sets skipRanking)
+        sel_coords = np.array(list(kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
+    else:
+        scores = rank(pred, cons, overlap_mask, patchshape, **kw)
+        out["scores"] = scores
+        ranked_coords, ranked_scores = rank_by_score(coords, scores)
+        out["ranked_coords"], out["ranked_scores"] = ranked_coords, ranked_scores
+        sel = foreground_cover(ranked_coords, ranked_scores, overlap_mask, mask_to_cover,
+                               pred, patchshape, **kw)
+        sel_coords = ranked_coords[sel]
+        out["cover_coords"] = sel_coords
     if not kw["skipThinCover"] and len(sel_coords) > 0:
         keep = thin_cover(sel_coords, mask_to_cover, pred, patchshape, **kw)
         sel_coords = sel_coords[keep]
         out["thin_coords"] = sel_coords
-    pts, pairs = patch_pairs(sel_coords, patchshape,
-                             include_single=kw["includeSinglePatchCCS"],
-                             max_ps_dist=kw.get("max_total_patch_distance_in_ps_multiples", 2))
+    if kw.get("selected_patch_pairs") is not None:      # vote_instances.py:400-406
+        pts = sel_coords
+        pairs = np.array(kw["selected_patch_pairs"], dtype=np.uint32).reshape(-1, 6)
+        pairs = pairs if len(pairs) else None
+    else:
+        pts, pairs = patch_pairs(sel_coords, patchshape,
+                                 include_single=kw["includeSinglePatchCCS"],
+                                 max_ps_dist=kw.get("max_total_patch_distance_in_ps_multiples", 2))
     out["selected_sorted"] = pts
     if pairs is None:
         return out

@@ -185,6 +185,10 @@ _SIGNATURES = {
     "ppp_synth_pred_box": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_uint32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                           ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_decode_tail": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_float,
+                                       ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_host_mws": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
@@ -919,6 +923,32 @@ def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True, voxel_
     check(lib().ppp_synth_pred(_dev_ptr(labels), _dev_ptr(pred), F16 if f16 else F32,
                                int(seed) & 0xFFFFFFFF, hi, lo, noise, int(voxel_offset),
                                ctypes.byref(P), _stream()))
+    return pred
+
+
+def decode_tail(x, w1, b1, w2, b2, w3, b3, dst, pred, patchshape):
+    """ppp_decode_tail: x float32 [n, 64, 4, 4, 4] (decoder features), dst int64 [n] voxel indices,
+    pred (C, ...) float16 / float32 device block -- written in place at pred[:, dst]."""
+    torch = _torch()
+    n = int(x.shape[0])
+    if n == 0:
+        return pred
+    P = Params()
+    P.abi_version = ABI_VERSION
+    vol = [int(v) for v in pred.shape[1:]]
+    while len(vol) < 3:
+        vol = [1] + vol
+    P.Z, P.Y, P.X = vol
+    P.pz, P.py, P.px = [int(p) for p in patchshape]
+    P.th = P.thi = 0.5
+    P.bg_rule, P.value_rule = BG_LESS_THAN_TH, VAL_COUNT
+    P.cons_box = Box(0, 0, 0, P.Z, P.Y, P.X)
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    x, w1, w2, w3 = f32(x), f32(w1).reshape(-1), f32(w2).reshape(-1), f32(w3).reshape(-1)
+    check(lib().ppp_decode_tail(_dev_ptr(x), n, int(x.shape[1]), int(x.shape[2]), _dev_ptr(w1), float(b1),
+                                _dev_ptr(w2), float(b2), _dev_ptr(w3), float(b3),
+                                _dev_ptr(dst.to(torch.int64).contiguous()), _dev_ptr(pred),
+                                pred_dtype_code(pred), ctypes.byref(P), _stream()))
     return pred
 
 

@@ -555,6 +555,23 @@ int ppp_synth_pred_box(const int32_t *d_labels, const int32_t *label_box, void *
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred_box");
 }
 
+int ppp_decode_tail(const float *d_x, int64_t n, int32_t fmaps, int32_t side, const float *d_w1, float b1,
+                    const float *d_w2, float b2, const float *d_w3, float b3, const int64_t *d_dst,
+                    void *d_pred, int pred_dtype, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n <= 0) return PPP_OK;
+    if (!d_x || !d_w1 || !d_w2 || !d_w3 || !d_dst || !d_pred) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_decode_tail(d_x, n, fmaps, side, d_w1, b1, d_w2, b2, d_w3, b3,
+                                           (const long long *)d_dst, d_pred, pred_dtype, G, (hipStream_t)stream);
+    if (e == hipErrorNotSupported)
+        return fail(PPP_ERR_UNSUPPORTED, "ppp_decode_tail serves the shipped decoder tail only: 64 feature maps "
+                                         "at 4^3, 3^3 kernels, 7^3 patches");
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_decode_tail");
+}
+
 int64_t ppp_cover_workspace_bytes(int64_t n, const ppp_params *p) {
     ppp::Geo G;
     if (make_geo(p, &G) != PPP_OK) return -1;

@@ -76,6 +76,10 @@ hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t s
 hipError_t launch_synth_box(const int32_t *labels, const int *lb, void *pred, int dtype, uint32_t seed,
                             float hi, float lo, float noise, const int *gdim, const Geo &G, hipStream_t s);
 
+hipError_t launch_decode_tail(const float *X, long long B, int F, int S, const float *W1, float b1,
+                              const float *W2, float b2, const float *W3, float b3, const long long *dst,
+                              void *pred, int dtype, const Geo &G, hipStream_t s);
+
 size_t cover_workspace_bytes(long long n, const Geo &G);
 hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
                           int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,

@@ -2,11 +2,15 @@
 (reference: experiments/flylight/setups/setup01/decode.py:16-130 and the decoder half of
 ``Autoencoder``, setup01/torch_model.py:452-544).
 
-The decoder is the only dense-contraction piece next to the hot path; it runs as plain
-torch-ROCm convolutions (MIOpen / rocBLAS), everything around it -- gathering the codes at the
-foreground voxels, scattering the decoded patches into the (C, Z, Y, X) prediction block -- is
-done on the device in whole batches instead of the reference's per-voxel Python loop
-(decode.py:43-65), and the result can be handed to ``to_instance_seg`` without leaving HBM.
+The decoder is the only dense-contraction piece next to the hot path.  Its head -- the 1x1
+``from_code`` and the first upsampling stage, 28 of the 30 M multiply-adds per voxel: dense 64 /
+128-channel convolutions at 4^3 -- runs as torch-ROCm convolutions (MIOpen / rocBLAS); its tail --
+the last stage, the crop, the conversion to float16 and the scatter into the (C, Z, Y, X)
+prediction block -- is one hand-written HIP kernel (csrc/ppp_decode.hip: f32 MFMA + LDS), so a
+batch goes from codes to float16 patch values in the block S1 reads with no float32 patch
+tensors and no per-voxel Python loop (decode.py:43-65).  ``decode_volume`` fills a resident float16
+block batch by batch; ``DecodeProvider`` decodes tile by tile on demand inside the tiled assembly
+(``patchperpix_amd.tiling``), for volumes whose decoded prediction would not fit.
 
 PARITY UNPINNED for the decoder arithmetic: the reference builds it from
 ``funlib.learn.torch`` (``ConvPass``, ``Upsample``; git dependency, branch ``ppp``, not vendored
@@ -74,18 +78,52 @@ class PatchDecoder(_torch().nn.Module):
         self.up = torch.nn.ModuleList(ups)
         self.up_conv = torch.nn.ModuleList(convs)
 
-    def forward(self, code):
+    def head(self, code):
+        """Everything but the last stage: (B, code_units) -> the features the last stage upsamples
+        (B, num_fmaps[0], s', ..) -- the dense 64 / 128-channel convolutions (library GEMMs)."""
         torch = _torch()
-        out = torch.reshape(code, self.code_shape)
-        out = self.from_code(out)
-        for up, conv in zip(self.up, self.up_conv):
+        out = self.from_code(torch.reshape(code, self.code_shape))
+        for up, conv in zip(self.up[:-1], self.up_conv[:-1]):
             out = conv(up(out))
-        # centre crop (PatchPerPix/util: crop) to the patch shape
+        return out
+
+    def tail(self, feats):
+        """The last stage + centre crop (PatchPerPix/util: crop) as torch ops (the restatement the
+        fused kernel ppp_decode_tail is checked against)."""
+        out = self.up_conv[-1](self.up[-1](feats))
         sl = [slice(None), slice(None)]
         for have, want in zip(out.shape[2:], self.patchshape):
             o = (have - want) // 2
             sl.append(slice(o, o + want))
         return out[tuple(sl)]
+
+    def forward(self, code):
+        return self.tail(self.head(code))
+
+    def fused_tail_params(self):
+        """(w1, b1, w2, b2, w3, b3) when the last stage is the shipped one -- 3-d, nearest x2, one
+        3^3 convolution to a single map + ReLU, two 3^3 single-map convolutions without
+        activation, 8^3 -> 7^3 crop -- which csrc/ppp_decode.hip runs fused with the scatter into
+        the prediction block; None otherwise (torch ops do the tail then)."""
+        torch = _torch()
+        if self.nd != 3 or self.patchshape != (7, 7, 7) or len(self.up) < 1:
+            return None
+        up, conv = self.up[-1], self.up_conv[-1]
+        ups, first = up[0], up[1]
+        convs = [m for m in first if isinstance(m, torch.nn.Conv3d)]
+        acts = [m for m in first if not isinstance(m, torch.nn.Conv3d)]
+        tail = [m for m in conv]
+        sf = ups.scale_factor if isinstance(ups.scale_factor, (tuple, list)) else (ups.scale_factor,) * 3
+        if tuple(float(f) for f in sf) != (2.0, 2.0, 2.0) or len(convs) != 1 or \
+                not (len(acts) == 1 and isinstance(acts[0], torch.nn.ReLU)) or \
+                len(tail) != 2 or not all(isinstance(m, torch.nn.Conv3d) for m in tail):
+            return None
+        c1 = convs[0]
+        if c1.in_channels != 64 or c1.out_channels != 1 or tuple(c1.kernel_size) != (3, 3, 3) or \
+                any(tuple(m.kernel_size) != (3, 3, 3) or m.in_channels != 1 or m.out_channels != 1 for m in tail):
+            return None
+        return (c1.weight, float(c1.bias.item()), tail[0].weight, float(tail[0].bias.item()),
+                tail[1].weight, float(tail[1].bias.item()))
 
 
 def foreground_from_numinst(pred_numinstfg, fg_thresh):
@@ -95,25 +133,92 @@ def foreground_from_numinst(pred_numinstfg, fg_thresh):
     return np.squeeze((pred_numinstfg >= fg_thresh).astype(np.uint8))
 
 
-def decode_volume(decoder, pred_code, pred_fg, batch_size=1024, device="cuda", out_dtype=None):
+def decode_into(decoder, codes, dst, pred, batch_size=1024, fused=None):
+    """Decode `codes` (B, code_units; device) and write patch k into pred[:, dst[k]] -- pred is the
+    (C, ...) prediction block (float16 or float32, device), dst int64 linear voxel indices.
+    The decoder's head runs as torch convolutions; the tail (last stage, crop, conversion to
+    pred's dtype, scatter) in ONE fused HIP kernel when the decoder has the shipped shape
+    (ppp_decode_tail, csrc/ppp_decode.hip), else as torch ops + an index assignment.
+    fused: None = the kernel when possible; False = torch ops; True = the kernel or an error."""
+    torch = _torch()
+    from . import backend
+    C = int(np.prod(decoder.patchshape))
+    tp = decoder.fused_tail_params() if fused is not False else None
+    if fused and tp is None:
+        raise RuntimeError("this decoder's tail has no fused kernel")
+    flat = pred.reshape(C, -1)
+    with torch.no_grad():
+        for s in range(0, int(dst.numel()), int(batch_size)):
+            sel = dst[s:s + batch_size]
+            feats = decoder.head(codes[s:s + batch_size])
+            if tp is not None:
+                backend.decode_tail(feats, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], sel, pred,
+                                    decoder.patchshape)
+            else:
+                flat[:, sel] = decoder.tail(feats).reshape(len(sel), C).t().to(pred.dtype)
+    return pred
+
+
+def decode_volume(decoder, pred_code, pred_fg, batch_size=1024, device="cuda", out_dtype=None,
+                  fused=None):
     """decode_sample (decode.py:16-66) on the device: returns the (C, *spatial) prediction
-    tensor (float32 unless out_dtype), zero outside the foreground."""
+    tensor (float32 unless out_dtype; float16 = the dtype it is written in, decode.py:104-109),
+    zero outside the foreground.  Batches of `batch_size` voxels go through the decoder and
+    straight into the block in its final dtype: no float32 (C, Z, Y, X) intermediate when
+    out_dtype is float16."""
     torch = _torch()
     out_dtype = out_dtype or torch.float32
-    code = torch.as_tensor(np.asarray(pred_code), device=device).float()
-    fg = torch.as_tensor(np.asarray(pred_fg) != 0, device=device)
+    code = torch.as_tensor(np.asarray(pred_code) if not torch.is_tensor(pred_code) else pred_code, device=device)
+    fg = torch.as_tensor(np.asarray(pred_fg) != 0 if not torch.is_tensor(pred_fg) else pred_fg != 0, device=device)
     units = code.shape[0]
     C = int(np.prod(decoder.patchshape))
     flat_code = code.reshape(units, -1)
     idx = torch.nonzero(fg.reshape(-1)).reshape(-1)
-    out = torch.zeros((C, flat_code.shape[1]), dtype=out_dtype, device=device)
+    out = torch.zeros((C,) + tuple(fg.shape), dtype=out_dtype, device=device)
     decoder = decoder.to(device).eval()
-    with torch.no_grad():
-        for s in range(0, int(idx.numel()), int(batch_size)):
-            sel = idx[s:s + batch_size]
-            patches = decoder(flat_code[:, sel].t().contiguous())       # (B, 1, *patch)
-            out[:, sel] = patches.reshape(len(sel), C).t().to(out_dtype)
-    return out.reshape((C,) + tuple(fg.shape))
+    # codes are gathered slab by slab (a transposed float32 copy of ALL codes would be as large
+    # as a third of the prediction)
+    chunk = max(int(batch_size), 1 << 18)
+    for s in range(0, int(idx.numel()), chunk):
+        sel = idx[s:s + chunk]
+        decode_into(decoder, flat_code[:, sel].t().float().contiguous(), sel, out, batch_size, fused)
+    return out
+
+
+class DecodeProvider:
+    """Prediction provider for patchperpix_amd.tiling.assemble in ppp+dec mode: pred_box() DECODES
+    the float16 prediction of a box on demand from the per-voxel code (code_units, Z, Y, X) -- a
+    rank never holds the decoded (C, Z, Y, X) volume (343 x 2 bytes per voxel at 7^3, 31 KB at
+    25^3), only the code (2 x code_units bytes per voxel) and one tile.  The price is decoding the
+    halo of every tile again (x2-x3 at 128^3 tiles), which is why volumes whose float16 prediction
+    fits HBM are decoded once (decode_volume) instead."""
+
+    def __init__(self, decoder, code, fg, batch_size=4096, device="cuda", fused=None, expit=False):
+        """expit: pass the decoded logits through the logistic function (in float16, like
+        loadAffinities does with the float16 array it reads, utilVoteInstances.py:249-250)."""
+        torch = _torch()
+        self.expit = bool(expit)
+        self.decoder = decoder.to(device).eval()
+        self.code = torch.as_tensor(code, device=device)
+        self.fg = torch.as_tensor(np.asarray(fg) != 0 if not torch.is_tensor(fg) else fg != 0, device=device)
+        self.batch_size, self.device, self.fused = int(batch_size), device, fused
+        self.voxels_decoded = 0
+
+    def pred_box(self, box):
+        torch = _torch()
+        z0, z1, y0, y1, x0, x1 = [int(v) for v in box]
+        C = int(np.prod(self.decoder.patchshape))
+        pred = torch.zeros((C, z1 - z0, y1 - y0, x1 - x0), dtype=torch.float16, device=self.device)
+        fg = self.fg[z0:z1, y0:y1, x0:x1]
+        dst = torch.nonzero(fg.reshape(-1)).reshape(-1)
+        if dst.numel():
+            codes = self.code[:, z0:z1, y0:y1, x0:x1].reshape(self.code.shape[0], -1)[:, dst].t().float().contiguous()
+            decode_into(self.decoder, codes, dst, pred, self.batch_size, self.fused)
+            self.voxels_decoded += int(dst.numel())
+            if self.expit:
+                flat = pred.reshape(C, -1)
+                flat[:, dst] = torch.sigmoid(flat[:, dst])
+        return pred
 
 
 def map_decoder_state(state, decoder):
@@ -188,10 +293,12 @@ def decode(**config):
             code = np.array(f[config["code_key"]])
             numinstfg = np.array(f[config.get("numinst_key", config.get("fg_key"))])
         fg = foreground_from_numinst(numinstfg, config.get("fg_thresh", 0.5))
-        pred = decode_volume(decoder, code, fg, config.get("decode_batch_size", 1024), device)
+        # decoded batch by batch straight into the float16 block that is written (decode.py:104-109)
+        pred = decode_volume(decoder, code, fg, config.get("decode_batch_size", 1024), device,
+                             out_dtype=torch.float16)
         name = os.path.basename(sample).split(".")[0]
         outfn = os.path.join(config["output_folder"], name + "." + config["output_format"])
-        data = pred.cpu().numpy().astype(np.float16)
+        data = pred.cpu().numpy()
         if config["output_format"] == "zarr":
             with io_hdflike.open_container(outfn, "a" if os.path.exists(outfn) else "w") as f:
                 # decode.py:104-109: no chunks / compressor given -> the container's defaults

@@ -1225,8 +1225,8 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
     # bounding box of the cleaned mask (stitch_patch_graph.py:745-767)
     mask = foreground
     if kw.get("ignore_small_comps", 0) > 0:
-        mask = clean_mask(foreground, ndimage.generate_binary_structure(3, 1),
-                          kw["ignore_small_comps"])
+        # (stitch_patch_graph.py:749-751: np.ones([3] * ndim), i.e. 26-connectivity)
+        mask = clean_mask(foreground, np.ones([3] * foreground.ndim), kw["ignore_small_comps"])
     if kw.get("only_bb", False) and mask.any():
         if kw.get("skeletonize_foreground"):
             # stitch_patch_graph.py:756-759: the bounding box is that of the SKELETON of the

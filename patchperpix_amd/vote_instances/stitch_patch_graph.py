@@ -118,9 +118,18 @@ def write_output(io_out, output, output_bounding_box):
 def main(pred_file, result_folder='.', **kwargs):
     """stitch_patch_graph.py:672-894 entry point.
 
-    The whole (bounding-boxed) volume is assembled in ONE pass on the device -- tiled
-    internally when the consensus array does not fit (patchperpix_amd.tiling) -- instead of
-    per-block graphs that are stitched afterwards.  Output datasets and dtypes follow the
-    reference: ``vote_instances``, ``vote_foreground``, ``vote_instances_masked`` (uint16)."""
+    Default (``blockwise_semantics="whole_volume"``): the whole (bounding-boxed) volume is
+    assembled in ONE pass on the device -- tiled internally when the consensus array does not
+    fit (patchperpix_amd.tiling) -- which equals the whole-volume result.
+    ``blockwise_semantics="reference"``: the reference's per-block cover, on-disk block graphs
+    (``volumes/blocks/<z_y_x>/{patch_pairs, aff_graph_mat}``), inter-block edges and global
+    labelling (patchperpix_amd.blockwise; pinned to goldens of the reference's own driver).
+    Output datasets and dtypes follow the reference: ``vote_instances``, ``vote_foreground``,
+    ``vote_instances_masked`` (uint16)."""
+    if kwargs.pop("blockwise_semantics", "whole_volume") == "reference":
+        # the reference's own function of the input: per-block cover, block graphs on disk,
+        # inter-block edges, one global labelling (patchperpix_amd/blockwise.py)
+        from .. import blockwise
+        return blockwise.main(pred_file, result_folder=result_folder, **kwargs)
     from .. import tiling
     return tiling.stitch_main(pred_file, result_folder=result_folder, **kwargs)

@@ -18,8 +18,10 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0]
-                  for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    # (bw_*.npz: goldens of the blockwise driver, tests/test_blockwise.py loads them itself)
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0]
+                              for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  if not n.startswith("bw_"))
 
 
 class Golden:

@@ -117,3 +117,90 @@ def test_decode_then_vote_without_leaving_hbm():
                               [5, 5, 5], **kw)
     assert np.array_equal(inst, ref["instances"])
     assert (pred16 > 0.5).any() and (pred16 < 0.5).any()
+
+
+AE_SHIPPED = dict(activation="relu", num_fmaps=[64, 128], downsample_factors=[[2, 2, 2], [2, 2, 2]],
+                  upsampling="resize_conv", kernel_size=3, num_repetitions=2, padding="same",
+                  code_fmaps=22, code_units=176, input_shape_squeezed=(7, 7, 7))
+
+
+def test_head_and_tail_compose_and_fused_tail_is_recognised():
+    torch.manual_seed(2)
+    d = dec.PatchDecoder(dict(AE_SHIPPED)).eval()
+    x = torch.randn(3, 176)
+    with torch.no_grad():
+        assert torch.equal(d(x), d.tail(d.head(x)))
+        assert tuple(d.head(x).shape) == (3, 64, 4, 4, 4)
+    assert d.fused_tail_params() is not None                       # the shipped shape
+    assert dec.PatchDecoder(dict(AE)).fused_tail_params() is None  # 8 feature maps: torch ops
+    assert dec.PatchDecoder(dict(AE_SHIPPED, input_shape_squeezed=(5, 5, 5))).fused_tail_params() is None
+
+
+@pytest.mark.gpu
+def test_fused_tail_kernel_matches_torch_tail():
+    """csrc/ppp_decode.hip (f32 MFMA over the channels, LDS gathers, crop, float16, scatter) against
+    the torch restatement of the same layers on seeded weights, 7^3 patches.  Tolerance: both sides
+    round to float16 at the end; before that the two float32 summation orders differ by a few
+    ulp, so a value may land on the neighbouring float16: |diff| <= 1 float16 ulp (2^-10 relative)
+    + 1e-4 absolute, and at least 99 % of the values identical."""
+    torch.manual_seed(11)
+    d = dec.PatchDecoder(dict(AE_SHIPPED)).cuda().eval()
+    shape = (6, 9, 11)
+    V = int(np.prod(shape))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    codes = torch.randn((401, 176), generator=g).cuda()
+    dst = torch.randperm(V, generator=g)[:401].sort().values.cuda()
+    want = torch.zeros((343,) + shape, dtype=torch.float16, device="cuda")
+    got = torch.zeros_like(want)
+    dec.decode_into(d, codes, dst, want, batch_size=128, fused=False)
+    dec.decode_into(d, codes, dst, got, batch_size=128, fused=True)
+    w, g2 = want.float().reshape(343, -1), got.float().reshape(343, -1)
+    assert not g2[:, torch.ones(V, dtype=torch.bool, device="cuda").index_fill(0, dst, False)].any()
+    diff = (w - g2).abs()
+    assert bool((diff <= w.abs() * 2.0 ** -10 + 1e-4).all()), float(diff.max())
+    assert float((diff[:, dst] == 0).float().mean()) > 0.99
+    assert float(w[:, dst].abs().max()) > 0        # the decoder produced something
+    # float32 destination block as well
+    got32 = torch.zeros((343,) + shape, dtype=torch.float32, device="cuda")
+    dec.decode_into(d, codes, dst, got32, batch_size=512, fused=True)
+    assert torch.equal(got32.to(torch.float16), got)
+
+
+@pytest.mark.gpu
+def test_decode_provider_votes_like_the_decoded_volume_p7():
+    """BASELINE config [4] at 7^3: decode -> vote.  (a) the whole volume decoded once into a
+    resident float16 block (fused tail kernel), then voted; (b) the prediction decoded TILE BY
+    TILE on demand inside the tiled assembly (DecodeProvider: a frame per tile and pass), never
+    materialised.  Same instance map, and equal to the CPU oracle voting on (a)'s block."""
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd import tiling
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch.manual_seed(7)
+    rng = np.random.default_rng(7)
+    d = dec.PatchDecoder(dict(AE_SHIPPED)).cuda().eval()
+    shape = (22, 24, 26)
+    code = torch.from_numpy(rng.normal(size=(176,) + shape).astype(np.float32)).cuda().half()
+    fg = rng.uniform(size=shape) < 0.9
+    # random weights: spread and centre the logits so that both classes occur
+    probe = dec.decode_volume(d, code, fg, batch_size=2048, out_dtype=torch.float32)
+    vals = probe[:, torch.as_tensor(fg, device="cuda")]
+    with torch.no_grad():
+        scale = 8.0 / float(vals.std())
+        d.up_conv[-1][-1].weight.mul_(scale)
+        d.up_conv[-1][-1].bias.mul_(scale).sub_(float(vals.median()) * scale)
+    del probe, vals
+    logits16 = dec.decode_volume(d, code, fg, batch_size=2048, out_dtype=torch.float16)
+    fg_t = torch.as_tensor(fg, device="cuda")
+    pred16 = torch.where(fg_t.expand_as(logits16), torch.sigmoid(logits16), torch.zeros_like(logits16))
+    assert (pred16 > 0.5).any() and (pred16 < 0.5).any()
+    kw = dict(FLYLIGHT, overlapping_inst=False)
+    ps = [7, 7, 7]
+    want, _ = vi.to_instance_seg(pred16, fg.copy(), fg.copy(), fg.astype(np.uint8), ps, **dict(kw, _n_slabs=1))
+    ref = orc.to_instance_seg(pred16.float().cpu().numpy(), fg, fg.copy(), fg.astype(np.uint8), ps, **kw)
+    assert np.array_equal(want, ref["instances"]) and want.any()
+    prov = dec.DecodeProvider(d, code, fg, batch_size=2048, expit=True)
+    got, _ = tiling.assemble(prov, 0, shape, fg.copy(), fg.copy(), fg.astype(np.uint8), ps,
+                             tiling.plan_slabs(shape[0], 2), _yx_tiles=(1, 2), **kw)
+    assert np.array_equal(got, want)
+    assert prov.voxels_decoded > int(fg.sum())        # halos are decoded again per tile
