@@ -396,6 +396,13 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
 int64_t ppp_host_thin_cover(const uint8_t *h_mask, const int32_t *vol, const int32_t *patchshape,
                             const int64_t *sel_lin, const uint32_t *bits, int64_t n,
                             uint8_t *keep);
+
+/* ppp_host_skeletonize_3d: the 3-d thinning behind `skeletonize_foreground` (vote_instances.py:
+ * 219-224, stitch_patch_graph.py:756-759: skimage.morphology.skeletonize_3d = Lee / Kashyap / Chu
+ * 1994, restated from the publication -- scikit-image is absent here, PARITY UNPINNED).
+ * h_mask uint8 (Z,Y,X) 0 / non-zero, vol = {Z,Y,X}, h_out uint8 (Z,Y,X) 0 / 1; returns the number
+ * of voxels kept or -1. */
+int64_t ppp_host_skeletonize_3d(const uint8_t *h_mask, const int32_t *vol, uint8_t *h_out);
 /* ppp_host_patch_pairs: computeAndStorePatchPairs (aff_patch_graph.py:43-110) with a grid
  *   hash instead of cKDTree; canonical row order (see file header of ppp_host.cpp).
  *   pairs == NULL returns the row count only.                                               */

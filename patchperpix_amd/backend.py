@@ -203,6 +203,7 @@ _SIGNATURES = {
     "ppp_host_thin_cover": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.c_void_p]),
+    "ppp_host_skeletonize_3d": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "ppp_host_patch_pairs": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                               ctypes.c_void_p]),
@@ -1113,6 +1114,18 @@ def host_thin_cover(mask, patchshape, sel_lin, bits):
     lib().ppp_host_thin_cover(_np_ptr(mask), _np_ptr(vol), _np_ptr(ps), _np_ptr(sel_lin),
                               _np_ptr(bits), len(sel_lin), _np_ptr(keep))
     return keep.astype(bool)
+
+
+def host_skeletonize_3d(mask):
+    """3-d thinning of a (Z, Y, X) (or (Y, X)) mask: bool array of the skeleton
+    (ppp_host_skeletonize_3d; Lee / Kashyap / Chu 1994, what skimage's skeletonize_3d implements)."""
+    m = np.ascontiguousarray(np.asarray(mask) != 0).astype(np.uint8)
+    shape = m.shape
+    m3 = m.reshape((1,) * (3 - m.ndim) + shape)
+    out = np.empty_like(m3)
+    if lib().ppp_host_skeletonize_3d(_np_ptr(m3), _np_ptr(_i32(m3.shape)), _np_ptr(out)) < 0:
+        raise RuntimeError("libppp_mi355x: ppp_host_skeletonize_3d: bad arguments")
+    return out.reshape(shape).astype(bool)
 
 
 def host_patch_pairs(sel_zyx, patchshape, max_ps_dist=2, include_single=True):

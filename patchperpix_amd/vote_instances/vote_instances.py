@@ -79,15 +79,15 @@ def get_arguments(check_required=True, argv=None):
 
 def _skeletonize(mask):
     """skimage.morphology.skeletonize_3d of the mask (vote_instances.py:219-224,
-    stitch_patch_graph.py:757-760).  scikit-image is a dependency of the reference that this
-    image lacks; without it the option raises -- it is never silently ignored."""
+    stitch_patch_graph.py:757-760) when scikit-image is importable; otherwise the library's own
+    restatement of the same published thinning (Lee / Kashyap / Chu 1994; csrc/ppp_host_skel.cpp)
+    -- PARITY UNPINNED against scikit-image, which this image lacks."""
     try:
         from skimage.morphology import skeletonize_3d
-    except ImportError as e:
-        raise NotImplementedError(
-            "skeletonize_foreground needs scikit-image (skimage.morphology.skeletonize_3d), "
-            "which is not installed") from e
-    return skeletonize_3d(mask) > 0
+        return skeletonize_3d(mask) > 0
+    except ImportError:
+        logger.info("scikit-image not available: thinning with ppp_host_skeletonize_3d")
+        return backend.host_skeletonize_3d(mask)
 
 
 def _pad(a, rad, channels=False):
