@@ -256,6 +256,7 @@ def label_graph(vol, rows, aff, shape, kwargs):
     if len(rows) == 0:
         return instances
     patchshape = [int(p) for p in kwargs["patchshape"]]
+    kwargs = {k: v for k, v in kwargs.items() if k != "patchshape"}
     if kwargs.get("mws"):
         nodes, labels, _n = backend.host_mws(rows, aff, shape)
     else:

@@ -349,6 +349,21 @@ class Array:
     def __getitem__(self, sel):
         ranges, squeeze = self._normalise(sel)
         out = np.full([b - a for a, b in ranges], self.fill_value, dtype=self.dtype)
+        self._read(ranges, out)
+        return np.squeeze(out, axis=squeeze) if squeeze else out
+
+    def read_into(self, sel, out):
+        """The selection decoded chunk by chunk straight into `out` (an array of the selection's
+        un-squeezed shape and this array's dtype -- e.g. the NumPy view of a pinned host buffer
+        that is then copied to the device: no intermediate array of the whole selection)."""
+        ranges, _ = self._normalise(sel)
+        if tuple(out.shape) != tuple(b - a for a, b in ranges) or out.dtype != self.dtype:
+            raise ValueError("read_into: `out` must have the selection's shape and the array's dtype")
+        out[...] = self.fill_value
+        self._read(ranges, out)
+        return out
+
+    def _read(self, ranges, out):
         pos, grids = self._chunks_of(ranges)
 
         def work(p):
@@ -371,7 +386,6 @@ class Array:
         else:
             for p in pos:
                 work(p)
-        return np.squeeze(out, axis=squeeze) if squeeze else out
 
     def __array__(self, dtype=None, copy=None):
         a = self[...]

@@ -207,6 +207,51 @@ class TorchDistComm:
 
 
 # ------------------------------------------------------------------------------------------
+# prediction providers
+# ------------------------------------------------------------------------------------------
+class ZarrProvider:
+    """Prediction provider over a stored ``volumes/pred_affs`` array (C, Z, Y, X) -- a
+    patchperpix_amd.minizarr / zarr array, or anything sliceable like one: pred_box() decodes only
+    the chunks that intersect the box, straight into a pinned host buffer, and copies that to the
+    device (zarr chunk -> pinned host -> HBM; the reference reads block-wise through
+    io_hdflike.IoZarr.read as well, :67-120).  Neither the host nor the device ever holds the
+    whole prediction.  expit: apply the logistic function to logits (loadAffinities decides that
+    from the value range of the whole array, utilVoteInstances.py:249-250; a provider is told)."""
+
+    def __init__(self, arr, device="cuda", expit=False):
+        self.arr, self.device, self.expit = arr, device, bool(expit)
+        self._pinned = None
+        self.bytes_read = 0
+
+    def pred_box(self, box):
+        import torch
+        z0, z1, y0, y1, x0, x1 = [int(v) for v in box]
+        C = int(self.arr.shape[0])
+        shape = (C, z1 - z0, y1 - y0, x1 - x0)
+        dtype = np.dtype(self.arr.dtype)
+        tdt = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32}.get(dtype)
+        sel = (slice(None), slice(z0, z1), slice(y0, y1), slice(x0, x1))
+        if tdt is None or not hasattr(self.arr, "read_into"):
+            host = torch.from_numpy(np.ascontiguousarray(np.asarray(self.arr[sel], dtype=np.float32)))
+        else:
+            n = int(np.prod(shape))
+            pin = str(self.device).startswith("cuda")
+            if self._pinned is None or self._pinned.numel() < n or self._pinned.dtype != tdt:
+                self._pinned = torch.empty((n,), dtype=tdt, pin_memory=pin)
+            host = self._pinned[:n].view(shape)
+            self.arr.read_into(sel, host.numpy())
+        self.bytes_read += host.numel() * host.element_size()
+        pred = host.to(self.device, non_blocking=True)
+        if str(self.device).startswith("cuda"):
+            torch.cuda.current_stream().synchronize()     # the pinned buffer is reused by the next box
+        elif pred.data_ptr() == host.data_ptr():
+            pred = pred.clone()
+        if self.expit:
+            pred = torch.sigmoid(pred)
+        return pred.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
 # device operations (the C ABI); tests substitute an oracle-backed object with the same API
 # ------------------------------------------------------------------------------------------
 class DeviceOps:
@@ -1188,6 +1233,64 @@ def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchsh
     return assemble(pred, 0, shape, foreground, mask_to_cover, numinst, patchshape, slabs, **kw)
 
 
+def _want_stream(pred_file, patchshape, kw):
+    """Stream the prediction from the zarr store instead of loading it?  ``stream_prediction`` =
+    True / False decides; "auto" (default, also PPP_STREAM_PRED=1 / 0): when the float16 array
+    would take more than half of the free HBM."""
+    import torch
+    want = kw.pop("stream_prediction", os.environ.get("PPP_STREAM_PRED", "auto"))
+    if want in (True, "1", 1):
+        return True
+    if want in (False, "0", 0):
+        return False
+    from .vote_instances import io_hdflike
+    with io_hdflike.open_container(pred_file, "r") as f:
+        key = kw.get("aff_key") or "volumes/pred_affs"
+        if key not in f:
+            return False
+        nbytes = 2.0 * float(np.prod(f[key].shape))
+    return torch.cuda.is_available() and nbytes > 0.5 * torch.cuda.mem_get_info()[0]
+
+
+def _stitch_streamed(provider, foreground, numinst, bb, shape, patchshape, pred_file, result_folder, kw):
+    """stitch_main with the prediction behind a provider: the bounding box becomes the volume the
+    tiled assembly sees (a provider shifted by the box origin)."""
+    import torch
+    from . import postprocess
+    from .vote_instances.vote_instances import write_result
+    off = [int(b.start) for b in bb]
+    bshape = tuple(int(b.stop - b.start) for b in bb)
+
+    class Shifted:
+        def pred_box(self, box):
+            return provider.pred_box((box[0] + off[0], box[1] + off[0], box[2] + off[1], box[3] + off[1],
+                                      box[4] + off[2], box[5] + off[2]))
+    fg_bb = np.ascontiguousarray(foreground[bb])
+    avail = torch.cuda.mem_get_info()[0]
+    n, ny, nx = tiles_needed(bshape, patchshape, max(avail - 120.0 * float(np.prod(bshape)) - 8e9, 0.25 * avail),
+                             safety=0.9, copies=2.0)
+    kw = dict(kw, _instances_dtype=np.uint32, blockwise=False, return_intermediates=False)
+    inst_bb, _ = assemble(Shifted(), 0, bshape, fg_bb, fg_bb.copy(), np.ascontiguousarray(numinst[bb]),
+                          patchshape, plan_slabs(bshape[0], n), _yx_tiles=(ny, nx), **kw)
+    instances = np.zeros(shape, dtype=np.uint32)
+    instances[bb] = inst_bb
+    if kw.get("remove_small_comps", 0) > 0:
+        instances = postprocess.relabel(postprocess.remove_small_components(instances, kw["remove_small_comps"]))
+    masked = instances.copy()
+    masked[foreground == 0] = 0
+    os.makedirs(result_folder, exist_ok=True)
+    fn = os.path.splitext(os.path.basename(pred_file.rstrip("/")))[0]
+    res_key = kw.get("res_key", "vote_instances")
+    datasets = {res_key: instances.astype(np.uint16), "vote_foreground": foreground.astype(np.uint16),
+                res_key + "_masked": masked.astype(np.uint16)}
+    if kw.get("dilate_instances", False):
+        dil = postprocess.dilate_instances(instances)
+        datasets[res_key + "_dil_1"] = dil.astype(np.uint16)
+        datasets[res_key + "_masked_dil_1"] = np.where(foreground == 0, 0, dil).astype(np.uint16)
+    write_result(os.path.join(result_folder, fn + ".hdf"), datasets)
+    return instances
+
+
 def stitch_main(pred_file, result_folder=".", **kwargs):
     """Entry point behind ``vote_instances.stitch_patch_graph.main`` (reference
     stitch_patch_graph.py:672-894): bounding box of the cleaned foreground, assembly of the
@@ -1210,6 +1313,26 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
         mid = int(np.prod(patchshape)) // 2
         foreground = np.array(affinities[mid]) > util.getFgThreshold(**kw)
         numinst = 1 * foreground
+    elif pred_file.rstrip("/").endswith(".zarr") and _want_stream(pred_file, patchshape, kw):
+        # the prediction stays on disk: chunks are decoded on demand into a pinned host buffer and
+        # copied to the device tile by tile (ZarrProvider); host memory holds the fields only
+        from .vote_instances import io_hdflike
+        cm = io_hdflike.open_container(pred_file, "r")
+        f = cm.__enter__()
+        aff_key = kw.setdefault("aff_key", "volumes/pred_affs")
+        arr = f[aff_key]
+        if len(arr.shape) != 4 or int(arr.shape[0]) != int(np.prod(patchshape)):
+            raise NotImplementedError("streaming needs a channels-first (C, Z, Y, X) prediction array")
+        for a in "zyx":
+            if kw.get("crop_%s_s" % a, 0) or kw.get("crop_%s_e" % a) is not None:
+                raise NotImplementedError("crops are not supported with a streamed prediction")
+        numinst = util.maybeLoadNuminst(f, **kw)
+        foreground, _ = util.loadFg(f, **dict(kw, patchshape=patchshape))
+        # logits are recognised from the centre channel (loadAffinities looks at the whole array,
+        # utilVoteInstances.py:249-250: reading it all is what streaming avoids)
+        mid = np.asarray(arr[int(np.prod(patchshape)) // 2])
+        affinities = ZarrProvider(arr, expit=bool(mid.min() < 0 and mid.max() > 1))
+        del mid
     else:
         loaded = util.loadAffinities(pred_file, "", patchshape=patchshape, **kw)
         if loaded is None:
@@ -1249,6 +1372,9 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
     # (default.toml:159, stitch_patch_graph.py:131-133); here the boxed volume is assembled as a
     # whole and the driver wants the instance map
     kw["return_intermediates"] = False
+    if isinstance(affinities, ZarrProvider):
+        return _stitch_streamed(affinities, foreground, numinst, bb, shape, patchshape, pred_file,
+                                result_folder, kw)
     fg_bb = np.ascontiguousarray(foreground[bb])
     # the stitched volume carries uint32 ids (stitch_patch_graph.py:120): with the shipped
     # mws = true + includeSinglePatchCCS = true every selected patch is issued an id

@@ -112,3 +112,35 @@ def test_label_task_on_reference_layout_zarr(tmp_path):
     assert np.array_equal(res["vote_foreground"], fg.astype(np.uint8))
     assert np.array_equal(res["vote_instances_masked"], np.where(fg, ref["instances"], 0))
     assert ref["instances"].max() > 1
+
+
+def test_streamed_prediction_equals_loaded_prediction(tmp_path):
+    """stitch_patch_graph.main with the prediction STREAMED from the zarr store (chunks ->
+    pinned host buffer -> HBM, tile by tile through ZarrProvider; `stream_prediction=True`)
+    against the same call with the array loaded whole: same datasets.  Logits are recognised
+    (from the centre channel) and passed through the logistic function in both."""
+    from patchperpix_amd import minizarr, run_ppp
+    from patchperpix_amd.vote_instances import stitch_patch_graph as spg
+    ps = (5, 5, 5)
+    c = synth.make_case((30, 34, 38), ps, seed=75, cell=[9, 9, 9], overlap_frac=0.03)
+    numinst = c["numinst"]
+    prob = np.zeros((3,) + numinst.shape, dtype=np.float16)
+    prob[0][numinst == 0] = 0.97
+    prob[1][numinst == 1] = 0.95
+    prob[2][numinst == 2] = 0.6
+    p = np.clip(c["pred"], 1e-3, 1 - 1e-3)
+    cfg = run_ppp.load_config([os.path.join(GOLDEN_DIR, "label_config_flylight_zarr.toml")])
+    kw = dict(cfg["vote_instances"], **cfg["model"])
+    kw["chunksize"] = [12, 12, 12]
+    for name, data in (("prob", c["pred"].astype(np.float16)), ("logit", np.log(p / (1 - p)).astype(np.float16))):
+        store = str(tmp_path / (name + ".zarr"))
+        zf = minizarr.open(store, "w")
+        zf.create_dataset("volumes/pred_affs", data=data, chunks=(data.shape[0], 8, 8, 8))
+        zf.create_dataset("volumes/pred_numinst", data=prob, chunks=(3, 8, 8, 8))
+        a = spg.main(store, result_folder=str(tmp_path / (name + "_a")), stream_prediction=False, **kw)
+        b = spg.main(store, result_folder=str(tmp_path / (name + "_b")), stream_prediction=True, **kw)
+        assert a.max() > 1 and np.array_equal(a.astype(np.uint32), b.astype(np.uint32))
+        ra, rb = _load_result(str(tmp_path / (name + "_a")), name), _load_result(str(tmp_path / (name + "_b")), name)
+        assert set(ra) == set(rb)
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k])

@@ -139,3 +139,25 @@ def test_bit_shuffle_layout():
     want[9, 0] = 1 << 3
     want[0, 1] = 1 << 2
     assert np.array_equal(sh, want)
+
+
+def test_read_into_and_zarr_provider(tmp_path):
+    """chunk-wise reads into a caller's buffer, and the prediction provider built on them (zarr
+    chunk -> (pinned) host buffer -> device; here the device is the CPU)."""
+    from patchperpix_amd import tiling
+    rng = np.random.default_rng(5)
+    a = rng.uniform(size=(27, 13, 17, 19)).astype(np.float16)
+    g = mz.open(str(tmp_path / "p.zarr"), "w")
+    g.create_dataset("volumes/pred_affs", data=a, chunks=(27, 6, 8, 8))
+    arr = mz.open(str(tmp_path / "p.zarr"), "r")["volumes/pred_affs"]
+    out = np.empty((27, 5, 9, 11), dtype=np.float16)
+    arr.read_into((slice(None), slice(4, 9), slice(3, 12), slice(8, 19)), out)
+    assert np.array_equal(out, a[:, 4:9, 3:12, 8:19])
+    import pytest
+    with pytest.raises(ValueError):
+        arr.read_into((slice(None), slice(0, 2)), np.empty((27, 3, 17, 19), np.float16))
+    prov = tiling.ZarrProvider(arr, device="cpu")
+    t = prov.pred_box((2, 13, 0, 17, 5, 14))
+    assert t.dtype.is_floating_point and np.array_equal(t.numpy(), a[:, 2:13, 0:17, 5:14])
+    t2 = prov.pred_box((0, 3, 0, 4, 0, 5))            # the host buffer is reused: the first result must not change
+    assert np.array_equal(t.numpy(), a[:, 2:13, 0:17, 5:14]) and np.array_equal(t2.numpy(), a[:, 0:3, 0:4, 0:5])
