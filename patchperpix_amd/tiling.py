@@ -247,7 +247,13 @@ class ZarrProvider:
         elif pred.data_ptr() == host.data_ptr():
             pred = pred.clone()
         if self.expit:
-            pred = torch.sigmoid(pred)
+            # loadAffinities: scipy.special.expit of the float16 array (evaluated in float64),
+            # later narrowed to float32 -- the same two roundings here, a few channels at a time
+            out = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+            step = max(1, (1 << 26) // max(1, int(np.prod(shape[1:]))))
+            for c0 in range(0, C, step):
+                out[c0:c0 + step] = torch.sigmoid(pred[c0:c0 + step].double()).float()
+            pred = out
         return pred.contiguous()
 
 
@@ -1268,7 +1274,7 @@ def _stitch_streamed(provider, foreground, numinst, bb, shape, patchshape, pred_
     fg_bb = np.ascontiguousarray(foreground[bb])
     avail = torch.cuda.mem_get_info()[0]
     n, ny, nx = tiles_needed(bshape, patchshape, max(avail - 120.0 * float(np.prod(bshape)) - 8e9, 0.25 * avail),
-                             safety=0.9, copies=2.0)
+                             safety=0.8 if getattr(provider, "expit", False) else 0.9, copies=2.0)
     kw = dict(kw, _instances_dtype=np.uint32, blockwise=False, return_intermediates=False)
     inst_bb, _ = assemble(Shifted(), 0, bshape, fg_bb, fg_bb.copy(), np.ascontiguousarray(numinst[bb]),
                           patchshape, plan_slabs(bshape[0], n), _yx_tiles=(ny, nx), **kw)
