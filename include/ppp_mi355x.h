@@ -290,6 +290,15 @@ int64_t ppp_cover_workspace_bytes(int64_t n, const ppp_params *p);
 int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
                    int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
                    const ppp_params *p, void *stream, int32_t *rounds);
+/* The same pass with the patch bits in a table that has one row per VOXEL (row of patch k =
+ * d_bits_by_voxel + (d_lin[k] - first_voxel) * words): the tiled assembly fills such a table
+ * tile by tile while the prediction of a tile is resident (prediction provider: the bits cannot
+ * be recomputed later) -- reordering it into rank order would need a second copy of it (92 bytes
+ * per voxel at 9^3).  Same selections as ppp_cover_pass (foreground_cover.py:111-180).        */
+int ppp_cover_pass_voxel_bits(uint8_t *d_mask, const uint32_t *d_bits_by_voxel, int64_t first_voxel,
+                              const int64_t *d_lin, int64_t n, int32_t pix_th, int32_t *d_state,
+                              int32_t *d_cleared, void *d_work, const ppp_params *p, void *stream,
+                              int32_t *rounds);
 
 /* --- S4: set-cover thinning on the device -------------------------------------------------
  * replaces thinOutForegroundCover (foreground_cover.py:183-256, sample == 1.0; a host loop in the

@@ -147,6 +147,11 @@ _SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_cover_pass_voxel_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.POINTER(Params), ctypes.c_void_p,
+                                                 ctypes.POINTER(ctypes.c_int32)]),
     "ppp_host_mws_sorted": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.c_int64, ctypes.c_void_p]),
     "ppp_rank_order_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
@@ -826,10 +831,12 @@ def patch_bits(pred, centres, thresh, P, scratch=None):
     return bits
 
 
-def cover_pass_device(mask, bits, lin, state, pix_th, P):
+def cover_pass_device(mask, bits, lin, state, pix_th, P, bits_first_voxel=None):
     """One pass of the greedy cover on the device (foreground_cover.py:111-180 without the stop
     rule, see ppp_cover_pass).  mask uint8 (Z,Y,X) is cleared in place; state int32 [n]
-    (0 = takes part; ends 1 selected / 2 not) is updated in place.
+    (0 = takes part; ends 1 selected / 2 not) is updated in place.  bits: int32 [n, words] in
+    list order, or -- bits_first_voxel given -- a table with a row per voxel whose first row
+    belongs to that linear voxel index (ppp_cover_pass_voxel_bits).
     Returns (cleared int32 [n], rounds)."""
     torch = _torch()
     n = int(state.numel())
@@ -839,9 +846,15 @@ def cover_pass_device(mask, bits, lin, state, pix_th, P):
     work = torch.empty(nbytes, dtype=torch.uint8, device=mask.device)
     rounds = ctypes.c_int32(0)
     with _timed("cover"):
-        check(lib().ppp_cover_pass(_dev_ptr(mask), _dev_ptr(bits), _dev_ptr(lin), n, int(pix_th),
-                                   _dev_ptr(state), _dev_ptr(cleared), _dev_ptr(work),
-                                   ctypes.byref(P), _stream(), ctypes.byref(rounds)))
+        if bits_first_voxel is None:
+            check(lib().ppp_cover_pass(_dev_ptr(mask), _dev_ptr(bits), _dev_ptr(lin), n, int(pix_th),
+                                       _dev_ptr(state), _dev_ptr(cleared), _dev_ptr(work),
+                                       ctypes.byref(P), _stream(), ctypes.byref(rounds)))
+        else:
+            check(lib().ppp_cover_pass_voxel_bits(_dev_ptr(mask), _dev_ptr(bits), int(bits_first_voxel),
+                                                  _dev_ptr(lin), n, int(pix_th), _dev_ptr(state),
+                                                  _dev_ptr(cleared), _dev_ptr(work), ctypes.byref(P),
+                                                  _stream(), ctypes.byref(rounds)))
     return cleared, int(rounds.value)
 
 

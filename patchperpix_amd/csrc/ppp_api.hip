@@ -578,23 +578,39 @@ int64_t ppp_cover_workspace_bytes(int64_t n, const ppp_params *p) {
     return (int64_t)ppp::cover_workspace_bytes(n < 0 ? 0 : n, G);
 }
 
-int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
-                   int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
-                   const ppp_params *p, void *stream, int32_t *rounds) {
+static int cover_pass_impl(uint8_t *d_mask, const uint32_t *d_bits, int64_t first_voxel, const int64_t *d_lin,
+                           int64_t n, int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
+                           const ppp_params *p, void *stream, int32_t *rounds, const char *who) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     if (rounds) *rounds = 0;
     if (n <= 0) return PPP_OK;
     if (n > 0x7F000000LL) return fail(PPP_ERR_INVALID_ARG, "too many ranked patches for one cover pass");
-    if (G.px > 32) return fail(PPP_ERR_UNSUPPORTED, "ppp_cover_pass needs patch rows of at most 32 voxels");
+    if (G.px > 32) return fail(PPP_ERR_UNSUPPORTED, "%s needs patch rows of at most 32 voxels", who);
     if (!d_mask || !d_bits || !d_lin || !d_state || !d_cleared || !d_work)
         return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
     PPP_TRY(need_device());
     int r = 0;
-    hipError_t e = ppp::run_cover_pass(d_mask, d_bits, (const long long *)d_lin, n, pix_th, d_state,
+    hipError_t e = ppp::run_cover_pass(d_mask, d_bits, first_voxel, (const long long *)d_lin, n, pix_th, d_state,
                                        d_cleared, d_work, G, (hipStream_t)stream, &r);
     if (rounds) *rounds = r;
-    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_pass");
+    return e == hipSuccess ? PPP_OK : hip_fail(e, who);
+}
+
+int ppp_cover_pass(uint8_t *d_mask, const uint32_t *d_bits, const int64_t *d_lin, int64_t n,
+                   int32_t pix_th, int32_t *d_state, int32_t *d_cleared, void *d_work,
+                   const ppp_params *p, void *stream, int32_t *rounds) {
+    return cover_pass_impl(d_mask, d_bits, -1, d_lin, n, pix_th, d_state, d_cleared, d_work, p, stream, rounds,
+                           "ppp_cover_pass");
+}
+
+int ppp_cover_pass_voxel_bits(uint8_t *d_mask, const uint32_t *d_bits_by_voxel, int64_t first_voxel,
+                              const int64_t *d_lin, int64_t n, int32_t pix_th, int32_t *d_state,
+                              int32_t *d_cleared, void *d_work, const ppp_params *p, void *stream,
+                              int32_t *rounds) {
+    if (first_voxel < 0) return fail(PPP_ERR_INVALID_ARG, "first_voxel must be >= 0");
+    return cover_pass_impl(d_mask, d_bits_by_voxel, first_voxel, d_lin, n, pix_th, d_state, d_cleared, d_work, p,
+                           stream, rounds, "ppp_cover_pass_voxel_bits");
 }
 
 int64_t ppp_rank_order_workspace_bytes(const ppp_params *p) {

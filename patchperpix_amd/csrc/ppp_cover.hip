@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(COUNT_THREADS)
     cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                        uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
-                       const int32_t *__restrict__ loc_vol, uint8_t *__restrict__ witness, const Geo G) {
+                       const int32_t *__restrict__ loc_vol, uint8_t *__restrict__ witness,
+                       const long long bits_vox, const Geo G) {
     __shared__ uint16_t s_list[COUNT_THREADS];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
@@ -151,7 +152,8 @@ __global__ void __launch_bounds__(COUNT_THREADS)
         const int words = (G.C + 31) / 32, XW = row_words(G);
         int cz, cy, cx;
         centre_of(G, v, cz, cy, cx);
-        const uint32_t *b = bits + (long long)k * words;
+        // (bits_vox >= 0: the table has a row per VOXEL, its first row belongs to voxel bits_vox)
+        const uint32_t *b = bits + (bits_vox >= 0 ? v - bits_vox : (long long)k) * words;
         const int start = cx - G.rx, wi = start >> 5, sh = start & 31;
         const bool two = sh + G.px > 32;
         const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
@@ -327,7 +329,7 @@ __global__ void __launch_bounds__(256)
                         const int32_t *__restrict__ nbr_min, int32_t *__restrict__ state,
                         int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
                         uint8_t *__restrict__ dirty, const int32_t *__restrict__ loc_vol,
-                        const int gZ, const Geo G) {
+                        const int gZ, const long long bits_vox, const Geo G) {
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int k = v < G.V ? rank_vol[v] : RANK_NONE;
@@ -342,7 +344,7 @@ __global__ void __launch_bounds__(256)
         const long long cc = v - lane + src;
         int cz, cy, cx;
         centre_of(G, cc, cz, cy, cx);
-        const uint32_t *b = bits + (long long)kk * words;
+        const uint32_t *b = bits + (bits_vox >= 0 ? cc - bits_vox : (long long)kk) * words;
         const int start = cx - G.rx, sh = start & 31;
         // window bits whose voxel is an interior x position
         uint32_t xin = 0;
@@ -403,9 +405,9 @@ static CoverWork carve(void *work, const Geo &G) {
 }
 
 // One pass of the cover loop without the stop rule.  Returns the number of rounds in *rounds.
-hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
-                          int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
-                          hipStream_t s, int *rounds) {
+hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vox, const long long *lin,
+                          long long n, int pix_th, int32_t *state, int32_t *cleared, void *work,
+                          const Geo &G, hipStream_t s, int *rounds) {
     *rounds = 0;
     if (n <= 0) return hipSuccess;
     PPP_GRID_CHECK((G.V + 255) / 256, 256);
@@ -425,11 +427,11 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *
         const dim3 cgrid((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), cblock(COUNT_THREADS);
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<cgrid, cblock, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
-                                                       W.counters + r, nullptr, W.witness, G);
+                                                       W.counters + r, nullptr, W.witness, bits_vox, G);
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
             minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
-                                                        W.dirty, nullptr, G.Z + G.oz, G);
+                                                        W.dirty, nullptr, G.Z + G.oz, bits_vox, G);
         }
         *rounds += COVER_BATCH;
         // "any patch undecided" at the start of the batch's last round; if none, that round
@@ -789,7 +791,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
     hipError_t e;
     if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
     cover_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
-        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, W.witness, G);
+        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, W.witness, -1ll, G);
     return hipGetLastError();
 }
 
@@ -803,7 +805,7 @@ hipError_t cover_step_select(const uint32_t *bits, int32_t *state, int32_t *clea
                              int gZ, const Geo &G, hipStream_t s) {
     CoverWork W = carve(work, G);
     cover_select_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
-        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, G);
+        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, -1ll, G);
     return hipGetLastError();
 }
 

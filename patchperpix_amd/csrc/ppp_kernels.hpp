@@ -81,9 +81,9 @@ hipError_t launch_decode_tail(const float *X, long long B, int F, int S, const f
                               void *pred, int dtype, const Geo &G, hipStream_t s);
 
 size_t cover_workspace_bytes(long long n, const Geo &G);
-hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, const long long *lin, long long n,
-                          int pix_th, int32_t *state, int32_t *cleared, void *work, const Geo &G,
-                          hipStream_t s, int *rounds);
+hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vox, const long long *lin,
+                          long long n, int pix_th, int32_t *state, int32_t *cleared, void *work,
+                          const Geo &G, hipStream_t s, int *rounds);
 
 size_t rank_order_workspace_bytes(const Geo &G);
 hipError_t run_rank_order(const float *score, const uint8_t *fg, long long *lin, float *out_score,

@@ -323,12 +323,15 @@ class DeviceOps:
         0 / 1 device tensor (Z, Y, X)."""
         return backend.rank_order_device(score_dev, foreground, ps, to_host=False)
 
-    def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw):
+    def greedy_cover(self, mask_to_cover, bits, lin, scores, never, pix_ths, radslice, P, kw,
+                     bits_first_voxel=None):
         """Greedy cover of the global mask (uint8 0 / 1 device tensor, not modified; replicated:
-        every rank runs the same rounds on its own device).  Returns a bool tensor over the
-        ranked list."""
+        every rank runs the same rounds on its own device).  bits: rows in list order, or one row
+        per voxel from linear voxel `bits_first_voxel` on.  Returns a bool tensor over the ranked
+        list."""
         from .vote_instances import foreground_cover as fc
-        sel, _ = fc.greedy_cover_device(mask_to_cover.clone(), bits, lin, never, pix_ths, radslice, P)
+        sel, _ = fc.greedy_cover_device(mask_to_cover.clone(), bits, lin, never, pix_ths, radslice, P,
+                                        bits_first_voxel=bits_first_voxel)
         return sel
 
     def thin_cover(self, mask_to_cover, bits, lin, P):
@@ -918,6 +921,11 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                                              mask_d, lin_t, never, pix_ths, radslice,
                                              lambda idx: bits_of_own(coords_t[idx], kw["fc_threshold"]),
                                              local_params)
+                elif provider and comm.world == 1 and hasattr(ops, "voxel_major_pool"):
+                    # the per-voxel bit table of stage A serves the cover as it is (a copy in rank
+                    # order would double its 92 bytes per voxel)
+                    selected = ops.greedy_cover(mask_d, bits_own, lin_t, rscores_t, never, pix_ths, radslice,
+                                                Pg, kw, bits_first_voxel=oz0 * plane)
                 else:
                     bits = gathered_bits(coords_t, kw["fc_threshold"], True)
                     selected = ops.greedy_cover(mask_d, bits, lin_t, rscores_t, never, pix_ths, radslice, Pg, kw)

@@ -82,10 +82,11 @@ def _pix_thresholds(patchshape, kwargs):
     return [t for t in [500, 100, 50, 10, 0] if t < mid]
 
 
-def greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P, silent=True):
+def greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P, silent=True, bits_first_voxel=None):
     """All passes of the cover on the device.  mask uint8 (Z,Y,X) device tensor (cleared in
-    place), bits int32 [n, words] patch bits in rank order, lin int64 [n] centres, never bool
-    [n] patches that do not take part.  Returns (selected bool [n] device, uncovered)."""
+    place), bits int32 [n, words] patch bits in rank order (or a row per voxel starting at linear
+    voxel `bits_first_voxel`), lin int64 [n] centres, never bool [n] patches that do not take
+    part.  Returns (selected bool [n] device, uncovered)."""
     import torch
     n = int(lin.numel())
     remaining = int(torch.count_nonzero(mask[tuple(radslice)]).item())
@@ -98,7 +99,8 @@ def greedy_cover_device(mask, bits, lin, never, pix_ths, radslice, P, silent=Tru
             logger.info("compute foreground cover, threshold %s", pix_th)
         # every pass restarts at rank 0 (the reference passes rpidx by value)
         state = torch.where(selected, 1, torch.where(never, 2, 0)).to(torch.int32)
-        cleared, rounds = backend.cover_pass_device(mask, bits, lin, state, pix_th, P)
+        cleared, rounds = backend.cover_pass_device(mask, bits, lin, state, pix_th, P,
+                                                    bits_first_voxel=bits_first_voxel)
         total_rounds += rounds
         idx = torch.nonzero((state == 1) & ~selected).flatten()       # rank order
         left = remaining - torch.cumsum(cleared[idx].long(), 0)

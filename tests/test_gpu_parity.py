@@ -363,6 +363,39 @@ def test_device_cover_matches_sequential_loop(variant, torch_cuda, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("passes", [False, True])
+def test_cover_with_a_bit_row_per_voxel_equals_rank_ordered_rows(passes, torch_cuda):
+    """ppp_cover_pass_voxel_bits (the table the tiled assembly fills tile by tile under a
+    prediction provider: a row per voxel, here starting a few voxels before the first centre)
+    selects what ppp_cover_pass selects from the rows in rank order."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from patchperpix_amd.vote_instances import foreground_cover as fc
+    from tests_flags import FLYLIGHT
+    kw = dict(FLYLIGHT, select_patches_for_sparse_data=not passes)
+    shape, ps = (24, 40, 44), (5, 5, 5)
+    c = synth.make_case(shape, ps, seed=63, cell=[9, 10, 11], overlap_frac=0.02)
+    pred, overlap, mask, ranked, radslice, rad = _cover_inputs(
+        torch_cuda, c["pred"], c["foreground"], c["numinst"], ps, kw)
+    P = backend.params_from_kwargs(shape, ps, kw)
+    dev = pred.device
+    lin = torch.from_numpy(ranked.lin(shape)).to(dev)
+    by_rank = backend.patch_bits(pred, torch.from_numpy(ranked.coords).to(dev), kw["fc_threshold"], P)
+    first = max(0, int(lin.min()) - 5)
+    V = int(np.prod(shape))
+    by_voxel = torch.full((V - first, by_rank.shape[1]), -1, dtype=torch.int32, device=dev)   # junk off the list
+    by_voxel[lin - first] = by_rank
+    never = torch.from_numpy(fc.never_selected(overlap, ranked.lin(shape), ranked.scores,
+                                               kw.get("score_threshold", False))).to(dev)
+    m = torch.from_numpy((np.asarray(mask) != 0).astype(np.uint8)).to(dev)
+    pix = fc._pix_thresholds(ps, kw)
+    a, ra = fc.greedy_cover_device(m.clone(), by_rank, lin, never, pix, radslice, P)
+    b, rb = fc.greedy_cover_device(m.clone(), by_voxel, lin, never, pix, radslice, P, bits_first_voxel=first)
+    assert int(a.sum()) > 20 and ra == rb
+    assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_patch_bits_dense_equals_per_centre(monkeypatch):
     """backend.patch_bits picks a per-voxel pass + row gather for many centres: same words as the
     wave-per-centre kernel, and as NumPy."""
