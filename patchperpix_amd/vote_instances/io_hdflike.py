@@ -1,11 +1,14 @@
 """HDF / zarr containers (reference: PatchPerPix/vote_instances/io_hdflike.py).
 
-zarr directory stores -- what the reference's prediction step writes (``output_format =
-"zarr"``, predict_no_gp.py:243-257) -- are read and written WITHOUT the ``zarr`` package:
-``patchperpix_amd.minizarr`` implements format 2 with the reference's Blosc-zstd-bitshuffle
-compressor.  When ``zarr`` is importable it is used instead.  HDF5 files still need ``h5py``
-(absent from this image): opening one without it raises; results are then written as a zarr
-store carrying the same dataset names and attributes (``write_datasets``).
+Neither ``zarr`` nor ``h5py`` is needed:
+
+* zarr directory stores -- what the reference's prediction step writes (``output_format =
+  "zarr"``, predict_no_gp.py:243-257) -- go through ``patchperpix_amd.minizarr`` (format 2 with
+  the reference's Blosc-zstd-bitshuffle compressor); when ``zarr`` is importable it is used;
+* HDF5 files -- ``.hdf`` predictions and the result files of the `label` task -- go through h5py
+  when it is importable, otherwise through ``patchperpix_amd.minihdf5`` (the HDF5 C library of the
+  image, bound with ctypes).  Only when neither exists are results written as a zarr store with
+  the same dataset names and attributes (``write_datasets``) and does opening a ``.hdf`` raise.
 """
 import contextlib
 import logging
@@ -27,16 +30,27 @@ def _zarr_module():
     return minizarr
 
 
+def _hdf5_module():
+    """h5py, else the ctypes layer over libhdf5, else None"""
+    if os.environ.get("PPP_HDF5", "auto") != "mini":
+        try:
+            import h5py
+            return h5py
+        except ImportError:
+            pass
+    from .. import minihdf5
+    return minihdf5 if minihdf5.available() else None
+
+
 @contextlib.contextmanager
 def open_container(path, mode="r"):
     if path.rstrip("/").endswith(".zarr"):
         yield _zarr_module().open(path, mode)
         return
-    try:
-        import h5py
-    except ImportError as e:  # pragma: no cover
-        raise RuntimeError("reading/writing %s needs the `h5py` package (zarr stores do not)" % path) from e
-    f = h5py.File(path, mode)
+    h5 = _hdf5_module()
+    if h5 is None:  # pragma: no cover
+        raise RuntimeError("reading/writing %s needs h5py or an HDF5 C library (zarr stores do not)" % path)
+    f = h5.File(path, mode)
     try:
         yield f
     finally:
@@ -46,22 +60,21 @@ def open_container(path, mode="r"):
 def write_datasets(out_fn, datasets, attrs=None):
     """The result file of the `label` task (vote_instances.py:542-554, stitch_patch_graph.py:
     849-870): datasets ``<res_key>`` / ``vote_foreground`` (/ ``<res_key>_masked``), gzip, attrs
-    ``offset`` and ``resolution``.  ``out_fn`` ending in ``.hdf`` is written with h5py when that
-    is importable; otherwise (and for ``.zarr`` names) a zarr store ``<stem>.zarr`` with the same
-    dataset names, dtypes and attributes is written.  Returns the path written."""
+    ``offset`` and ``resolution``.  ``out_fn`` ending in ``.hdf`` is written as HDF5 (h5py, or
+    the HDF5 C library through ``minihdf5``); without either (and for ``.zarr`` names) a zarr store
+    ``<stem>.zarr`` with the same dataset names, dtypes and attributes is written.  Returns the path written."""
     attrs = attrs or {"offset": (0, 0, 0), "resolution": (1, 1, 1)}
     if not out_fn.endswith(".zarr"):
-        try:
-            import h5py
-            with h5py.File(out_fn, "w") as f2:
+        h5 = _hdf5_module()
+        if h5 is not None:
+            with h5.File(out_fn, "w") as f2:
                 for key, data in datasets.items():
                     f2.create_dataset(key, data=data, compression="gzip")
                     for k, v in attrs.items():
                         f2[key].attrs[k] = v
             return out_fn
-        except ImportError:
-            out_fn = os.path.splitext(out_fn)[0] + ".zarr"
-            logger.warning("h5py not available: writing %s (same datasets and attributes)", out_fn)
+        out_fn = os.path.splitext(out_fn)[0] + ".zarr"
+        logger.warning("no HDF5 library available: writing %s (same datasets and attributes)", out_fn)
     zf = _zarr_module().open(out_fn, mode="w")
     for key, data in datasets.items():
         data = np.asarray(data)

@@ -349,8 +349,8 @@ def do_all(aff_file, patchshape=np.array([1, 25, 25]), **kwargs):
 
 
 def write_result(out_fn, datasets):
-    """HDF5 via h5py when it is importable (the reference's format, vote_instances.py:542-554),
-    otherwise a zarr store ``<stem>.zarr`` with the same dataset names, dtypes and attributes
+    """HDF5 (the reference's format, vote_instances.py:542-554) through h5py or the HDF5 C library;
+    without either a zarr store ``<stem>.zarr`` with the same dataset names, dtypes and attributes
     (io_hdflike.write_datasets)."""
     return io_hdflike.write_datasets(out_fn, datasets)
 

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 def _load_result(folder, name):
     hdf, zr = os.path.join(folder, name + ".hdf"), os.path.join(folder, name + ".zarr")
     if os.path.exists(hdf):
-        import h5py
-        with h5py.File(hdf, "r") as f:
+        from patchperpix_amd.vote_instances import io_hdflike
+        with io_hdflike.open_container(hdf, "r") as f:
             return {k: np.array(f[k]) for k in f.keys()}
     from patchperpix_amd import minizarr
     f = minizarr.open(zr)
