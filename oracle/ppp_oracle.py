@@ -458,8 +458,42 @@ def paint_instances(ccs, pred, patchshape, shape, th, dtype=np.uint16):
     return inst
 
 
+def paint_per_channel(ccs, pred, patchshape, shape, th, packed, dtype=np.uint16):
+    """graph_to_labeling.py:57-115 with one_instance_per_channel (packed = False: a volume per
+    component) or no_overlap_per_channel (packed = True: a component of more than 2000 voxels goes
+    into the first channel it does not overlap, else a new one; smaller ones into channel 0)."""
+    patchshape = [int(p) for p in patchshape]
+    rad = np.array([p // 2 for p in patchshape])
+    channels = []
+    for k, cc in enumerate(ccs):
+        cur = np.zeros(shape, dtype=dtype)
+        for c in cc:
+            c = np.array(c)
+            patch = pred[(slice(None),) + tuple(int(v) for v in c)].reshape(patchshape)
+            cur[_window(c, rad)][patch > th] = k + 1
+        if not packed:
+            channels.append(cur)
+        elif not channels:
+            channels.append(cur)
+        else:
+            m = cur > 0
+            if np.sum(m) > 2000:
+                for ch in channels:
+                    if np.all(ch[m] == 0):
+                        ch[m] = k + 1
+                        break
+                else:
+                    channels.append(cur)
+            else:
+                channels[0][m] = k + 1
+    return np.stack(channels, axis=0)
+
+
 def label(pairs, aff, pred, patchshape, shape, **kw):
     ccs = mutex_watershed(pairs, aff) if kw.get("mws") else connected_components(pairs, aff)
+    if kw.get("one_instance_per_channel") or kw.get("no_overlap_per_channel"):
+        return paint_per_channel(ccs, pred, patchshape, shape, kw["patch_threshold"],
+                                 packed=not kw.get("one_instance_per_channel"))
     return paint_instances(ccs, pred, patchshape, shape, kw["patch_threshold"])
 
 

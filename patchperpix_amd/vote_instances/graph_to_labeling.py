@@ -56,9 +56,10 @@ def affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, debug_output
     (uint16 single volume, uint32 when stitching); painting happens on the device with
     "largest component id wins", which is what the reference's in-order overwrite yields."""
     import torch
-    for opt in ("one_instance_per_channel", "no_overlap_per_channel", "sparse_labels"):
-        if kwargs.get(opt, False):
-            raise NotImplementedError("%s is not supported" % opt)
+    if kwargs.get("sparse_labels", False):
+        # (patches handed in as a dict keyed by centre: only stitch_vote_instances does that,
+        # stitch_patch_graph.py:380-399 -- served by patchperpix_amd.blockwise.label_graph)
+        raise NotImplementedError("sparse_labels is served by patchperpix_amd.blockwise, not here")
     if not isinstance(affinity_graph, AffGraph):   # a networkx graph from outside
         rows = [(tuple(a) + tuple(b), w) for a, b, w in affinity_graph.edges.data("aff")]
         affinity_graph = AffGraph([w for _, w in rows], [r for r, _ in rows],
@@ -70,16 +71,56 @@ def affGraphToInstances(affinity_graph, pred_affs, patchshape, rad, debug_output
     out_dtype = instances.dtype
     if len(labels) and labels.max() > np.iinfo(out_dtype).max:
         raise OverflowError("%d instances do not fit %s" % (labels.max(), out_dtype))
-    inst_dev = torch.from_numpy(np.ascontiguousarray(instances).astype(np.int32)).to(pred_affs.device)
-    if len(nodes):
-        backend.paint_instances(pred_affs,
-                                torch.from_numpy(np.ascontiguousarray(nodes)).to(pred_affs.device),
-                                torch.from_numpy(labels.astype(np.int32)).to(pred_affs.device),
-                                inst_dev, P)
-    instances = inst_dev.cpu().numpy().astype(out_dtype)
+    dev = pred_affs.device
+    per_channel = kwargs.get("one_instance_per_channel", False)
+    packed = kwargs.get("no_overlap_per_channel", False)
+    if per_channel or packed:
+        # graph_to_labeling.py:57-115: every component is painted into a volume of its own;
+        # one_instance_per_channel stacks them, no_overlap_per_channel puts a component of more
+        # than 2000 voxels into the first channel it does not overlap (a new one if none) and
+        # every smaller one into channel 0 (whatever is there)
+        nodes_dev = torch.from_numpy(np.ascontiguousarray(nodes)).to(dev)
+        labels_dev = torch.from_numpy(labels.astype(np.int32)).to(dev)
+        channels = []
+        n_comp = int(labels.max()) if len(labels) else 0
+        for value in range(1, n_comp + 1):
+            own = torch.nonzero(labels_dev == value).reshape(-1)
+            cur = torch.zeros(instances.shape, dtype=torch.int32, device=dev)
+            if own.numel():
+                backend.paint_instances(pred_affs, nodes_dev[own].contiguous(), labels_dev[own].contiguous(), cur, P)
+            if per_channel:
+                channels.append(cur)
+            if packed:
+                if not channels:
+                    channels.append(cur)
+                    continue
+                m = cur > 0
+                if int(m.sum().item()) > 2000:
+                    for ch in channels:
+                        if not bool((ch[m] != 0).any().item()):
+                            ch[m] = value
+                            break
+                    else:
+                        channels.append(cur)
+                else:
+                    channels[0][m] = value
+        if channels:
+            instances = torch.stack(channels, 0).cpu().numpy().astype(out_dtype)
+        else:
+            # (np.stack of an empty list raises in the reference; a volume without components
+            # leaves the early-outs of to_instance_seg before it gets here)
+            instances = np.zeros((0,) + tuple(instances.shape), dtype=out_dtype)
+    else:
+        inst_dev = torch.from_numpy(np.ascontiguousarray(instances).astype(np.int32)).to(dev)
+        if len(nodes):
+            backend.paint_instances(pred_affs, torch.from_numpy(np.ascontiguousarray(nodes)).to(dev),
+                                    torch.from_numpy(labels.astype(np.int32)).to(dev), inst_dev, P)
+        instances = inst_dev.cpu().numpy().astype(out_dtype)
     logger.info("done compute labeling")
     if kwargs.get("pad_with_ps", False):
-        sl = tuple(slice(int(rad[i]), instances.shape[i] - int(rad[i])) for i in range(3))
-        instances = instances[sl]
+        # (:139-151: the spatial axes are the last three, also of the stacked map)
+        sp = instances.shape[-3:]
+        sl = tuple(slice(int(rad[i]), sp[i] - int(rad[i])) for i in range(3))
+        instances = instances[(Ellipsis,) + sl]
         foreground = foreground[sl]
     return instances, foreground.astype(np.uint8)

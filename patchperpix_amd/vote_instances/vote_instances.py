@@ -164,7 +164,8 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     plain = kwargs.get("save_no_intermediates", False) and not kwargs.get("debug", False) \
         and not any(kwargs.get(k) for k in ("skipConsensus", "skipRanking",
                                             "termAfterThinCover", "termAfterPatchGraph",
-                                            "save_consensus", "blockwise")) \
+                                            "save_consensus", "blockwise",
+                                            "one_instance_per_channel", "no_overlap_per_channel")) \
         and os.environ.get("PPP_PIPELINE", "fused") != "stages"
     if n_slabs and (n_slabs > 1 or yx_tiles or plain) and not kwargs.get("graphToInst") \
             and kwargs.get("aff_graph") is None and not kwargs.get("pad_with_ps", False):
@@ -342,7 +343,9 @@ def do_all(aff_file, patchshape=np.array([1, 25, 25]), **kwargs):
         return
     foreground = foreground.astype(np.uint8)
     if kwargs.get('crop_to_foreground', True):
-        instances[foreground == 0] = 0
+        # (:535-540: channel by channel for the stacked map; boolean indexing of the leading
+        # axes would not broadcast)
+        instances[..., foreground == 0] = 0
     fn = os.path.splitext(os.path.basename(aff_file))[0]
     out_fn = os.path.join(kwargs['result_folder'], fn + ".hdf")
     write_result(out_fn, {res_key + res_ext: instances, 'vote_foreground' + res_ext: foreground})

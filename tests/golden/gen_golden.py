@@ -390,13 +390,20 @@ CASES = {
                         dict(skipThinCover=False, mws=True)),
     "c3d_p7_thin_mws": ((16, 18, 20), (7, 7, 7), dict(kind="cells", seed=17, cell=[9, 9, 9]),
                         dict(skipThinCover=False, mws=True)),
+    # graph_to_labeling.py:57-115: a channel per instance / instances packed into channels
+    # without overlap (components above 2000 voxels are placed, the others go to channel 0)
+    "c3d_p3_per_channel": ((12, 13, 14), (3, 3, 3), dict(kind="cells", seed=18, cell=[5, 5, 5]),
+                           dict(one_instance_per_channel=True)),
+    "c3d_p3_packed_channels": ((22, 30, 32), (3, 3, 3),
+                               dict(kind="cells", seed=19, cell=[11, 15, 16], overlap_frac=0.02),
+                               dict(no_overlap_per_channel=True, skipThinCover=False)),
     "c3d_empty": ((10, 10, 10), (3, 3, 3), dict(kind="empty", seed=0), {}),
     "c3d_single_patch": ((3, 3, 3), (3, 3, 3), dict(kind="cells", seed=1, cell=[9, 9, 9]),
                          {}),
 }
 # cases whose consensus array is too big to commit: keep a SHA-256 of the float bits
 HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells", "c3d_p9_cells", "c2d_p25_cells",
-                  "c3d_p5_thin_mws", "c3d_p7_thin_mws"}
+                  "c3d_p5_thin_mws", "c3d_p7_thin_mws", "c3d_p3_packed_channels"}
 # cases that are ALSO run through the reference's NumPy path (cuda=False; int16 +-1 votes,
 # SURVEY 8c "recipe A").  Different arithmetic from the kernels: only the final instance map
 # is stored, to document that both semantics agree on well separated instances.
