@@ -120,7 +120,10 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
         const hipError_t e3 = launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
         if (e3 != hipErrorNotSupported) { g_s1_kernel = "consensus_v3_kernel"; return e3; }
         const hipError_t e2 = launch_consensus_v2(pred, dtype, ov, cons, cnt, G, s);
-        if (e2 != hipErrorNotSupported) { g_s1_kernel = "consensus_v2_kernel"; return e2; }
+        if (e2 != hipErrorNotSupported) {
+            g_s1_kernel = G.px == 25 ? "consensus_wide_kernel" : "consensus_v2_kernel";   // (the 25-wide one lives in the v2 file)
+            return e2;
+        }
     }
     g_s1_kernel = "consensus_gather_kernel";
     if (dtype == PPP_F16)

@@ -136,6 +136,28 @@ def test_head_and_tail_compose_and_fused_tail_is_recognised():
     assert dec.PatchDecoder(dict(AE_SHIPPED, input_shape_squeezed=(5, 5, 5))).fused_tail_params() is None
 
 
+@pytest.mark.parametrize("cfg", ["shipped", "small"])
+def test_dense_head_equals_convolution_head(cfg):
+    """enable_dense_head: every convolution of the head (the first with the upsampling in front
+    of it) as x @ W + b, W made by pushing the identity through the layer.  Same weights, another
+    summation order: |diff| <= 1e-5 * max|value| in float32."""
+    torch.manual_seed(5)
+    d = dec.PatchDecoder(dict(AE_SHIPPED if cfg == "shipped" else AE)).eval()
+    x = torch.randn(9, d.code_units)
+    with torch.no_grad():
+        want = d.head(x)
+        assert d.enable_dense_head()
+        assert len(d._dense["stages"]) == 3 and d._dense["stages"][-1][0].shape[1] == int(np.prod(want.shape[1:]))
+        got = d.head(x)
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        # the whole decoder through the dense head
+        assert float((d(x) - d.tail(want)).abs().max()) <= 1e-5 * max(1.0, float(d.tail(want).abs().max()))
+    # a matrix above the limit: nothing changes
+    d2 = dec.PatchDecoder(dict(AE_SHIPPED)).eval()
+    assert not d2.enable_dense_head(max_bytes=1 << 20) and getattr(d2, "_dense", None) is None
+
+
 @pytest.mark.gpu
 def test_fused_tail_kernel_matches_torch_tail():
     """csrc/ppp_decode.hip (f32 MFMA over the channels, LDS gathers, crop, float16, scatter) against

@@ -36,8 +36,10 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
     pred = _dev(torch, pred_host.astype(np.float16) if f16 else pred_host.astype(np.float32))
     ov = _dev(torch, (overlap_mask > 0).astype(np.uint8)) if P.use_overlap else None
     cons = backend.consensus(pred, ov, P)
+    s1_kernel = backend.lib().ppp_consensus_kernel_name().decode()
     score = backend.rank_patches(pred, cons, ov, P)
-    out = dict(cons=cons.cpu().numpy(), score=score.cpu().numpy(), P=P, pred=pred, cons_dev=cons)
+    out = dict(cons=cons.cpu().numpy(), score=score.cpu().numpy(), P=P, pred=pred, cons_dev=cons,
+               s1_kernel=s1_kernel)
     if backend.rank_vm_available(P):
         # the row-stationary ranking kernel on the voxel-major layout: same bits as the gather kernel
         vm0, Pv0 = backend.cons_to_voxel_major(cons, P)
@@ -123,7 +125,16 @@ CASES = [
     # anisotropic patches through the specialised kernels (px = 7 / 9, pz, py smaller)
     ((10, 16, 30), (3, 5, 7), dict(seed=27, cell=[4, 7, 9], overlap_frac=0.02), {}),
     ((12, 17, 21), (5, 9, 9), dict(seed=28, cell=[6, 11, 11]), {}),
+    # a patch width without a specialised kernel: the generic gather kernels
+    ((1, 40, 44), (1, 11, 11), dict(seed=29, cell=[1, 13, 13]), dict(overlapping_inst=False)),
 ]
+
+
+# the S1 kernel that serves each case (ppp_consensus_kernel_name): every family meets the oracle
+# directly, not only through the kernel it replaced
+S1_KERNEL = ["consensus_v3_kernel", "consensus_v2_kernel", "consensus_v2_kernel", "consensus_v2_kernel",
+             "consensus_v3_kernel", "consensus_wide_kernel", "consensus_v3_kernel", "consensus_v3_kernel",
+             "consensus_gather_kernel"]
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -141,6 +152,7 @@ def test_kernels_match_oracle_on_fresh_inputs(case, torch_cuda):
     ref = orc.to_instance_seg(pred, c["foreground"], c["foreground"].copy(), c["numinst"], ps, **kw)
     assert "aff" in ref
     o = _stage_outputs(torch_cuda, pred, ov, ps, kw, ref["pairs"])
+    assert o["s1_kernel"] == S1_KERNEL[case]
     assert np.array_equal(_bits(o["cons"]), _bits(orc.positive_planes(ref["cons"], ps)))
     assert np.array_equal(_bits(o["score"]), _bits(ref["scores"]))
     assert np.array_equal(_bits(o["aff"]), _bits(ref["aff"]))
@@ -298,6 +310,38 @@ def test_large_volume_consistency(torch_cuda):
                                   **dict(kw, _n_slabs=3))
     assert whole.max() > 50
     assert np.array_equal(whole, tiled)
+
+
+def test_tiled_equals_untiled_at_128_cubed_with_9_cubed_patches(torch_cuda):
+    """128^3 / 9^3 with the shipped flags (thinning + mutex watershed, uint32 ids): the untiled
+    assembly (41 GB of consensus), a 2 x 2 x 2 tile grid and a 3-slab one with the prediction behind
+    a provider give the same instance map.  The sizes and flags of BASELINE config [2], an
+    eighth of its edge."""
+    from patchperpix_amd import backend, synth, tiling
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    shape, ps = (128, 128, 128), (9, 9, 9)
+    kw = dict(FLYLIGHT, _instances_dtype=np.uint32)
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, [24, 24, 24], seed=0)
+    pred = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=0, f16=True)
+    fg = lab != 0
+    args = lambda: (fg.copy(), fg.copy(), fg.astype(np.uint8), ps)    # noqa: E731
+    whole, _ = vi.to_instance_seg(pred, *args(), **dict(kw, _n_slabs=1))
+    assert whole.dtype == np.uint32 and whole.max() > 1000
+    tiled, _ = vi.to_instance_seg(pred, *args(), **dict(kw, _n_slabs=2, _yx_tiles=(2, 2)))
+    assert np.array_equal(whole, tiled)
+
+    class Provider:
+        def pred_box(self, box):
+            z0, z1, y0, y1, x0, x1 = box
+            return pred[:, z0:z1, y0:y1, x0:x1].contiguous()
+    fg_d = _dev(torch, fg.astype(np.uint8))
+    flags = {k: v for k, v in kw.items()}
+    prov, _ = tiling.assemble(Provider(), 0, shape, fg_d, fg_d.clone(), fg_d, ps, tiling.plan_slabs(shape[0], 3),
+                              _yx_tiles=(1, 2), **flags)
+    assert np.array_equal(whole, np.asarray(prov))
 
 
 def _cover_inputs(torch, pred_host, foreground, numinst, ps, kw):
