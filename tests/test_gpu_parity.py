@@ -776,7 +776,7 @@ def test_consensus_wide_patch_kernel_equals_generic(rule, torch_cuda, monkeypatc
             monkeypatch.setenv("PPP_S1_WIDE", wide)
             cons, cnt = backend.consensus(pred, ov, P, want_count=True)
             out[wide] = (cons.cpu().numpy(), cnt.cpu().numpy(), backend.NOTES.get("s1_kernel"))
-        assert out["0"][2] == "consensus_gather_kernel" and out["1"][2] == "consensus_v2_kernel"
+        assert out["0"][2] == "consensus_gather_kernel" and out["1"][2] == "consensus_wide_kernel"
         assert np.array_equal(out["0"][1], out["1"][1]), (box, "counts")
         assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32)), box
         assert np.count_nonzero(out["0"][0]) > 1000
