@@ -101,12 +101,54 @@ __global__ void __launch_bounds__(256)
     if (k < n && state[k] == 0) rank_vol[lin[k]] = k;
 }
 
-// Recount of ONE undecided patch k centred at voxel v: true = it can still cover more than pix_th
-// voxels (it stays undecided), false = rejected for good.
-__device__ __forceinline__ bool cover_recount(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
-                                              const long long v, const int k, const int pix_th,
-                                              uint8_t *__restrict__ witness, const long long bits_vox,
-                                              const Geo &G) {
+// Count step.  Thread per voxel; a workgroup of 1024 voxels first COMPACTS its undecided patches
+// whose neighbourhood changed into a list in LDS (and consumes the dirty marks; "any patch still
+// undecided" is flagged), then its first lanes recount them (per row of the window: mask bits AND
+// patch bits, popcount) and reject those that can cover <= pix_th voxels.  Recounting inside the
+// per-voxel sweep left one or two lanes of almost every wave walking the 49-row window while the
+// others idled -- a few per cent of the voxels are dirty candidates, scattered.  (A global list
+// costs a same-address atomic per wave: 4x slower than no compaction at all.)
+static constexpr int COUNT_THREADS = 1024;
+__global__ void __launch_bounds__(COUNT_THREADS)
+    cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
+                       uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
+                       int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
+                       const int32_t *__restrict__ loc_vol, uint8_t *__restrict__ witness,
+                       const long long bits_vox, const Geo G) {
+    __shared__ uint16_t s_list[COUNT_THREADS];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const long long v0 = blockIdx.x * (long long)blockDim.x;
+    {
+        const long long v = v0 + threadIdx.x;
+        const bool in = v < G.V;
+        int k = in ? rank_vol[v] : RANK_NONE;
+        // sharded: rank_vol holds GLOBAL ranks (also of the neighbour's patches in the halo);
+        // only the own centres are worked on, through their local table index
+        if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
+        const bool alive = k != RANK_NONE;
+        const bool marked = in && dirty[v] != 0;
+        if (marked) dirty[v] = 0;
+        const unsigned long long m = __ballot(alive && marked);
+        if (m != 0ull) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
+            base = __shfl(base, 0);
+            if (alive && marked) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        }
+        // "is any patch still undecided" AFTER this step: a plain store of the same value from
+        // every wave that has one that is not recounted now (same-address atomics from ~V/64
+        // waves would dominate the kernel); the recounted ones report below if they survive
+        if (__ballot(alive && !marked) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const long long v = v0 + s_list[t];
+        int k = rank_vol[v];
+        if (loc_vol) k = loc_vol[v];
         const int words = (G.C + 31) / 32, XW = row_words(G);
         int cz, cy, cx;
         centre_of(G, v, cz, cy, cx);
@@ -126,7 +168,8 @@ __device__ __forceinline__ bool cover_recount(const uint32_t *__restrict__ mbits
             if (wr != 0xFF) {
                 const uint32_t *row = mbits + ((long long)(cz + wr / G.py - G.rz) * G.Y + (cy + wr % G.py - G.ry)) * XW;
                 if (bit_window(row, start, G.px, XW) & bit_window(b, wr * G.px, G.px, words)) {
-                    return true;
+                    *n_alive = 1;
+                    continue;
                 }
             }
         }
@@ -181,64 +224,12 @@ __device__ __forceinline__ bool cover_recount(const uint32_t *__restrict__ mbits
                 }
             }
         }
-        if (hits <= pix_th) return false;
-        if (use_wit && wit_new < 0xFF) witness[v] = (uint8_t)wit_new;
-        return true;
-}
-
-// Count step.  Thread per voxel; a workgroup of 1024 voxels first COMPACTS its undecided patches
-// whose neighbourhood changed into a list in LDS (and consumes the dirty marks; "any patch still
-// undecided" is flagged), then its first lanes recount them (per row of the window: mask bits AND
-// patch bits, popcount) and reject those that can cover <= pix_th voxels.  Recounting inside the
-// per-voxel sweep left one or two lanes of almost every wave walking the 49-row window while the
-// others idled -- a few per cent of the voxels are dirty candidates, scattered.  (A global list
-// costs a same-address atomic per wave: 4x slower than no compaction at all.)
-static constexpr int COUNT_THREADS = 1024;
-__global__ void __launch_bounds__(COUNT_THREADS)
-    cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
-                       uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
-                       int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
-                       const int32_t *__restrict__ loc_vol, uint8_t *__restrict__ witness,
-                       const long long bits_vox, const Geo G) {
-    __shared__ uint16_t s_list[COUNT_THREADS];
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const long long v0 = blockIdx.x * (long long)blockDim.x;
-    {
-        const long long v = v0 + threadIdx.x;
-        const bool in = v < G.V;
-        int k = in ? rank_vol[v] : RANK_NONE;
-        // sharded: rank_vol holds GLOBAL ranks (also of the neighbour's patches in the halo);
-        // only the own centres are worked on, through their local table index
-        if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
-        const bool alive = k != RANK_NONE;
-        const bool marked = in && dirty[v] != 0;
-        if (marked) dirty[v] = 0;
-        const unsigned long long m = __ballot(alive && marked);
-        if (m != 0ull) {
-            const int lane = threadIdx.x & 63;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
-            base = __shfl(base, 0);
-            if (alive && marked) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
-        }
-        // "is any patch still undecided" AFTER this step: a plain store of the same value from
-        // every wave that has one that is not recounted now (same-address atomics from ~V/64
-        // waves would dominate the kernel); the recounted ones report below if they survive
-        if (__ballot(alive && !marked) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
-    }
-    __syncthreads();
-    const int n = s_n;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
-        const long long v = v0 + s_list[t];
-        int k = rank_vol[v];
-        if (loc_vol) k = loc_vol[v];
-        if (cover_recount(mbits, bits, v, k, pix_th, witness, bits_vox, G)) {
-            *n_alive = 1;
-        } else {
+        if (hits <= pix_th) {
             state[k] = 2;
             rank_vol[v] = RANK_NONE;
+        } else {
+            if (use_wit && wit_new < 0xFF) witness[v] = (uint8_t)wit_new;
+            *n_alive = 1;
         }
     }
 }
@@ -330,13 +321,27 @@ __device__ __forceinline__ T zmin_at(const T *__restrict__ xy, long long v, cons
     return m;
 }
 
-// One wave selects patch kk centred at voxel cc: clears its voxels from the running mask (lane per
-// window row), marks every centre within p-1 dirty, returns the cleared interior voxels.
-__device__ __forceinline__ int cover_select_one(uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
-                                                uint8_t *__restrict__ dirty, const long long cc, const int kk,
-                                                const int lane, const int gZ, const long long bits_vox,
-                                                const Geo &G) {
-        const int words = (G.C + 31) / 32, XW = row_words(G);
+// Thread per voxel: the best ranked undecided patch of its neighbourhood selects itself; its
+// wave clears the voxels (lane per window row) and marks the centres whose counts may have
+// changed.  Selected patches never share a voxel, but they may share a mask word.
+__global__ void __launch_bounds__(256)
+    cover_select_kernel(uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
+                        const int32_t *__restrict__ nbr_min, int32_t *__restrict__ state,
+                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
+                        uint8_t *__restrict__ dirty, const int32_t *__restrict__ loc_vol,
+                        const int gZ, const long long bits_vox, const Geo G) {
+    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int k = v < G.V ? rank_vol[v] : RANK_NONE;
+    bool ready = k != RANK_NONE && zmin_at<int32_t>(nbr_min, v, G) == k;   // nbr_min: xy-filtered ranks
+    if (loc_vol && ready) { k = loc_vol[v]; ready = k >= 0; }   // own centres only; local index
+    unsigned long long todo = __ballot(ready);
+    const int words = (G.C + 31) / 32, XW = row_words(G);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int kk = __shfl(k, src);
+        const long long cc = v - lane + src;
         int cz, cy, cx;
         centre_of(G, cc, cz, cy, cx);
         const uint32_t *b = bits + (bits_vox >= 0 ? cc - bits_vox : (long long)kk) * words;
@@ -369,147 +374,6 @@ __device__ __forceinline__ int cover_select_one(uint32_t *__restrict__ mbits, co
             uint8_t *d = dirty + vox(G, z0 + row / ny, y0 + row % ny, x0);
             for (int x = 0; x < nx; ++x) d[x] = 1;
         }
-        return cleared;
-}
-
-// ---- sparse rounds ----------------------------------------------------------------------------
-// The dense round sweeps the whole volume three times (count, x/y minimum, select with the z
-// minimum): ~12 GB of traffic at 512^3 whatever the number of undecided patches -- and most of
-// the ~700 rounds of a dense volume have only a few thousand left (chains of dependent
-// decisions).  Once few enough are undecided the rounds run over a LIST of them: recount the
-// dirty ones, test "lowest rank within p-1" by scanning the patch's own neighbourhood of the rank
-// volume, select.  Same decisions in the same rounds as the dense form.
-__global__ void __launch_bounds__(256)
-    cover_alive_count_kernel(const int32_t *__restrict__ rank_vol, const long long V,
-                             unsigned long long *__restrict__ total) {
-    long long n = 0;
-    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < V; v += (long long)gridDim.x * blockDim.x)
-        n += rank_vol[v] != RANK_NONE;
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, (unsigned long long)n);
-}
-// voxels that hold an undecided patch -> list (any order: every step below is order-free)
-__global__ void __launch_bounds__(256)
-    cover_list_build_kernel(const int32_t *__restrict__ rank_vol, const long long V, int32_t *__restrict__ list,
-                            unsigned long long *__restrict__ n_out) {
-    for (long long v0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) & ~63ll; v0 < V;
-         v0 += (long long)gridDim.x * blockDim.x) {
-        const long long v = v0 + (threadIdx.x & 63);
-        const bool alive = v < V && rank_vol[v] != RANK_NONE;
-        const unsigned long long m = __ballot(alive);
-        if (m == 0ull) continue;
-        const int lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
-        base = __shfl(base, 0);
-        if (alive) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)v;
-    }
-}
-__global__ void __launch_bounds__(256)
-    cover_list_compact_kernel(const int32_t *__restrict__ in, const long long n_in,
-                              const int32_t *__restrict__ rank_vol, int32_t *__restrict__ out,
-                              unsigned long long *__restrict__ n_out) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const int v = i < n_in ? in[i] : -1;
-    const bool alive = v >= 0 && rank_vol[v] != RANK_NONE;
-    const unsigned long long m = __ballot(alive);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0);
-    if (alive) out[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
-}
-// thread per listed patch: consume its dirty mark, recount, reject
-__global__ void __launch_bounds__(256)
-    cover_sparse_count_kernel(const int32_t *__restrict__ list, const long long n_list,
-                              const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
-                              uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
-                              int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
-                              uint8_t *__restrict__ witness, const long long bits_vox, const Geo G) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= n_list) return;
-    const long long v = list[i];
-    const int k = rank_vol[v];
-    if (k == RANK_NONE) return;
-    if (dirty[v] == 0) { *n_alive = 1; return; }
-    dirty[v] = 0;
-    if (cover_recount(mbits, bits, v, k, pix_th, witness, bits_vox, G)) {
-        *n_alive = 1;
-    } else {
-        state[k] = 2;
-        rank_vol[v] = RANK_NONE;
-    }
-}
-// wave per listed patch: is it the lowest rank among the undecided patches within p-1 of it?
-__global__ void __launch_bounds__(256)
-    cover_sparse_ready_kernel(const int32_t *__restrict__ list, const long long n_list,
-                              const int32_t *__restrict__ rank_vol, uint8_t *__restrict__ ready, const Geo G) {
-    const long long i = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= n_list) return;
-    const int lane = threadIdx.x & 63;
-    const long long v = list[i];
-    const int k = rank_vol[v];
-    bool lower = false;
-    if (k != RANK_NONE) {
-        int cz, cy, cx;
-        centre_of(G, v, cz, cy, cx);
-        const int z0 = max(cz - (G.pz - 1), 0), z1 = min(cz + G.pz - 1, G.Z - 1);
-        const int y0 = max(cy - (G.py - 1), 0), y1 = min(cy + G.py - 1, G.Y - 1);
-        const int x0 = max(cx - (G.px - 1), 0), x1 = min(cx + G.px - 1, G.X - 1);
-        const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
-        const int per_slice = ny * nx;
-        for (int z = z0; z <= z1; ++z) {
-            const int32_t *sl = rank_vol + vox(G, z, 0, 0);
-            bool hit = false;
-            for (int e = lane; e < per_slice; e += 64)
-                hit |= sl[(long long)(y0 + e / nx) * G.X + x0 + e % nx] < k;
-            if (__ballot(hit) != 0ull) { lower = true; break; }
-        }
-    }
-    if (lane == 0) ready[i] = (k != RANK_NONE && !lower) ? 1 : 0;
-}
-// wave per listed patch: the ready ones select themselves
-__global__ void __launch_bounds__(256)
-    cover_sparse_select_kernel(const int32_t *__restrict__ list, const long long n_list,
-                               const uint8_t *__restrict__ ready, uint32_t *__restrict__ mbits,
-                               const uint32_t *__restrict__ bits, int32_t *__restrict__ state,
-                               int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
-                               uint8_t *__restrict__ dirty, const int gZ, const long long bits_vox, const Geo G) {
-    const long long i = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= n_list || ready[i] == 0) return;
-    const int lane = threadIdx.x & 63;
-    const long long cc = list[i];
-    const int kk = rank_vol[cc];
-    const int cleared = cover_select_one(mbits, bits, dirty, cc, kk, lane, gZ, bits_vox, G);
-    if (lane == 0) {
-        state[kk] = 1;
-        rank_vol[cc] = RANK_NONE;
-        cleared_interior[kk] = cleared;
-    }
-}
-
-// Thread per voxel: the best ranked undecided patch of its neighbourhood selects itself; its
-// wave clears the voxels (lane per window row) and marks the centres whose counts may have
-// changed.  Selected patches never share a voxel, but they may share a mask word.
-__global__ void __launch_bounds__(256)
-    cover_select_kernel(uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
-                        const int32_t *__restrict__ nbr_min, int32_t *__restrict__ state,
-                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
-                        uint8_t *__restrict__ dirty, const int32_t *__restrict__ loc_vol,
-                        const int gZ, const long long bits_vox, const Geo G) {
-    const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int k = v < G.V ? rank_vol[v] : RANK_NONE;
-    bool ready = k != RANK_NONE && zmin_at<int32_t>(nbr_min, v, G) == k;   // nbr_min: xy-filtered ranks
-    if (loc_vol && ready) { k = loc_vol[v]; ready = k >= 0; }   // own centres only; local index
-    unsigned long long todo = __ballot(ready);
-    while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int kk = __shfl(k, src);
-        const long long cc = v - lane + src;
-        const int cleared = cover_select_one(mbits, bits, dirty, cc, kk, lane, gZ, bits_vox, G);
         if (lane == src) {
             state[kk] = 1;
             rank_vol[cc] = RANK_NONE;
@@ -558,46 +422,8 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
     cover_pack_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(mask, W.mbits, G);
     cover_init_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(lin, state, (int)n, W.rank_vol);
     int32_t n_alive = 1;
-    // sparse rounds once at most V / sparse_div patches are undecided (PPP_COVER_SPARSE_DIV, 0 =
-    // never; a listed patch costs a (2p-1)^3 scan of the rank volume per round, a dense round ~90
-    // bytes per voxel)
-    static const long long sparse_div = [] {
-        const char *e = getenv("PPP_COVER_SPARSE_DIV");
-        return e ? atoll(e) : 256ll;
-    }();
-    unsigned long long *cnt64 = reinterpret_cast<unsigned long long *>(W.counters + 16);   // two 64-bit counters
-    const long long list_cap = G.V / 2;
-    int32_t *list = W.tmp, *list_b = W.nbr_min;                       // [V] / first half of [V]
-    uint8_t *ready = reinterpret_cast<uint8_t *>(W.nbr_min + list_cap + 1);
-    long long n_list = -1;                                            // >= 0: sparse mode
     while (n_alive > 0) {
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
-        if (n_list >= 0) {
-            // ---- a batch of sparse rounds over the list
-            const dim3 tgrid((unsigned)((n_list + 255) / 256)), wgrid((unsigned)((n_list + 3) / 4));
-            for (int r = 0; r < COVER_BATCH && n_list > 0; ++r) {
-                cover_sparse_count_kernel<<<tgrid, block, 0, s>>>(list, n_list, W.mbits, bits, W.dirty, pix_th, state,
-                                                                  W.rank_vol, W.counters + r, W.witness, bits_vox, G);
-                cover_sparse_ready_kernel<<<wgrid, block, 0, s>>>(list, n_list, W.rank_vol, ready, G);
-                cover_sparse_select_kernel<<<wgrid, block, 0, s>>>(list, n_list, ready, W.mbits, bits, state, W.rank_vol,
-                                                                   cleared, W.dirty, G.Z + G.oz, bits_vox, G);
-            }
-            *rounds += COVER_BATCH;
-            if ((e = hipMemsetAsync(cnt64, 0, 16, s)) != hipSuccess) return e;
-            if (n_list > 0)
-                cover_list_compact_kernel<<<tgrid, block, 0, s>>>(list, n_list, W.rank_vol, list_b, cnt64);
-            unsigned long long n_new = 0;
-            if ((e = hipMemcpyAsync(&n_alive, W.counters + COVER_BATCH - 1, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-            if ((e = hipMemcpyAsync(&n_new, cnt64, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            std::swap(list, list_b);
-            // (the compacted list lives in whichever buffer is `list` now; the ready flags sit
-            // behind the first half of nbr_min, which a list of <= V / 2 entries never reaches)
-            n_list = (long long)n_new;
-            if (n_list == 0) n_alive = 0;
-            continue;
-        }
         const dim3 cgrid((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), cblock(COUNT_THREADS);
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<cgrid, cblock, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
@@ -610,12 +436,6 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
         *rounds += COVER_BATCH;
         // "any patch undecided" at the start of the batch's last round; if none, that round
         // was a no-op and nothing is left
-        unsigned long long alive_now = 0;
-        if (sparse_div > 0) {
-            if ((e = hipMemsetAsync(cnt64, 0, 16, s)) != hipSuccess) return e;
-            cover_alive_count_kernel<<<dim3(2048), block, 0, s>>>(W.rank_vol, G.V, cnt64);
-            if ((e = hipMemcpyAsync(&alive_now, cnt64, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-        }
         if ((e = hipMemcpyAsync(&n_alive, W.counters + COVER_BATCH - 1, 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
             return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
@@ -626,15 +446,6 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
             long long a = 0, sel = 0;
             for (long long i = 0; i < n; ++i) { a += h[i] == 0; sel += h[i] == 1; }
             fprintf(stderr, "cover rounds %d: undecided %lld selected %lld\n", *rounds, a, sel);
-        }
-        if (n_alive > 0 && sparse_div > 0 && (long long)alive_now * sparse_div <= G.V && (long long)alive_now <= list_cap) {
-            if ((e = hipMemsetAsync(cnt64, 0, 16, s)) != hipSuccess) return e;
-            cover_list_build_kernel<<<dim3(2048), block, 0, s>>>(W.rank_vol, G.V, list, cnt64);
-            unsigned long long n_new = 0;
-            if ((e = hipMemcpyAsync(&n_new, cnt64, 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-            n_list = (long long)n_new;
-            if (n_list == 0) n_alive = 0;
         }
     }
     cover_unpack_kernel<<<vgrid, block, 0, s>>>(W.mbits, mask, G);

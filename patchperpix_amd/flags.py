@@ -6,10 +6,13 @@
                      ``skipThinCover = false`` (default.toml:134,141).  Deviations, each forced
                      by this package's scope and stated wherever the set is reported:
                      ``blockwise = false`` (whole-volume assembly; the tiled path reproduces the
-                     whole-volume result instead of the per-block cover),
-                     ``skeletonize_foreground`` absent (needs scikit-image, which the image lacks;
-                     asking for it raises), ``removeIntersection`` kept but without effect (the
-                     reference reads it in its NumPy branch only, aff_patch_graph.py:244).
+                     whole-volume result instead of the per-block cover, DESIGN.md section 6;
+                     the per-block scheme is ``blockwise_semantics="reference"`` of the
+                     blockwise driver), ``skeletonize_foreground`` not set in the benchmark sets
+                     (the synthetic volumes are dense cells, not tubes; the option itself is
+                     served -- scikit-image, else the library's own 3-d thinning),
+                     ``removeIntersection`` kept but without effect (the reference reads it in
+                     its NumPy branch only, aff_patch_graph.py:244).
 ``FLYLIGHT_CC``      the same with ``mws = false`` -- the value the config's own validation sweep
                      uses (default.toml:99): connected components instead of the mutex watershed.
 ``FLYLIGHT_NOTHIN_CC`` additionally ``skipThinCover = true``: the kernels-only pipeline
