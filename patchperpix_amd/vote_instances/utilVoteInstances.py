@@ -67,56 +67,121 @@ def getFgThreshold(**kwargs):
     return kwargs["patch_threshold"]
 
 
-def _numinst_from_prob(numinst_prob, **kwargs):
-    numinst = np.argmax(numinst_prob, axis=0).astype(np.uint8)
-    if kwargs.get("numinst_threshs"):
-        numinst = np.zeros(numinst_prob.shape[1:], dtype=np.uint8)
-        for i in range(len(kwargs["numinst_threshs"])):
-            numinst[numinst_prob[i + 1] > kwargs["numinst_threshs"][i]] = i + 1
-    return numinst
+def numinst_from_prob(prob, numinst_threshs=None, **_ignored):
+    """Per-voxel instance count from the (K, ...) probabilities of "k instances here"
+    (utilVoteInstances.py:254-270): class k = 1, 2, .. wherever its probability exceeds its
+    threshold (later classes over earlier ones) when thresholds are configured, else the argmax."""
+    if numinst_threshs:
+        out = np.zeros(prob.shape[1:], dtype=np.uint8)
+        for k, th in enumerate(numinst_threshs, start=1):
+            out[prob[k] > th] = k
+        return out
+    return np.argmax(prob, axis=0).astype(np.uint8)
+
+
+_numinst_from_prob = numinst_from_prob
+
+
+class PredictionFile:
+    """What the `label` task reads from one prediction container (a zarr store or an HDF5 file,
+    opened by io_hdflike.open_container): the patch affinities as (C, Z, Y, X), the instance
+    count and the foreground mask, with the reference's conventions for where the channel axis
+    sits, 2-d data, crops and key defaults (utilVoteInstances.py:136-303).  The functions with
+    the reference's names below are views of this object; the streaming reader
+    (tiling.ZarrProvider) uses ``dataset`` / ``numinst`` / ``foreground`` and never ``affinities``."""
+
+    def __init__(self, container, patchshape=None, **kwargs):
+        self.f, self.kw = container, dict(kwargs)
+        self.patchshape = None if patchshape is None else [int(p) for p in patchshape]
+        # the prediction step writes under `volumes/`; older files keep `images/pred_affs`
+        self.modern = "volumes" in container.keys()
+        if self.kw.get("aff_key") is None:
+            self.kw["aff_key"] = "volumes/pred_affs" if self.modern else "images/pred_affs"
+
+    # ---- the affinity dataset ------------------------------------------------------------
+    @property
+    def dataset(self):
+        return self.f[self.kw["aff_key"]]
+
+    @property
+    def channels_last(self):
+        """(.., C) instead of (C, ..): recognised by the channel count (utilVoteInstances.py:170)"""
+        if self.patchshape is None:
+            return False
+        shape, lin = self.dataset.shape, int(np.prod(self.patchshape))
+        return shape[-1] == lin and shape[0] != lin
+
+    def _crop(self, axes):
+        return tuple(slice(self.kw.get("crop_%s_s" % a, 0), self.kw.get("crop_%s_e" % a, None)) for a in axes)
+
+    def affinities(self):
+        """(C, Z, Y, X) values as stored (Z = 1 for 2-d data), cropped; logits are NOT mapped here."""
+        if not self.modern:
+            aff = np.array(self.dataset)
+            return aff if aff.shape[1] == 1 else np.expand_dims(aff, axis=1)
+        ds = self.dataset
+        nd = len(ds.shape) - 1
+        if nd not in (2, 3):
+            raise RuntimeError("check dimensions of array %s" % (self.kw["aff_key"],))
+        spatial = self._crop("zyx"[-nd:])
+        if self.channels_last:
+            aff = np.ascontiguousarray(np.moveaxis(np.squeeze(np.array(ds[spatial + (slice(None),)])), -1, 0))
+        else:
+            aff = np.squeeze(np.array(ds[(slice(None),) + spatial]))
+        if nd == 2:
+            aff = np.expand_dims(aff, axis=1)
+        if self.kw.get("isbiHack"):
+            aff = aff[:, :, ::2, ::2]
+        return aff
+
+    # ---- instance count and foreground -----------------------------------------------------
+    def numinst(self):
+        """uint8 per voxel, or None without a numinst_key (utilVoteInstances.py:260-272)."""
+        key = self.kw.get("numinst_key")
+        if key is None:
+            return None
+        prob = np.squeeze(np.array(self.f[key]))
+        if prob.ndim == 3:                      # 2-d data: (K, Y, X) -> (K, 1, Y, X)
+            prob = np.expand_dims(prob, axis=1)
+        return numinst_from_prob(prob, **self.kw)
+
+    def foreground(self):
+        """(mask, key it came from): the fg_key dataset, else numinst > 0, else the centre channel
+        of the affinities -- thresholded; the last two with a leading axis of size 1
+        (utilVoteInstances.py:275-303)."""
+        th = getFgThreshold(**self.kw)
+        if self.kw.get("fg_key") is not None:
+            return np.array(self.f[self.kw["fg_key"]]) > th, self.kw["fg_key"]
+        if self.kw.get("numinst_key") is not None:
+            numinst = numinst_from_prob(np.array(self.f[self.kw["numinst_key"]]), **self.kw)
+            return np.expand_dims((numinst > 0).astype(np.float32), axis=0) > th, self.kw["numinst_key"]
+        mid = int(np.prod(self.patchshape)) // 2
+        return np.expand_dims(np.array(self.dataset[mid]), axis=0) > th, self.kw["aff_key"]
+
+    def load(self):
+        """(affinities, numinst, foreground) of loadAffinities"""
+        return self.affinities(), self.numinst(), self.foreground()[0]
 
 
 def maybeLoadNuminst(f, **kwargs):
     """utilVoteInstances.py:260-272."""
-    if kwargs.get("numinst_key") is None:
-        return None
-    numinst_prob = np.squeeze(np.array(f[kwargs["numinst_key"]]))
-    if len(numinst_prob.shape) == 3:
-        numinst_prob = np.expand_dims(numinst_prob, axis=1)
-    return _numinst_from_prob(numinst_prob, **kwargs)
+    return PredictionFile(f, **kwargs).numinst() if kwargs.get("numinst_key") is not None else None
 
 
 def loadFg(f, **kwargs):
     """utilVoteInstances.py:275-303 (note the leading axis of size 1 it adds)."""
-    aff_key = kwargs["aff_key"]
-    fg_key = kwargs.get("fg_key", None)
-    numinst_key = kwargs.get("numinst_key", None)
-    fg_thresh = getFgThreshold(**kwargs)
-    if fg_key is not None:
-        foreground = np.array(f[fg_key])
-        key = fg_key
-    elif numinst_key is not None:
-        numinst = _numinst_from_prob(np.array(f[numinst_key]), **kwargs)
-        foreground = np.expand_dims((numinst > 0).astype(np.float32), axis=0)
-        key = numinst_key
-    else:
-        mid = np.prod(kwargs["patchshape"]) // 2
-        foreground = np.expand_dims(np.array(f[aff_key][mid]), axis=0)
-        key = aff_key
-    return foreground > fg_thresh, key
+    return PredictionFile(f, **kwargs).foreground()
 
 
 def returnFg(affs, numinst, fg, **kwargs):
-    """utilVoteInstances.py:306-322."""
-    fg_thresh = getFgThreshold(**kwargs)
-    if kwargs.get("fg_key", None) is not None:
-        foreground = np.squeeze(fg)
-    elif kwargs.get("numinst_key", None) is not None:
-        foreground = numinst > 0
+    """utilVoteInstances.py:306-322: the foreground of a block already in memory."""
+    if kwargs.get("fg_key") is not None:
+        source = np.squeeze(fg)
+    elif kwargs.get("numinst_key") is not None:
+        source = numinst > 0
     else:
-        mid = np.prod(kwargs["patchshape"]) // 2
-        foreground = affs[mid]
-    return foreground > fg_thresh
+        source = affs[int(np.prod(kwargs["patchshape"])) // 2]
+    return source > getFgThreshold(**kwargs)
 
 
 def getResKey(**kwargs):
@@ -131,65 +196,24 @@ def getResKey(**kwargs):
     return res_ext
 
 
-def _crop(kwargs, axes):
-    return tuple(slice(kwargs.get("crop_%s_s" % a, 0), kwargs.get("crop_%s_e" % a, None))
-                 for a in axes)
-
-
 def loadAffinities(aff_file, res_ext, patchshape=None, **kwargs):
     """utilVoteInstances.py:136-251: returns (affinities (C,Z,Y,X), numinst, foreground) or
     None when the result key already exists."""
-    numinst = None
     if aff_file.endswith((".hdf", ".zarr")):
         with io_hdflike.open_container(aff_file, "r") as f:
             if "vote_instances" + res_ext in f.keys():
                 logger.info("%s vote_instances %s already computed", aff_file, res_ext)
                 return None
-            if "volumes" in f.keys():
-                aff_key = kwargs.get("aff_key")
-                if aff_key is None:
-                    aff_key = "volumes/pred_affs"
-                    kwargs["aff_key"] = aff_key
-                ds = f[aff_key]
-                shape = ds.shape
-                rotate_axes = False
-                if patchshape is not None:
-                    lin = int(np.prod(patchshape))
-                    rotate_axes = shape[-1] == lin and shape[0] != lin
-                if len(shape) == 3:
-                    if rotate_axes:
-                        aff = np.squeeze(np.array(ds[_crop(kwargs, "yx") + (slice(None),)]))
-                        aff = np.ascontiguousarray(np.moveaxis(aff, -1, 0))
-                    else:
-                        aff = np.squeeze(np.array(ds[(slice(None),) + _crop(kwargs, "yx")]))
-                    affinities = np.expand_dims(aff, axis=1)
-                elif len(shape) == 4:
-                    if rotate_axes:
-                        aff = np.squeeze(np.array(ds[_crop(kwargs, "zyx") + (slice(None),)]))
-                        affinities = np.ascontiguousarray(np.moveaxis(aff, -1, 0))
-                    else:
-                        affinities = np.squeeze(np.array(ds[(slice(None),) + _crop(kwargs, "zyx")]))
-                else:
-                    raise RuntimeError("check dimensions of array %s %s" % (aff_file, aff_key))
-                if kwargs.get("isbiHack"):
-                    affinities = affinities[:, :, ::2, ::2]
-            else:
-                affinities = np.array(f["images/pred_affs"])
-                if affinities.shape[1] != 1:
-                    affinities = np.expand_dims(affinities, axis=1)
-                kwargs.setdefault("aff_key", "images/pred_affs")
-            numinst = maybeLoadNuminst(f, **kwargs)
-            foreground, _ = loadFg(f, **dict(kwargs, patchshape=patchshape))
+            affinities, numinst, foreground = PredictionFile(f, patchshape=patchshape, **kwargs).load()
     elif aff_file.endswith("npy"):
         affinities = np.load(aff_file)
         if affinities.shape[1] != 1:
             affinities = np.expand_dims(affinities, axis=1)
-        mid = np.prod(patchshape) // 2
-        foreground = np.array(affinities[mid]) > getFgThreshold(**kwargs)
+        foreground = np.array(affinities[int(np.prod(patchshape)) // 2]) > getFgThreshold(**kwargs)
         numinst = 1 * foreground
     else:
         logger.info("invalid affinities file, zarr, hdf or npy")
         raise SystemExit(-1)
-    if np.min(affinities) < 0 and np.max(affinities) > 1:
+    if np.min(affinities) < 0 and np.max(affinities) > 1:     # logits
         affinities = scipy.special.expit(affinities)
     return affinities, numinst, foreground
