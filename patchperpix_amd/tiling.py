@@ -215,35 +215,87 @@ class ZarrProvider:
     the chunks that intersect the box, straight into a pinned host buffer, and copies that to the
     device (zarr chunk -> pinned host -> HBM; the reference reads block-wise through
     io_hdflike.IoZarr.read as well, :67-120).  Neither the host nor the device ever holds the
-    whole prediction.  expit: apply the logistic function to logits (loadAffinities decides that
-    from the value range of the whole array, utilVoteInstances.py:249-250; a provider is told)."""
+    whole prediction.  ``prefetch(box)`` -- called by the tiled assembly with the box it will ask
+    for next -- decodes that box into a second pinned buffer on a worker thread while the device
+    works on the current tile (chunk decompression runs in C, outside the interpreter lock).
+    expit: apply the logistic function to logits (loadAffinities decides that from the value
+    range of the whole array, utilVoteInstances.py:249-250; a provider is told)."""
 
     def __init__(self, arr, device="cuda", expit=False):
         self.arr, self.device, self.expit = arr, device, bool(expit)
-        self._pinned = None
+        self._pinned = [None, None]
+        self._cur = 0
+        self._ahead = None            # (box, thread, buffer index, error holder)
         self.bytes_read = 0
+        self.boxes_prefetched = 0
+
+    def _torch_dtype(self):
+        import torch
+        return {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32}.get(np.dtype(self.arr.dtype))
+
+    def _shape(self, box):
+        z0, z1, y0, y1, x0, x1 = box
+        return (int(self.arr.shape[0]), z1 - z0, y1 - y0, x1 - x0)
+
+    def _buffer(self, which, shape):
+        import torch
+        n, tdt = int(np.prod(shape)), self._torch_dtype()
+        buf = self._pinned[which]
+        if buf is None or buf.numel() < n or buf.dtype != tdt:
+            buf = self._pinned[which] = torch.empty((n,), dtype=tdt, pin_memory=str(self.device).startswith("cuda"))
+        return buf[:n].view(shape)
+
+    def _read(self, box, host, err):
+        z0, z1, y0, y1, x0, x1 = box
+        try:
+            self.arr.read_into((slice(None), slice(z0, z1), slice(y0, y1), slice(x0, x1)), host.numpy())
+        except BaseException as e:          # reported by the pred_box that consumes the buffer
+            err.append(e)
+
+    def prefetch(self, box):
+        """Start decoding `box` (None: nothing) in the background."""
+        import threading
+        if box is None or self._torch_dtype() is None or not hasattr(self.arr, "read_into"):
+            return
+        box = tuple(int(v) for v in box)
+        if self._ahead is not None:
+            if self._ahead[0] == box:
+                return
+            self._ahead[1].join()
+        which = 1 - self._cur
+        host, err = self._buffer(which, self._shape(box)), []
+        th = threading.Thread(target=self._read, args=(box, host, err), daemon=True)
+        th.start()
+        self._ahead = (box, th, which, err, host)
 
     def pred_box(self, box):
         import torch
-        z0, z1, y0, y1, x0, x1 = [int(v) for v in box]
-        C = int(self.arr.shape[0])
-        shape = (C, z1 - z0, y1 - y0, x1 - x0)
-        dtype = np.dtype(self.arr.dtype)
-        tdt = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32}.get(dtype)
-        sel = (slice(None), slice(z0, z1), slice(y0, y1), slice(x0, x1))
-        if tdt is None or not hasattr(self.arr, "read_into"):
+        box = tuple(int(v) for v in box)
+        shape = self._shape(box)
+        C = shape[0]
+        if self._torch_dtype() is None or not hasattr(self.arr, "read_into"):
+            z0, z1, y0, y1, x0, x1 = box
+            sel = (slice(None), slice(z0, z1), slice(y0, y1), slice(x0, x1))
             host = torch.from_numpy(np.ascontiguousarray(np.asarray(self.arr[sel], dtype=np.float32)))
         else:
-            n = int(np.prod(shape))
-            pin = str(self.device).startswith("cuda")
-            if self._pinned is None or self._pinned.numel() < n or self._pinned.dtype != tdt:
-                self._pinned = torch.empty((n,), dtype=tdt, pin_memory=pin)
-            host = self._pinned[:n].view(shape)
-            self.arr.read_into(sel, host.numpy())
+            ahead, self._ahead = self._ahead, None
+            if ahead is not None:
+                ahead[1].join()
+            if ahead is not None and ahead[0] == box:
+                if ahead[3]:
+                    raise ahead[3][0]
+                host, self._cur = ahead[4], ahead[2]
+                self.boxes_prefetched += 1
+            else:
+                host = self._buffer(self._cur, shape)
+                err = []
+                self._read(box, host, err)
+                if err:
+                    raise err[0]
         self.bytes_read += host.numel() * host.element_size()
         pred = host.to(self.device, non_blocking=True)
         if str(self.device).startswith("cuda"):
-            torch.cuda.current_stream().synchronize()     # the pinned buffer is reused by the next box
+            torch.cuda.current_stream().synchronize()     # the pinned buffer is reused two boxes on
         elif pred.data_ptr() == host.data_ptr():
             pred = pred.clone()
         if self.expit:
@@ -694,12 +746,16 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     if not provider:
         whole = _Frame(pred_local, field_box(ov_d, (lo, hi, 0, Y, 0, X)), (lo, 0, 0), (hi - lo, Y, X))
 
-    def frame_for(box):
+    def frame_for(box, next_box=None):
+        """next_box: the box that will be asked for after this one (a provider that can work
+        ahead -- ZarrProvider -- decodes it while this tile is on the device)"""
         if whole is not None:
             return whole
         z0, z1, y0, y1, x0, x1 = box
         with backend.host_timer("provider"):
             pred_t = pred_local.pred_box(box)
+            if next_box is not None and hasattr(pred_local, "prefetch"):
+                pred_local.prefetch(next_box)
         backend.note_add("provider_voxels", (z1 - z0) * (y1 - y0) * (x1 - x0))
         return _Frame(pred_t, field_box(ov_d, box), (z0, y0, x0), (z1 - z0, y1 - y0, x1 - x0))
 
@@ -761,10 +817,13 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     bits_own = None
     if provider:
         bits_own = torch.zeros(((oz1 - oz0) * plane, words), dtype=torch.int32, device=dev)
-    for t in my_tiles:
+    def scores_frame_box(t):
+        return grow(bases_for_pairs(t) if keep_cons else bases_for_scores(t), 2 * rad)
+
+    for ti, t in enumerate(my_tiles):
         z0, z1, y0, y1, x0, x1 = t
         cbox = bases_for_pairs(t) if keep_cons else bases_for_scores(t)
-        fr = frame_for(grow(cbox, 2 * rad))
+        fr = frame_for(scores_frame_box(t), scores_frame_box(my_tiles[ti + 1]) if ti + 1 < len(my_tiles) else None)
         o = fr.origin
         P = params(fr, cbox)
         with backend.host_timer("s1_consensus"):
@@ -974,15 +1033,23 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         and kw.get("_stream_pairs", os.environ.get("PPP_STREAM_PAIRS", "1") != "0") \
         and hasattr(ops, "label_state")
 
+    def pairs_frame_box(t):
+        # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
+        # to 2 p away) and their windows: the tile grown by the halo
+        return grow(t, (H, 2 * ps[1] + int(rad[1]), 2 * ps[2] + int(rad[2])))
+
+    def next_of(t):
+        i = my_tiles.index(t)
+        return my_tiles[i + 1] if i + 1 < len(my_tiles) else None
+
     def tile_consensus(t):
         """(frame, cons, P) for the pairs whose patch A lies in tile t"""
         if keep_cons:
             cons, P, fr = kept.pop(t)
             return fr, cons, P
         cbox = bases_for_pairs(t)
-        # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
-        # to 2 p away) and their windows: the tile grown by the halo
-        fr = frame_for(grow(t, (H, 2 * ps[1] + int(rad[1]), 2 * ps[2] + int(rad[2]))))
+        nxt = next_of(t)
+        fr = frame_for(pairs_frame_box(t), pairs_frame_box(nxt) if nxt is not None else None)
         cons, P = consensus_of(fr, params(fr, cbox), pool)
         return fr, cons, P
 
@@ -1140,7 +1207,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 near = torch.nonzero(near).reshape(-1)
                 if near.numel() == 0:
                     continue
-                fr = frame_for(grow(t, rad))
+                nxt = next_of(t)
+                fr = frame_for(grow(t, rad), grow(nxt, rad) if nxt is not None else None)
                 o = fr.origin
                 inst_l = torch.zeros(fr.shape, dtype=torch.int32, device=dev)
                 ops.paint(fr.pred, to_local(lab_nodes[near], fr), labels[near].contiguous(), inst_l, params(fr))

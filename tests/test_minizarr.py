@@ -161,3 +161,40 @@ def test_read_into_and_zarr_provider(tmp_path):
     assert t.dtype.is_floating_point and np.array_equal(t.numpy(), a[:, 2:13, 0:17, 5:14])
     t2 = prov.pred_box((0, 3, 0, 4, 0, 5))            # the host buffer is reused: the first result must not change
     assert np.array_equal(t.numpy(), a[:, 2:13, 0:17, 5:14]) and np.array_equal(t2.numpy(), a[:, 0:3, 0:4, 0:5])
+
+
+def test_zarr_provider_works_ahead(tmp_path):
+    """prefetch(box): the next box is decoded on a worker thread into the other host buffer; the
+    pred_box that asks for it takes it from there, a different request discards it; the tiled
+    assembly announces its boxes (oracle-backed ops: the same instance map as from the array)."""
+    import torch
+    from oracle_ops import OracleOps
+    from patchperpix_amd import synth, tiling
+    from tests_flags import FLYLIGHT
+    ps = (3, 3, 3)
+    c = synth.make_case((14, 16, 18), ps, seed=41, cell=[6, 6, 6])
+    a = c["pred"].astype(np.float16)
+    g = mz.open(str(tmp_path / "q.zarr"), "w")
+    g.create_dataset("volumes/pred_affs", data=a, chunks=(27, 5, 6, 7))
+    arr = mz.open(str(tmp_path / "q.zarr"), "r")["volumes/pred_affs"]
+    prov = tiling.ZarrProvider(arr, device="cpu")
+    b1, b2, b3 = (0, 7, 0, 16, 0, 9), (5, 14, 2, 16, 4, 18), (1, 4, 1, 5, 1, 6)
+    t1 = prov.pred_box(b1)
+    prov.prefetch(b2)
+    t2 = prov.pred_box(b2)
+    assert prov.boxes_prefetched == 1
+    prov.prefetch(b1)                       # announced, then something else is asked for
+    t3 = prov.pred_box(b3)
+    assert prov.boxes_prefetched == 1
+    for t, b in ((t1, b1), (t2, b2), (t3, b3)):
+        assert np.array_equal(t.numpy(), a[:, b[0]:b[1], b[2]:b[3], b[4]:b[5]])
+    # through the tiled assembly: 2 x 2 x 1 tiles, every pass announces its next box
+    fg = torch.from_numpy(c["foreground"].astype(np.uint8))
+    kw = dict(FLYLIGHT)
+    prov = tiling.ZarrProvider(arr, device="cpu")
+    got, _ = tiling.assemble(prov, 0, a.shape[1:], fg, fg.clone(), fg, ps, tiling.plan_slabs(a.shape[1], 2),
+                             ops=OracleOps(**kw), _yx_tiles=(2, 1), **kw)
+    want, _ = tiling.assemble(torch.from_numpy(a), 0, a.shape[1:], fg, fg.clone(), fg, ps,
+                              tiling.plan_slabs(a.shape[1], 1), ops=OracleOps(**kw), **kw)
+    assert prov.boxes_prefetched >= 3 and np.asarray(want).max() > 1
+    assert np.array_equal(np.asarray(got), np.asarray(want))
