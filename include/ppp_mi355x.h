@@ -101,6 +101,10 @@ const char *ppp_last_error(void);
 /* name of the kernel the last ppp_consensus call launched (which generation / specialisation
  * served the shape): "consensus_v3_kernel", "consensus_v2_kernel" or "consensus_gather_kernel" */
 const char *ppp_consensus_kernel_name(void);
+/* Development switches (PPP_* environment variables naming a kernel variant or a tile shape)
+ * are read once per process, at their first use; ppp_reload_env() makes the next use read them
+ * again (tests that compare variants within one process).                                   */
+void ppp_reload_env(void);
 /* number of HIP devices visible; 0 if none (never fails) */
 int ppp_device_count(void);
 

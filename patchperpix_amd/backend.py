@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ppp_abi_version": (ctypes.c_int, []),
     "ppp_last_error": (ctypes.c_char_p, []),
     "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
+    "ppp_reload_env": (None, []),
     "ppp_consensus_writes_voxel_major": (ctypes.c_int, [ctypes.POINTER(Params)]),
     "ppp_device_count": (ctypes.c_int, []),
     "ppp_cons_planes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
@@ -397,6 +398,12 @@ def pred_dtype_code(t):
     if t.dtype == torch.float16:
         return F16
     raise TypeError("pred must be float32 or float16, got %s" % t.dtype)
+
+
+def reload_env():
+    """The library reads its PPP_* development switches once; after changing one in a running
+    process (tests that compare kernel variants) this makes it look again."""
+    lib().ppp_reload_env()
 
 
 def to_device_pred(pred, device="cuda", keep_f16=True):

@@ -116,11 +116,19 @@ int check_dtype(int dt) {
         if (rc_ != PPP_OK) return rc_; \
     } while (0)
 
+namespace ppp {
+static int g_env_epoch = 0;
+int env_epoch() { return g_env_epoch; }
+void env_reload() { ++g_env_epoch; }
+}  // namespace ppp
+
 extern "C" {
 
 int ppp_abi_version(void) { return PPP_ABI_VERSION; }
 const char *ppp_last_error(void) { return g_err; }
 const char *ppp_consensus_kernel_name(void) { return ppp::last_consensus_kernel(); }
+
+void ppp_reload_env(void) { ppp::env_reload(); }
 
 int ppp_device_count(void) {
     int n = 0;

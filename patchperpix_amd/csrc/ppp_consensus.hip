@@ -114,7 +114,8 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
         if (cnt && (e = hipMemsetAsync(cnt, 0, bytes, s)) != hipSuccess) return e;
     }
     // specialised kernel for px in {3,5,7,9}; PPP_CONSENSUS_GENERIC=1 forces the generic one
-    static const bool force_generic = getenv("PPP_CONSENSUS_GENERIC") != nullptr;
+    static EnvSwitch generic_sw("PPP_CONSENSUS_GENERIC");
+    const bool force_generic = generic_sw.get() != nullptr;
     if (!force_generic) {
         // packed two-slice kernel (TH = 0.5, normalised product), else the general v2
         const hipError_t e3 = launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);

@@ -384,8 +384,9 @@ static hipError_t launch_v2f(const T *pred, const uint8_t *ov, float *cons, floa
     // per-lane element offsets are 32-bit byte offsets within PX channel volumes (+ one line)
     if (((long long)(PX - 1) * G.V + 2ll * G.X) * (long long)sizeof(T) >= (1ll << 32)) return hipErrorNotSupported;
     const dim3 grid((unsigned)n_blocks), block(64 * V2_WAVES);
+    static EnvSwitch no_th05("PPP_S1_NO_TH05");
     if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
-        G.bg_lt <= 0.5f && !getenv("PPP_S1_NO_TH05"))
+        G.bg_lt <= 0.5f && !no_th05.get())
         consensus_v2_kernel<T, PX, PPP_VAL_NORM_PROB_PRODUCT, true, FLAT><<<grid, block, 0, s>>>(
             pred, ov, cons, cnt, G, n_rows, runs_per_line, n_waves);
     else if (G.value_rule == PPP_VAL_NORM_PROB_PRODUCT)
@@ -406,7 +407,8 @@ static hipError_t launch_v2(const T *pred, const uint8_t *ov, float *cons, float
     // Flattened runs pay when the lines leave idle lanes (bX not a multiple of 64); they need
     // lines of at least 64 base voxels (a run then touches two lines at most), a patch with
     // py >= 3 (see load_tile) and more than one line.  PPP_S1_FLAT=0 / 1 overrides.
-    const char *e = getenv("PPP_S1_FLAT");
+    static EnvSwitch sw("PPP_S1_FLAT");
+    const char *e = sw.get();
     bool flat = G.bX >= 64 && G.bX % 64 != 0 && G.py >= 3 && G.bY > 1;
     if (e && e[0] == '0') flat = false;
     if (e && e[0] == '1' && G.bX >= 64 && G.py >= 3) flat = true;
@@ -647,7 +649,8 @@ hipError_t launch_consensus_v2(const void *pred, int dtype, const uint8_t *ov, f
         PPP_V2_CASE(9)
     case 25:
         // (2-d patches only: a 25-wide 3-d patch has 15 625 channels)
-        if (G.pz != 1 || (getenv("PPP_S1_WIDE") && getenv("PPP_S1_WIDE")[0] == '0')) return hipErrorNotSupported;
+        static EnvSwitch wide("PPP_S1_WIDE");
+        if (G.pz != 1 || (wide.get() && wide.get()[0] == '0')) return hipErrorNotSupported;
         return dtype == PPP_F16 ? launch_wide<__half, 25>((const __half *)pred, ov, cons, cnt, G, s)
                                 : launch_wide<float, 25>((const float *)pred, ov, cons, cnt, G, s);
     default:

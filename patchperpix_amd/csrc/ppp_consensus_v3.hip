@@ -622,7 +622,8 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
 template <typename T, int PX>
 static hipError_t launch_v3(const T *pred, const uint8_t *ov, float *cons, float *cnt,
                             const Geo &G, hipStream_t s) {
-    const char *e = getenv("PPP_S1_FLAT");     // same rule as v2
+    static EnvSwitch sw("PPP_S1_FLAT");        // same rule as v2
+    const char *e = sw.get();
     bool flat = G.bX >= 64 && G.bX % 64 != 0 && G.py >= 3 && G.bY > 1;
     if (e && e[0] == '0') flat = false;
     if (e && e[0] == '1' && G.bX >= 64 && G.py >= 3) flat = true;
@@ -632,7 +633,8 @@ static hipError_t launch_v3(const T *pred, const uint8_t *ov, float *cons, float
 
 // the shapes / rules the packed kernel serves (and with them the direct voxel-major output)
 bool consensus_v3_supported(const Geo &G) {
-    const char *e = getenv("PPP_S1_V3");
+    static EnvSwitch sw("PPP_S1_V3");
+    const char *e = sw.get();
     if (e && e[0] == '0') return false;
     return G.value_rule == PPP_VAL_NORM_PROB_PRODUCT && G.th2 == 0.25 && G.den == 0.75 &&
            G.th_gt == 0.5f && G.bg_lt == 0.5f && (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9);

@@ -440,7 +440,8 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
             return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if (getenv("PPP_COVER_TRACE")) {   // development aid: undecided / selected patches per batch
+        static EnvSwitch trace("PPP_COVER_TRACE");
+        if (trace.get()) {   // development aid: undecided / selected patches per batch
             std::vector<int32_t> h((size_t)n);
             (void)hipMemcpy(h.data(), state, (size_t)n * 4, hipMemcpyDeviceToHost);
             long long a = 0, sel = 0;

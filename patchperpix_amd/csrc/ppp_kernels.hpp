@@ -1,8 +1,34 @@
 // ppp_kernels.hpp -- launchers implemented by the .hip translation units.
 #pragma once
+#include <stdlib.h>
+#include <string.h>
 #include "ppp_common.hpp"
 
 namespace ppp {
+
+// Development switches (PPP_* environment variables that select a kernel variant or a tile
+// shape) are read ONCE per process -- at their first use, and again only after ppp_reload_env()
+// (what the tests call after changing one) -- never on every launch.
+int env_epoch();
+void env_reload();
+struct EnvSwitch {
+    const char *name;
+    int seen = -1;
+    bool is_set = false;
+    char val[32] = {0};
+    explicit EnvSwitch(const char *n) : name(n) {}
+    // the variable's value, nullptr when unset
+    const char *get() {
+        if (seen != env_epoch()) {
+            const char *e = getenv(name);
+            is_set = e != nullptr;
+            if (e) { strncpy(val, e, sizeof(val) - 1); val[sizeof(val) - 1] = 0; }
+            seen = env_epoch();
+        }
+        return is_set ? val : nullptr;
+    }
+};
+
 
 hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, float *cons,
                             float *cnt, const Geo &G, hipStream_t s);

@@ -437,7 +437,8 @@ hipError_t launch_patch_graph(const void *pred, int dtype, const float *cons,
     const uint64_t per_block = 64ull * PG_WAVES;
     PPP_GRID_CHECK((n + per_block - 1) / per_block, 64 * PG_WAVES);
     const dim3 grid((unsigned)((n + per_block - 1) / per_block));
-    static const bool vm_generic = getenv("PPP_PATCH_GRAPH_GENERIC") != nullptr;
+    static EnvSwitch generic_sw("PPP_PATCH_GRAPH_GENERIC");
+    const bool vm_generic = generic_sw.get() != nullptr;
     if (G.layout == PPP_CONS_VOXEL_MAJOR && !vm_generic &&
         (G.px == 3 || G.px == 5 || G.px == 7 || G.px == 9)) {
 #define PPP_PG_CASE(P)                                                                                          \

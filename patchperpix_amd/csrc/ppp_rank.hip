@@ -82,7 +82,8 @@ hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uin
     const long long n = (long long)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
     if (n <= 0) return hipSuccess;
     // specialised kernel for px in {3,5,7,9}; PPP_RANK_GENERIC=1 forces the generic one
-    static const bool force_generic = getenv("PPP_RANK_GENERIC") != nullptr;
+    static EnvSwitch generic_sw("PPP_RANK_GENERIC");
+    const bool force_generic = generic_sw.get() != nullptr;
     if (!force_generic) {
         const hipError_t e2 = launch_rank_v2(pred, dtype, cons, ov, score, sb, G, s);
         if (e2 != hipErrorNotSupported) return e2;

@@ -356,7 +356,8 @@ static hipError_t launch_rv(const T *pred, const float *S, const uint8_t *ov, fl
     // 7^3: five slices of centres instead of four -- an inner voxel then serves 5 * 49 = 245
     // (centre, a) items = 3.8 chunks of 64 lanes instead of 196 = 3.06 (the fourth chunk 6 % full)
     if (tile_kind == 2 && shape_id == 7) tile_kind = 4;
-    if (const char *e = getenv("PPP_RANK_TILE"))
+    static EnvSwitch tile_sw("PPP_RANK_TILE");
+    if (const char *e = tile_sw.get())
         tile_kind = strcmp(e, "8x8x16") == 0 ? 1 : (strcmp(e, "4x8x8") == 0 ? 2 : (strcmp(e, "8x8x8") == 0 ? 0 :
                     (strcmp(e, "5x8x8") == 0 ? 4 : (strcmp(e, "7x8x8") == 0 ? 5 : tile_kind))));
     if (shape_id > 100) tile_kind = 3;

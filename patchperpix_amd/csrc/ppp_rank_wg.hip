@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(64 * RW_WAVES, 4)
 static size_t up256w(size_t v) { return (v + 255) / 256 * 256; }
 
 bool rank_wg_supported(const Geo &G) {
-    static const bool off = [] { const char *e = getenv("PPP_RANK_WG"); return e && e[0] == '0'; }();
+    static EnvSwitch wg_sw("PPP_RANK_WG");
+    const bool off = wg_sw.get() && wg_sw.get()[0] == '0';
     if (off) return false;       // (PPP_RANK_WG=0: the one-wave kernel of ppp_rank_vm.hip, read once)
     return G.pz == G.py && G.py == G.px && (G.px == 5 || G.px == 7 || G.px == 9) && !G.count_pos_neg &&
            G.layout == PPP_CONS_VOXEL_MAJOR;
@@ -386,7 +387,8 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     // PPP_RANK_WG_TILE=8x8x16 | 8x16x16 overrides.
     const long long big_tiles = (long long)((sZ + 7) / 8) * ((sY + 15) / 16) * ((sX + 15) / 16);
     bool big = big_tiles >= 4 * 256;
-    if (const char *e = getenv("PPP_RANK_WG_TILE")) big = strcmp(e, "8x16x16") == 0 ? true : (strcmp(e, "8x8x16") == 0 ? false : big);
+    static EnvSwitch tile_sw("PPP_RANK_WG_TILE");
+    if (const char *e = tile_sw.get()) big = strcmp(e, "8x16x16") == 0 ? true : (strcmp(e, "8x8x16") == 0 ? false : big);
     const int TZ = 8, TY = big ? 16 : 8, TX = 16;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;

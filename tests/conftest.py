@@ -60,3 +60,15 @@ def same_partition(a, b):
     pairs = np.unique(np.stack([a, b], axis=1), axis=0)
     return len(np.unique(pairs[:, 0])) == len(pairs) and \
         len(np.unique(pairs[:, 1])) == len(pairs)
+
+
+@pytest.fixture(autouse=True)
+def _library_switches_follow_the_environment():
+    """The library reads its PPP_* development switches once.  A test that changed one
+    (monkeypatch.setenv + backend.reload_env) must not leave its value behind: after every test
+    -- this fixture is set up first, hence finalised after monkeypatch has restored the
+    environment -- a loaded library is told to look again."""
+    yield
+    from patchperpix_amd import backend
+    if backend._LIB is not None:
+        backend.reload_env()

@@ -685,6 +685,7 @@ def test_consensus_flat_runs_equal_line_runs(ps, shape, torch_cuda, monkeypatch)
         out = {}
         for flat in ("0", "1"):
             monkeypatch.setenv("PPP_S1_FLAT", flat)
+            backend.reload_env()
             cons, cnt = backend.consensus(pred, ov, P, want_count=True)
             out[flat] = (cons.cpu().numpy(), cnt.cpu().numpy())
         assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
@@ -711,9 +712,11 @@ def test_consensus_two_slice_packed_kernel_equals_v2(ps, shape, dtype, torch_cud
         P = backend.make_params(shape, ps, cons_box=box, **kw)
         for flat in ("0", "1"):
             monkeypatch.setenv("PPP_S1_FLAT", flat)
+            backend.reload_env()
             out = {}
             for v3 in ("0", "1"):
                 monkeypatch.setenv("PPP_S1_V3", v3)
+                backend.reload_env()
                 cons, cnt = backend.consensus(pred, ov, P, want_count=True)
                 out[v3] = (cons.cpu().numpy(), cnt.cpu().numpy())
             assert np.array_equal(out["0"][1], out["1"][1]), (box, flat, "counts")
@@ -740,6 +743,7 @@ def test_consensus_written_voxel_major_directly(ps, shape, torch_cuda, monkeypat
         assert backend.lib().ppp_consensus_writes_voxel_major(P) == 1
         for flat in ("0", "1"):
             monkeypatch.setenv("PPP_S1_FLAT", flat)
+            backend.reload_env()
             monkeypatch.setenv("PPP_S1_DIRECT_VM", "0")
             want, _ = backend.consensus_voxel_major(pred, ov, P)
             monkeypatch.setenv("PPP_S1_DIRECT_VM", "1")
@@ -774,6 +778,7 @@ def test_consensus_wide_patch_kernel_equals_generic(rule, torch_cuda, monkeypatc
         out = {}
         for wide in ("0", "1"):
             monkeypatch.setenv("PPP_S1_WIDE", wide)
+            backend.reload_env()
             cons, cnt = backend.consensus(pred, ov, P, want_count=True)
             out[wide] = (cons.cpu().numpy(), cnt.cpu().numpy(), backend.NOTES.get("s1_kernel"))
         assert out["0"][2] == "consensus_gather_kernel" and out["1"][2] == "consensus_wide_kernel"
