@@ -625,6 +625,16 @@ def main():
                                   "instances_found": count_instances(torch, vinst),
                                   "differs_in": {k: vkw[k] for k in ("mws", "skipThinCover")}}
             out["variants"] = variants
+        if os.environ.get("PPP_BENCH_CALIBRATE") == "1" and getattr(wl, "pred", None) is not None:
+            # counter calibration (tools/profile_round.sh sets this for its --pmc passes): a known
+            # byte count read from the resident prediction / written to a scratch buffer, outside
+            # the timed region
+            n_read = min(int(wl.pred.numel()), 1 << 31)
+            scratch = torch.empty((1 << 28,), dtype=torch.float32, device="cuda")
+            rb, wb = backend.counter_calibration(wl.pred.reshape(-1), n_read, scratch, scratch.numel())
+            torch.cuda.synchronize()
+            out["counter_calibration_bytes"] = {"read": rb, "write": wb}
+            del scratch
         wl.free(torch)
         # ---- the north-star shape of the scoring kernel, in this run (when the timed workload is
         # not that shape itself)
@@ -668,7 +678,7 @@ def pmc_traffic(kernel, workload):
                 "traffic_note": "no PMC profile of %s from these kernel sources is committed (%d from "
                                 "other sources): rerun tools/profile_round.sh" % (workload, stale)}
     f, meta = match[-1]
-    vals, calib = {}, {}
+    vals, calib, known = {}, {}, {}
     for ln in open(f):
         parts = ln.split()
         for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -678,12 +688,25 @@ def pmc_traffic(kernel, workload):
                     vals[name] = v
                 if "cons_voxel_major_kernel" in ln:
                     calib[name] = v
+                if ("calib_read_kernel" in ln and name == "FETCH_SIZE") or \
+                        ("calib_write_kernel" in ln and name == "WRITE_SIZE"):
+                    known[name] = v
     if len(vals) < 2:
         return {"traffic": None, "traffic_note": "kernel not in %s" % os.path.relpath(f, ROOT)}
     out = {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "traffic_read": vals["FETCH_SIZE"],
            "traffic_write": vals["WRITE_SIZE"],
            "traffic_source": os.path.relpath(f, ROOT) + " (raw counters, mean per launch)"}
-    if len(calib) == 2 and meta.get("transpose_true_read_bytes"):
+    if len(known) == 2 and meta.get("calib_read_bytes"):
+        # MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"
+        r = known["FETCH_SIZE"] / meta["calib_read_bytes"]
+        w = known["WRITE_SIZE"] / meta["calib_write_bytes"]
+        out["counter_over_true_bytes"] = {
+            "read": r, "write": w,
+            "from": "calib_read_kernel / calib_write_kernel of the same profile: %.3g GB read with one "
+                    "prediction element per lane and load, %.3g GB written with one float per lane and store"
+                    % (meta["calib_read_bytes"] / 1e9, meta["calib_write_bytes"] / 1e9)}
+        out["traffic_corrected"] = vals["FETCH_SIZE"] / r + vals["WRITE_SIZE"] / w
+    elif len(calib) == 2 and meta.get("transpose_true_read_bytes"):
         out["counter_over_true_bytes"] = {
             "read": calib["FETCH_SIZE"] / meta["transpose_true_read_bytes"],
             "write": calib["WRITE_SIZE"] / meta["transpose_true_write_bytes"],

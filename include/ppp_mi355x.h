@@ -466,6 +466,14 @@ int ppp_mws_edges(const uint32_t *d_pairs, const float *d_aff, int64_t n_rows, c
 int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32_t seed,
                    float hi, float lo, float noise, uint64_t voxel_offset, const ppp_params *p,
                    void *stream);
+/* Counter calibration (bench / profiles only; no counterpart in the reference): moves a KNOWN
+ * number of bytes -- n_read elements of d_src read with one element per lane and load, n_write
+ * floats written to d_dst with one float per lane and store -- so that a rocprofv3 --pmc pass
+ * containing the call yields counter / true-bytes ratios for FETCH_SIZE and WRITE_SIZE
+ * (kernels calib_read_kernel / calib_write_kernel).                                          */
+int ppp_counter_calibration(const void *d_src, int src_dtype, int64_t n_read, float *d_dst, int64_t n_write,
+                            void *stream);
+
 /* The same generator for a BOX of a larger volume (tile-wise generation, BASELINE config [3]:
  * a rank of the 1024^3 workload holds one tile + halo of the prediction at a time).
  * p: Z / Y / X = extent of the prediction box, origin_* = its position in the volume;

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "ppp_last_error": (ctypes.c_char_p, []),
     "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
     "ppp_reload_env": (None, []),
+    "ppp_counter_calibration": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "ppp_consensus_writes_voxel_major": (ctypes.c_int, [ctypes.POINTER(Params)]),
     "ppp_device_count": (ctypes.c_int, []),
     "ppp_cons_planes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
@@ -398,6 +400,14 @@ def pred_dtype_code(t):
     if t.dtype == torch.float16:
         return F16
     raise TypeError("pred must be float32 or float16, got %s" % t.dtype)
+
+
+def counter_calibration(src, n_read, dst, n_write):
+    """ppp_counter_calibration: read n_read elements of `src` (float16 / float32 device tensor),
+    write n_write floats to `dst` (float32 device tensor).  Returns the true (read, write) bytes."""
+    check(lib().ppp_counter_calibration(_dev_ptr(src), pred_dtype_code(src), int(n_read), _dev_ptr(dst),
+                                        int(n_write), _stream()))
+    return int(n_read) * src.element_size(), int(n_write) * 4
 
 
 def reload_env():

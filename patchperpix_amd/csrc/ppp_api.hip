@@ -563,6 +563,15 @@ int ppp_synth_pred_box(const int32_t *d_labels, const int32_t *label_box, void *
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_synth_pred_box");
 }
 
+int ppp_counter_calibration(const void *d_src, int src_dtype, int64_t n_read, float *d_dst, int64_t n_write,
+                            void *stream) {
+    PPP_TRY(check_dtype(src_dtype));
+    if ((n_read > 0 && !d_src) || !d_dst || n_read < 0 || n_write < 0) return fail(PPP_ERR_INVALID_ARG, "bad argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_counter_calibration(d_src, src_dtype, n_read, d_dst, n_write, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_counter_calibration");
+}
+
 int ppp_decode_tail(const float *d_x, int64_t n, int32_t fmaps, int32_t side, const float *d_w1, float b1,
                     const float *d_w2, float b2, const float *d_w3, float b3, const int64_t *d_dst,
                     void *d_pred, int pred_dtype, const ppp_params *p, void *stream) {

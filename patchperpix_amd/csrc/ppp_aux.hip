@@ -174,4 +174,33 @@ hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t s
     return hipGetLastError();
 }
 
+// ---- counter calibration (bench / profiles only) ---------------------------------------------
+// MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are exact only for some access widths; "calibrate
+// on a known byte count in your own access pattern".  These two kernels move a KNOWN number of
+// bytes with the widths of the hot kernels' global accesses -- one element of the prediction's
+// type per lane and load (S1's staging loads), one float per lane and store -- so that a PMC pass
+// that contains them yields the counter / true-bytes ratios next to the kernels' raw values.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    calib_read_kernel(const T *__restrict__ src, const long long n, float *__restrict__ sink) {
+    float acc = 0.0f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc += ldf(src, i);
+    if (acc == 123456.789f) sink[0] = acc;          // keeps the loads alive; practically never taken
+}
+__global__ void __launch_bounds__(256) calib_write_kernel(float *__restrict__ dst, const long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (float)(i & 1023);
+}
+hipError_t launch_counter_calibration(const void *src, int dtype, long long n_read, float *dst, long long n_write,
+                                      hipStream_t s) {
+    const dim3 grid(256 * 32), block(256);
+    if (n_read > 0) {
+        if (dtype == PPP_F16) calib_read_kernel<__half><<<grid, block, 0, s>>>((const __half *)src, n_read, dst);
+        else calib_read_kernel<float><<<grid, block, 0, s>>>((const float *)src, n_read, dst);
+    }
+    if (n_write > 0) calib_write_kernel<<<grid, block, 0, s>>>(dst, n_write);
+    return hipGetLastError();
+}
+
 }  // namespace ppp

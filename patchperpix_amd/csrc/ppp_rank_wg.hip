@@ -43,6 +43,10 @@
 
 namespace ppp {
 
+// waves per SIMD the register budget must allow (experiments: -DPPP_RW_MINWAVES(PX)=n)
+#ifndef PPP_RW_MINWAVES
+#define PPP_RW_MINWAVES(PX) 4
+#endif
 static constexpr int RW_PAD = 8;
 static constexpr int RW_WAVES = 4;
 typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp2;
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(256)
 
 // ---- main kernel ---------------------------------------------------------------------------
 template <int PZ, int PY, int PX, int TZ, int TY, int TX>
-__global__ void __launch_bounds__(64 * RW_WAVES, 4)
+__global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     rank_wg_kernel(const float *__restrict__ S, const uint32_t *__restrict__ M,
                    const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,

@@ -15,9 +15,14 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py "$@" > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --no-cpu-baseline --no-north-star --no-variants > $out/bench_under_rocprof.json 2>> $out/bench.err
 python3 tools/summarize_prof.py $out/stats $out/kernel_stats.txt > /dev/null
+# (the PMC passes also run the library's counter-calibration kernels: a known byte count, read and
+# written with the access widths of the hot kernels -- MI355X_MICROARCH.md, "calibrate on a known
+# byte count in your own access pattern")
+export PPP_BENCH_CALIBRATE=1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-variants > /dev/null 2>> $out/bench.err
+  rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-variants > $out/bench_pmc_$c.json 2>> $out/bench.err
 done
+unset PPP_BENCH_CALIBRATE
 python3 - <<PY
 import glob, json, os, shutil, sys
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
@@ -32,11 +37,17 @@ line = json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
 ps, vol = line["config"]["patchshape"], line["config"]["volume"]
 W = (2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1)
 BV = vol[0] * vol[1] * vol[2]
+cal = {}
+try:
+    cal = json.loads(open("$out/bench_pmc_FETCH_SIZE.json").read().strip().splitlines()[-1]).get("counter_calibration_bytes", {})
+except Exception:
+    pass
 json.dump({"src_sha16": bench.source_sha16(), "command": "python3 bench.py $*",
            "workload": line["config"]["workload"], "flag_set": line["config"]["flag_set"],
+           "calib_read_bytes": cal.get("read"), "calib_write_bytes": cal.get("write"),
            "transpose_true_read_bytes": (W - 1) // 2 * BV * 4.0, "transpose_true_write_bytes": W * BV * 4.0},
           open("$out/meta.json", "w"), indent=1)
 PY
-rm -rf $out/pmc_all $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/stats/*/*kernel_trace.csv
+rm -rf $out/pmc_all $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/stats/*/*kernel_trace.csv $out/bench_pmc_*.json
 head -12 $out/kernel_stats.txt
 cat $out/bench.json
