@@ -43,7 +43,9 @@
 
 namespace ppp {
 
-// waves per SIMD the register budget must allow (experiments: -DPPP_RW_MINWAVES(PX)=n)
+// waves per SIMD the register budget must allow (experiments: -DPPP_RW_MINWAVES(PX)=n).  More
+// resident waves do not help: 9^3 at 5 per SIMD (96 VGPRs, 14 spilled) 205 -> 247 ms on the 128^3
+// launch, 7^3 at 6 per SIMD (75 VGPRs, nothing spilled) 72.5 -> 73.1 ms at 140^3.
 #ifndef PPP_RW_MINWAVES
 #define PPP_RW_MINWAVES(PX) 4
 #endif
