@@ -585,8 +585,8 @@ def main():
                            (", yx tiles %dx%d" % tuple(args.yx) if args.yx else "")),
                        "prediction": "resident in HBM" if wl.mode == "resident" else
                                      ("decoded inside the timed step from the resident float16 code (%d units per voxel; "
-                                      "random-init decoder of the shipped architecture: torch convolutions + the fused "
-                                      "tail kernel)" % DECODER["code_units"] if wl.mode == "decode" else
+                                      "random-init decoder of the shipped architecture: head as float32 library GEMMs, tail as "
+                                      "the fused MFMA kernel)" % DECODER["code_units"] if wl.mode == "decode" else
                                       "generated tile by tile (provider): largest tile %.1f GB" % (wl.provider.bytes_max / 1e9)),
                        "result": "whole instance map on every rank" if wl.mode != "provider" else
                                  "own z-range per rank (instances_found / crc32: rank 0's range %s)" % (list(wl.own_range),),

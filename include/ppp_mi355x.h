@@ -135,12 +135,8 @@ int ppp_consensus_writes_voxel_major(const ppp_params *p);
  * by radius + p - 1 for the pair rows); on a 144 x 152 x 152 box at 9^3 the zeroing pass is 8.7 GB
  * of scattered 4-byte stores, 40 ms next to the kernel's 220.  Same interface and errors as
  * ppp_consensus otherwise (fillConsensusArray.cu:5-218, normConsensusArray.cu:5-43). */
-/* rows_box (may be NULL = every row of cons_box): the voxels whose rows will be read.  The pairs
- * pass of a tile computes base voxels up to p - 1 beyond its rows box only for the mirrored entries
- * they contribute to rows inside it; work whose base voxels AND target voxels (base + offset) both
- * lie outside rows_box is skipped, and rows outside it are left undefined.                      */
 int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
-                       const ppp_box *rows_box, const ppp_params *p, void *stream);
+                       const ppp_params *p, void *stream);
 
 /* --- S2: patch ranking ---------------------------------------------------------------
  * replaces rank_patches_cuda (ranked_patches.py:33-74) + kernel rankPatches

@@ -74,8 +74,7 @@ _SIGNATURES = {
                                      ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_consensus_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params),
-                                          ctypes.c_void_p]),
+                                          ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_rank_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.POINTER(Box), ctypes.POINTER(Params),
@@ -435,7 +434,7 @@ def to_device_pred(pred, device="cuda", keep_f16=True):
 # ----------------------------------------------------------------------------------------
 # device stages
 # ----------------------------------------------------------------------------------------
-def consensus(pred, overlap, P, want_count=False, out=None, open_rows=False, rows_box=None):
+def consensus(pred, overlap, P, want_count=False, out=None, open_rows=False):
     """S1.  Returns cons (and count) as device float32 tensors shaped
     [planes, bz, by, bx] (compact), [bz, by, bx, W] (voxel-major) or [NSZ, NSY, NSX, Z, Y, X]
     (reference layout).  out: a flat float32 device tensor to carve the result from (the tiled
@@ -460,10 +459,8 @@ def consensus(pred, overlap, P, want_count=False, out=None, open_rows=False, row
     with _timed("consensus"):
         if open_rows and P.cons_layout == CONS_VOXEL_MAJOR and cnt is None:
             # rows for the library's own consumers: no zeroing of entries they never read
-            # (rows_box (z0, y0, x0, z1, y1, x1): only the rows of these voxels will be read)
-            rb = None if rows_box is None else ctypes.byref(Box(*[int(v) for v in rows_box]))
             check(L.ppp_consensus_rows(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
-                                       _dev_ptr(cons), rb, ctypes.byref(P), _stream()))
+                                       _dev_ptr(cons), ctypes.byref(P), _stream()))
         else:
             check(L.ppp_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap),
                                   _dev_ptr(cons), _dev_ptr(cnt), ctypes.byref(P), _stream()))
@@ -595,17 +592,11 @@ def patch_graph_auto(pred, cons_compact, pairs, P):
         cons_compact._ppp_vm = None
     else:
         vm, Pv = cons_to_voxel_major(cons_compact, P)
-    if patch_graph_reads_own_rows_only(Pv):
+    if os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and \
+            int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv))) > 0 and \
+            max(P.pz, P.py) <= P.px:
         return patch_graph_by_patch(pred, vm, pairs, Pv)
     return patch_graph(pred, vm, pairs, Pv, order=pair_order(pairs, Pv))
-
-
-def patch_graph_reads_own_rows_only(P):
-    """True when patch_graph_auto takes the workgroup-per-patch kernel, which reads the rows
-    S[u][.] of the pixels u of the pair's FIRST patch only (the pair-per-lane kernels read the
-    row of the earlier pixel of every pixel pair, which may belong to the partner patch)."""
-    return os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and \
-        int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(P))) > 0 and max(P.pz, P.py) <= P.px
 
 
 def device_patch_pairs(sorted_zyx, P, max_ps_dist=2, include_single=True):
@@ -775,14 +766,14 @@ def direct_voxel_major(P):
         lib().ppp_consensus_writes_voxel_major(ctypes.byref(Pv)) == 1
 
 
-def consensus_voxel_major(pred, overlap, P, out=None, open_rows=False, rows_box=None):
+def consensus_voxel_major(pred, overlap, P, out=None, open_rows=False):
     """S1 straight into the symmetric voxel-major layout when the library can do that for these
     parameters (ppp_consensus_writes_voxel_major), else COMPACT + ppp_cons_to_voxel_major.
     Returns (tensor [bz, by, bx, W], params with cons_layout = VOXEL_MAJOR).  out: see consensus."""
     Pv = P.copy()
     Pv.cons_layout = CONS_VOXEL_MAJOR
     if direct_voxel_major(P):
-        return consensus(pred, overlap, Pv, out=out, open_rows=open_rows, rows_box=rows_box), Pv
+        return consensus(pred, overlap, Pv, out=out, open_rows=open_rows), Pv
     Pc = P.copy()
     Pc.cons_layout = CONS_COMPACT
     cons = consensus(pred, overlap, Pc)

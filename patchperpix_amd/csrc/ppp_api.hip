@@ -166,7 +166,7 @@ int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, 
 }
 
 int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
-                       const ppp_box *rows_box, const ppp_params *p, void *stream) {
+                       const ppp_params *p, void *stream) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     PPP_TRY(check_dtype(pred_dtype));
@@ -177,14 +177,6 @@ int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_over
                                          "(see ppp_consensus_writes_voxel_major)");
     PPP_TRY(need_device());
     G.vm_open = 1;
-    if (rows_box) {
-        if (rows_box->z0 > rows_box->z1 || rows_box->y0 > rows_box->y1 || rows_box->x0 > rows_box->x1)
-            return fail(PPP_ERR_INVALID_ARG, "rows_box is not a box");
-        G.rows_on = 1;
-        G.rz0 = rows_box->z0; G.rz1 = rows_box->z1;
-        G.ry0 = rows_box->y0; G.ry1 = rows_box->y1;
-        G.rx0 = rows_box->x0; G.rx1 = rows_box->x1;
-    }
     hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, nullptr, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus_rows");
 }

@@ -35,8 +35,6 @@ struct Geo {
     int n_planes;       // compact: ((2pz-1)(2py-1)(2px-1)-1)/2
     int oz, oy, ox;     // global coordinate of local voxel (0,0,0)
     int vm_open;        // voxel-major output: entries with a source outside the box stay undefined
-    int rows_on;        // vm_open: only the rows of the voxels in [r?0, r?1) are read by the caller
-    int rz0, rz1, ry0, ry1, rx0, rx1;
 };
 
 // A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch

@@ -249,19 +249,6 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
         ux0 = G.bx0 + xr * 64;
         nA = 64;
     }
-    if (G.rows_on) {
-        // Only the rows S[v][.] of the voxels v of the rows box are read afterwards (the pairs
-        // pass of a tile computes the bases up to p-1 beyond that box only for the mirrored
-        // entries they contribute to ITS rows).  This wave writes the rows of its base voxels and
-        // the mirrored entries in the rows of its target voxels (base + (dz, dy, dx)): when
-        // neither the bases nor the targets can meet the rows box, nothing it would write is
-        // read.  Conservative tests (an interval that might touch the box counts as touching).
-        const int uz_hi = uz + 1, uy_hi = uy + (FLAT ? 1 : 0);
-        const bool x_any = FLAT ? true : (ux0 + 63 + (PX - 1) >= G.rx0 && ux0 - (PX - 1) < G.rx1);
-        const bool base_in = uz_hi >= G.rz0 && uz < G.rz1 && uy_hi >= G.ry0 && uy < G.ry1 && x_any;
-        const bool tgt_in = uz_hi + dz >= G.rz0 && uz + dz < G.rz1 && uy_hi + dy >= G.ry0 && uy + dy < G.ry1 && x_any;
-        if (!base_in && !tgt_in) return;
-    }
     const bool have_s1 = uz + 1 < G.bz0 + G.bZ;                    // slice 1 exists (wave-uniform)
     const bool in_b = FLAT && lane >= nA;                          // this lane sits on line B
     const bool have_b = FLAT && nA < 64 && uy + 1 < G.by0 + G.bY;  // (wave-uniform)

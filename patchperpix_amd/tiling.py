@@ -331,13 +331,11 @@ class DeviceOps:
     def to_voxel_major(self, cons, P):
         return backend.cons_to_voxel_major(cons, P)
 
-    def consensus_voxel_major(self, pred, ov, P, out=None, rows_box=None):
+    def consensus_voxel_major(self, pred, ov, P, out=None):
         # (rows only read by the ranking and patch-graph kernels of patches inside the volume:
-        # entries beyond the box need no zeroing, ppp_consensus_rows; rows_box: the voxels whose
-        # rows are read at all)
+        # entries beyond the box need no zeroing, ppp_consensus_rows)
         return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P, out=out,
-                                             open_rows=os.environ.get("PPP_VM_OPEN", "1") != "0",
-                                             rows_box=rows_box if os.environ.get("PPP_ROWS_BOX", "1") != "0" else None)
+                                             open_rows=os.environ.get("PPP_VM_OPEN", "1") != "0")
 
     def voxel_major_pool(self, P, n_voxels):
         """One flat buffer for the voxel-major consensus of every tile (both passes) when S1
@@ -795,17 +793,11 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     words = (int(np.prod(ps)) + 31) // 32
     can_vm = hasattr(ops, "consensus_voxel_major")
 
-    def consensus_of(fr, P, pool, rows=None):
-        """rows: global box (z0, z1, y0, y1, x0, x1) of the voxels whose rows the pass reads"""
+    def consensus_of(fr, P, pool):
         if can_vm and ops.rank_on_voxel_major(P):
             # ranking and patch graph both read the voxel-major layout: S1 writes it directly
             # where the library can (else compact planes + one re-layout, planes dropped)
-            extra = {"out": pool} if pool is not None else {}
-            if rows is not None and hasattr(ops, "voxel_major_pool") and backend.patch_graph_reads_own_rows_only(P):
-                o = fr.origin
-                extra["rows_box"] = (rows[0] - o[0], rows[2] - o[1], rows[4] - o[2],
-                                     rows[1] - o[0], rows[3] - o[1], rows[5] - o[2])
-            return ops.consensus_voxel_major(fr.pred, fr.ov, P, **extra)
+            return ops.consensus_voxel_major(fr.pred, fr.ov, P, **({"out": pool} if pool is not None else {}))
         return ops.consensus(fr.pred, fr.ov, P), P
 
     # ---- stage A: consensus + scores per tile ----------------------------------------------
@@ -1058,8 +1050,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         cbox = bases_for_pairs(t)
         nxt = next_of(t)
         fr = frame_for(pairs_frame_box(t), pairs_frame_box(nxt) if nxt is not None else None)
-        # the patch-graph kernel stages the rows of the pixels of patches A centred in t: t +- rad
-        cons, P = consensus_of(fr, params(fr, cbox), pool, rows=grow(t, rad))
+        cons, P = consensus_of(fr, params(fr, cbox), pool)
         return fr, cons, P
 
     state = None

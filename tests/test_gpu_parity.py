@@ -344,53 +344,6 @@ def test_tiled_equals_untiled_at_128_cubed_with_9_cubed_patches(torch_cuda):
     assert np.array_equal(whole, np.asarray(prov))
 
 
-@pytest.mark.parametrize("ps,shape", [((5, 5, 5), (26, 40, 150)), ((9, 9, 9), (30, 44, 90)), ((7, 7, 7), (24, 37, 64))])
-def test_consensus_rows_box_prunes_only_what_is_not_read(ps, shape, torch_cuda):
-    """ppp_consensus_rows with a rows box (the pairs pass of a tile: bases up to p-1 beyond the
-    rows the patch-graph kernel stages, computed only for their mirrored contributions): inside
-    the rows box every entry whose source voxel lies in the consensus box is bit-identical to
-    the unpruned rows, whatever the buffers held before."""
-    from patchperpix_amd import backend, synth
-    from tests_flags import FLYLIGHT
-    torch = torch_cuda
-    kw = dict(FLYLIGHT)
-    c = synth.make_case(shape, ps, seed=91, cell=[9, 11, 13], overlap_frac=0.02)
-    pred = _dev(torch, c["pred"].astype(np.float16))
-    ov = _dev(torch, (c["numinst"] > 1).astype(np.uint8))
-    g = [p - 1 for p in ps]
-    rows = (g[0] + 2, g[1] + 3, g[2] + 1, shape[0] - 3, shape[1] - g[1] - 2, shape[2] - g[2] - 5)   # z0 y0 x0 z1 y1 x1
-    cbox = (rows[0] - g[0], rows[1] - g[1], rows[2] - g[2], rows[3], rows[4] + g[1], rows[5] + g[2])
-    P = backend.make_params(shape, ps, cons_box=cbox, cons_layout=backend.CONS_VOXEL_MAJOR, **kw)
-    assert backend.direct_voxel_major(P)
-    W = int(np.prod([2 * p - 1 for p in ps]))
-    n = int(np.prod([cbox[3 + a] - cbox[a] for a in range(3)])) * W
-    full = backend.consensus(pred, ov, P, out=torch.full((n,), 3.0, device="cuda"), open_rows=True).cpu().numpy()
-    part = backend.consensus(pred, ov, P, out=torch.full((n,), float("nan"), device="cuda"), open_rows=True,
-                             rows_box=rows).cpu().numpy()
-    assert backend.NOTES.get("s1_kernel") == "consensus_v3_kernel"
-    lo = [rows[a] - cbox[a] for a in range(3)]
-    hi = [rows[3 + a] - cbox[a] for a in range(3)]
-    f = full[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].view(np.uint32)
-    q = part[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]].view(np.uint32)
-    # entry L <-> offset (dz, dy, dx); defined iff the offset is lexicographically >= 0 (written by
-    # the voxel's own waves) or the source voxel v + offset lies inside the consensus box
-    wz, wy, wx = [2 * p - 1 for p in ps]
-    zz, yy, xx = np.meshgrid(np.arange(lo[0], hi[0]), np.arange(lo[1], hi[1]), np.arange(lo[2], hi[2]), indexing="ij")
-    ext = [cbox[3 + a] - cbox[a] for a in range(3)]
-    checked = 0
-    for L in range(W):
-        dz, dy, dx = L // (wy * wx) - (ps[0] - 1), (L // wx) % wy - (ps[1] - 1), L % wx - (ps[2] - 1)
-        positive = (dz, dy, dx) >= (0, 0, 0)
-        inside = (zz + dz >= 0) & (zz + dz < ext[0]) & (yy + dy >= 0) & (yy + dy < ext[1]) & \
-                 (xx + dx >= 0) & (xx + dx < ext[2])
-        defined = inside | positive
-        assert np.array_equal(f[..., L][defined], q[..., L][defined]), (L, dz, dy, dx)
-        checked += int(defined.sum())
-    assert checked > 0.9 * f.size and np.count_nonzero(full[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]) > 1000
-    # and something WAS skipped: rows outside the rows box keep what the buffer held
-    assert np.isnan(part).any()
-
-
 def _cover_inputs(torch, pred_host, foreground, numinst, ps, kw):
     """ranked list + mask exactly as to_instance_seg builds them."""
     from patchperpix_amd import backend
