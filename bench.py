@@ -562,6 +562,16 @@ def main():
             "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["patch_graph"]),
             "launches": len(ev["patch_graph"]), "pair_rows_per_s": rows / (ms * 1e-3),
             "pair_rows_in_list_per_step": notes["n_pairs"]}
+    # A checksum that does not depend on how the volume was split: crc32 of the per-slice crc32s
+    # in z order.  With the result gathered every rank holds all slices; in provider mode a rank
+    # returns its own z-range only and the per-slice values are gathered.
+    arr = np.ascontiguousarray(inst)
+    slice_crc = np.array([zlib.crc32(arr[z].tobytes()) for z in range(arr.shape[0])], dtype=np.int64)
+    if dist is not None and getattr(wl, "mode", "") == "provider" and arr.shape[0] != gshape[0]:
+        sizes = [None] * world
+        dist.all_gather_object(sizes, (int(wl.own_range[0]), slice_crc.tolist()))
+        slice_crc = np.array([c for _, cs in sorted(sizes) for c in cs], dtype=np.int64)
+    volume_crc = int(zlib.crc32(slice_crc.tobytes())) if len(slice_crc) == gshape[0] else None
     out = None
     if rank == 0:
         per_step = ("s1_base_voxels", "s2_base_voxels", "s5_rows_dispatched", "s1_output_bytes")
@@ -579,6 +589,7 @@ def main():
                        "instance_ids": wl.ids, "foreground_fraction": wl.fg_fraction,
                        "instances_found": count_instances(torch, inst),
                        "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
+                       "instances_slice_crc32": volume_crc,
                        "global_volume": list(gshape),
                        "parallelism": ("z-ranges x%d ranks" % n_gpus) + (
                            ", %d x %d x %d tiles per rank" % wl.tiles if getattr(wl, "tiles", None) else
