@@ -195,6 +195,28 @@ def north_star_s1(torch, backend, kw):
     return r
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+    bench.py <same arguments>`` as a child process (this process has not imported torch nor
+    touched the GPU; nothing is exec'ed over it), pass its output through and return its exit
+    code.  The child's ranks check WORLD_SIZE == --gpus and the visible device count."""
+    import socket
+    import subprocess
+    port = os.environ.get("PPP_BENCH_MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def set_host_allocator():
     """Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
     a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
@@ -280,6 +302,8 @@ class Workload:
             self.provider = SynthProvider(torch, gshape, ps, cell, kw)
             self.tiles = (len(mine), yx[0], yx[1])
             self.own_range = (oz0, oz1)
+            self.plan = {"rank": rank, "own_z": [oz0, oz1], "held_z": [lo, hi],
+                         "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx)}
 
             def step(flag_kw=kw):
                 inst, _ = tiling.assemble(self.provider, lo, gshape, fg, fg.clone(), fg, ps, mine, comm=comm,
@@ -376,6 +400,8 @@ class Workload:
                                             safety=0.92, copies=2.0)
             mine = [(oz0 + a, oz0 + b) for a, b in tiling.plan_slabs(oz1 - oz0, args.slabs or n)]
             yx = tuple(args.yx) if args.yx else (ny, nx)
+            self.plan = {"rank": rank, "own_z": [oz0, oz1], "held_z": [lo, hi],
+                         "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx)}
             self.tiles = (len(mine), yx[0], yx[1])
 
             def step(flag_kw=kw):
@@ -417,6 +443,12 @@ def main():
     ap.add_argument("--yx", type=int, nargs=2, default=None, metavar=("NY", "NX"),
                     help="cut every z-slab into NY x NX tiles (single-GPU tiled path)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): start the N ranks ourselves, as a CHILD
+        # launcher, before anything in this process touches torch or the GPU
+        sys.exit(self_launch(args.gpus))
 
     allocator = set_host_allocator()
     import torch
@@ -431,18 +463,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # PPP_BENCH_ONE_GPU=1 (a check of the multi-rank path on a 1-GPU box): every rank on device 0,
     # gloo as the transport -- numbers from such a run mean nothing
     one_gpu = os.environ.get("PPP_BENCH_ONE_GPU", "0") == "1"
+    # The line must describe the run that happened: the number of ranks IS --gpus, and every rank
+    # has a device of its own (device_count() does not initialise the GPU).
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- start it as `python bench.py --gpus %d` (it "
+                 "launches its ranks itself) or through torch.distributed.run with --nproc-per-node %d"
+                 % (args.gpus, world, args.gpus, args.gpus))
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    if not one_gpu and n_dev < world:
+        sys.exit("bench.py: --gpus %d but only %d device(s) visible (PPP_BENCH_ONE_GPU=1 lets the ranks "
+                 "share device 0 for a functional check; its timings mean nothing)" % (world, n_dev))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(0 if one_gpu else local_rank)
     dist = comm = None
+    collective_ranks = 1
+    transport = "none (one rank)"
     if world > 1:
         import torch.distributed as dist
         from patchperpix_amd import tiling
         dist.init_process_group("gloo" if one_gpu else "nccl")  # "nccl" = RCCL
         comm = tiling.TorchDistComm()
-    n_gpus = max(args.gpus, world)
+        # how many ranks the data path's collectives really span: a 1-element SUM all-reduce
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if one_gpu else "cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        collective_ranks = int(one.item())
+        transport = "gloo through the host (PPP_BENCH_ONE_GPU=1: ranks share device 0)" if one_gpu \
+            else "RCCL (torch.distributed backend nccl)"
+        if collective_ranks != world:
+            sys.exit("bench.py: all-reduce over the group counted %d ranks, expected %d" % (collective_ranks, world))
+    n_gpus = world
 
     def barrier():
         torch.cuda.synchronize()
@@ -572,6 +626,11 @@ def main():
         dist.all_gather_object(sizes, (int(wl.own_range[0]), slice_crc.tolist()))
         slice_crc = np.array([c for _, cs in sorted(sizes) for c in cs], dtype=np.int64)
     volume_crc = int(zlib.crc32(slice_crc.tobytes())) if len(slice_crc) == gshape[0] else None
+    plan = getattr(wl, "plan", None)
+    if dist is not None and plan is not None:
+        plans = [None] * world
+        dist.all_gather_object(plans, plan)
+        plan = sorted(plans, key=lambda p: p["rank"])
     out = None
     if rank == 0:
         per_step = ("s1_base_voxels", "s2_base_voxels", "s5_rows_dispatched", "s1_output_bytes")
@@ -602,6 +661,9 @@ def main():
                        "result": "whole instance map on every rank" if wl.mode != "provider" else
                                  "own z-range per rank (instances_found / crc32: rank 0's range %s)" % (list(wl.own_range),),
                        "per_rank_peak_hbm_gb": peak_gb,
+                       "ranks": world, "rccl_ranks": collective_ranks if not one_gpu else None,
+                       "collective_ranks": collective_ranks, "transport": transport,
+                       "plan": plan,
                        "host_allocator": allocator},
             "roofline": roofline,
             "roofline_other_kernels": roofline_other,

@@ -68,3 +68,51 @@ def test_workloads_name_the_baseline_configurations():
         assert bench.WORKLOADS[name][0] == shape and bench.WORKLOADS[name][1] == ps
     assert bench.DEFAULT_WORKLOAD == "synth512_p9" and bench.FALLBACK_WORKLOAD == "flylight140_p7"
     assert "synth1024_p9" in bench.PROVIDER_WORKLOADS and "dec256_p7" in bench.DECODE_WORKLOADS
+
+
+def _run_bench(args, env=None, timeout=600):
+    import subprocess
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, timeout=timeout,
+                          capture_output=True, text=True)
+
+
+def test_gpus_n_must_match_the_ranks_that_run():
+    """`--gpus 8` inside a 1-rank environment must not print a line that claims 8 GPUs."""
+    r = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_plain_gpus_2_launches_two_ranks_and_fails_loudly_without_devices():
+    """`python bench.py --gpus 2` with no launcher starts its ranks itself (a child
+    torch.distributed.run); on a box with fewer than 2 devices every rank refuses and the exit code
+    of the child is passed on -- no JSON line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices: the run would succeed")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "synth64_p5",
+                    "--no-cpu-baseline"])
+    assert "launching 2 ranks" in r.stderr and "--nproc-per-node 2" in r.stderr
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "needs a GPU" in r.stderr or "device(s) visible" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_launched_ranks_reproduce_the_one_rank_checksum():
+    """`python bench.py --gpus 2` (ranks sharing device 0, gloo: PPP_BENCH_ONE_GPU=1) = the 1-rank
+    run: same split-independent checksum, and the line says how many ranks the collectives span."""
+    common = ["--workload", "synth64x2_p5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = _run_bench(common)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    two = _run_bench(["--gpus", "2"] + common, env={"PPP_BENCH_ONE_GPU": "1", "PPP_BENCH_RANK_HBM_GB": "40"})
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert b["config"]["collective_ranks"] == 2 and b["config"]["ranks"] == 2
+    assert len(b["config"]["plan"]) == 2 and b["config"]["plan"][0]["own_z"][0] == 0
+    assert a["config"]["instances_slice_crc32"] is not None
+    assert a["config"]["instances_slice_crc32"] == b["config"]["instances_slice_crc32"]
+    assert a["config"]["instances_found"] == b["config"]["instances_found"]
