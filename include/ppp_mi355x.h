@@ -252,6 +252,15 @@ int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_no
                         const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
                         const ppp_params *p, void *stream);
 
+/* ppp_paint_patch_rows: the same painting with the patches given as a table instead of a dense
+ * prediction block: d_rows [n_nodes][C] (float16 / float32), row k = pred[:, node k].  Serves
+ * affGraphToInstances(sparse_labels=True) of the blockwise driver (graph_to_labeling.py:66-72,
+ * stitch_patch_graph.py:388-396), where the patch of every node of the GLOBAL graph is read
+ * from the prediction store -- here gathered chunk by chunk into the table.               */
+int ppp_paint_patch_rows(const void *d_rows, int rows_dtype, const uint32_t *d_nodes,
+                         const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
+                         const ppp_params *p, void *stream);
+
 /* --- layout helper ---------------------------------------------------------------------
  * expand a whole-volume COMPACT consensus into the reference's [NSZ][NSY][NSX][Z][Y][X]
  * array (what create_consensus_array_cuda returns / save_consensus writes).             */

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "ppp_last_error": (ctypes.c_char_p, []),
     "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
     "ppp_reload_env": (None, []),
+    "ppp_paint_patch_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(Params),
+                                            ctypes.c_void_p]),
     "ppp_counter_calibration": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "ppp_consensus_writes_voxel_major": (ctypes.c_int, [ctypes.POINTER(Params)]),
@@ -755,6 +758,17 @@ def paint_instances(pred, nodes, labels, instances, P):
         check(lib().ppp_paint_instances(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(nodes),
                                         _dev_ptr(labels), int(nodes.shape[0]),
                                         _dev_ptr(instances), ctypes.byref(P), _stream()))
+    return instances
+
+
+def paint_patch_rows(rows, nodes, labels, instances, P):
+    """S6 (paint) from a patch table: rows float16 / float32 [K, C] (row k = pred[:, node k]),
+    nodes int32 [K, 3], labels int32 [K], instances int32 (Z, Y, X) in place."""
+    assert rows.is_contiguous() and rows.shape[0] == nodes.shape[0]
+    with _timed("paint_instances"):
+        check(lib().ppp_paint_patch_rows(_dev_ptr(rows), pred_dtype_code(rows), _dev_ptr(nodes),
+                                         _dev_ptr(labels), int(nodes.shape[0]),
+                                         _dev_ptr(instances), ctypes.byref(P), _stream()))
     return instances
 
 

@@ -272,32 +272,60 @@ def label_graph(vol, rows, aff, shape, kwargs):
         nodes, labels = nodes[valid], np.searchsorted(uniq, keys[valid]) + 1
     if len(nodes) == 0:
         return instances
-    # paint: the patch of every node is read from the prediction (sparse_labels) -- here a
-    # gathered (C, n) block on the device; "largest id wins" = the reference's in-order overwrite
+    # paint: the patch of every node is read from the prediction (sparse_labels).  The patches
+    # are gathered into a TABLE (n, C) -- one read per touched chunk of the store, never a dense
+    # (C, Z, Y, X) block -- and painted from the table (ppp_paint_patch_rows); "largest id wins"
+    # = the reference's in-order overwrite
     dev = torch.device("cuda")
-    C = int(np.prod(patchshape))
     nodes = np.asarray(nodes, dtype=np.int64)
-    rad = np.array([p // 2 for p in patchshape])
+    labels = np.asarray(labels, dtype=np.int32)
     inst_dev = torch.zeros(shape, dtype=torch.int32, device=dev)
-    th = np.float32(kwargs["patch_threshold"])
-    for s in range(0, len(nodes), 65536):
-        nd = nodes[s:s + 65536]
-        lo = np.maximum(nd.min(axis=0) - rad, 0)
-        hi = np.minimum(nd.max(axis=0) + rad + 1, shape)
-        # the patches of this batch: a small dense volume that holds only their centre columns
-        sub = np.zeros((C,) + tuple(int(v) for v in (hi - lo)), dtype=np.float32)
-        for c in nd:
-            sub[(slice(None),) + tuple(int(v) for v in (c - lo))] = np.asarray(
-                vol.affs[(slice(None),) + tuple(int(v) for v in c)])
-        Pl = backend.params_from_kwargs(sub.shape[1:], patchshape, kwargs)
-        inst_l = torch.zeros(sub.shape[1:], dtype=torch.int32, device=dev)
-        backend.paint_instances(torch.from_numpy(sub).to(dev),
-                                torch.from_numpy((nd - lo).astype(np.int32)).to(dev),
-                                torch.from_numpy(np.asarray(labels[s:s + 65536], dtype=np.int32)).to(dev),
-                                inst_l, Pl)
-        region = inst_dev[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
-        torch.maximum(region, inst_l, out=region)
+    P = backend.params_from_kwargs(shape, patchshape, kwargs)
+    # batches bounded by table bytes (256 MB of float32 rows), nodes grouped by chunk inside
+    C = int(np.prod(patchshape))
+    per = max(1, (256 << 20) // (4 * C))
+    order = _chunk_order(vol.affs, nodes)
+    for s0 in range(0, len(nodes), per):
+        idx = order[s0:s0 + per]
+        rows = gather_patch_rows(vol.affs, nodes[idx])
+        backend.paint_patch_rows(torch.from_numpy(rows).to(dev),
+                                 torch.from_numpy(nodes[idx].astype(np.int32)).to(dev),
+                                 torch.from_numpy(labels[idx]).to(dev), inst_dev, P)
     return inst_dev.cpu().numpy().view(np.uint32)
+
+
+def _chunk_grid(affs):
+    """spatial chunk shape of the prediction store (one chunk = everything for an ndarray)"""
+    ch = getattr(affs, "chunks", None)
+    if ch is None or len(ch) != 4:
+        return tuple(int(v) for v in affs.shape[1:])
+    return tuple(max(1, int(c)) for c in ch[1:])
+
+
+def _chunk_order(affs, nodes):
+    """node indices sorted by the chunk that holds the node (then z, y, x)"""
+    cz, cy, cx = _chunk_grid(affs)
+    key = np.stack([nodes[:, 2], nodes[:, 1], nodes[:, 0], nodes[:, 2] // cx, nodes[:, 1] // cy, nodes[:, 0] // cz])
+    return np.lexsort(key)
+
+
+def gather_patch_rows(affs, nodes):
+    """(n, C) float32 table: row k = affs[:, node k].  Every chunk that holds a node is read ONCE,
+    and only the bounding box of its nodes."""
+    cz, cy, cx = _chunk_grid(affs)
+    n = len(nodes)
+    out = np.empty((n, int(affs.shape[0])), dtype=np.float32)
+    cid = (nodes[:, 0] // cz, nodes[:, 1] // cy, nodes[:, 2] // cx)
+    key = (cid[0] * (1 << 40)) + (cid[1] * (1 << 20)) + cid[2]
+    order = np.argsort(key, kind="stable")
+    bounds = np.flatnonzero(np.diff(key[order])) + 1
+    for grp in np.split(order, bounds):
+        nd = nodes[grp]
+        lo, hi = nd.min(axis=0), nd.max(axis=0) + 1
+        block = np.asarray(affs[(slice(None),) + tuple(slice(int(a), int(b)) for a, b in zip(lo, hi))])
+        rel = nd - lo
+        out[grp] = block[:, rel[:, 0], rel[:, 1], rel[:, 2]].T
+    return out
 
 
 def main(pred_file, result_folder=".", **kwargs):
@@ -331,7 +359,7 @@ def main(pred_file, result_folder=".", **kwargs):
         if kwargs.get("ignore_small_comps", 0) > 0:
             mask = clean_mask(mask, np.ones([3] * mask.ndim), kwargs["ignore_small_comps"]).astype(np.uint8)
         if kwargs.get("skeletonize_foreground"):
-            mask = _skeletonize(mask).astype(np.uint8)
+            mask = _skeletonize(mask, kwargs.get("skeletonize_backend")).astype(np.uint8)
         nz = np.transpose(np.nonzero(mask))
         bb_offset, shape = nz.min(axis=0), nz.max(axis=0) - nz.min(axis=0) + 1
     else:

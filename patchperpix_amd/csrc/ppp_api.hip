@@ -486,6 +486,19 @@ int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_no
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_paint_instances");
 }
 
+int ppp_paint_patch_rows(const void *d_rows, int rows_dtype, const uint32_t *d_nodes,
+                         const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
+                         const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(rows_dtype));
+    if (n_nodes == 0) return PPP_OK;
+    if (!d_rows || !d_nodes || !d_labels || !d_instances) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_paint_rows(d_rows, rows_dtype, d_nodes, d_labels, n_nodes, d_instances, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_paint_patch_rows");
+}
+
 int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
                           const ppp_params *p, void *stream) {
     ppp::Geo G;

@@ -84,6 +84,8 @@ hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *key
                                   hipStream_t s);
 hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
                             hipStream_t s);
+hipError_t launch_paint_rows(const void *rows, int dtype, const uint32_t *nodes, const uint32_t *labels,
+                             uint64_t n, uint32_t *inst, const Geo &G, hipStream_t s);
 hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,
                         const uint32_t *labels, uint64_t n, uint32_t *inst, const Geo &G,
                         hipStream_t s);

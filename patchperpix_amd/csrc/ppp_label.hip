@@ -201,6 +201,44 @@ __global__ void __launch_bounds__(256)
     atomicMax(&inst[vox(G, z, y, x)], lab);
 }
 
+// the same painting with the patches given as a TABLE: rows[k][r] = channel r at node k
+// (blockwise driver: the patches of the global graph's nodes are gathered chunk by chunk from the
+// prediction store; no dense (C, Z, Y, X) block exists)
+template <typename T>
+__global__ void __launch_bounds__(256)
+    paint_rows_kernel(const T *__restrict__ rows, const uint32_t *__restrict__ nodes,
+                      const uint32_t *__restrict__ labels, uint64_t n, uint32_t *inst, float th_f32,
+                      const Geo G) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (uint64_t)G.C) return;
+    const uint64_t k = t / G.C;
+    const int r = (int)(t % G.C);
+    const uint32_t lab = labels[k];
+    if (lab == 0) return;
+    if (!(ldf(rows, (long long)t) > th_f32)) return;
+    const int cz = (int)nodes[k * 3], cy = (int)nodes[k * 3 + 1], cx = (int)nodes[k * 3 + 2];
+    const int z = cz + r / (G.py * G.px) - G.rz;
+    const int y = cy + (r / G.px) % G.py - G.ry;
+    const int x = cx + r % G.px - G.rx;
+    if (z < 0 || z >= G.Z || y < 0 || y >= G.Y || x < 0 || x >= G.X) return;
+    atomicMax(&inst[vox(G, z, y, x)], lab);
+}
+
+hipError_t launch_paint_rows(const void *rows, int dtype, const uint32_t *nodes, const uint32_t *labels,
+                             uint64_t n, uint32_t *inst, const Geo &G, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t per = ((1ull << 31) / (uint64_t)G.C) & ~255ull;
+    for (uint64_t k0 = 0; k0 < n; k0 += per) {
+        const uint64_t m = n - k0 < per ? n - k0 : per;
+        const dim3 grid((unsigned)((m * (uint64_t)G.C + 255) / 256));
+        if (dtype == PPP_F16)
+            paint_rows_kernel<__half><<<grid, dim3(256), 0, s>>>((const __half *)rows + k0 * G.C, nodes + k0 * 3, labels + k0, m, inst, G.th_rn, G);
+        else
+            paint_rows_kernel<float><<<grid, dim3(256), 0, s>>>((const float *)rows + k0 * G.C, nodes + k0 * 3, labels + k0, m, inst, G.th_rn, G);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,
                         const uint32_t *labels, uint64_t n, uint32_t *inst, const Geo &G,
                         hipStream_t s) {

@@ -1438,7 +1438,7 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
             # cleaned mask (the cover mask itself is not thinned in blockwise mode,
             # vote_instances.py:219)
             from .vote_instances.vote_instances import _skeletonize
-            mask = _skeletonize(mask)
+            mask = _skeletonize(mask, kw.get("skeletonize_backend"))
         nz = np.nonzero(mask)
         rad = patchshape // 2
         bb = tuple(slice(max(0, int(nz[i].min()) - int(rad[i])),

@@ -85,7 +85,7 @@ def write_datasets(out_fn, datasets, attrs=None):
             ds = zf.create(key, shape=data.shape, chunks=chunks, dtype=data.dtype, overwrite=True)
             ds[...] = data
         for k, v in attrs.items():
-            ds.attrs[k] = list(v)
+            ds.attrs[k] = v if isinstance(v, str) else list(v)
     return out_fn
 
 

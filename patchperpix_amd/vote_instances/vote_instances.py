@@ -77,17 +77,39 @@ def get_arguments(check_required=True, argv=None):
     return args
 
 
-def _skeletonize(mask):
+SKELETONIZE_SERVED_BY = None     # which implementation thinned the last mask (written to the result's attrs)
+
+
+def _skeletonize(mask, backend_name=None):
     """skimage.morphology.skeletonize_3d of the mask (vote_instances.py:219-224,
-    stitch_patch_graph.py:757-760) when scikit-image is importable; otherwise the library's own
-    restatement of the same published thinning (Lee / Kashyap / Chu 1994; csrc/ppp_host_skel.cpp)
-    -- PARITY UNPINNED against scikit-image, which this image lacks."""
-    try:
-        from skimage.morphology import skeletonize_3d
+    stitch_patch_graph.py:757-760).  With scikit-image importable that is what runs.  Without it
+    the option RAISES, as the reference's import would -- unless the caller opts in to the
+    library's own thinning with ``skeletonize_backend="ppp"`` (kwarg / TOML entry, or
+    PPP_SKELETONIZE=ppp): ``ppp_host_skeletonize_3d`` restates the same published algorithm (Lee /
+    Kashyap / Chu 1994; csrc/ppp_host_skel.cpp) but is PARITY UNPINNED against scikit-image, which
+    this image lacks, and deliberately deviates in its sequential re-check (all three deletion
+    conditions instead of the simple-point test alone, which erases plates two voxels thick) --
+    so the cover mask / bounding box may differ from a scikit-image run.  The choice is logged at
+    WARNING and recorded in ``SKELETONIZE_SERVED_BY`` (the drivers copy it into the output attrs)."""
+    global SKELETONIZE_SERVED_BY
+    import os
+    choice = backend_name or os.environ.get("PPP_SKELETONIZE") or "skimage"
+    if choice not in ("skimage", "ppp"):
+        raise ValueError("skeletonize_backend must be 'skimage' or 'ppp', not %r" % (choice,))
+    if choice == "skimage":
+        try:
+            from skimage.morphology import skeletonize_3d
+        except ImportError as e:
+            raise ImportError(
+                "skeletonize_foreground needs scikit-image (skimage.morphology.skeletonize_3d); pass "
+                "skeletonize_backend='ppp' (or PPP_SKELETONIZE=ppp) to use the library's own thinning, "
+                "whose result is not pinned to scikit-image's") from e
+        SKELETONIZE_SERVED_BY = "skimage.morphology.skeletonize_3d"
         return skeletonize_3d(mask) > 0
-    except ImportError:
-        logger.info("scikit-image not available: thinning with ppp_host_skeletonize_3d")
-        return backend.host_skeletonize_3d(mask)
+    logger.warning("skeletonize_foreground: thinning with ppp_host_skeletonize_3d (skeletonize_backend='ppp'); "
+                   "not pinned to scikit-image's skeletonize_3d -- the cover mask / bounding box may differ")
+    SKELETONIZE_SERVED_BY = "ppp_host_skeletonize_3d"
+    return backend.host_skeletonize_3d(mask)
 
 
 def _pad(a, rad, channels=False):
@@ -134,7 +156,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     # vote_instances.py:219-224: the mask is thinned BEFORE anything else looks at it, so this
     # happens ahead of the dispatch to the tiled path (which must cover the same mask)
     if not kwargs.get('blockwise', False) and kwargs.get('skeletonize_foreground'):
-        mask_to_cover = _skeletonize(mask_to_cover)
+        mask_to_cover = _skeletonize(mask_to_cover, kwargs.get("skeletonize_backend"))
     # Volumes whose consensus does not fit in HBM are assembled slab by slab (identical result,
     # patchperpix_amd/tiling.py); `_n_slabs` forces a slab count.
     n_slabs = kwargs.get("_n_slabs")
@@ -355,7 +377,11 @@ def write_result(out_fn, datasets):
     """HDF5 (the reference's format, vote_instances.py:542-554) through h5py or the HDF5 C library;
     without either a zarr store ``<stem>.zarr`` with the same dataset names, dtypes and attributes
     (io_hdflike.write_datasets)."""
-    return io_hdflike.write_datasets(out_fn, datasets)
+    attrs = None
+    if SKELETONIZE_SERVED_BY is not None:
+        # which thinning produced the cover mask / bounding box of this result
+        attrs = {"offset": (0, 0, 0), "resolution": (1, 1, 1), "skeletonize_foreground": SKELETONIZE_SERVED_BY}
+    return io_hdflike.write_datasets(out_fn, datasets, attrs)
 
 
 def main(**kwargs):

@@ -142,3 +142,32 @@ def test_blockwise_matches_reference_gpu(name, tmp_path, monkeypatch):
     out2 = str(tmp_path / "out2")
     inst2 = spg.main(str(tmp_path / "sample.zarr"), result_folder=out2, blockwise_semantics="reference", **kw)
     assert np.array_equal(inst2, inst)
+
+
+def test_patch_rows_are_gathered_chunk_by_chunk():
+    """label_graph's patch table: row k = affs[:, node k], every touched chunk of the store read
+    once (and only the bounding box of its nodes) -- no dense (C, Z, Y, X) scratch."""
+    from patchperpix_amd import blockwise as bw
+    rng = np.random.default_rng(3)
+    data = rng.random((27, 20, 33, 41)).astype(np.float16)
+
+    class Chunked:
+        shape, chunks, dtype = data.shape, (27, 8, 16, 16), data.dtype
+        reads = []
+
+        def __getitem__(self, sel):
+            self.reads.append(sel)
+            return data[sel]
+    arr = Chunked()
+    lin = rng.choice(20 * 33 * 41, size=500, replace=False)
+    nodes = np.stack(np.unravel_index(lin, (20, 33, 41)), axis=1).astype(np.int64)
+    rows = bw.gather_patch_rows(arr, nodes)
+    assert rows.dtype == np.float32 and np.array_equal(rows, data[:, nodes[:, 0], nodes[:, 1], nodes[:, 2]].T.astype(np.float32))
+    n_chunks = len({(z // 8, y // 16, x // 16) for z, y, x in nodes.tolist()})
+    assert len(arr.reads) == n_chunks
+    order = bw._chunk_order(arr, nodes)
+    assert sorted(order.tolist()) == list(range(500))
+    cid = [(z // 8, y // 16, x // 16) for z, y, x in nodes[order].tolist()]
+    assert cid == sorted(cid)                                      # nodes of a chunk are consecutive
+    # an ndarray is one chunk
+    assert np.array_equal(bw.gather_patch_rows(data, nodes[:7]), rows[:7])

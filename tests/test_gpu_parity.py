@@ -4,6 +4,7 @@
 bit-exact on every float stage (compared as uint32 bit patterns; tolerance 0 ulp) and on
 every integer stage."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -785,3 +786,50 @@ def test_consensus_wide_patch_kernel_equals_generic(rule, torch_cuda, monkeypatc
         assert np.array_equal(out["0"][1], out["1"][1]), (box, "counts")
         assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32)), box
         assert np.count_nonzero(out["0"][0]) > 1000
+
+
+@pytest.mark.parametrize("name", ["s96_p9", "s64_p7"])
+def test_benchmark_scale_against_the_oracle(name, torch_cuda):
+    """The HIP path against the ORACLE at a benchmark-like size: bench.py's generator and the
+    shipped flylight flags (thinning + mutex watershed, uint32 ids) at 96^3 / 9^3 (BASELINE config
+    [2]'s patch) and 64^3 / 7^3 (config [1]'s).  The expected values come from
+    tests/golden/scale_<name>.npz = oracle/ppp_oracle_scale.to_instance_seg run by
+    tests/golden/gen_scale_fixture.py (a quarter of an hour of 8 cores for 96^3; the scale forms
+    of the oracle's host stages are held equal to the literal ones by tests/test_oracle_scale.py).
+    Scores and pair affinities bit-exact (sha256 of the float32 arrays), selected patches, pair
+    rows and the instance map identical -- untiled AND cut into 2 x 2 x 2 tiles."""
+    import hashlib
+    import json
+    import zlib
+    from conftest import GOLDEN_DIR
+    from patchperpix_amd import backend, synth
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    z = np.load(os.path.join(GOLDEN_DIR, "scale_%s.npz" % name))
+    shape, ps, cell = tuple(int(v) for v in z["shape"]), [int(v) for v in z["patchshape"]], [int(v) for v in z["cell"]]
+    kw = json.loads(str(z["flags"]))
+    kw["_instances_dtype"] = np.uint32
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, cell, seed=int(z["seed"]))
+    pred = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=int(z["seed"]), f16=True)
+    assert zlib.crc32(pred.cpu().numpy().tobytes()) == int(z["pred_f16_crc32"])      # same input
+    fg = lab != 0
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()    # noqa: E731
+    args = lambda: (fg.copy(), fg.copy(), fg.astype(np.uint8), ps)                   # noqa: E731
+    # float stages
+    ov = torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    cons = backend.consensus(pred, ov, P)
+    score = backend.rank_patches(pred, cons, ov, P).cpu().numpy()
+    del cons
+    assert sha(score.astype(np.float32)) == str(z["scores_sha256"])
+    pairs, aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, _n_slabs=1))
+    assert len(pairs) == int(z["n_pairs"])
+    assert sha(np.ascontiguousarray(pairs, dtype=np.uint32)) == str(z["pairs_sha256"])
+    assert sha(np.ascontiguousarray(aff, dtype=np.float32)) == str(z["aff_sha256"])
+    # the instance map: untiled, and 2 x 2 x 2 tiles
+    want = z["instances"]
+    whole, _ = vi.to_instance_seg(pred, *args(), **dict(kw, _n_slabs=1))
+    assert whole.dtype == np.uint32 and np.array_equal(whole, want)
+    tiled, _ = vi.to_instance_seg(pred, *args(), **dict(kw, _n_slabs=2, _yx_tiles=(2, 2)))
+    assert np.array_equal(tiled, want)
+    assert len(np.unique(want)) - 1 > 20

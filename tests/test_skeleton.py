@@ -68,10 +68,25 @@ def test_single_slice_and_2d_input():
     assert np.array_equal(backend.host_skeletonize_3d(m[0]), s[0])
 
 
-def test_skeletonize_foreground_option_is_served():
-    """the option used to raise without scikit-image; now the library's thinning serves it"""
-    from patchperpix_amd.vote_instances.vote_instances import _skeletonize
+def test_skeletonize_foreground_is_opt_in_without_scikit_image(monkeypatch):
+    """Without scikit-image the option raises like the reference's import would; the library's
+    own thinning (not pinned to scikit-image's) serves it only when asked for, and says so."""
+    from patchperpix_amd.vote_instances import vote_instances as vi
     m = np.zeros((9, 9, 20), bool)
     m[3:6, 3:6, 2:18] = True
-    s = _skeletonize(m)
+    try:
+        import skimage  # noqa: F401
+        have = True
+    except ImportError:
+        have = False
+    monkeypatch.delenv("PPP_SKELETONIZE", raising=False)
+    if not have:
+        with pytest.raises(ImportError, match="skeletonize_backend"):
+            vi._skeletonize(m)
+    s = vi._skeletonize(m, "ppp")
+    assert vi.SKELETONIZE_SERVED_BY == "ppp_host_skeletonize_3d"
     assert s.dtype == bool and s.sum() == 14 and not (s & ~m).any()
+    monkeypatch.setenv("PPP_SKELETONIZE", "ppp")
+    assert np.array_equal(vi._skeletonize(m), s)
+    with pytest.raises(ValueError):
+        vi._skeletonize(m, "itk")
