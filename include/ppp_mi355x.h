@@ -261,6 +261,35 @@ int ppp_paint_patch_rows(const void *d_rows, int rows_dtype, const uint32_t *d_n
                          const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
                          const ppp_params *p, void *stream);
 
+/* --- the reference's NumPy-semantics stages (`cuda=False`) ------------------
+ * A different function from the kernels above: integer votes.  Per interior foreground centre c
+ * (utilVoteInstances.py:59-92, get_patch_sets.py:32-79; float32 compares):
+ *     pf_c = { v in win(c) : pred[r_v][c] > th     and foreground[v] }
+ *     pb_c = { v in win(c) : pred[r_v][c] < 1 - th and foreground[v] }
+ * Votes: int16 [ppp_np_vote_planes(p)][Z][Y][X]; plane q >= 1 = the lexicographically positive
+ * offset with linear signed index (dz (2py-1) + dy)(2px-1) + dx = q (the COMPACT plane order),
+ * plane 0 = the zero offset (only ever non-zero for th < 0.5).  cons_box must be the whole volume.
+ *
+ * ppp_np_consensus    replaces create_consensus_array (consensus_array.py:18-68) + fillLookup
+ *                     (utilVoteInstances.py:19-56): +1 per centre on the key of every unordered
+ *                     pair of pf_c, -1 per centre on every DISTINCT key of a pair (pf_c, pb_c).
+ * ppp_np_rank_patches replaces rank_patches (ranked_patches.py:76-105): d_score int32 (Z,Y,X),
+ *                     #(ff votes > 0) - #(ff votes <= 0) + #(fb votes < 0) - #(fb votes >= 0) for
+ *                     interior foreground centres, 0 elsewhere.
+ * ppp_np_patch_graph  replaces computePatchGraph's NumPy branch (aff_patch_graph.py:209-282) for
+ *                     the candidate rows d_rows int32 [n][6] = (A, B): d_weight[i] = sum of the
+ *                     votes over all (p in pf_A, q in pf_B), |p - q| < patch shape on every axis,
+ *                     p != q, with pf taken against d_mask (= mask_to_cover); d_count[i] = the
+ *                     number of such pairs (the edge exists iff it is > 0).                      */
+int64_t ppp_np_vote_planes(const ppp_params *p);
+int ppp_np_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_foreground, int16_t *d_votes,
+                     const ppp_params *p, void *stream);
+int ppp_np_rank_patches(const void *d_pred, int pred_dtype, const uint8_t *d_foreground, const int16_t *d_votes,
+                        int32_t *d_score, const ppp_params *p, void *stream);
+int ppp_np_patch_graph(const void *d_pred, int pred_dtype, const uint8_t *d_mask, const int16_t *d_votes,
+                       const int32_t *d_rows, uint64_t n_rows, int64_t *d_weight, int32_t *d_count,
+                       const ppp_params *p, void *stream);
+
 /* --- layout helper ---------------------------------------------------------------------
  * expand a whole-volume COMPACT consensus into the reference's [NSZ][NSY][NSX][Z][Y][X]
  * array (what create_consensus_array_cuda returns / save_consensus writes).             */

@@ -64,6 +64,14 @@ _SIGNATURES = {
     "ppp_last_error": (ctypes.c_char_p, []),
     "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
     "ppp_reload_env": (None, []),
+    "ppp_np_vote_planes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
+    "ppp_np_consensus": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_np_rank_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_np_patch_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_paint_patch_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(Params),
                                             ctypes.c_void_p]),
@@ -759,6 +767,44 @@ def paint_instances(pred, nodes, labels, instances, P):
                                         _dev_ptr(labels), int(nodes.shape[0]),
                                         _dev_ptr(instances), ctypes.byref(P), _stream()))
     return instances
+
+
+# ---- the reference's NumPy-semantics stages (cuda=False) -------------------------------------------
+def np_consensus(pred, foreground, P):
+    """create_consensus_array (consensus_array.py:18-68) on the device: int16 votes
+    [planes, Z, Y, X] (plane 0 = zero offset, plane q = COMPACT plane q - 1)."""
+    torch = _torch()
+    planes = int(lib().ppp_np_vote_planes(ctypes.byref(P)))
+    votes = torch.empty((planes, P.Z, P.Y, P.X), dtype=torch.int16, device=pred.device)
+    with _timed("np_consensus"):
+        check(lib().ppp_np_consensus(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(foreground), _dev_ptr(votes),
+                                     ctypes.byref(P), _stream()))
+    return votes
+
+
+def np_rank_patches(pred, foreground, votes, P):
+    """rank_patches (ranked_patches.py:76-105) on the device: int32 scores (Z, Y, X)."""
+    torch = _torch()
+    score = torch.empty((P.Z, P.Y, P.X), dtype=torch.int32, device=pred.device)
+    with _timed("np_rank_patches"):
+        check(lib().ppp_np_rank_patches(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(foreground), _dev_ptr(votes),
+                                        _dev_ptr(score), ctypes.byref(P), _stream()))
+    return score
+
+
+def np_patch_graph(pred, mask, votes, rows, P):
+    """computePatchGraph's NumPy branch (aff_patch_graph.py:209-282) for candidate rows int32 [n, 6]:
+    (weight int64 [n], count int32 [n])."""
+    torch = _torch()
+    n = int(rows.shape[0])
+    weight = torch.zeros((n,), dtype=torch.int64, device=pred.device)
+    count = torch.zeros((n,), dtype=torch.int32, device=pred.device)
+    if n:
+        with _timed("np_patch_graph"):
+            check(lib().ppp_np_patch_graph(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(mask), _dev_ptr(votes),
+                                           _dev_ptr(rows), n, _dev_ptr(weight), _dev_ptr(count), ctypes.byref(P),
+                                           _stream()))
+    return weight, count
 
 
 def paint_patch_rows(rows, nodes, labels, instances, P):

@@ -486,6 +486,51 @@ int ppp_paint_instances(const void *d_pred, int pred_dtype, const uint32_t *d_no
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_paint_instances");
 }
 
+// ---- the reference's NumPy-semantics stages (cuda=False) -----------------------------------------
+int64_t ppp_np_vote_planes(const ppp_params *p) {
+    ppp::Geo G;
+    if (!p || make_geo(p, &G) != PPP_OK) return -1;
+    return (int64_t)G.n_planes + 1;
+}
+
+int ppp_np_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_foreground, int16_t *d_votes,
+                     const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_foreground || !d_votes) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_np_consensus(d_pred, pred_dtype, d_foreground, d_votes, G, p->th, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_np_consensus");
+}
+
+int ppp_np_rank_patches(const void *d_pred, int pred_dtype, const uint8_t *d_foreground, const int16_t *d_votes,
+                        int32_t *d_score, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_foreground || !d_votes || !d_score) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.C > 32768) return fail(PPP_ERR_UNSUPPORTED, "patch too large for ppp_np_rank_patches");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_np_rank(d_pred, pred_dtype, d_foreground, d_votes, d_score, G, p->th, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_np_rank_patches");
+}
+
+int ppp_np_patch_graph(const void *d_pred, int pred_dtype, const uint8_t *d_mask, const int16_t *d_votes,
+                       const int32_t *d_rows, uint64_t n_rows, int64_t *d_weight, int32_t *d_count,
+                       const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n_rows == 0) return PPP_OK;
+    if (!d_pred || !d_mask || !d_votes || !d_rows || !d_weight || !d_count) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.C > 16384) return fail(PPP_ERR_UNSUPPORTED, "patch too large for ppp_np_patch_graph");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_np_graph(d_pred, pred_dtype, d_mask, d_votes, d_rows, n_rows, (long long *)d_weight, d_count,
+                                        G, p->th, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_np_patch_graph");
+}
+
 int ppp_paint_patch_rows(const void *d_rows, int rows_dtype, const uint32_t *d_nodes,
                          const uint32_t *d_labels, uint64_t n_nodes, uint32_t *d_instances,
                          const ppp_params *p, void *stream) {

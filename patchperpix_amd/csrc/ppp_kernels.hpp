@@ -84,6 +84,14 @@ hipError_t launch_pair_group_keys(const uint32_t *rows, uint64_t n, int64_t *key
                                   hipStream_t s);
 hipError_t launch_pair_keys(const uint32_t *rows, uint64_t n, int64_t *keys, const Geo &G,
                             hipStream_t s);
+// the reference's NumPy-semantics stages (cuda=False), ppp_numpy_path.hip
+hipError_t launch_np_consensus(const void *pred, int dtype, const uint8_t *fg, int16_t *cons, const Geo &G,
+                               double th, hipStream_t s);
+hipError_t launch_np_rank(const void *pred, int dtype, const uint8_t *fg, const int16_t *cons, int32_t *score,
+                          const Geo &G, double th, hipStream_t s);
+hipError_t launch_np_graph(const void *pred, int dtype, const uint8_t *mask, const int16_t *cons,
+                           const int32_t *rows, uint64_t n, long long *weight, int32_t *count, const Geo &G,
+                           double th, hipStream_t s);
 hipError_t launch_paint_rows(const void *rows, int dtype, const uint32_t *nodes, const uint32_t *labels,
                              uint64_t n, uint32_t *inst, const Geo &G, hipStream_t s);
 hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,

@@ -334,8 +334,13 @@ class DeviceOps:
     def consensus_voxel_major(self, pred, ov, P, out=None):
         # (rows only read by the ranking and patch-graph kernels of patches inside the volume:
         # entries beyond the box need no zeroing, ppp_consensus_rows)
+        open_rows = os.environ.get("PPP_VM_OPEN", "1") != "0"
+        if out is not None and os.environ.get("PPP_VM_POISON") == "1":
+            # test switch: the entries open rows leave unwritten must never reach a result --
+            # make them NaN (the rank / patch-graph kernels multiply, they do not select)
+            out.fill_(float("nan"))
         return backend.consensus_voxel_major(pred, ov if P.use_overlap else None, P, out=out,
-                                             open_rows=os.environ.get("PPP_VM_OPEN", "1") != "0")
+                                             open_rows=open_rows)
 
     def voxel_major_pool(self, P, n_voxels):
         """One flat buffer for the voxel-major consensus of every tile (both passes) when S1

@@ -1,0 +1,154 @@
+"""The reference's ``cuda=False`` path (BASELINE config [0]'s wording) with its
+three own stages computed ON THE DEVICE, bit-exactly (they are integer arithmetic).
+
+Reference: ``create_consensus_array`` (consensus_array.py:18-68; int16 +-1 votes, keys from
+``fillLookup`` utilVoteInstances.py:19-56, sets from ``computeFGBGsets`` :59-92 /
+get_patch_sets.py:32-79), ``rank_patches`` (ranked_patches.py:76-105; integer sign counts) and the
+NumPy branch of ``computePatchGraph`` (aff_patch_graph.py:209-282; weight = sum of the votes over
+ALL pixel pairs of two patches, candidate patch pairs = every (r1 <= r2) of the x-sorted selection
+within one patch shape of each other -- the cKDTree pair list is only consulted for the "no pairs"
+early-out).  Cover, thinning and labelling are the stages both paths share.
+
+``removeIntersection`` and ``sample < 1`` draw from Python's unseeded ``random`` in the reference
+(on a set: not a function of the input); they raise here.  There is no host fallback: the three
+stages run through ppp_np_consensus / ppp_np_rank_patches / ppp_np_patch_graph.
+"""
+import logging
+
+import numpy as np
+
+from .. import backend
+from .aff_patch_graph import AffGraph, computeAndStorePatchPairs
+from .foreground_cover import computeForegroundCover, thinOutForegroundCover
+from .graph_to_labeling import affGraphToInstances
+from .ranked_patches import PatchList
+
+logger = logging.getLogger(__name__)
+
+
+def _params(shape, patchshape, kwargs):
+    kw = dict(kwargs)
+    # the float-kernel flags are irrelevant here; make_params only needs a consistent set
+    kw.setdefault("vi_bg_use_inv_th", True)
+    return backend.params_from_kwargs(shape, patchshape, kw)
+
+
+def create_consensus_array(pred_affs, foreground_dev, patchshape, **kwargs):
+    """consensus_array.py:18-68 -> device int16 [planes, Z, Y, X] (ppp_np_consensus)."""
+    P = _params(pred_affs.shape[1:], patchshape, kwargs)
+    return backend.np_consensus(pred_affs, foreground_dev, P)
+
+
+def rank_patches(pred_affs, foreground_dev, consensus_vote_array, foreground, patchshape, **kwargs):
+    """ranked_patches.py:76-105 + the sort (:100): PatchList of the interior foreground centres,
+    score descending, ties in raster order."""
+    P = _params(pred_affs.shape[1:], patchshape, kwargs)
+    score = backend.np_rank_patches(pred_affs, foreground_dev, consensus_vote_array, P).cpu().numpy()
+    rad = [int(p) // 2 for p in patchshape]
+    coords = np.transpose(np.where(foreground))
+    shp = np.array(foreground.shape)
+    coords = coords[np.all(coords >= rad, axis=1) & np.all(coords < shp - rad, axis=1)]
+    s = score[tuple(coords.T)].astype(np.int64)
+    order = np.argsort(-s, kind="stable")
+    return PatchList(coords[order], s[order]), score
+
+
+def candidate_rows(selected_sorted, overlap_mask, patchshape, include_single):
+    """the (r1, r2) loops of computePatchGraph (:222-240): rows in loop order."""
+    sel = np.asarray(selected_sorted, dtype=np.int64).reshape(-1, 3)
+    n = len(sel)
+    ps = np.array([int(p) for p in patchshape])
+    ov = overlap_mask[tuple(sel.T)] > 0 if n else np.zeros(0, bool)
+    rows = []
+    for r1 in range(n):
+        r2 = np.arange(r1 if include_single else r1 + 1, n)
+        if len(r2) == 0:
+            continue
+        keep = ~np.any(np.abs(sel[r2] - sel[r1]) > ps, axis=1)
+        if ov[r1]:
+            keep &= ~ov[r2]
+        r2 = r2[keep]
+        rows.append(np.concatenate([np.repeat(sel[r1][None], len(r2), axis=0), sel[r2]], axis=1))
+    return np.concatenate(rows).astype(np.int32) if rows else np.zeros((0, 6), np.int32)
+
+
+def computePatchGraph(selected_sorted, pred_affs, mask_to_cover, overlap_mask, consensus_vote_array,
+                      patchshape, **kwargs):
+    """aff_patch_graph.py:209-282 -> (rows int32 [n, 6], weight int64 [n]) of the edges, in the
+    order the reference adds them."""
+    import torch
+    P = _params(pred_affs.shape[1:], patchshape, kwargs)
+    rows = candidate_rows(selected_sorted, overlap_mask, patchshape, kwargs["includeSinglePatchCCS"])
+    if len(rows) == 0:
+        return rows, np.zeros(0, np.int64)
+    dev = pred_affs.device
+    mask_dev = torch.from_numpy(np.ascontiguousarray(mask_to_cover).astype(np.uint8)).to(dev)
+    weight, count = backend.np_patch_graph(pred_affs, mask_dev, consensus_vote_array,
+                                           torch.from_numpy(rows).to(dev), P)
+    keep = count.cpu().numpy() > 0
+    return rows[keep], weight.cpu().numpy()[keep]
+
+
+def order_preserving_float32(weight):
+    """The labelling stages take float32 affinities; the integer weights (up to C^2 * C) need not
+    fit.  They only use the SIGN of a weight and the ORDER of the magnitudes (connected components:
+    aff > 0; mutex watershed: stable sort by |aff|, graph_mws.py:20-26), so every weight is replaced
+    by sign * (dense rank of |weight|) -- exact in float32 -- with rank 0 for weight 0 (a zero
+    edge is repulsive with the smallest magnitude: it is processed last and only adds a mutex
+    constraint, which nothing after it consults)."""
+    mag = np.abs(weight)
+    uniq = np.unique(mag)
+    if len(uniq) >= (1 << 24):
+        raise OverflowError("more than 2^24 distinct edge weights")
+    rank = np.searchsorted(uniq, mag) + (0 if len(uniq) and uniq[0] == 0 else 1)
+    return (np.sign(weight) * rank).astype(np.float32)
+
+
+def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, **kwargs):
+    """vote_instances.py:150-452 with ``cuda=False``.  pred_affs: device tensor (C, Z, Y, X);
+    the three fields host arrays.  Returns (instances uint16, foreground uint8)."""
+    import torch
+    if kwargs.get("removeIntersection", False):
+        raise NotImplementedError("removeIntersection draws from Python's unseeded random on a set in the "
+                                  "reference's NumPy path (aff_patch_graph.py:244-253): not reproducible")
+    if kwargs.get("sample", 1.0) < 1:
+        raise NotImplementedError("sample < 1 draws from Python's unseeded random (get_patch_sets.py:52,77)")
+    if kwargs.get("return_intermediates", False):
+        raise AssertionError("only works with cuda, otherwise graph is built directly")   # vote_instances.py:436
+    patchshape = np.array([int(p) for p in patchshape])
+    rad = patchshape // 2
+    foreground = np.asarray(foreground).astype(bool)
+    mask_to_cover = np.asarray(mask_to_cover).astype(bool)
+    numinst = np.asarray(numinst)
+    shape = tuple(foreground.shape)
+    radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
+    overlap_mask = 1 * (numinst > 1)
+    mask_to_cover[overlap_mask > 0] = 0
+    instances = np.zeros(shape, dtype=np.uint16)
+    if np.count_nonzero(mask_to_cover[radslice]) == 0 or np.count_nonzero(foreground[radslice]) == 0:
+        return instances, foreground.astype(np.uint8)
+    dev = pred_affs.device
+    fg_dev = torch.from_numpy(foreground.astype(np.uint8)).to(dev)
+    with backend.host_timer("s1_consensus"):
+        votes = create_consensus_array(pred_affs, fg_dev, patchshape, **kwargs)
+    with backend.host_timer("s2_rank_and_sort"):
+        ranked, _ = rank_patches(pred_affs, fg_dev, votes, foreground, patchshape, **kwargs)
+    with backend.host_timer("s3_cover"):
+        selected, n_sel = computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked, radslice,
+                                                 pred_affs, rad, None, None, **kwargs)
+    if not kwargs.get("skipThinCover") and n_sel > 0:
+        with backend.host_timer("s4_thin"):
+            selected, n_sel = thinOutForegroundCover(mask_to_cover, selected, radslice, pred_affs, rad,
+                                                     patchshape, **kwargs)
+    # computeAndStorePatchPairs sorts the selection by x and decides the "no pairs" early-out
+    pairs = computeAndStorePatchPairs(selected, patchshape, _volume_shape=shape, _device=dev, **kwargs)
+    if pairs is None:
+        return instances, foreground.astype(np.uint8)
+    with backend.host_timer("s5_patch_graph"):
+        rows, weight = computePatchGraph(pairs.nodes, pred_affs, mask_to_cover, overlap_mask, votes,
+                                         patchshape, **kwargs)
+    del votes
+    graph = AffGraph(order_preserving_float32(weight), rows.astype(np.uint32), device=dev)
+    graph.weights = weight
+    with backend.host_timer("s6_label_paint"):
+        return affGraphToInstances(graph, pred_affs, patchshape, rad, None, None, instances, foreground, **kwargs)

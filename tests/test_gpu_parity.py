@@ -833,3 +833,33 @@ def test_benchmark_scale_against_the_oracle(name, torch_cuda):
     tiled, _ = vi.to_instance_seg(pred, *args(), **dict(kw, _n_slabs=2, _yx_tiles=(2, 2)))
     assert np.array_equal(tiled, want)
     assert len(np.unique(want)) - 1 > 20
+
+
+@pytest.mark.parametrize("ps,shape,cell", [((7, 7, 7), (48, 52, 56), 18), ((9, 9, 9), (44, 48, 60), 24), ((5, 5, 5), (40, 44, 48), 12)])
+def test_open_rows_never_reach_a_result(ps, shape, cell, torch_cuda, monkeypatch):
+    """Tiled path: S1 leaves the voxel-major entries without a source voxel in the consensus box
+    unwritten (ppp_consensus_rows, PPP_VM_OPEN=1).  With the pool poisoned with NaN before every
+    tile's consensus the pair affinities (bit patterns) and the instance map equal those of fully
+    zeroed rows (PPP_VM_OPEN=0): no open entry is ever read for an active lane."""
+    from patchperpix_amd import backend, synth
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    kw = dict(FLYLIGHT, _instances_dtype=np.uint32)
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, [cell] * 3, seed=5)
+    pred = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=5, f16=True)
+    fg = lab != 0
+    args = lambda: (fg.copy(), fg.copy(), fg.astype(np.uint8), list(ps))     # noqa: E731
+    grid = dict(_n_slabs=2, _yx_tiles=(2, 2))
+    monkeypatch.setenv("PPP_VM_OPEN", "0")
+    want = vi.to_instance_seg(pred, *args(), **dict(kw, **grid))[0]
+    want_pairs, want_aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, **grid))
+    monkeypatch.setenv("PPP_VM_OPEN", "1")
+    monkeypatch.setenv("PPP_VM_POISON", "1")
+    got = vi.to_instance_seg(pred, *args(), **dict(kw, **grid))[0]
+    got_pairs, got_aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, **grid))
+    assert np.array_equal(want_pairs, got_pairs)
+    assert not np.isnan(got_aff).any()
+    assert np.array_equal(_bits(want_aff), _bits(got_aff))
+    assert np.array_equal(want, got) and want.max() > 5

@@ -1,0 +1,188 @@
+"""The reference's NumPy path (``cuda=False``; SURVEY 8(a) row a11, BASELINE config [0]'s wording):
+int16 +-1 votes, integer sign-count ranking, graph weights over all pixel pairs.
+
+tests/golden/np_*.npz hold the outputs of the reference's OWN functions (create_consensus_array,
+rank_patches, computeForegroundCover, thinOutForegroundCover, computePatchGraph's NumPy branch,
+affGraphToInstances), made by tests/golden/gen_golden_numpy_path.py with
+``removeIntersection=False, sample=1.0``.
+
+* CPU: oracle/ppp_oracle_np.py against those goldens (every stage, exact);
+* GPU: the HIP kernels (ppp_np_consensus / ppp_np_rank_patches / ppp_np_patch_graph, through the
+  C ABI) and ``to_instance_seg(cuda=False)`` against the goldens and, on fresh inputs, the oracle.
+Everything is integer arithmetic: equality is exact."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+from oracle import ppp_oracle as orc
+from oracle import ppp_oracle_np as onp
+
+NAMES = sorted(os.path.splitext(os.path.basename(p))[0][3:] for p in glob.glob(os.path.join(GOLDEN_DIR, "np_*.npz")))
+
+
+class NpGolden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN_DIR, "np_%s.npz" % name))
+        self.pred = self.z["pred_f16"].astype(np.float32)
+        self.foreground = self.z["foreground"].astype(bool)
+        self.numinst = self.z["numinst"]
+        self.ps = [int(p) for p in self.z["patchshape"]]
+        self.kw = json.loads(str(self.z["flags"]))
+        self.kw.setdefault("max_total_patch_distance_in_ps_multiples", 2)
+        self.kw.update(save_no_intermediates=True, result_folder="/tmp")
+        self.th = float(self.kw["patch_threshold"])
+        self.overlap = 1 * (self.numinst > 1)
+        self.mask = self.foreground.copy()
+        self.mask[self.overlap > 0] = 0
+
+    def votes(self):
+        """the golden's sparse (L_ref, z, y, x) -> value list as the dense plane layout"""
+        ps = self.ps
+        ns1, ns2 = 2 * ps[1], 2 * ps[2]
+        wy, wx = 2 * ps[1] - 1, 2 * ps[2] - 1
+        out = np.zeros((onp.n_planes(ps),) + self.foreground.shape, dtype=np.int16)
+        idx, val = self.z["cons_index"], self.z["cons_value"]
+        L = idx[:, 0].astype(np.int64)
+        dx = L % ns2
+        m = L // ns2 + (dx > ps[2] - 1)
+        dx = np.where(dx > ps[2] - 1, dx - ns2, dx)
+        dy = m % ns1
+        dz = m // ns1 + (dy > ps[1] - 1)
+        dy = np.where(dy > ps[1] - 1, dy - ns1, dy)
+        q = (dz * wy + dy) * wx + dx
+        assert np.all(q >= 0) and np.all(q < out.shape[0]) and np.all(dz < ps[0])
+        out[q, idx[:, 1], idx[:, 2], idx[:, 3]] = val
+        return out
+
+
+@pytest.fixture(params=NAMES)
+def g(request):
+    return NpGolden(request.param)
+
+
+def test_there_are_goldens():
+    assert len(NAMES) >= 5
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU: the oracle is pinned
+# ---------------------------------------------------------------------------------------------
+def test_oracle_stages_match_the_reference(g):
+    votes = onp.consensus(g.pred, g.foreground, g.ps, g.th)
+    assert votes.dtype == np.int16 and np.array_equal(votes, g.votes())
+    cs, scores = onp.rank(g.pred, g.foreground, votes, g.ps, g.th)
+    rc, rs = onp.ranked(cs, scores)
+    assert np.array_equal(rc, g.z["ranked_coords"]) and np.array_equal(rs, g.z["ranked_scores"])
+    sel = orc.foreground_cover(rc, rs, g.overlap, g.mask, g.pred, g.ps, **g.kw)
+    assert np.array_equal(rc[sel], g.z["cover_coords"])
+    chosen = rc[sel]
+    if "thin_coords" in g.z.files:
+        chosen = chosen[orc.thin_cover(chosen, g.mask, g.pred, g.ps, **g.kw)]
+        assert np.array_equal(chosen, g.z["thin_coords"])
+    srt = chosen[np.argsort(chosen[:, 2], kind="stable")]
+    assert np.array_equal(srt, g.z["selected_sorted"])
+    if not int(g.z["has_pairs"]):
+        return
+    rows, w = onp.patch_graph(g.pred, g.mask, g.overlap, votes, srt, g.ps, g.th,
+                              include_single=g.kw["includeSinglePatchCCS"])
+    # networkx reports the edges in its own iteration order; as sets with weights they agree, and
+    # the rows' loop order reproduces that iteration order (orc._graph_edges)
+    nodes, edges = orc._graph_edges(rows, w)
+    assert [list(u) + list(v) for u, v, _ in edges] == g.z["edge_rows"].tolist()
+    assert [int(x) for _, _, x in edges] == g.z["edge_weight"].tolist()
+    assert [list(n) for n in nodes] == g.z["node_order"].tolist()
+    inst = orc.label(rows.astype(np.uint32), w, g.pred, g.ps, g.foreground.shape, **g.kw)
+    assert np.array_equal(inst, g.z["instances"])
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU: the HIP kernels through the C ABI
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    from patchperpix_amd import backend
+    assert torch.cuda.is_available() and backend.device_count() >= 1
+    return torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f16", [False, True])
+def test_device_stages_match_the_reference(g, f16, torch_cuda):
+    from patchperpix_amd import backend
+    from patchperpix_amd.vote_instances import numpy_semantics as ns
+    torch = torch_cuda
+    pred = _dev(torch, g.pred.astype(np.float16) if f16 else g.pred)        # (goldens hold float16 values)
+    fg = _dev(torch, g.foreground.astype(np.uint8))
+    votes = ns.create_consensus_array(pred, fg, g.ps, **g.kw)
+    assert votes.dtype == torch.int16 and np.array_equal(votes.cpu().numpy(), g.votes())
+    ranked, _ = ns.rank_patches(pred, fg, votes, g.foreground, g.ps, **g.kw)
+    assert np.array_equal(ranked.coords, g.z["ranked_coords"])
+    assert np.array_equal(ranked.scores.astype(np.int64), g.z["ranked_scores"])
+    if int(g.z["has_pairs"]):
+        rows, w = ns.computePatchGraph(g.z["selected_sorted"], pred, g.mask, g.overlap, votes, g.ps, **g.kw)
+        nodes, edges = orc._graph_edges(rows, w)
+        assert [list(u) + list(v) for u, v, _ in edges] == g.z["edge_rows"].tolist()
+        assert [int(x) for _, _, x in edges] == g.z["edge_weight"].tolist()
+
+
+@pytest.mark.gpu
+def test_to_instance_seg_with_cuda_false_matches_the_reference(g, torch_cuda):
+    """the drop-in entry with the reference's own switch: identical ids"""
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    kw = dict(g.kw, cuda=False)
+    inst, fg = vi.to_instance_seg(g.pred.copy(), g.foreground.copy(), g.foreground.copy(), g.numinst.copy(),
+                                  g.ps, **kw)
+    assert inst.dtype == np.uint16 and np.array_equal(inst, g.z["instances"])
+    assert np.array_equal(fg, g.foreground.astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,ps,th,seed", [((9, 10, 11), (3, 3, 3), 0.5, 1), ((1, 20, 22), (1, 5, 5), 0.7, 2),
+                                              ((8, 9, 10), (3, 5, 3), 0.45, 3)])
+def test_device_stages_match_the_oracle_on_fresh_inputs(shape, ps, th, seed, torch_cuda):
+    from patchperpix_amd import synth
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import numpy_semantics as ns
+    torch = torch_cuda
+    rng = np.random.default_rng(seed)
+    case = synth.make_case(shape, list(ps), seed=seed, cell=[max(1, min(5, s)) for s in shape], overlap_frac=0.03)
+    pred = (case["pred"] + rng.uniform(-0.3, 0.3, size=case["pred"].shape)).astype(np.float16).astype(np.float32)
+    fg = case["foreground"].astype(bool)
+    overlap = 1 * (case["numinst"] > 1)
+    mask = fg.copy()
+    mask[overlap > 0] = 0
+    kw = dict(FLYLIGHT, patch_threshold=th, cuda=False, removeIntersection=False)
+    votes_o = onp.consensus(pred, fg, list(ps), th)
+    cs, sc = onp.rank(pred, fg, votes_o, list(ps), th)
+    rc, rs = onp.ranked(cs, sc)
+    pd, fd = _dev(torch, pred), _dev(torch, fg.astype(np.uint8))
+    votes = ns.create_consensus_array(pd, fd, list(ps), **kw)
+    assert np.array_equal(votes.cpu().numpy(), votes_o)
+    ranked, _ = ns.rank_patches(pd, fd, votes, fg, list(ps), **kw)
+    assert np.array_equal(ranked.coords, rc) and np.array_equal(ranked.scores.astype(np.int64), rs)
+    sel = rc[::7]
+    sel = sel[np.argsort(sel[:, 2], kind="stable")]
+    rows_o, w_o = onp.patch_graph(pred, mask, overlap, votes_o, sel, list(ps), th, include_single=True)
+    rows, w = ns.computePatchGraph(sel, pd, mask, overlap, votes, list(ps), **kw)
+    assert np.array_equal(rows, rows_o) and np.array_equal(w, w_o)
+
+
+def test_order_preserving_weights():
+    from patchperpix_amd.vote_instances.numpy_semantics import order_preserving_float32 as f
+    w = np.array([5, -5, 0, 1 << 40, -(1 << 40) - 1, 3, 0, -3], dtype=np.int64)
+    r = f(w)
+    assert r.dtype == np.float32 and np.array_equal(np.sign(r), np.sign(w))
+    a = np.abs(w).astype(object)
+    for i in range(len(w)):
+        for j in range(len(w)):
+            assert (abs(r[i]) < abs(r[j])) == (a[i] < a[j]) and (abs(r[i]) == abs(r[j])) == (a[i] == a[j])
+    assert np.array_equal(f(np.array([2, 7, -7], np.int64)), np.array([1, 2, -2], np.float32))
