@@ -43,12 +43,25 @@ def build_library(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"]
 
+    headers = glob.glob(os.path.join(CSRC, "*.hpp")) + \
+        [os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "ppp_mi355x.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    stamp = " ".join(cflags + extra)
+
     def compile_one(src):
+        # an object is reused when it is newer than its source and every header and was built
+        # with the same flags (PPP_EXTRA_FLAGS variants keep their own object directory)
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        flag_file = obj + ".flags"
+        if os.path.exists(obj) and os.path.exists(flag_file) and open(flag_file).read() == stamp and \
+                os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj
         cmd = [hipcc] + cflags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(flag_file, "w") as f:
+            f.write(stamp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:

@@ -51,6 +51,15 @@ namespace ppp {
 #endif
 static constexpr int RW_PAD = 8;
 static constexpr int RW_WAVES = 4;
+// Mask words per centre, padded to whole 16-byte loads.  The masks are stored CENTRE-MAJOR,
+// M[centre][word]: a lane reads the 184 bytes of ITS centre with twelve 16-byte loads, and the
+// centres of a wave's chunk (9-runs of x neighbours) cover their cache lines densely.  The earlier
+// word-major layout M[word][centre] made each of the 46 loads of a chunk touch eight 128-byte lines
+// for 36 bytes apiece: 47 KB of line traffic per chunk for 11.8 KB of masks -- and because a
+// workgroup's masks (377 KB) are re-read on every one of the 729 steps while 128 workgroups per
+// XCD share a 4 MB L2, most of those lines came over the fabric (the kernel ran at the fabric's
+// bandwidth: profiles/r04_b_s2_ablations.txt -- 205 ms, 126 ms without the mask loads).
+static constexpr int rw_mask_words(int C) { return (((C + 15) / 16) + 3) & ~3; }
 typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp2;
 
 // acc + r * c with c a float16 in the low / high half of a register: the compiler selects
@@ -123,9 +132,10 @@ __global__ void __launch_bounds__(256)
                 if (valid && val > G.th_gt) p |= 1u << b;
                 if (valid && val < G.bg_lt) n |= 1u << b;
             }
-            M[(long long)w * sbV + t] = interleave16(p, n);
+            M[t * (long long)rw_mask_words(G.C) + w] = interleave16(p, n);
             nP += __popc(p);
         }
+        for (int w = words16; w < rw_mask_words(G.C); ++w) M[t * (long long)rw_mask_words(G.C) + w] = 0u;
         // fgCnt = |P| (|V| - 1) - |P| (|P| - 1) / 2   (rankPatches.cu:139, see ppp_rank_v2.hip)
         const unsigned fg_cnt = nP ? nP * (nV - 1u) - nP * (nP - 1u) / 2u : 0u;
         inf = 0x80000000u | fg_cnt;
@@ -151,6 +161,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
                    const int tiles_x, const int n_tiles) {
     constexpr int C = PZ * PY * PX, W16 = (C + 15) / 16, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
+    constexpr int W16P = rw_mask_words(C);
     constexpr int WZ = 2 * PZ - 1, WY = 2 * PY - 1, WX = 2 * PX - 1, W = WZ * WY * WX, LC = (W - 1) / 2;
     constexpr int NTHR = 64 * RW_WAVES;
     constexpr int NST = (W + NTHR - 1) / NTHR;
@@ -249,7 +260,11 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int e = tid + i * NTHR;
+#ifdef PPP_RW_ABL_NOROW
+                st[i] = (float)e;                      // (timing experiment: no row fetches)
+#else
                 st[i] = e < W ? src[e] : 0.0f;
+#endif
             }
         }
         // pixels a of this voxel whose centre c = u + R - a lies in the tile
@@ -271,13 +286,28 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             const long long t = sb_index(lz, ly, lx);
             bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
             // is a in P?  P bit of partner s: bit 8 (s >> 2 & 3) + (s & 3) of word s >> 4
-            if (active) active = ((M[(long long)(a >> 4) * sbV + t] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
+            if (active) active = ((M[t * (long long)W16P + (a >> 4)] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
             if (__ballot(active) == 0) continue;
             uint32_t mw[W16];
             // (unconditional loads -- t is a centre of the tile for every lane -- then one select
             // per word: a predicated load is a branch per word)
+#ifdef PPP_RW_ABL_NOMASK
+            // (timing experiment: no mask loads -- every partner in P)
 #pragma unroll
-            for (int w = 0; w < W16; ++w) mw[w] = M[(long long)w * sbV + t];
+            for (int w = 0; w < W16; ++w) mw[w] = 0x0F0F0F0Fu + (uint32_t)(t & 0);
+#else
+            {
+                const uint4 *mc = reinterpret_cast<const uint4 *>(M + t * (long long)W16P);
+#pragma unroll
+                for (int q = 0; q < W16P / 4; ++q) {
+                    const uint4 v = mc[q];
+                    if (4 * q < W16) mw[4 * q] = v.x;
+                    if (4 * q + 1 < W16) mw[4 * q + 1] = v.y;
+                    if (4 * q + 2 < W16) mw[4 * q + 2] = v.z;
+                    if (4 * q + 3 < W16) mw[4 * q + 3] = v.w;
+                }
+            }
+#endif
 #pragma unroll
             for (int w = 0; w < W16; ++w) mw[w] = active ? mw[w] : 0u;
             float acc = active ? accs[cl] : 0.0f;
@@ -304,7 +334,11 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #pragma unroll
                     for (int i2 = 0; i2 < 4; ++i2) {
                         const int b = w * 16 + j * 4 + i2;
+#ifdef PPP_RW_ABL_NOLDS
+                        if (b < C) r[i2] = __builtin_bit_cast(float, 0x3F800000u + (uint32_t)(lane + b));   // (timing experiment)
+#else
                         if (b < C) r[i2] = row[((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX];
+#endif
                     }
                 };
                 load_rows(0, rv[0]);
@@ -364,7 +398,7 @@ bool rank_wg_supported(const Geo &G) {
 
 size_t rank_wg_workspace_bytes(const ppp_box &sb, const Geo &G) {
     const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
-    const size_t words16 = (size_t)(G.C + 15) / 16;
+    const size_t words16 = (size_t)rw_mask_words(G.C);
     return up256w(words16 * sbV * 4) + up256w(sbV * 4) + up256w((size_t)G.V);
 }
 
@@ -373,7 +407,7 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
                              const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
     const size_t sbV = (size_t)sX * sY * sZ;
-    const size_t words16 = (size_t)(G.C + 15) / 16;
+    const size_t words16 = (size_t)rw_mask_words(G.C);
     char *p = (char *)work;
     uint32_t *M = (uint32_t *)p;    p += up256w(words16 * sbV * 4);
     uint32_t *info = (uint32_t *)p; p += up256w(sbV * 4);
