@@ -443,6 +443,15 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
                             const float *ranked_score, const uint32_t *bits, int64_t n,
                             int32_t pix_th, double score_threshold, uint8_t *selected,
                             int64_t *remaining, int32_t *stopped);
+/* ppp_host_cover_pass_marked: the same pass with `mark_close_neighboorhood`
+ * (foreground_cover.py:141-143, 162-168): h_marked uint8 (Z,Y,X), in/out, shared by the passes of
+ * one cover (NULL = the plain pass); a ranked patch with a marked centre is skipped, a selected
+ * patch marks the box (0, +-3, +-3) around its centre with NumPy's slice semantics.         */
+int64_t ppp_host_cover_pass_marked(uint8_t *h_mask_running, const uint8_t *h_overlap, const int32_t *vol,
+                                   const int32_t *patchshape, const int64_t *ranked_lin,
+                                   const float *ranked_score, const uint32_t *bits, int64_t n,
+                                   int32_t pix_th, double score_threshold, uint8_t *selected,
+                                   int64_t *remaining, int32_t *stopped, uint8_t *h_marked);
 /* ppp_host_thin_cover: thinOutForegroundCover (foreground_cover.py:183-256), keep[n] out.   */
 int64_t ppp_host_thin_cover(const uint8_t *h_mask, const int32_t *vol, const int32_t *patchshape,
                             const int64_t *sel_lin, const uint32_t *bits, int64_t n,

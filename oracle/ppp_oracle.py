@@ -239,46 +239,77 @@ def _window(c, rad):
     return tuple(slice(int(c[i] - rad[i]), int(c[i] + rad[i] + 1)) for i in range(3))
 
 
+def _cover_loop(running, radslice, coords, scores, overlap_mask, pred, patchshape, rad, selected, pix_th,
+                marked, kw):
+    """computeForegroundCoverLoop (foreground_cover.py:111-180), restarting at rank 0."""
+    fc = kw["fc_threshold"]
+    n = len(coords)
+    r = 0
+    while np.max(running[radslice]) > 0 and r < n:
+        i = r
+        r += 1
+        if selected[i]:
+            continue
+        if isinstance(kw.get("score_threshold", False), float) and scores[i] < kw["score_threshold"]:
+            break
+        c = coords[i]
+        if kw.get("mark_close_neighboorhood", False) and marked[tuple(c)]:
+            continue
+        if overlap_mask[tuple(c)] > 0:
+            continue
+        patch = pred[(slice(None),) + tuple(int(v) for v in c)].reshape(patchshape)
+        win = _window(c, rad)
+        if np.count_nonzero(running[win][patch > fc]) > pix_th:
+            selected[i] = True
+            if kw.get("mark_close_neighboorhood", False):
+                m_rad = np.array([0, 3, 3])
+                m_start, m_stop = np.asarray(c) - m_rad, np.asarray(c) + m_rad + 1
+                # (plain slices: a negative start wraps around, exactly like the reference's)
+                marked[tuple(slice(int(m_start[k]), int(m_stop[k])) for k in range(3))] = True
+            running[win][patch > fc] = 0
+
+
 def foreground_cover(ranked_coords, ranked_scores, overlap_mask, mask_to_cover, pred,
-                     patchshape, **kw):
-    """foreground_cover.py:15-180 (without the optional mark/overlap-neighbourhood
-    branches, which no shipped config enables).  Returns indices into the ranked list."""
+                     patchshape, scores_array=None, **kw):
+    """foreground_cover.py:15-126 incl. `mark_close_neighboorhood` and
+    `select_patches_overlap_neighborhood`.  Returns indices into the ranked list -- or, with
+    `select_patches_overlap_neighborhood`, the (coords, scores) the reference rebuilds in raster
+    order (:83-85; needs the score volume)."""
+    import scipy.ndimage
     patchshape = [int(p) for p in patchshape]
     rad = np.array([p // 2 for p in patchshape])
     radslice = tuple(slice(rad[i], mask_to_cover.shape[i] - rad[i]) for i in range(3))
     running = mask_to_cover.copy()
     n = len(ranked_coords)
     selected = np.zeros(n, dtype=bool)
+    marked = np.zeros(running.shape, dtype=bool)
     if kw["select_patches_for_sparse_data"]:
         pix_ths = [0]
     else:
         mid = int(np.prod(patchshape) / 2)
         pix_ths = [t for t in [500, 100, 50, 10, 0] if t < mid]
-    fc = kw["fc_threshold"]
     for pix_th in pix_ths:
-        r = 0  # every pass restarts at rank 0 (rpidx is passed by value)
-        remaining = int(np.count_nonzero(running[radslice]))
-        while remaining > 0 and r < n:
-            i = r
-            r += 1
-            if selected[i]:
-                continue
-            if isinstance(kw.get("score_threshold", False), float) and \
-                    ranked_scores[i] < kw["score_threshold"]:
-                break
-            c = ranked_coords[i]
-            if overlap_mask[tuple(c)] > 0:
-                continue
-            patch = pred[(slice(None),) + tuple(int(v) for v in c)].reshape(patchshape)
-            win = _window(c, rad)
-            hit = running[win] & (patch > fc)
-            if np.count_nonzero(hit) > pix_th:
-                selected[i] = True
-                running[win][patch > fc] = 0
-                remaining = int(np.count_nonzero(running[radslice]))
+        _cover_loop(running, radslice, ranked_coords, ranked_scores, overlap_mask, pred, patchshape, rad,
+                    selected, pix_th, marked, kw)
         if np.sum(running[radslice]) < 1:
             break
-    return np.nonzero(selected)[0]
+    if not kw.get("select_patches_overlap_neighborhood", False):
+        return np.nonzero(selected)[0]
+    chosen = np.zeros(mask_to_cover.shape, dtype=bool)
+    for c in ranked_coords[selected]:
+        chosen[tuple(c)] = True
+    overlap = overlap_mask.copy()
+    overlap_t = scipy.ndimage.binary_dilation(overlap, iterations=2)
+    overlap_dil = scipy.ndimage.binary_dilation(overlap, iterations=5)
+    fg_dil_mask = np.logical_and(np.logical_and(np.logical_not(overlap_t), overlap_dil), mask_to_cover)
+    keep = np.array([(not chosen[tuple(c)]) and bool(fg_dil_mask[tuple(c)]) for c in ranked_coords], dtype=bool)
+    sub_c, sub_s = ranked_coords[keep], np.asarray(ranked_scores)[keep]
+    sel2 = np.zeros(len(sub_c), dtype=bool)
+    _cover_loop(fg_dil_mask, radslice, sub_c, sub_s, overlap_mask, pred, patchshape, rad, sel2, pix_th, marked, kw)
+    for c in sub_c[sel2]:
+        chosen[tuple(c)] = True
+    coords = np.argwhere(chosen)
+    return coords, np.asarray(scores_array)[tuple(coords.T)]
 
 
 def thin_cover(sel_coords, mask_to_cover, pred, patchshape, **kw):
@@ -529,8 +560,8 @@ def to_instance_seg(pred, foreground, mask_to_cover, numinst, patchshape, **kw):
         ranked_coords, ranked_scores = rank_by_score(coords, scores)
         out["ranked_coords"], out["ranked_scores"] = ranked_coords, ranked_scores
         sel = foreground_cover(ranked_coords, ranked_scores, overlap_mask, mask_to_cover,
-                               pred, patchshape, **kw)
-        sel_coords = ranked_coords[sel]
+                               pred, patchshape, scores_array=scores, **kw)
+        sel_coords = sel[0] if isinstance(sel, tuple) else ranked_coords[sel]
         out["cover_coords"] = sel_coords
     if not kw["skipThinCover"] and len(sel_coords) > 0:
         keep = thin_cover(sel_coords, mask_to_cover, pred, patchshape, **kw)

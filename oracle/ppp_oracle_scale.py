@@ -274,8 +274,9 @@ def to_instance_seg(pred, foreground, mask_to_cover, numinst, patchshape, dtype=
     s = scores[tuple(coords.T)]
     order = np.argsort(-s.astype(np.float64), kind="stable")      # stable, score descending
     ranked_coords, ranked_scores = coords[order], s[order]
-    sel = orc.foreground_cover(ranked_coords, ranked_scores, overlap_mask, mask_to_cover, pred, ps, **kw)
-    sel_coords = ranked_coords[sel]
+    sel = orc.foreground_cover(ranked_coords, ranked_scores, overlap_mask, mask_to_cover, pred, ps,
+                               scores_array=scores, **kw)
+    sel_coords = sel[0] if isinstance(sel, tuple) else ranked_coords[sel]
     out["cover_coords"] = sel_coords
     if not kw["skipThinCover"] and len(sel_coords) > 0:
         sel_coords = sel_coords[thin_cover(sel_coords, mask_to_cover, pred, ps, **kw)]

@@ -219,6 +219,12 @@ _SIGNATURES = {
                                              ctypes.c_double, ctypes.c_void_p,
                                              ctypes.POINTER(ctypes.c_int64),
                                              ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_host_cover_pass_marked": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                    ctypes.c_double, ctypes.c_void_p,
+                                                    ctypes.POINTER(ctypes.c_int64),
+                                                    ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]),
     "ppp_host_thin_cover": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.c_void_p]),
@@ -1184,17 +1190,18 @@ def rank_order_device(score, foreground, patchshape, to_host=True):
 
 
 def host_cover_pass(mask_running, overlap, patchshape, ranked_lin, ranked_score, bits, pix_th,
-                    score_threshold, selected, remaining):
-    """In place on mask_running (uint8) and selected (uint8); returns (new `remaining`,
-    stopped-by-score-threshold)."""
+                    score_threshold, selected, remaining, marked=None):
+    """In place on mask_running (uint8), selected (uint8) and -- mark_close_neighboorhood --
+    marked (uint8 volume); returns (new `remaining`, stopped-by-score-threshold)."""
     vol, ps = _i32(mask_running.shape), _i32(patchshape)
     rem = ctypes.c_int64(int(remaining))
     stopped = ctypes.c_int32(0)
     thr = float("nan") if score_threshold is None else float(score_threshold)
-    lib().ppp_host_cover_pass(_np_ptr(mask_running), _np_ptr(overlap), _np_ptr(vol), _np_ptr(ps),
-                              _np_ptr(ranked_lin), _np_ptr(ranked_score), _np_ptr(bits),
-                              len(ranked_lin), int(pix_th), thr, _np_ptr(selected),
-                              ctypes.byref(rem), ctypes.byref(stopped))
+    lib().ppp_host_cover_pass_marked(_np_ptr(mask_running), _np_ptr(overlap), _np_ptr(vol), _np_ptr(ps),
+                                     _np_ptr(ranked_lin), _np_ptr(ranked_score), _np_ptr(bits),
+                                     len(ranked_lin), int(pix_th), thr, _np_ptr(selected),
+                                     ctypes.byref(rem), ctypes.byref(stopped),
+                                     None if marked is None else _np_ptr(marked))
     return rem.value, bool(stopped.value)
 
 

@@ -105,11 +105,31 @@ int64_t ppp_host_rank_order(const float *h_score, const uint8_t *h_foreground, c
 //   remaining      : in/out, number of set interior voxels of the running mask
 //   score_threshold: NaN = disabled (foreground_cover.py:136-138)
 // Returns the number of newly selected patches.
+int64_t ppp_host_cover_pass_marked(uint8_t *h_mask_running, const uint8_t *h_overlap, const int32_t *vol,
+                                   const int32_t *patchshape, const int64_t *ranked_lin,
+                                   const float *ranked_score, const uint32_t *bits, int64_t n,
+                                   int32_t pix_th, double score_threshold, uint8_t *selected,
+                                   int64_t *remaining, int32_t *stopped, uint8_t *h_marked);
+
 int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, const int32_t *vol,
                             const int32_t *patchshape, const int64_t *ranked_lin,
                             const float *ranked_score, const uint32_t *bits, int64_t n,
                             int32_t pix_th, double score_threshold, uint8_t *selected,
                             int64_t *remaining, int32_t *stopped) {
+    return ppp_host_cover_pass_marked(h_mask_running, h_overlap, vol, patchshape, ranked_lin, ranked_score, bits, n,
+                                      pix_th, score_threshold, selected, remaining, stopped, nullptr);
+}
+
+// The same pass with `mark_close_neighboorhood` (foreground_cover.py:141-143, 162-168): h_marked
+// (uint8 (Z,Y,X), in/out, shared by the passes of a cover) -- a ranked patch whose centre is marked
+// is skipped, and a selected patch marks the box (0, +-3, +-3) around its centre.  The reference
+// builds that box as NumPy slices: a NEGATIVE start (centre closer than 3 to the low y / x border)
+// makes the slice wrap around and select nothing, so such a patch marks nothing; the high end clips.
+int64_t ppp_host_cover_pass_marked(uint8_t *h_mask_running, const uint8_t *h_overlap, const int32_t *vol,
+                                   const int32_t *patchshape, const int64_t *ranked_lin,
+                                   const float *ranked_score, const uint32_t *bits, int64_t n,
+                                   int32_t pix_th, double score_threshold, uint8_t *selected,
+                                   int64_t *remaining, int32_t *stopped, uint8_t *h_marked) {
     const Dims D(vol, patchshape);
     int64_t picked = 0;
     if (stopped) *stopped = 0;
@@ -140,6 +160,7 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
         }
         const int64_t c = ranked_lin[i];
         if (h_overlap && h_overlap[c] > 0) continue;
+        if (h_marked && h_marked[c]) continue;
         const int cx = (int)(c % D.X), cy = (int)((c / D.X) % D.Y), cz = (int)(c / ((int64_t)D.X * D.Y));
         if (pix_th >= 0 && window_empty(cz, cy, cx)) continue;   // count 0 is never > pix_th
         const uint32_t *b = bits + i * D.words;
@@ -169,6 +190,19 @@ int64_t ppp_host_cover_pass(uint8_t *h_mask_running, const uint8_t *h_overlap, c
                     }
                 }
             *remaining -= cleared;
+            if (h_marked) {
+                // marked[z, cy-3:cy+4, cx-3:cx+4] = True with NumPy's slice rule: a negative
+                // start counts from the end (an empty slice on any axis wider than 7)
+                auto bounds = [](int start, int stop, int size, int &a, int &b) {
+                    a = start < 0 ? std::max(start + size, 0) : std::min(start, size);
+                    b = stop < 0 ? std::max(stop + size, 0) : std::min(stop, size);
+                };
+                int ya, yb, xa, xb;
+                bounds(cy - 3, cy + 4, D.Y, ya, yb);
+                bounds(cx - 3, cx + 4, D.X, xa, xb);
+                for (int y = ya; y < yb; ++y)
+                    for (int x = xa; x < xb; ++x) h_marked[D.lin(cz, y, x)] = 1;
+            }
         }
     }
     return picked;

@@ -30,19 +30,23 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
                            radslice, pred_affs, rad, debug_output1, scores_array,
                            silent=False, **kwargs):
     """foreground_cover.py:15-126.  Returns (selected PatchList in rank order, count)."""
-    for opt in ("mark_close_neighboorhood", "select_patches_overlap_neighborhood"):
-        if kwargs.get(opt, False):
-            raise NotImplementedError("%s is not supported" % opt)
     ranked = PatchList.from_any(ranked_patches_list)
     P = backend.params_from_kwargs(pred_affs.shape[1:], patchshape, kwargs)
+    # `mark_close_neighboorhood` (:141-143, 162-168) and `select_patches_overlap_neighborhood`
+    # (:53-85) make a patch's fate depend on marks left by earlier selections anywhere in its
+    # slice, not only on overlapping windows: they take the sequential native loop
+    mark = bool(kwargs.get("mark_close_neighboorhood", False))
+    near_overlap = bool(kwargs.get("select_patches_overlap_neighborhood", False))
     # the device form packs a window row into one 32-bit word; wider patches (none of the
     # reference's configurations) take the sequential native loop
-    if os.environ.get("PPP_COVER", "device") != "host" and int(patchshape[2]) <= 32:
+    if os.environ.get("PPP_COVER", "device") != "host" and int(patchshape[2]) <= 32 and not mark \
+            and not near_overlap:
         return _cover_on_device(overlap_mask, mask_to_cover, patchshape, ranked, radslice,
                                 pred_affs, P, silent, **kwargs)
     running, _owner = backend.padded_mask(mask_to_cover)
     overlap = np.ascontiguousarray(np.asarray(overlap_mask) > 0).astype(np.uint8)
     selected = np.zeros(len(ranked), dtype=np.uint8)
+    marked = np.zeros(running.shape, dtype=np.uint8) if mark else None
     if kwargs["select_patches_for_sparse_data"]:
         pix_ths = [0]
     else:
@@ -63,16 +67,63 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
             bits = _bits_for(pred_affs, ranked.coords[s:e], kwargs["fc_threshold"], P)
             remaining, stopped = backend.host_cover_pass(
                 running, overlap, patchshape, lin[s:e], ranked.scores[s:e], bits, pix_th, thr,
-                selected[s:e], remaining)
+                selected[s:e], remaining, marked=marked)
             if stopped:
                 break  # the pass hit the score threshold
         if remaining < 1:
             break
+    if near_overlap:
+        return _select_near_overlap(overlap_mask, mask_to_cover, patchshape, ranked, selected, radslice,
+                                    pred_affs, P, pix_th, thr, marked, scores_array, **kwargs)
     sel = ranked[np.flatnonzero(selected)]
     if len(sel) and not silent:
         logger.info("num patches to cover foreground: %s best score: %s, worst score: %s, "
                     "uncovered: %s", len(sel), sel.scores[0], sel.scores[-1], remaining)
     return sel, len(sel)
+
+
+def _select_near_overlap(overlap_mask, mask_to_cover, patchshape, ranked, selected, radslice, pred_affs, P,
+                         pix_th, thr, marked, scores_array, **kwargs):
+    """foreground_cover.py:53-85 (`select_patches_overlap_neighborhood`): a second cover of the
+    foreground ring between 2 and 5 dilations of the overlap voxels, by the not yet selected
+    ranked patches whose centre lies in that ring, with the LAST pixel threshold of the first
+    cover and restarting at rank 0.  The result is every selected centre in RASTER order with
+    its score from the score volume (the reference rebuilds the list with np.argwhere)."""
+    import scipy.ndimage
+    import torch
+    shape = tuple(np.asarray(mask_to_cover).shape)
+    chosen = np.zeros(shape, dtype=bool)
+    first = ranked.coords[np.flatnonzero(selected)]
+    chosen[tuple(first.T)] = True
+    overlap = np.asarray(overlap_mask).copy()
+    overlap_t = scipy.ndimage.binary_dilation(overlap, iterations=2)
+    overlap_dil = scipy.ndimage.binary_dilation(overlap, iterations=5)
+    fg_dil_mask = np.logical_and(np.logical_and(np.logical_not(overlap_t), overlap_dil), mask_to_cover)
+    keep = ~chosen[tuple(ranked.coords.T)] & fg_dil_mask[tuple(ranked.coords.T)]
+    sub = ranked[np.flatnonzero(keep)]
+    if len(sub):
+        running, _owner = backend.padded_mask(fg_dil_mask)
+        sel2 = np.zeros(len(sub), dtype=np.uint8)
+        remaining = int(np.count_nonzero(running[radslice]))
+        lin = sub.lin(shape)
+        ov8 = np.ascontiguousarray(np.asarray(overlap_mask) > 0).astype(np.uint8)
+        for s in range(0, len(sub), COVER_CHUNK):
+            if remaining <= 0:
+                break
+            e = min(len(sub), s + COVER_CHUNK)
+            bits = _bits_for(pred_affs, sub.coords[s:e], kwargs["fc_threshold"], P)
+            remaining, stopped = backend.host_cover_pass(running, ov8, patchshape, lin[s:e], sub.scores[s:e], bits,
+                                                         pix_th, thr, sel2[s:e], remaining, marked=marked)
+            if stopped:
+                break
+        more = sub.coords[np.flatnonzero(sel2)]
+        chosen[tuple(more.T)] = True
+    coords = np.argwhere(chosen)
+    if torch.is_tensor(scores_array):
+        scores_array = scores_array.cpu().numpy()
+    scores = np.asarray(scores_array)[tuple(coords.T)] if len(coords) else np.zeros(0, np.float32)
+    out = PatchList(coords, scores)
+    return out, len(out)
 
 
 def _pix_thresholds(patchshape, kwargs):

@@ -397,13 +397,22 @@ CASES = {
     "c3d_p3_packed_channels": ((22, 30, 32), (3, 3, 3),
                                dict(kind="cells", seed=19, cell=[11, 15, 16], overlap_frac=0.02),
                                dict(no_overlap_per_channel=True, skipThinCover=False)),
+    # the two optional branches of the greedy cover (foreground_cover.py:53-85, 141-143, 162-168)
+    "c2d_p5_mark": ((1, 28, 30), (1, 5, 5), dict(kind="cells", seed=24, cell=[1, 9, 9]),
+                    dict(mark_close_neighboorhood=True)),
+    "c3d_p3_mark_nosparse": ((8, 13, 14), (3, 3, 3), dict(kind="cells", seed=26, cell=[4, 6, 6]),
+                             dict(mark_close_neighboorhood=True, select_patches_for_sparse_data=False)),
+    "c3d_p3_near_overlap": ((12, 13, 14), (3, 3, 3),
+                            dict(kind="cells", seed=25, cell=[6, 6, 6], overlap_frac=0.04),
+                            dict(select_patches_overlap_neighborhood=True)),
     "c3d_empty": ((10, 10, 10), (3, 3, 3), dict(kind="empty", seed=0), {}),
     "c3d_single_patch": ((3, 3, 3), (3, 3, 3), dict(kind="cells", seed=1, cell=[9, 9, 9]),
                          {}),
 }
 # cases whose consensus array is too big to commit: keep a SHA-256 of the float bits
 HASH_ONLY_CONS = {"c3d_p5_cells", "c3d_p7_cells", "c3d_p9_cells", "c2d_p25_cells",
-                  "c3d_p5_thin_mws", "c3d_p7_thin_mws", "c3d_p3_packed_channels"}
+                  "c3d_p5_thin_mws", "c3d_p7_thin_mws", "c3d_p3_packed_channels",
+                  "c3d_p3_near_overlap", "c3d_p3_mark_nosparse"}
 # cases that are ALSO run through the reference's NumPy path (cuda=False; int16 +-1 votes,
 # SURVEY 8c "recipe A").  Different arithmetic from the kernels: only the final instance map
 # is stored, to document that both semantics agree on well separated instances.

@@ -98,19 +98,39 @@ def test_host_stages_match_reference(golden):
         pix_ths = [0]
     else:
         pix_ths = [t for t in [500, 100, 50, 10, 0] if t < int(np.prod(ps) / 2)]
+    # (mark_close_neighboorhood: one mark volume shared by the passes)
+    marked = np.zeros(shape, dtype=np.uint8) if g.kw.get("mark_close_neighboorhood") else None
+    ov8 = (g.overlap_mask > 0).astype(np.uint8)
     for t in pix_ths:
         remaining, _ = backend.host_cover_pass(
-            running, (g.overlap_mask > 0).astype(np.uint8), ps, lin,
-            np.ascontiguousarray(g["ranked_scores"]), bits, t, None, selected, remaining)
+            running, ov8, ps, lin,
+            np.ascontiguousarray(g["ranked_scores"]), bits, t, None, selected, remaining, marked=marked)
         if remaining < 1:
             break
     cover = coords[selected.astype(bool)]
+    cover_lin, cover_bits = lin[selected.astype(bool)], bits[selected.astype(bool)]
+    if g.kw.get("select_patches_overlap_neighborhood"):
+        # foreground_cover.py:53-85: a second cover of the ring around the overlap voxels
+        from scipy import ndimage
+        ring = ~ndimage.binary_dilation(g.overlap_mask, iterations=2) & \
+            ndimage.binary_dilation(g.overlap_mask, iterations=5) & mask
+        keep = ~selected.astype(bool) & ring.reshape(-1)[lin]
+        run2, _owner2 = backend.padded_mask(ring)
+        sel2 = np.zeros(int(keep.sum()), dtype=np.uint8)
+        backend.host_cover_pass(run2, ov8, ps, np.ascontiguousarray(lin[keep]),
+                                np.ascontiguousarray(g["ranked_scores"][keep]), np.ascontiguousarray(bits[keep]),
+                                t, None, sel2, int(np.count_nonzero(run2[radslice])), marked=marked)
+        chosen = np.zeros(int(np.prod(shape)), dtype=bool)
+        chosen[cover_lin] = True
+        chosen[lin[keep][sel2.astype(bool)]] = True
+        cover_lin = np.flatnonzero(chosen)                             # raster order (np.argwhere)
+        cover = np.stack(np.unravel_index(cover_lin, shape), axis=1)
+        cover_bits = _bits(g.pred, cover, g.kw["fc_threshold"])
     assert np.array_equal(cover, g["cover_coords"])
     sel = cover
     if g.has("thin_coords"):
-        sel_lin = np.ascontiguousarray(lin[selected.astype(bool)])
-        keep = backend.host_thin_cover(mask.astype(np.uint8), ps, sel_lin,
-                                       np.ascontiguousarray(bits[selected.astype(bool)]))
+        keep = backend.host_thin_cover(mask.astype(np.uint8), ps, np.ascontiguousarray(cover_lin),
+                                       np.ascontiguousarray(cover_bits))
         sel = cover[keep]
         assert np.array_equal(sel, g["thin_coords"])
     # pairs

@@ -361,7 +361,7 @@ def _cover_inputs(torch, pred_host, foreground, numinst, ps, kw):
     ranked = rp.rank_patches_by_score(None, score, foreground=fg, patchshape=ps)
     mask = fg.copy()
     mask[overlap > 0] = 0
-    return pred, overlap, mask, ranked, radslice, rad
+    return pred, overlap, mask, ranked, radslice, rad, score
 
 
 def test_device_cover_matches_reference_goldens(golden, torch_cuda, monkeypatch):
@@ -369,13 +369,15 @@ def test_device_cover_matches_reference_goldens(golden, torch_cuda, monkeypatch)
     g = golden
     if not g.has("cover_coords"):
         pytest.skip("early-out case")
-    pred, overlap, mask, ranked, radslice, rad = _cover_inputs(
+    pred, overlap, mask, ranked, radslice, rad, score = _cover_inputs(
         torch_cuda, g.pred, g.foreground, g.numinst, g.patchshape, g.kw)
     assert np.array_equal(ranked.coords, g["ranked_coords"])
+    # (goldens with mark_close_neighboorhood / select_patches_overlap_neighborhood take the
+    # sequential native loop in either mode, foreground_cover.py:53-85, 141-168)
     for mode in ("device", "host"):
         monkeypatch.setenv("PPP_COVER", mode)
         sel, n = fc.computeForegroundCover(overlap, mask.copy(), g.patchshape, ranked, radslice,
-                                           pred, rad, None, None, silent=True, **g.kw)
+                                           pred, rad, None, score, silent=True, **g.kw)
         assert np.array_equal(sel.coords, g["cover_coords"]), mode
 
 
@@ -395,7 +397,7 @@ def test_device_cover_matches_sequential_loop(variant, torch_cuda, monkeypatch):
     elif variant == "p7":
         shape, ps, skw = (30, 44, 52), (7, 7, 7), dict(seed=62, cell=[12, 12, 12], noise=0.25)
     c = synth.make_case(shape, ps, **skw)
-    pred, overlap, mask, ranked, radslice, rad = _cover_inputs(
+    pred, overlap, mask, ranked, radslice, rad, _score = _cover_inputs(
         torch_cuda, c["pred"], c["foreground"], c["numinst"], ps, kw)
     out = {}
     for mode in ("device", "host"):
@@ -420,7 +422,7 @@ def test_cover_with_a_bit_row_per_voxel_equals_rank_ordered_rows(passes, torch_c
     kw = dict(FLYLIGHT, select_patches_for_sparse_data=not passes)
     shape, ps = (24, 40, 44), (5, 5, 5)
     c = synth.make_case(shape, ps, seed=63, cell=[9, 10, 11], overlap_frac=0.02)
-    pred, overlap, mask, ranked, radslice, rad = _cover_inputs(
+    pred, overlap, mask, ranked, radslice, rad, _score = _cover_inputs(
         torch_cuda, c["pred"], c["foreground"], c["numinst"], ps, kw)
     P = backend.params_from_kwargs(shape, ps, kw)
     dev = pred.device
