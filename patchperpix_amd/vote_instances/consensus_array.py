@@ -50,10 +50,41 @@ def _device_overlap(overlap_mask, like):
 def loadOrComputeConsensus(instances, patchshape, neighshape, all_patches, pred_affs, rad,
                            foreground, lookup, overlap_mask, **kwargs):
     """consensus_array.py:209-246.  Only the device branch exists in this package."""
-    if kwargs.get("consensus") is not None and os.path.exists(kwargs["consensus"]):
-        raise NotImplementedError("loading a pickled consensus array is not supported")
     if not kwargs["cuda"]:
-        raise RuntimeError("patchperpix_amd only implements the device path (cuda=True); "
-                           "there is no CPU fallback")
+        raise RuntimeError("the NumPy-semantics stages (cuda=False) live in numpy_semantics.py; "
+                           "this function is the kernel path's (cuda=True)")
+    path = kwargs.get("consensus")
+    if path is not None and os.path.exists(path):
+        # consensus_array.py:213-218 (resume).  What the kernel path stores is the array
+        # `save_consensus` writes (:202-206): float32 [NSZ, NSY, NSX, Z, Y, X] (.npy / hdf / zarr
+        # with `consensus_key`); a `consensus.pickle` of the NumPy path holds int16 votes of another
+        # function and is refused here.  (The reference unpacks the loaded object into three names,
+        # which only works for that pickle: its own .npy cannot be resumed from.)
+        from .utilVoteInstances import loadFromFile
+        arr = loadFromFile(path, key=kwargs.get("consensus_key"))
+        if isinstance(arr, (list, tuple)) or np.asarray(arr).dtype != np.float32:
+            raise ValueError("%s does not hold a float32 consensus array of the kernel path" % path)
+        return load_reference_layout(np.asarray(arr), pred_affs, patchshape, **kwargs), None, None
     cons = create_consensus_array_cuda(pred_affs, overlap_mask, patchshape, neighshape, **kwargs)
     return cons, None, None
+
+
+def load_reference_layout(arr, pred_affs, patchshape, **kwargs):
+    """[NSZ, NSY, NSX, Z, Y, X] (or flipped, `flip_cons_arr_axes`) float32 host array -> the
+    compact plane layout on the device: plane (dz, dy, dx) lexicographically positive =
+    arr[dz + pz - 1, dy + py - 1, dx + px - 1]."""
+    import torch
+    ps = [int(p) for p in patchshape]
+    shape = tuple(int(v) for v in pred_affs.shape[1:])
+    if kwargs.get("flip_cons_arr_axes", False):
+        arr = np.moveaxis(arr, (3, 4, 5), (0, 1, 2))
+    ns = (2 * ps[0] if ps[0] > 1 else ps[0], 2 * ps[1], 2 * ps[2])
+    if tuple(arr.shape) != ns + shape:
+        raise ValueError("consensus array of shape %s, expected %s" % (tuple(arr.shape), ns + shape))
+    planes = []
+    for dz in range(0, ps[0]):
+        for dy in range(-(ps[1] - 1), ps[1]):
+            for dx in range(-(ps[2] - 1), ps[2]):
+                if (dz, dy, dx) > (0, 0, 0):
+                    planes.append(arr[dz + ps[0] - 1, dy + ps[1] - 1, dx + ps[2] - 1])
+    return torch.from_numpy(np.ascontiguousarray(np.stack(planes, axis=0), dtype=np.float32)).to(pred_affs.device)

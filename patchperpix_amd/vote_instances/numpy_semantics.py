@@ -21,7 +21,7 @@ from .. import backend
 from .aff_patch_graph import AffGraph, computeAndStorePatchPairs
 from .foreground_cover import computeForegroundCover, thinOutForegroundCover
 from .graph_to_labeling import affGraphToInstances
-from .ranked_patches import PatchList
+from .ranked_patches import PatchList, load_ranked_patches, store_ranked_patches
 
 logger = logging.getLogger(__name__)
 
@@ -37,6 +37,61 @@ def create_consensus_array(pred_affs, foreground_dev, patchshape, **kwargs):
     """consensus_array.py:18-68 -> device int16 [planes, Z, Y, X] (ppp_np_consensus)."""
     P = _params(pred_affs.shape[1:], patchshape, kwargs)
     return backend.np_consensus(pred_affs, foreground_dev, P)
+
+
+def _ref_plane_index(patchshape):
+    """index L of the reference's vote array (utilVoteInstances.py:36-44: offsets linearised over
+    neighshape) for every plane q of the device layout (q = 0: the zero offset)."""
+    ps = [int(p) for p in patchshape]
+    ns1, ns2 = 2 * ps[1], 2 * ps[2]
+    idx = [0]
+    for dz in range(0, ps[0]):
+        for dy in range(-(ps[1] - 1), ps[1]):
+            for dx in range(-(ps[2] - 1), ps[2]):
+                if (dz, dy, dx) > (0, 0, 0):
+                    idx.append(dz * ns1 * ns2 + dy * ns2 + dx)
+    return np.array(idx, dtype=np.int64)
+
+
+def load_consensus(pred_affs, patchshape, **kwargs):
+    """consensus_array.py:213-218: resume from the reference's ``consensus.pickle``
+    ([int16 votes (prod(neighshape), Z, Y, X), offsets_bases_ff, offsets_bases_fb], :238-246).  The
+    two offset lists only serve the reference's ranking loop; the ranking kernel recomputes the
+    sets from the prediction, so they are not needed."""
+    import os
+    import torch
+    path = kwargs.get("consensus")
+    if path is None or not os.path.exists(path):
+        return None
+    from .utilVoteInstances import loadFromFile
+    obj = loadFromFile(path, key=kwargs.get("consensus_key"))
+    arr = np.asarray(obj[0] if isinstance(obj, (list, tuple)) else obj)
+    ps = [int(p) for p in patchshape]
+    ns = (2 * ps[0] if ps[0] > 1 else ps[0]) * 2 * ps[1] * 2 * ps[2]
+    shape = tuple(int(v) for v in pred_affs.shape[1:])
+    if arr.dtype != np.int16 or tuple(arr.shape) != (ns,) + shape:
+        raise ValueError("%s: expected the int16 vote array %s of the NumPy path, found %s %s"
+                         % (path, (ns,) + shape, arr.dtype, tuple(arr.shape)))
+    return torch.from_numpy(np.ascontiguousarray(arr[_ref_plane_index(ps)])).to(pred_affs.device)
+
+
+def store_consensus(votes, patchshape, **kwargs):
+    """consensus_array.py:238-246: ``consensus.pickle`` unless save_no_intermediates -- the vote
+    array in the reference's layout; the two per-centre offset lists the reference appends are left
+    empty (they exist for ITS ranking loop; this package's resume does not read them)."""
+    import os
+    import pickle
+    if kwargs.get("save_no_intermediates", True):
+        return None
+    ps = [int(p) for p in patchshape]
+    ns = (2 * ps[0] if ps[0] > 1 else ps[0]) * 2 * ps[1] * 2 * ps[2]
+    v = votes.cpu().numpy()
+    full = np.zeros((ns,) + v.shape[1:], dtype=np.int16)
+    full[_ref_plane_index(ps)] = v
+    fn = os.path.join(kwargs["result_folder"], "consensus.pickle")
+    with open(fn, "wb") as f:
+        pickle.dump([full, [], []], f, protocol=4)
+    return fn
 
 
 def rank_patches(pred_affs, foreground_dev, consensus_vote_array, foreground, patchshape, **kwargs):
@@ -130,9 +185,15 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     dev = pred_affs.device
     fg_dev = torch.from_numpy(foreground.astype(np.uint8)).to(dev)
     with backend.host_timer("s1_consensus"):
-        votes = create_consensus_array(pred_affs, fg_dev, patchshape, **kwargs)
+        votes = load_consensus(pred_affs, patchshape, **kwargs)         # consensus_array.py:213-218
+        if votes is None:
+            votes = create_consensus_array(pred_affs, fg_dev, patchshape, **kwargs)
+            store_consensus(votes, patchshape, **kwargs)                # :238-246
     with backend.host_timer("s2_rank_and_sort"):
-        ranked, _ = rank_patches(pred_affs, fg_dev, votes, foreground, patchshape, **kwargs)
+        ranked = load_ranked_patches(**kwargs)                          # ranked_patches.py:137-139
+        if ranked is None:
+            ranked, _ = rank_patches(pred_affs, fg_dev, votes, foreground, patchshape, **kwargs)
+            store_ranked_patches(ranked, **kwargs)                      # :188-192
     with backend.host_timer("s3_cover"):
         selected, n_sel = computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked, radslice,
                                                  pred_affs, rad, None, None, **kwargs)

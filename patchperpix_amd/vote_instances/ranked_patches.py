@@ -1,5 +1,6 @@
 """Step 2: patch ranking (reference: PatchPerPix/vote_instances/ranked_patches.py)."""
 import logging
+import os
 
 import numpy as np
 
@@ -78,12 +79,42 @@ def rank_patches_by_score(all_patches_idx, rank_scores, foreground=None, patchsh
     return PatchList(coords[order], s[order])
 
 
+def load_ranked_patches(**kwargs):
+    """ranked_patches.py:137-139: the stored ranked list, or None."""
+    path = kwargs.get("ranked_patches")
+    if path is None or not os.path.exists(path):
+        return None
+    from .utilVoteInstances import loadFromFile
+    obj = loadFromFile(path)
+    if isinstance(obj, np.ndarray) and obj.ndim == 2 and obj.shape[1] == 4:
+        return PatchList(obj[:, :3].astype(np.int32), obj[:, 3])
+    return PatchList.from_any(obj)
+
+
+def store_ranked_patches(ranked, **kwargs):
+    """ranked_patches.py:188-192: ``ranking.pickle`` in the result folder -- the reference's own
+    format (a list of (coordinate array, score)), unless save_no_intermediates."""
+    if kwargs.get("save_no_intermediates", True):
+        return None
+    import pickle
+    fn = os.path.join(kwargs["result_folder"], "ranking.pickle")
+    with open(fn, "wb") as f:
+        pickle.dump([(np.array(c), s.item() if hasattr(s, "item") else s) for c, s in ranked], f, protocol=4)
+    return fn
+
+
 def loadOrComputePatchRanking(pred_affs=None, consensus_vote_array=None, offsets_bases_ff=None,
                               offsets_bases_fb=None, overlap_mask=None, all_patches=None,
                               patchshape=None, neighshape=None, rad=None, **kwargs):
-    """ranked_patches.py:108-213 (device branch)."""
+    """ranked_patches.py:108-213 (device branch).  A stored ranking (`ranked_patches`: the
+    reference's ``ranking.pickle`` -- a list of (coordinate, score) in rank order -- or an .npy of
+    rows (z, y, x, score)) is loaded instead of computed (:137-139); the score volume is then
+    unknown (None), as in the reference."""
+    stored = load_ranked_patches(**kwargs)
+    if stored is not None:
+        return stored, None
     if not kwargs["cuda"]:
-        raise RuntimeError("patchperpix_amd only implements the device path (cuda=True)")
+        raise RuntimeError("the NumPy-semantics ranking (cuda=False) lives in numpy_semantics.py")
     scores = rank_patches_cuda(pred_affs, consensus_vote_array, patchshape, neighshape,
                                overlap_mask, **kwargs)
     scores_array = scores.cpu().numpy()

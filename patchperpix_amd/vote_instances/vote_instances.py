@@ -192,7 +192,9 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
     # With nothing to store or load between the stages, the single-slab case takes the same
     # code path: it keeps the ranked patch list on the device instead of materialising the
     # reference's host lists between the stage functions (PPP_PIPELINE=stages keeps them).
-    plain = kwargs.get("save_no_intermediates", False) and not kwargs.get("debug", False) \
+    resume = any(kwargs.get(k) is not None and os.path.exists(str(kwargs.get(k)))
+                 for k in ("consensus", "ranked_patches"))     # stored stages: stage path
+    plain = kwargs.get("save_no_intermediates", False) and not kwargs.get("debug", False) and not resume \
         and not any(kwargs.get(k) for k in ("skipConsensus", "skipRanking",
                                             "termAfterThinCover", "termAfterPatchGraph",
                                             "save_consensus", "blockwise",

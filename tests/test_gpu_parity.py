@@ -865,3 +865,38 @@ def test_open_rows_never_reach_a_result(ps, shape, cell, torch_cuda, monkeypatch
     assert not np.isnan(got_aff).any()
     assert np.array_equal(_bits(want_aff), _bits(got_aff))
     assert np.array_equal(want, got) and want.max() > 5
+
+
+def test_resume_from_a_saved_consensus(torch_cuda, tmp_path):
+    """Kernel path: `save_consensus` writes the reference-layout array (consensus_array.py:202-206);
+    a later call with `consensus=<that file>` (:213-218) loads it instead of running S1 -- same
+    planes bit for bit, same instances; a stored ranking (`ranked_patches`, ranked_patches.py:
+    137-139) is taken as is."""
+    import pickle
+    from conftest import Golden
+    from patchperpix_amd import backend
+    from patchperpix_amd.vote_instances import consensus_array as ca
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    g = Golden("c3d_p5_cells")
+    kw = dict(g.kw, debug=False, isbiHack=False, save_no_intermediates=True, sample=1.0,
+              result_folder=str(tmp_path), affinities="vol.zarr")
+    args = lambda: (g.pred.copy(), g.foreground.copy(), g.foreground.copy(), g.numinst.copy(), g.patchshape)   # noqa: E731
+    assert vi.to_instance_seg(*args(), **dict(kw, save_consensus=True)) == (None, None)
+    path = str(tmp_path / "vol_consensus.npy")
+    assert os.path.exists(path)
+    pred = _dev(torch, g.pred)
+    P = backend.make_params(g.pred.shape[1:], g.patchshape, **g.kw)
+    ov = _dev(torch, (g.overlap_mask > 0).astype(np.uint8)) if P.use_overlap else None
+    want = backend.consensus(pred, ov, P).cpu().numpy()
+    got, _, _ = ca.loadOrComputeConsensus(None, g.patchshape, None, None, pred, None, None, None, g.overlap_mask,
+                                          **dict(kw, consensus=path))
+    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want))
+    inst, _ = vi.to_instance_seg(*args(), **dict(kw, consensus=path))
+    assert np.array_equal(inst, g["instances"])
+    # a stored ranking in the reference's pickle format
+    ranking = str(tmp_path / "ranking.pickle")
+    with open(ranking, "wb") as f:
+        pickle.dump([(np.array(c), float(s)) for c, s in zip(g["ranked_coords"], g["ranked_scores"])], f)
+    inst2, _ = vi.to_instance_seg(*args(), **dict(kw, consensus=path, ranked_patches=ranking))
+    assert np.array_equal(inst2, g["instances"])

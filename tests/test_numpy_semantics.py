@@ -186,3 +186,39 @@ def test_order_preserving_weights():
         for j in range(len(w)):
             assert (abs(r[i]) < abs(r[j])) == (a[i] < a[j]) and (abs(r[i]) == abs(r[j])) == (a[i] == a[j])
     assert np.array_equal(f(np.array([2, 7, -7], np.int64)), np.array([1, 2, -2], np.float32))
+
+
+@pytest.mark.gpu
+def test_resume_from_stored_consensus_and_ranking(torch_cuda, tmp_path):
+    """consensus_array.py:213-218 / ranked_patches.py:137-139 (checkpoint / resume).
+    NumPy path: the reference's own ``consensus.pickle`` content (its int16 array, rebuilt from the
+    golden) loads into the device layout; a run with save_no_intermediates=False writes
+    consensus.pickle + ranking.pickle, and a run resumed from them gives the same instances."""
+    import pickle
+    from patchperpix_amd.vote_instances import numpy_semantics as ns
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    g = NpGolden("c3d_p3_cells_thin_mws")
+    # the reference's array: (prod(neighshape), Z, Y, X) int16
+    full = np.zeros(tuple(int(v) for v in g.z["cons_shape"]), dtype=np.int16)
+    idx = g.z["cons_index"]
+    full[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = g.z["cons_value"]
+    ref_pickle = str(tmp_path / "consensus.pickle")
+    with open(ref_pickle, "wb") as f:
+        pickle.dump([full, [b"x"], [b"y"]], f, protocol=4)
+    pred = _dev(torch, g.pred)
+    votes = ns.load_consensus(pred, g.ps, consensus=ref_pickle)
+    assert np.array_equal(votes.cpu().numpy(), g.votes())
+    # write, then resume
+    out = tmp_path / "run"
+    out.mkdir()
+    kw = dict(g.kw, cuda=False, save_no_intermediates=False, result_folder=str(out))
+    args = lambda: (g.pred.copy(), g.foreground.copy(), g.foreground.copy(), g.numinst.copy(), g.ps)   # noqa: E731
+    a, _ = vi.to_instance_seg(*args(), **kw)
+    assert (out / "consensus.pickle").exists() and (out / "ranking.pickle").exists()
+    ranked = pickle.load(open(out / "ranking.pickle", "rb"))
+    assert [list(c) for c, _ in ranked] == g.z["ranked_coords"].tolist()
+    assert [int(s) for _, s in ranked] == g.z["ranked_scores"].tolist()
+    b, _ = vi.to_instance_seg(*args(), **dict(kw, save_no_intermediates=True, consensus=str(out / "consensus.pickle"),
+                                              ranked_patches=str(out / "ranking.pickle")))
+    assert np.array_equal(a, g.z["instances"]) and np.array_equal(b, a)
