@@ -218,20 +218,10 @@ def self_launch(n):
 
 
 def set_host_allocator():
-    """Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
-    a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
-    unmapped again on every call by glibc (~5 ms per step of page faults at 140^3).  Same effect
-    as MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment; PPP_BENCH_MALLOPT=0
-    skips it.  Returns what was done (reported in the JSON)."""
-    if os.environ.get("PPP_BENCH_MALLOPT", "1") == "0":
-        return "off"
-    try:
-        import ctypes
-        libc = ctypes.CDLL("libc.so.6")
-        ok = libc.mallopt(-1, 1 << 30) and libc.mallopt(-3, 1 << 30)   # M_TRIM_ / M_MMAP_THRESHOLD
-        return "trim/mmap thresholds 1 GiB" if ok else "mallopt refused"
-    except OSError:
-        return "no libc"
+    """backend.tune_host_allocator (the package's drivers call the same function); reported in
+    the JSON."""
+    from patchperpix_amd import backend
+    return backend.tune_host_allocator()
 
 
 class SynthProvider:

@@ -427,6 +427,31 @@ def counter_calibration(src, n_read, dst, n_write):
     return int(n_read) * src.element_size(), int(n_write) * 4
 
 
+_HOST_ALLOCATOR = None
+
+
+def tune_host_allocator():
+    """Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
+    a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
+    unmapped again on every call by glibc (~5 ms per step of page faults at 140^3).  Same effect
+    as MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment.  Called once by the
+    drivers (run_ppp, vote_instances.main, stitch_patch_graph.main, bench.py); PPP_MALLOPT=0 (or
+    the older PPP_BENCH_MALLOPT=0) skips it.  Returns what was done."""
+    global _HOST_ALLOCATOR
+    if _HOST_ALLOCATOR is not None:
+        return _HOST_ALLOCATOR
+    if os.environ.get("PPP_MALLOPT", os.environ.get("PPP_BENCH_MALLOPT", "1")) == "0":
+        _HOST_ALLOCATOR = "off"
+        return _HOST_ALLOCATOR
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        ok = libc.mallopt(-1, 1 << 30) and libc.mallopt(-3, 1 << 30)   # M_TRIM_ / M_MMAP_THRESHOLD
+        _HOST_ALLOCATOR = "trim/mmap thresholds 1 GiB" if ok else "mallopt refused"
+    except OSError:
+        _HOST_ALLOCATOR = "no libc"
+    return _HOST_ALLOCATOR
+
+
 def reload_env():
     """The library reads its PPP_* development switches once; after changing one in a running
     process (tests that compare kernel variants) this makes it look again."""

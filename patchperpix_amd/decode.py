@@ -269,8 +269,11 @@ class DecodeProvider:
     fits HBM are decoded once (decode_volume) instead."""
 
     def __init__(self, decoder, code, fg, batch_size=4096, device="cuda", fused=None, expit=False):
-        """expit: pass the decoded logits through the logistic function (in float16, like
-        loadAffinities does with the float16 array it reads, utilVoteInstances.py:249-250)."""
+        """expit: pass the decoded logits through the logistic function the way loadAffinities
+        does with the float16 array it reads (utilVoteInstances.py:249-250: scipy.special.expit;
+        with the scipy of this image -- loops d, f, g -- a float16 array is evaluated in float64,
+        the result narrowed to float32 later): the tile is then float32, like ZarrProvider's.
+        PARITY UNPINNED in the last bit against another scipy / libm."""
         torch = _torch()
         self.expit = bool(expit)
         self.decoder = decoder.to(device).eval()
@@ -290,9 +293,17 @@ class DecodeProvider:
             codes = self.code[:, z0:z1, y0:y1, x0:x1].reshape(self.code.shape[0], -1)[:, dst].t().float().contiguous()
             decode_into(self.decoder, codes, dst, pred, self.batch_size, self.fused)
             self.voxels_decoded += int(dst.numel())
-            if self.expit:
-                flat = pred.reshape(C, -1)
-                flat[:, dst] = torch.sigmoid(flat[:, dst])
+        if self.expit:
+            # float16 logits -> float64 logistic -> float32 (background voxels stay 0, as decode
+            # leaves them: the reference applies expit to the whole array, where logit 0 -> 0.5;
+            # those voxels are outside the foreground and never read by the vote)
+            out = torch.zeros(pred.shape, dtype=torch.float32, device=self.device)
+            if dst.numel():
+                flat, oflat = pred.reshape(C, -1), out.reshape(C, -1)
+                step = max(1, (1 << 24) // max(1, int(dst.numel())))
+                for c0 in range(0, C, step):
+                    oflat[c0:c0 + step, dst] = torch.sigmoid(flat[c0:c0 + step, dst].double()).float()
+            return out
         return pred
 
 

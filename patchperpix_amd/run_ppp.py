@@ -90,6 +90,8 @@ def decode(args, config):
 
 
 def main(argv=None):
+    from patchperpix_amd import backend as _backend
+    _backend.tune_host_allocator()
     ap = argparse.ArgumentParser()
     ap.add_argument("-c", "--config", action="append", required=True)
     ap.add_argument("-a", "--app", default="flylight")

@@ -1383,6 +1383,29 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
     stitch_patch_graph.py:672-894): bounding box of the cleaned foreground, assembly of the
     boxed volume (tiled when ``chunksize`` asks for it), result file with ``vote_instances``,
     ``vote_foreground`` and ``vote_instances_masked``."""
+    import contextlib
+    # (a streamed prediction keeps its container open while the tiles are read; it is closed
+    # when the call ends, whatever way it ends)
+    with contextlib.ExitStack() as stack:
+        return _stitch_main(stack, pred_file, result_folder, **kwargs)
+
+
+def _logits_in(arr, patchshape):
+    """loadAffinities' test for logits, ``min < 0 and max > 1`` over the WHOLE array
+    (utilVoteInstances.py:249-250), evaluated chunk by chunk along z so that a streamed
+    prediction is never resident; stops as soon as both have been seen."""
+    lo = hi = False
+    step = max(1, int(getattr(arr, "chunks", arr.shape)[1]))
+    for z0 in range(0, int(arr.shape[1]), step):
+        blk = np.asarray(arr[:, z0:z0 + step])
+        lo = lo or bool(blk.min() < 0)
+        hi = hi or bool(blk.max() > 1)
+        if lo and hi:
+            return True
+    return False
+
+
+def _stitch_main(stack, pred_file, result_folder=".", **kwargs):
     import os
     from scipy import ndimage
     from .vote_instances import utilVoteInstances as util
@@ -1404,8 +1427,7 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
         # the prediction stays on disk: chunks are decoded on demand into a pinned host buffer and
         # copied to the device tile by tile (ZarrProvider); host memory holds the fields only
         from .vote_instances import io_hdflike
-        cm = io_hdflike.open_container(pred_file, "r")
-        f = cm.__enter__()
+        f = stack.enter_context(io_hdflike.open_container(pred_file, "r"))
         aff_key = kw.setdefault("aff_key", "volumes/pred_affs")
         arr = f[aff_key]
         if len(arr.shape) != 4 or int(arr.shape[0]) != int(np.prod(patchshape)):
@@ -1415,11 +1437,10 @@ def stitch_main(pred_file, result_folder=".", **kwargs):
                 raise NotImplementedError("crops are not supported with a streamed prediction")
         numinst = util.maybeLoadNuminst(f, **kw)
         foreground, _ = util.loadFg(f, **dict(kw, patchshape=patchshape))
-        # logits are recognised from the centre channel (loadAffinities looks at the whole array,
-        # utilVoteInstances.py:249-250: reading it all is what streaming avoids)
-        mid = np.asarray(arr[int(np.prod(patchshape)) // 2])
-        affinities = ZarrProvider(arr, expit=bool(mid.min() < 0 and mid.max() > 1))
-        del mid
+        # logits: loadAffinities' test over the whole array (utilVoteInstances.py:249-250), one
+        # z-chunk at a time; `logits=True / False` in the configuration skips the scan
+        logits = kw.get("logits")
+        affinities = ZarrProvider(arr, expit=_logits_in(arr, patchshape) if logits is None else bool(logits))
     else:
         loaded = util.loadAffinities(pred_file, "", patchshape=patchshape, **kw)
         if loaded is None:

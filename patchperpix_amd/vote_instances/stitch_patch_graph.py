@@ -4,7 +4,7 @@ The reference scales to large volumes by cutting them into ``chunksize`` blocks,
 ``do_block(return_intermediates)`` per block, recomputing inter-block edges on the face
 overlaps and labelling one global patch graph (:110-399, :553-669, :672-894).  On MI355X a
 288 GB device holds what the reference needed blocks for, and scale-out is done by the
-spatial tiling in ``patchperpix_amd.tiling`` / ``patchperpix_amd.distributed``.  This module
+spatial tiling in ``patchperpix_amd.tiling``.  This module
 keeps the reference's helper functions and the ``main`` entry point.
 """
 import logging
@@ -126,6 +126,8 @@ def main(pred_file, result_folder='.', **kwargs):
     labelling (patchperpix_amd.blockwise; pinned to goldens of the reference's own driver).
     Output datasets and dtypes follow the reference: ``vote_instances``, ``vote_foreground``,
     ``vote_instances_masked`` (uint16)."""
+    from patchperpix_amd import backend as _backend
+    _backend.tune_host_allocator()
     if kwargs.pop("blockwise_semantics", "whole_volume") == "reference":
         # the reference's own function of the input: per-block cover, block graphs on disk,
         # inter-block edges, one global labelling (patchperpix_amd/blockwise.py)

@@ -401,6 +401,7 @@ def main(**kwargs):
     """Whole-volume driver (vote_instances.py:557-604): command-line arguments overridden by
     keyword arguments; ``affinities`` is one prediction file or a directory of ``*.hdf``
     files, otherwise ``<basedir>/<mode>/processed/<checkpoint>/*.hdf``."""
+    backend.tune_host_allocator()
     from_cli = not kwargs
     required = kwargs['check_required'] if 'check_required' in kwargs else True
     args = vars(get_arguments(check_required=required, argv=None if from_cli else []))

@@ -214,7 +214,9 @@ def test_decode_provider_votes_like_the_decoded_volume_p7():
     del probe, vals
     logits16 = dec.decode_volume(d, code, fg, batch_size=2048, out_dtype=torch.float16)
     fg_t = torch.as_tensor(fg, device="cuda")
-    pred16 = torch.where(fg_t.expand_as(logits16), torch.sigmoid(logits16), torch.zeros_like(logits16))
+    # loadAffinities' expit of the float16 logits: float64 evaluation, narrowed to float32
+    pred16 = torch.where(fg_t.expand_as(logits16), torch.sigmoid(logits16.double()).float(),
+                         torch.zeros(logits16.shape, dtype=torch.float32, device="cuda"))
     assert (pred16 > 0.5).any() and (pred16 < 0.5).any()
     kw = dict(FLYLIGHT, overlapping_inst=False)
     ps = [7, 7, 7]
