@@ -596,7 +596,17 @@ def main():
             "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["rank_patches"]),
             "launches": len(ev["rank_patches"]),
-            "bytes": "voxel-major consensus rows of the launch's box once + the prediction block once"}
+            "bytes": "voxel-major consensus rows of the launch's box once + the prediction block once",
+            "algorithmic_bytes_per_launch": b / len(ev["rank_patches"])}
+        if rank == 0 and world == 1 and not args.slabs and not args.yx:
+            t = pmc_traffic("rank_wg_kernel", wl.name, read_width="float")
+            if t.get("traffic") is not None:
+                rd = t.get("traffic_read_corrected", t["traffic_read"])
+                roofline_other["rank_patches"].update(
+                    traffic_read=t["traffic_read"], traffic_read_corrected=t.get("traffic_read_corrected"),
+                    counter_over_true_bytes=t.get("counter_over_true_bytes"), traffic_source=t["traffic_source"],
+                    traffic_over_algorithmic=rd / (b / len(ev["rank_patches"])),
+                    fabric_gb_per_s=rd / (ms / len(ev["rank_patches"]) * 1e-3) / 1e9)
     if ev.get("patch_graph") and notes.get("n_pairs"):
         ms = float(np.sum(ev["patch_graph"]))
         rows = float(notes.get("s5_rows_dispatched", notes["n_pairs"] * args.steps))
@@ -606,6 +616,14 @@ def main():
             "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["patch_graph"]),
             "launches": len(ev["patch_graph"]), "pair_rows_per_s": rows / (ms * 1e-3),
             "pair_rows_in_list_per_step": notes["n_pairs"]}
+        if rank == 0 and world == 1 and not args.slabs and not args.yx:
+            t = pmc_traffic("patch_graph_pa_kernel", wl.name, read_width="float")
+            if t.get("traffic") is not None:
+                rd = t.get("traffic_read_corrected", t["traffic_read"])
+                roofline_other["patch_graph"].update(
+                    traffic_read=t["traffic_read"], traffic_read_corrected=t.get("traffic_read_corrected"),
+                    counter_over_true_bytes=t.get("counter_over_true_bytes"), traffic_source=t["traffic_source"],
+                    fabric_gb_per_s=rd / (ms / len(ev["patch_graph"]) * 1e-3) / 1e9)
     # A checksum that does not depend on how the volume was split: crc32 of the per-slice crc32s
     # in z order.  With the result gathered every rank holds all slices; in provider mode a rank
     # returns its own z-range only and the per-slice values are gathered.
@@ -695,8 +713,10 @@ def main():
             n_read = min(int(wl.pred.numel()), 1 << 31)
             scratch = torch.empty((1 << 28,), dtype=torch.float32, device="cuda")
             rb, wb = backend.counter_calibration(wl.pred.reshape(-1), n_read, scratch, scratch.numel())
+            # the same bytes read back as floats (4 bytes per lane: the width of S2's / S5's loads)
+            rb32, _ = backend.counter_calibration(scratch, scratch.numel(), scratch[:1], 0)
             torch.cuda.synchronize()
-            out["counter_calibration_bytes"] = {"read": rb, "write": wb}
+            out["counter_calibration_bytes"] = {"read": rb, "write": wb, "read_f32": rb32}
             del scratch
         wl.free(torch)
         # ---- the north-star shape of the scoring kernel, in this run (when the timed workload is
@@ -711,7 +731,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, workload):
+def pmc_traffic(kernel, workload, read_width="pred"):
     """HBM traffic of `kernel` per launch from the committed rocprofv3 PMC passes of THIS workload
     (profiles/*_pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE, separate --pmc passes, KiB,
     per-dispatch means) -- only from a profile taken from the kernel sources of THIS tree (its
@@ -751,7 +771,11 @@ def pmc_traffic(kernel, workload):
                     vals[name] = v
                 if "cons_voxel_major_kernel" in ln:
                     calib[name] = v
-                if ("calib_read_kernel" in ln and name == "FETCH_SIZE") or \
+                # read calibration in the kernel's own access width: calib_read_kernel<__half> (one
+                # 2-byte prediction element per lane: S1's staging loads) or <float> (4 bytes per
+                # lane: the row and mask loads of S2 / S5)
+                want_read = "calib_read_kernel<float>" if read_width == "float" else "calib_read_kernel<__half>"
+                if (want_read in ln and name == "FETCH_SIZE") or \
                         ("calib_write_kernel" in ln and name == "WRITE_SIZE"):
                     known[name] = v
     if len(vals) < 2:
@@ -759,16 +783,19 @@ def pmc_traffic(kernel, workload):
     out = {"traffic": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "traffic_read": vals["FETCH_SIZE"],
            "traffic_write": vals["WRITE_SIZE"],
            "traffic_source": os.path.relpath(f, ROOT) + " (raw counters, mean per launch)"}
-    if len(known) == 2 and meta.get("calib_read_bytes"):
+    read_bytes = meta.get("calib_read_f32_bytes") if read_width == "float" else meta.get("calib_read_bytes")
+    if len(known) == 2 and read_bytes:
         # MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"
-        r = known["FETCH_SIZE"] / meta["calib_read_bytes"]
+        r = known["FETCH_SIZE"] / read_bytes
         w = known["WRITE_SIZE"] / meta["calib_write_bytes"]
         out["counter_over_true_bytes"] = {
             "read": r, "write": w,
-            "from": "calib_read_kernel / calib_write_kernel of the same profile: %.3g GB read with one "
-                    "prediction element per lane and load, %.3g GB written with one float per lane and store"
-                    % (meta["calib_read_bytes"] / 1e9, meta["calib_write_bytes"] / 1e9)}
+            "from": "calib_read_kernel<%s> / calib_write_kernel of the same profile: %.3g GB read with one "
+                    "%s per lane and load, %.3g GB written with one float per lane and store"
+                    % ("float" if read_width == "float" else "__half", read_bytes / 1e9,
+                       "float" if read_width == "float" else "prediction element", meta["calib_write_bytes"] / 1e9)}
         out["traffic_corrected"] = vals["FETCH_SIZE"] / r + vals["WRITE_SIZE"] / w
+        out["traffic_read_corrected"] = vals["FETCH_SIZE"] / r
     elif len(calib) == 2 and meta.get("transpose_true_read_bytes"):
         out["counter_over_true_bytes"] = {
             "read": calib["FETCH_SIZE"] / meta["transpose_true_read_bytes"],

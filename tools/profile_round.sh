@@ -45,6 +45,7 @@ except Exception:
 json.dump({"src_sha16": bench.source_sha16(), "command": "python3 bench.py $*",
            "workload": line["config"]["workload"], "flag_set": line["config"]["flag_set"],
            "calib_read_bytes": cal.get("read"), "calib_write_bytes": cal.get("write"),
+           "calib_read_f32_bytes": cal.get("read_f32"),
            "transpose_true_read_bytes": (W - 1) // 2 * BV * 4.0, "transpose_true_write_bytes": W * BV * 4.0},
           open("$out/meta.json", "w"), indent=1)
 PY
