@@ -79,10 +79,19 @@ PROVIDER_WORKLOADS = ("synth1024_p9", "synth256_p9_provider", "synth128_p7_provi
 # ships), random codes: the decoded patches are noise -- a throughput workload, not a segmentation.
 WORKLOADS["dec256_p7"] = ((256, 256, 256), (7, 7, 7), (18, 18, 18))
 WORKLOADS["dec96_p7"] = ((96, 96, 96), (7, 7, 7), (18, 18, 18))
-DECODE_WORKLOADS = ("dec256_p7", "dec96_p7")
+# variant (ii) of SURVEY 8(d): the 2-d decoder with 25 x 25 patches on 256 slices of 256^2, patch
+# shape (1, 25, 25) -- where the reference uses 25-wide patches at all (vote_instances.py:488)
+WORKLOADS["dec256x256_p25"] = ((256, 256, 256), (1, 25, 25), (1, 40, 40))
+WORKLOADS["dec8x256_p25"] = ((8, 256, 256), (1, 25, 25), (1, 40, 40))
+DECODE_WORKLOADS = ("dec256_p7", "dec96_p7", "dec256x256_p25", "dec8x256_p25")
 DECODER = dict(activation="relu", num_fmaps=[64, 128], downsample_factors=[[2, 2, 2], [2, 2, 2]],
                upsampling="resize_conv", kernel_size=3, num_repetitions=2, padding="same",
                code_fmaps=32, code_units=256, input_shape_squeezed=(7, 7, 7))
+# the same Autoencoder in 2-d (torch_model.py:452-544 is shape-generic): 256 units -> 16 x 4^2,
+# three stages 4 -> 8 -> 16 -> 32, crop to 25 x 25
+DECODER_2D = dict(activation="relu", num_fmaps=[32, 64, 128], downsample_factors=[[2, 2], [2, 2], [2, 2]],
+                  upsampling="resize_conv", kernel_size=3, num_repetitions=2, padding="same",
+                  code_fmaps=16, code_units=256, input_shape_squeezed=(25, 25))
 DEFAULT_WORKLOAD = "synth512_p9"      # BASELINE.json configs[2]
 FALLBACK_WORKLOAD = "flylight140_p7"  # BASELINE.json configs[1]
 NORTH_STAR = ((512, 512, 512), (9, 9, 9), (24, 24, 24))   # BASELINE.json configs[2]
@@ -309,14 +318,15 @@ class Workload:
             self.mode = "decode"
             self.gshape = shape
             torch.manual_seed(0)
-            decoder = dec.PatchDecoder(dict(DECODER)).cuda().eval()
+            dcfg = DECODER_2D if ps[0] == 1 else DECODER
+            decoder = dec.PatchDecoder(dict(dcfg)).cuda().eval()
             fg = (device_labels(torch, shape, cell, seed=0) != 0).to(torch.uint8)
             g = torch.Generator(device="cuda").manual_seed(1)
-            code = torch.randn((DECODER["code_units"],) + tuple(shape), generator=g, device="cuda",
+            code = torch.randn((dcfg["code_units"],) + tuple(shape), generator=g, device="cuda",
                                dtype=torch.float16)
             # random weights: spread and centre the logits so that both classes occur
             with torch.no_grad():
-                probe = decoder(code[:, :4].reshape(DECODER["code_units"], -1).t().float()[:4096])
+                probe = decoder(code[:, :4].reshape(dcfg["code_units"], -1).t().float()[:4096])
                 scale = 8.0 / float(probe.std())
                 decoder.up_conv[-1][-1].weight.mul_(scale)
                 decoder.up_conv[-1][-1].bias.mul_(scale).sub_(float(probe.median()) * scale)
@@ -324,7 +334,26 @@ class Workload:
             self.pred = code
             fused = os.environ.get("PPP_DECODE_FUSED", "1") != "0"
 
+            def step_2d(flag_kw=kw):
+                # 2-d patches are for 2-d data: the slices are decoded and voted one image at a
+                # time, as the reference processes 2-d samples (a stack with 2-d patches has no
+                # defined result there: vote_instances.to_instance_seg refuses it)
+                out = []
+                for z in range(shape[0]):
+                    fz = fg[z:z + 1]
+                    with backend.host_timer("decode"):
+                        pred = dec.decode_volume(decoder, code[:, z:z + 1], fz, batch_size=int(os.environ.get("PPP_DECODE_BATCH", "8192")),
+                                                 out_dtype=torch.float16, fused=False)
+                        flat = pred.reshape(pred.shape[0], -1)
+                        idx = torch.nonzero(fz.reshape(-1)).reshape(-1)
+                        flat[:, idx] = torch.sigmoid(flat[:, idx])
+                    inst, _ = vi.to_instance_seg(pred, fz, fz.clone(), fz, ps, **dict(flag_kw, **extra))
+                    out.append(np.asarray(inst))
+                return np.concatenate(out, axis=0)
+
             def step(flag_kw=kw):
+                if ps[0] == 1:
+                    return step_2d(flag_kw)
                 with backend.host_timer("decode"):
                     pred = dec.decode_volume(decoder, code, fg, batch_size=int(os.environ.get("PPP_DECODE_BATCH", "8192")),
                                              out_dtype=torch.float16, fused=None if fused else False)
@@ -663,8 +692,11 @@ def main():
                            (", yx tiles %dx%d" % tuple(args.yx) if args.yx else "")),
                        "prediction": "resident in HBM" if wl.mode == "resident" else
                                      ("decoded inside the timed step from the resident float16 code (%d units per voxel; "
-                                      "random-init decoder of the shipped architecture: head as float32 library GEMMs, tail as "
-                                      "the fused MFMA kernel)" % DECODER["code_units"] if wl.mode == "decode" else
+                                      "random-init decoder of the shipped architecture: %s)" % (
+                                          DECODER["code_units"],
+                                          "2-d, 25 x 25 patches, torch-ROCm convolutions (MIOpen) + index scatter" if ps[0] == 1 else
+                                          "head as float32 library GEMMs, tail as the fused MFMA kernel")
+                                      if wl.mode == "decode" else
                                       "generated tile by tile (provider): largest tile %.1f GB" % (wl.provider.bytes_max / 1e9)),
                        "result": "whole instance map on every rank" if wl.mode != "provider" else
                                  "own z-range per rank (instances_found / crc32: rank 0's range %s)" % (list(wl.own_range),),

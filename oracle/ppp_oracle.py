@@ -536,6 +536,10 @@ def to_instance_seg(pred, foreground, mask_to_cover, numinst, patchshape, **kw):
     reference's return values."""
     pred = np.ascontiguousarray(pred, dtype=np.float32)
     patchshape = [int(p) for p in patchshape]
+    if patchshape[0] == 1 and foreground.shape[0] > 1:
+        # pairs across slices make computePatchGraph.cu:98-105 read plane zo = 1 of a consensus
+        # array with NSZ = 1: undefined in the reference, nothing to restate
+        raise ValueError("2-d patches need 2-d data (Z = 1)")
     rad = np.array([p // 2 for p in patchshape])
     radslice = tuple(slice(rad[i], foreground.shape[i] - rad[i]) for i in range(3))
     out = {}

@@ -85,6 +85,7 @@ class PatchDecoder(_torch().nn.Module):
         torch = _torch()
         out = self.from_code(torch.reshape(code, self.code_shape))
         dense = getattr(self, "_dense", None)
+        first = 0
         if dense is not None:
             shape = dense["out_shape"]
             out = out.reshape(out.shape[0], -1)
@@ -92,12 +93,13 @@ class PatchDecoder(_torch().nn.Module):
                 out = torch.addmm(b, out, W)
                 if act is not None:
                     out = act(out)
-            return out.reshape((-1,) + shape)
-        for up, conv in zip(self.up[:-1], self.up_conv[:-1]):
+            out = out.reshape((-1,) + shape)
+            first = dense["n_stages"]
+        for up, conv in zip(self.up[first:-1], self.up_conv[first:-1]):
             out = conv(up(out))
         return out
 
-    def enable_dense_head(self, max_bytes=1 << 30):
+    def enable_dense_head(self, max_bytes=1 << 30, max_flop_ratio=3.0):
         """Turn the head's convolutions into plain GEMMs.  At the 2^3 -> 4^3 grids of the head a
         "same"-padded 3^3 convolution is a DENSE linear map between (channels x positions)
         vectors -- every output position sees most input positions -- so each convolution
@@ -108,8 +110,11 @@ class PatchDecoder(_torch().nn.Module):
         float32 library GEMMs instead of 4^3-sized convolutions.  W is made by pushing the
         identity through the layer itself, so it holds exactly the layer's weights; the
         summation order differs from the convolution's (tests/test_decode.py states the
-        tolerance).  Returns False (and changes nothing) when a matrix would exceed max_bytes
-        or there is no head stage."""
+        tolerance).  Stages are converted from the code outwards while that pays: a stage whose
+        matrices would exceed max_bytes, or whose dense form costs more than `max_flop_ratio` times
+        the multiply-adds of its convolutions (grids beyond ~4^3 / 8^2: the 2-d 25 x 25 decoder's
+        16^2 stage would cost 28x), stays a convolution, and so do the stages after it.  Returns
+        False (and changes nothing) when no stage qualifies."""
         torch = _torch()
         if len(self.up) < 2:
             return False
@@ -117,8 +122,22 @@ class PatchDecoder(_torch().nn.Module):
         dev, s0 = p0.device, self.code_shape[2:]
         in_shape = (int(self.from_code[0].out_channels),) + tuple(int(v) for v in s0)
         stages = []
+        done_stages, done_units, done_shape = 0, 0, in_shape
         with torch.no_grad():
             for up, conv in zip(self.up[:-1], self.up_conv[:-1]):
+                # multiply-adds of the stage as convolutions / as dense maps
+                direct = dense_cost = 0
+                shp = in_shape
+                z = torch.zeros((1,) + shp, device=dev, dtype=p0.dtype)
+                for m in [up[0]] + list(up[1]) + list(conv):
+                    if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d)):
+                        direct += int(np.prod(z.shape[2:])) * m.in_channels * m.out_channels * int(np.prod(m.kernel_size))
+                    z = m(z)
+                    if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d)):
+                        dense_cost += int(np.prod(shp)) * int(np.prod(z.shape[1:]))
+                        shp = tuple(int(v) for v in z.shape[1:])
+                if dense_cost > max_flop_ratio * direct:
+                    break
                 units = []              # (linear part, activation or None)
                 mods = [up[0]] + list(up[1]) + list(conv)
                 lin = []
@@ -142,7 +161,9 @@ class PatchDecoder(_torch().nn.Module):
                     out_shape = tuple(int(v) for v in y0.shape[1:])
                     n = int(np.prod(out_shape))
                     if k * n * 4 > max_bytes:
-                        return False
+                        stages = stages[:done_units]
+                        in_shape = done_shape
+                        break
                     W = torch.empty((k, n), device=dev, dtype=p0.dtype)
                     step = max(1, (1 << 26) // max(n, k))
                     for a in range(0, k, step):
@@ -155,7 +176,13 @@ class PatchDecoder(_torch().nn.Module):
                         W[a:b] = (y - y0).reshape(b - a, n)
                     stages.append((W, y0.reshape(1, n).clone(), act))
                     in_shape = out_shape
-        self._dense = {"stages": stages, "out_shape": in_shape}
+                else:
+                    done_stages, done_units, done_shape = done_stages + 1, len(stages), in_shape
+                    continue
+                break
+        if done_stages == 0:
+            return False
+        self._dense = {"stages": stages[:done_units], "out_shape": done_shape, "n_stages": done_stages}
         return True
 
     def tail(self, feats):

@@ -139,6 +139,14 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
             raise NotImplementedError("%s is not supported" % opt)
     patchshape = np.array([int(p) for p in patchshape])
     rad = np.array([p // 2 for p in patchshape])
+    if int(patchshape[0]) == 1 and int(np.shape(foreground)[0]) > 1:
+        # 2-d patches are for 2-d data, which the reference carries with a Z axis of 1
+        # (utilVoteInstances.py:187).  On a stack of slices its pair enumeration links patches of
+        # neighbouring slices (|dz| <= 2 p_z = 2, aff_patch_graph.py:61-69) and computePatchGraph
+        # then indexes the consensus array at zo = |dz| < 2 * PSZ although it has NSZ = 1 plane
+        # (computePatchGraph.cu:98-105): an out-of-bounds read, i.e. no defined result to match.
+        raise ValueError("patch shape %s with %d slices: 2-d patches need 2-d data (Z = 1); call once per "
+                         "slice" % (patchshape.tolist(), int(np.shape(foreground)[0])))
 
     if kwargs.get("pad_with_ps", False):
         assert not kwargs.get('blockwise'), "can only pad whole volumes"

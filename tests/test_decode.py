@@ -228,3 +228,67 @@ def test_decode_provider_votes_like_the_decoded_volume_p7():
                              tiling.plan_slabs(shape[0], 2), _yx_tiles=(1, 2), **kw)
     assert np.array_equal(got, want)
     assert prov.voxels_decoded > int(fg.sum())        # halos are decoded again per tile
+
+
+AE_2D_25 = dict(activation="relu", num_fmaps=[8, 16, 32], downsample_factors=[[2, 2], [2, 2], [2, 2]],
+                upsampling="resize_conv", kernel_size=3, num_repetitions=2, padding="same",
+                code_fmaps=16, code_units=256, input_shape_squeezed=(25, 25))
+
+
+def test_decoder_shapes_2d_25():
+    """the 2-d Autoencoder (torch_model.py:452-544 is shape-generic: spatial_dims =
+    len(input_shape_squeezed)): 256 units -> 16 x 4^2 -> 8^2 -> 16^2 -> 32^2 -> crop 25^2"""
+    torch.manual_seed(0)
+    d = dec.PatchDecoder(dict(AE_2D_25))
+    assert d.nd == 2 and d.code_shape == (-1, 16, 4, 4) and len(d.up) == 3
+    out = d(torch.randn(3, 256))
+    assert out.shape == (3, 1, 25, 25)
+    assert d.fused_tail_params() is None            # (the fused tail kernel is the 7^3 one)
+    # the dense-GEMM head does not pay at 8^2 / 16^2 grids: the stages stay convolutions
+    assert d.enable_dense_head() is False
+
+
+@pytest.mark.gpu
+def test_decode_2d_25_then_vote():
+    """BASELINE config [4], variant (ii) of SURVEY 8(d): the 2-d decoder with 25 x 25 patches on a
+    stack of slices, patch shape (1, 25, 25) -- decode_volume against the reference's per-voxel
+    loop (decode.py:43-65) on the same decoder, then the vote on the decoded block against the
+    oracle.  (Decoder ARITHMETIC unpinned: no funlib, no checkpoint.)"""
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd.flags import FLYLIGHT
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    d = dec.PatchDecoder(dict(AE_2D_25)).cuda().eval()
+    with torch.no_grad():
+        d.up_conv[-1][-1].weight.mul_(40.0)
+    shape = (2, 40, 44)
+    code = rng.normal(size=(256,) + shape).astype(np.float32)
+    fg = rng.uniform(size=shape) < 0.85
+    logits = dec.decode_volume(d, code, fg, batch_size=256, device="cuda", out_dtype=torch.float32)
+    assert tuple(logits.shape) == (625,) + shape
+    # literal loop of the reference on a few voxels
+    scale = float(logits.abs().max())
+    with torch.no_grad():
+        for c in np.transpose(np.nonzero(fg))[::97]:
+            v = torch.as_tensor(code[(slice(None),) + tuple(c)].reshape(1, 256)).cuda()
+            want = d(v).reshape(-1)
+            got = logits[(slice(None),) + tuple(int(x) for x in c)]
+            # batched vs single-sample convolutions (MIOpen picks its algorithm per shape): 1e-3 of
+            # the logits' range
+            assert torch.allclose(got, want, rtol=1e-3, atol=1e-3 * scale)
+    assert not logits[:, torch.as_tensor(~fg, device="cuda")].any()
+    sel = torch.as_tensor(fg, device="cuda").expand_as(logits)
+    pred = torch.sigmoid(logits - logits[sel].median()) * torch.as_tensor(fg, device="cuda").float()
+    pred16 = pred.to(torch.float16)
+    kw = dict(FLYLIGHT, overlapping_inst=False, patch_threshold=0.5)
+    ps = [1, 25, 25]
+    # 2-d patches are for 2-d data (Z = 1): a stack is refused (pairs across slices are undefined
+    # in the reference), the slices are voted one by one
+    with pytest.raises(ValueError, match="2-d patches"):
+        vi.to_instance_seg(pred16, fg.copy(), fg.copy(), fg.astype(np.uint8), ps, **kw)
+    for z in range(shape[0]):
+        p16, f = pred16[:, z:z + 1].contiguous(), fg[z:z + 1]
+        inst, _ = vi.to_instance_seg(p16, f.copy(), f.copy(), f.astype(np.uint8), ps, **kw)
+        ref = orc.to_instance_seg(p16.float().cpu().numpy(), f, f.copy(), f.astype(np.uint8), ps, **kw)
+        assert np.array_equal(inst, ref["instances"]) and inst.max() > 0
