@@ -49,6 +49,22 @@ namespace ppp {
 #ifndef PPP_RW_MINWAVES
 #define PPP_RW_MINWAVES(PX) 4
 #endif
+// LDS bank conflicts of the row reads.  A half-wave is 32 consecutive items; an item reads the row
+// image at -(plane * az + 17 * ay + ax) + const.  Enumerated (ax, ay, az) -- x-runs of nine lanes,
+// consecutive runs 17 floats apart -- the runs of ay and ay + 2 share seven banks: every read
+// took two passes (half of the LDS's active cycles were conflicts, r03/r04 profiles).  Enumerated
+// (ax, az, ay) with the image's PLANE stride padded from 289 to 297 (= 9 mod 32), consecutive
+// runs sit 9 banks apart -- 0-8, 9-17, 18-26, 27-31 -- and conflicts remain only where a
+// half-wave straddles the step from the last az of one ay to the first of the next.
+// (-DPPP_RW_ZRUNS=0: the old enumeration and image.)
+// Measured (tools/time_s2.py, profiles/r04_j_s2_zruns.txt): 9^3 190 -> 166 ms at 128^3, 102 -> 84 ms
+// at 96^3; 7^3 (plane stride 169 = 9 mod 32 already, conflicts mild before) 62.2 -> 64.7 ms at
+// 140^3 -- so only 9^3 takes it.  With all nine az present (rows in the z-interior of a tile at
+// least 9 thick) the step to the next ay continues the lattice (81 = 17 mod 32 = the y stride):
+// the 16 x 8 x 16 tile has half of its items in such rows.
+#ifndef PPP_RW_ZRUNS
+#define PPP_RW_ZRUNS(PX) ((PX) == 9)
+#endif
 static constexpr int RW_PAD = 8;
 static constexpr int RW_WAVES = 4;
 // Mask words per centre, padded to whole 16-byte loads.  The masks are stored CENTRE-MAJOR,
@@ -167,7 +183,12 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     constexpr int NST = (W + NTHR - 1) / NTHR;
     constexpr int NT = TZ * TY * TX;
     constexpr int UB = (TZ + 2 * RZ) * (TY + 2 * RY) * (TX + 2 * RX);
-    __shared__ float rowbuf[W + 2 * RW_PAD];
+    // plane stride of the row image (see PPP_RW_ZRUNS)
+    constexpr int SZ = WY * WX;
+    constexpr int SZP = PPP_RW_ZRUNS(PX) ? SZ + ((9 - SZ % 32) + 32) % 32 : SZ;
+    constexpr int LCP = LC + (PZ - 1) * (SZP - SZ);
+    auto img = [](int e) -> int { return SZP == SZ ? e : (e / SZ) * SZP + e % SZ; };
+    __shared__ float rowbuf[WZ * SZP + 2 * RW_PAD];
     __shared__ float accs[NT];
     __shared__ uint32_t act_bits[(NT + 31) / 32];
     __shared__ uint2 coefT[256];
@@ -247,7 +268,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int e = tid + i * NTHR;
-            if (e < W) rowbuf[RW_PAD + e] = src[e] * 32.0f;
+            if (e < W) rowbuf[RW_PAD + img(e)] = src[e] * 32.0f;
         }
     }
     __syncthreads();
@@ -279,7 +300,9 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             const int i = i0 + lane;
             const bool in = i < n_box;
             const int ii = in ? i : 0;
-            const int ax = ax0 + ii % nx, ay = ay0 + (ii / nx) % ny, az = az0 + ii / (nx * ny);
+            const int ax = ax0 + ii % nx;
+            const int ay = PPP_RW_ZRUNS(PX) ? ay0 + ii / (nx * nz) : ay0 + (ii / nx) % ny;
+            const int az = PPP_RW_ZRUNS(PX) ? az0 + (ii / nx) % nz : az0 + ii / (nx * ny);
             const int lz = uz + RZ - az - c0z, ly = uy + RY - ay - c0y, lx = ux + RX - ax - c0x;
             const int cl = (lz * TY + ly) * TX + lx;
             const int a = (az * PY + ay) * PX + ax;
@@ -311,7 +334,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #pragma unroll
             for (int w = 0; w < W16; ++w) mw[w] = active ? mw[w] : 0u;
             float acc = active ? accs[cl] : 0.0f;
-            lds_f32_cvp2 row = (lds_f32_cvp2)(rowbuf + RW_PAD + LC - ((az * WY + ay) * WX + ax));
+            lds_f32_cvp2 row = (lds_f32_cvp2)(rowbuf + RW_PAD + LCP - (az * SZP + ay * WX + ax));
             const int aw = a >> 4;
             // b in P counts only for b > a: P bits of the partners <= a go (N bits stay)
             const uint32_t above16 = ~((2u << (a & 15)) - 1u) & 0xFFFFu;
@@ -337,7 +360,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #ifdef PPP_RW_ABL_NOLDS
                         if (b < C) r[i2] = __builtin_bit_cast(float, 0x3F800000u + (uint32_t)(lane + b));   // (timing experiment)
 #else
-                        if (b < C) r[i2] = row[((b / (PY * PX)) * WY + (b / PX) % PY) * WX + b % PX];
+                        if (b < C) r[i2] = row[(b / (PY * PX)) * SZP + ((b / PX) % PY) * WX + b % PX];
 #endif
                     }
                 };
@@ -369,7 +392,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int e = tid + i * NTHR;
-                if (e < W) rowbuf[RW_PAD + e] = st[i] * 32.0f;
+                if (e < W) rowbuf[RW_PAD + img(e)] = st[i] * 32.0f;
             }
         }
         __syncthreads();
@@ -429,7 +452,12 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     bool big = big_tiles >= 4 * 256;
     static EnvSwitch tile_sw("PPP_RANK_WG_TILE");
     if (const char *e = tile_sw.get()) big = strcmp(e, "8x16x16") == 0 ? true : (strcmp(e, "8x8x16") == 0 ? false : big);
-    const int TZ = 8, TY = big ? 16 : 8, TX = 16;
+    // 9^3 with the z-run enumeration: 8 x 8 x 16 also at large boxes (a 112 x 176 x 176 launch,
+    // the size of the 512^3 tiles: 256 ms against 265 ms for 8 x 16 x 16 -- and for a 16 x 8 x 16 tile,
+    // which has half of its items in conflict-free rows: profiles/r04_k_s2_tiles*.txt)
+    if (G.px == 9 && PPP_RW_ZRUNS(9) && !tile_sw.get()) big = false;
+    const bool tall = tile_sw.get() && strcmp(tile_sw.get(), "16x8x16") == 0;
+    const int TZ = tall ? 16 : 8, TY = tall ? 8 : (big ? 16 : 8), TX = 16;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
@@ -439,7 +467,8 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
         S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles)
 #define PPP_RW_CASE(P)                                                                                      \
     case P:                                                                                                 \
-        if (big) PPP_RW_LAUNCH(P, 8, 16, 16);                                                               \
+        if (tall) PPP_RW_LAUNCH(P, 16, 8, 16);                                                              \
+        else if (big) PPP_RW_LAUNCH(P, 8, 16, 16);                                                          \
         else PPP_RW_LAUNCH(P, 8, 8, 16);                                                                    \
         break;
     switch (G.px) {
