@@ -1,3 +1,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for t in 16x8x16 8x16x16 8x8x16; do echo -n "$t "; PPP_RANK_WG_TILE=$t python3 tools/time_s2.py --case 176p9 --reps 2 2>/dev/null | tail -1; done > gpurun_out/r04_k_s2_tiles_176.txt
-cat gpurun_out/r04_k_s2_tiles_176.txt
+timeout 1500 python3 bench.py > gpurun_out/r04_l_bench_default.json 2> gpurun_out/r04_l_bench_default.err
+python3 - <<'PY'
+import json
+d=json.load(open("gpurun_out/r04_l_bench_default.json"))
+print(d["value"], d["unit"], d["ms_per_step"], d["config"]["workload"], d["config"]["instances_found"], d["config"]["instances_crc32"])
+print({k: round(v) for k,v in d["stage_wall_ms"].items()})
+print({k: round(v) for k,v in d["kernel_ms"].items()})
+print(d["roofline"]["frac"], d["roofline"]["avg_ms"], d["roofline_other_kernels"]["rank_patches"]["avg_ms"], d["roofline_other_kernels"]["patch_graph"]["avg_ms"])
+print(d["cpu_baseline"]["value"], d["cpu_baseline"]["sample"])
+PY
