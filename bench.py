@@ -83,7 +83,8 @@ WORKLOADS["dec96_p7"] = ((96, 96, 96), (7, 7, 7), (18, 18, 18))
 # shape (1, 25, 25) -- where the reference uses 25-wide patches at all (vote_instances.py:488)
 WORKLOADS["dec256x256_p25"] = ((256, 256, 256), (1, 25, 25), (1, 40, 40))
 WORKLOADS["dec8x256_p25"] = ((8, 256, 256), (1, 25, 25), (1, 40, 40))
-DECODE_WORKLOADS = ("dec256_p7", "dec96_p7", "dec256x256_p25", "dec8x256_p25")
+WORKLOADS["dec32x256_p25"] = ((32, 256, 256), (1, 25, 25), (1, 40, 40))
+DECODE_WORKLOADS = ("dec256_p7", "dec96_p7", "dec256x256_p25", "dec8x256_p25", "dec32x256_p25")
 DECODER = dict(activation="relu", num_fmaps=[64, 128], downsample_factors=[[2, 2, 2], [2, 2, 2]],
                upsampling="resize_conv", kernel_size=3, num_repetitions=2, padding="same",
                code_fmaps=32, code_units=256, input_shape_squeezed=(7, 7, 7))

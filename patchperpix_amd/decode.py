@@ -249,15 +249,26 @@ def decode_into(decoder, codes, dst, pred, batch_size=1024, fused=None):
             os.environ.get("PPP_DECODE_HEAD", "dense") != "conv" and not getattr(decoder, "_dense_tried", False):
         decoder._dense_tried = True
         decoder.enable_dense_head()
+    # Convolutions go through MIOpen, which searches for an algorithm the first time it sees a
+    # problem SHAPE -- seconds per new batch size.  A ragged last batch (a different size for every
+    # call: every slice, every tile) is therefore padded to the full batch whenever a convolution
+    # will see it; the padded rows are decoded and dropped.  (GEMM head + fused tail: no MIOpen.)
+    convs_run = tp is None or getattr(decoder, "_dense", None) is None or \
+        decoder._dense["n_stages"] < len(decoder.up) - 1
     with torch.no_grad():
         for s in range(0, int(dst.numel()), int(batch_size)):
             sel = dst[s:s + batch_size]
-            feats = decoder.head(codes[s:s + batch_size])
+            cb = codes[s:s + batch_size]
+            n = int(sel.numel())
+            if convs_run and n < int(batch_size) and pred.is_cuda:
+                cb = torch.cat([cb, cb.new_zeros((int(batch_size) - n,) + tuple(cb.shape[1:]))], 0)
+            feats = decoder.head(cb)
             if tp is not None:
-                backend.decode_tail(feats, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], sel, pred,
+                backend.decode_tail(feats[:n].contiguous() if feats.shape[0] != n else feats,
+                                    tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], sel, pred,
                                     decoder.patchshape)
             else:
-                flat[:, sel] = decoder.tail(feats).reshape(len(sel), C).t().to(pred.dtype)
+                flat[:, sel] = decoder.tail(feats)[:n].reshape(n, C).t().to(pred.dtype)
     return pred
 
 
