@@ -60,6 +60,19 @@ typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f_cvp;
 #define PPP_S1V3_MINWAVES(PX) ((PX) <= 7 ? 3 : 2)
 #endif
 
+// "about w" image: PPP_S1V3_SPLIT=1 keeps {t slice 0, t slice 1} (8 bytes) and the codes (4 bytes)
+// in two arrays -- a ds_read_b64 and a ds_read_b32 per vote pair, 12 bytes instead of the 16 of
+// the {t0, t1, codes, pad} element read by ds_read_b128: the LDS pipe is what this kernel keeps
+// busiest (~80 % next to 46 % VALU issue), and a quarter of its bytes were padding.
+// Measured (tools/time_s1.py, profiles/r04_q_s1_split.txt): 7^3 46.2 -> 41.3 ms on the 140^3 volume
+// and 66.0 -> 62.7 ms on the 512^2 slab; 9^3 264.7 -> 268.3 ms (the second LDS instruction per pair
+// costs more than the bytes save there): taken up to 7^3.
+#ifndef PPP_S1V3_SPLIT
+#define PPP_S1V3_SPLIT(PX) ((PX) <= 7)
+#endif
+typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp;
+typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_cvp;
+
 template <int PX, bool FLAT>
 struct V3 {
     static constexpr int RX = PX / 2;
@@ -109,7 +122,7 @@ __device__ __forceinline__ uint32_t pack_codes(v2f pos, v2f neg) {
 // processed in groups of GS whose chains are interleaved stage by stage; the LDS reads of the
 // next group are issued before the arithmetic of the current one.
 template <int PX, int NC, bool ROW0, bool EXACT>
-__device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt,
+__device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt, const v2f *bt2, const uint32_t *ct,
                                             const double th2, const double den,
                                             v2f (&acc)[2 * PX - 1], uint32_t (&tc)[2 * PX - 1]) {
     // fl(4/3) and fl(4/3 - fl(4/3)): y = fma(d, c43, d * c43lo) is the correctly rounded d / 0.75
@@ -129,7 +142,18 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt,
         if (jg == 0) t = at[kx * NC - kx];
 #pragma unroll
         for (int g = 0; g < GS; ++g)
-            if (used(kx, jg + g)) b[g] = bt[(jg + g) * NC - kx];
+            if (used(kx, jg + g)) {
+                if constexpr (PPP_S1V3_SPLIT(PX)) {
+                    const v2f t2 = bt2[(jg + g) * NC - kx];
+                    b[g] = (v4f){t2.x, t2.y, __uint_as_float(ct[(jg + g) * NC - kx]), 0.0f};
+                } else {
+#ifdef PPP_S1_ABL_NOLDS
+                    b[g] = (v4f){t.x * 0.9f, t.y * 0.8f, __uint_as_float(0x00010001u), 0.0f};   // (timing experiment)
+#else
+                    b[g] = bt[(jg + g) * NC - kx];
+#endif
+                }
+            }
     };
     load_group(0, bcur, ta);
 #pragma unroll
@@ -186,7 +210,9 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt,
             if (!used(kx, jg + g)) continue;
             const int i = jg + g - kx + PX - 1;
             acc[i] = acc[i] + y[g];
+#ifndef PPP_S1_ABL_NOCNT
             tc[i] = pk_mad_u16(ca, cb[g], tc[i]);
+#endif
         }
         if (n + 1 < NG) {
 #pragma unroll
@@ -214,7 +240,10 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
     using K = V3<PX, FLAT>;
     constexpr int NIT = K::NIT;
     constexpr int V3_WAVES = PPP_S1V3_WAVES(PX);
-    __shared__ v4f lds_bt[V3_WAVES][K::NELP];
+    constexpr bool SPLIT = PPP_S1V3_SPLIT(PX);
+    __shared__ v4f lds_bt[V3_WAVES][SPLIT ? 1 : K::NELP];
+    __shared__ v2f lds_bt2[V3_WAVES][SPLIT ? K::NELP : 1];
+    __shared__ uint32_t lds_ct[V3_WAVES][SPLIT ? K::NELP : 1];
     __shared__ v2f lds_at[V3_WAVES][K::NELP];
     __shared__ v2f lds_cf[V3_WAVES][K::NC];
     __shared__ uint8_t lds_valid[V3_WAVES][2][2][K::NT + 2];
@@ -338,6 +367,8 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
 
     v2f *at = lds_at[wave], *cf = lds_cf[wave];
     v4f *bt = lds_bt[wave];
+    v2f *bt2 = lds_bt2[wave];
+    uint32_t *ct = lds_ct[wave];
 
     if (w_row_ok) {
         const int kz_hi = min(G.pz - 1, G.pz - 1 - dz), kz_lo = max(0, -dz);
@@ -374,10 +405,15 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             const long long chb = (long long)(((z + dz) * G.py + (y + dy)) * PX) * G.V;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
+#ifdef PPP_S1_ABL_NOLOAD
+                ra[0][it] = ra[1][it] = 0.9f + 1e-3f * (float)((el_off[it] + (unsigned)(cha + crow0)) & 15u);   // (timing experiment)
+                rb[0][it] = rb[1][it] = 0.1f + 1e-3f * (float)((el_off[it] + (unsigned)(chb + crow1)) & 15u);
+#else
                 ra[0][it] = ldf_at3(pred + cha + crow0, el_off[it]);
                 ra[1][it] = ldf_at3(pred + cha + crow1, el_off[it]);
                 rb[0][it] = ldf_at3(pred + chb + crow0, el_off[it]);
                 rb[1][it] = ldf_at3(pred + chb + crow1, el_off[it]);
+#endif
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -428,7 +464,8 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
                     bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
                     const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
                     const v2f t = pk_fma(v, g + h, -h);
-                    bt[e] = (v4f){t.x, t.y, __uint_as_float(pack_codes(g, h)), 0.0f};
+                    if constexpr (SPLIT) { bt2[e] = t; ct[e] = pack_codes(g, h); }
+                    else bt[e] = (v4f){t.x, t.y, __uint_as_float(pack_codes(g, h)), 0.0f};
                 }
             }
             // a value outside [0, 1] (as an unsigned bit pattern: > 1.0f, negative, inf, nan) sends
@@ -452,7 +489,8 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
                         code |= (xb > 0.0f ? 1u : (xb < 0.0f ? 256u : 0u)) << (16 * s);
                     }
                     at[e] = ta;
-                    bt[e] = (v4f){tb.x, tb.y, __uint_as_float(code), 0.0f};
+                    if constexpr (SPLIT) { bt2[e] = tb; ct[e] = code; }
+                    else bt[e] = (v4f){tb.x, tb.y, __uint_as_float(code), 0.0f};
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -462,13 +500,15 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             if (PREFETCH && have) load_tile(kz, ky);
             // ---- votes
             const v2f *ia = at + pos_l;
-            lds_v4f_cvp ib = (lds_v4f_cvp)(bt + pos_l);
+            lds_v4f_cvp ib = (lds_v4f_cvp)(bt + (SPLIT ? 0 : pos_l));
+            const v2f *ib2 = bt2 + (SPLIT ? pos_l : 0);
+            const uint32_t *ic = ct + (SPLIT ? pos_l : 0);
             if (!any_big) {
-                if (row0) tile_votes3<PX, K::NC, true, false>(ia, ib, G.th2, G.den, acc, tc);
-                else tile_votes3<PX, K::NC, false, false>(ia, ib, G.th2, G.den, acc, tc);
+                if (row0) tile_votes3<PX, K::NC, true, false>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, false>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
             } else {
-                if (row0) tile_votes3<PX, K::NC, true, true>(ia, ib, G.th2, G.den, acc, tc);
-                else tile_votes3<PX, K::NC, false, true>(ia, ib, G.th2, G.den, acc, tc);
+                if (row0) tile_votes3<PX, K::NC, true, true>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, true>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
             }
             if (++n_fold == K::FOLD) {
                 n_fold = 0;
