@@ -850,7 +850,8 @@ def cpu_baseline(ps, cell, kw):
                    "S2 over centres, S5 over pair rows) + host stages (ppp_host_* C++, one thread)"}
     runs = []
     # bounded samples (10-30 s each): the per-voxel work grows with C^2 (4.5x from 7^3 to 9^3)
-    samples = ((1, (24, 24, 24)), (cores, (48, 48, 48))) if int(np.prod(ps)) > 343 else \
+    # (all cores: the 64^3 sample SURVEY 8(d) prescribes -- about half a minute of 16 cores at 9^3)
+    samples = ((1, (24, 24, 24)), (cores, (64, 64, 64))) if int(np.prod(ps)) > 343 else \
         ((1, (32, 32, 32)), (cores, (64, 64, 64)))
     for threads, sshape in samples:
         sshape = tuple(min(s, 64) if p > 1 else 1 for s, p in zip(sshape, ps))

@@ -351,7 +351,12 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
                 uint2 cf[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
+#ifdef PPP_RW_ABL_NOTABLE
+                    // (timing experiment: no table reads)
+                    if (w * 16 + j * 4 < C) { const uint32_t q = (m >> (8 * j)) & 0xFFu; cf[j] = make_uint2(0x28002800u ^ (q << 15), 0xA800A800u ^ (q << 7)); }
+#else
                     if (w * 16 + j * 4 < C) cf[j] = coefT[(m >> (8 * j)) & 0xFFu];
+#endif
                 float rv[2][4];
                 auto load_rows = [&](int j, float (&r)[4]) {
 #pragma unroll
