@@ -141,7 +141,8 @@ def source_sha16():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "patchperpix_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        # (device code only: the host-only translation units ppp_host*.cpp hold no kernel)
+        if f.endswith((".hip", ".hpp")) or (f.endswith(".cpp") and not f.startswith("ppp_host")):
             h.update(f.encode())
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]

@@ -9,8 +9,8 @@
 //     stably sorted by |aff| descending (graph_mws.py:23-29);
 //   * component membership lives in a union-find whose roots carry the reference's component id;
 //     a new component gets max(ids in use) + 1, a merge keeps the smaller id (:37-38, :66-72);
-//   * "is there a mutex edge between these components" (:46-48, :59-62) is answered from, per
-//     component, the set of nodes that have a mutex edge into it, merged small-to-large;
+//   * "is there a mutex edge between these components" (:46-48, :59-62) is one lookup in a hash
+//     set of (root, root) keys that is rewritten, small-to-large, when components merge;
 //   * the output order is the creation order of the ids -- a re-issued id keeps its first
 //     position and a component emptied by a merge stays in the list (:79-82) -- so the instance
 //     label of a node is 1 + position of its component's id in that order.
@@ -43,43 +43,111 @@ struct Dsu {
     }
 };
 
+// Open-addressing set of 64-bit keys (linear probing, tombstones), grown by doubling.
+struct KeySet {
+    static constexpr uint64_t EMPTY = ~0ull, TOMB = ~0ull - 1;
+    std::vector<uint64_t> slot;
+    size_t used = 0, live = 0;     // used: non-EMPTY slots (incl. tombstones)
+    explicit KeySet(size_t cap = 1024) : slot(cap, EMPTY) {}
+    static size_t hash(uint64_t k) {
+        k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+        return (size_t)k;
+    }
+    void grow() {
+        std::vector<uint64_t> old;
+        old.swap(slot);
+        slot.assign(live * 4 + 1024 > old.size() ? old.size() * 2 : old.size(), EMPTY);
+        used = live = 0;
+        for (uint64_t k : old)
+            if (k != EMPTY && k != TOMB) insert(k);
+    }
+    bool contains(uint64_t k) const {
+        const size_t m = slot.size() - 1;
+        for (size_t i = hash(k) & m;; i = (i + 1) & m) {
+            if (slot[i] == k) return true;
+            if (slot[i] == EMPTY) return false;
+        }
+    }
+    // true if the key was not there
+    bool insert(uint64_t k) {
+        if ((used + 1) * 2 > slot.size()) grow();
+        const size_t m = slot.size() - 1;
+        size_t tomb = (size_t)-1;
+        for (size_t i = hash(k) & m;; i = (i + 1) & m) {
+            if (slot[i] == k) return false;
+            if (slot[i] == TOMB && tomb == (size_t)-1) tomb = i;
+            if (slot[i] == EMPTY) {
+                if (tomb != (size_t)-1) { slot[tomb] = k; }
+                else { slot[i] = k; ++used; }
+                ++live;
+                return true;
+            }
+        }
+    }
+    void erase(uint64_t k) {
+        const size_t m = slot.size() - 1;
+        for (size_t i = hash(k) & m;; i = (i + 1) & m) {
+            if (slot[i] == k) { slot[i] = TOMB; --live; return; }
+            if (slot[i] == EMPTY) return;
+        }
+    }
+};
+
 // The loop of graph_mws.mws (:31-77) over edges that are already in visiting order.
 //   eu / ev [n_edges]: node numbers, bit 31 of ev = attractive; label [n_nodes] out: 1 + position
 //   of the node's component id in creation order, 0 = the node ended in no component.
 // Every node is a union-find element from the start (an unassigned node is a singleton without
-// a component id).  A root carries the list of the far endpoints of the mutex edges incident to
-// its members; "is there a mutex edge between two clusters" walks the shorter list and asks
-// whether an endpoint lives in the other cluster.  Lists are appended small-to-large on a merge
-// (duplicates are harmless).  A mutex edge inside one cluster can never matter again (clusters
-// only grow) and is not recorded.
+// a component id).  "Is there a mutex edge between two clusters" (:46-48, :59-62) is ONE lookup:
+// the set `mutex` holds a key (smaller root, larger root) for every pair of CURRENT clusters with
+// a repulsive edge between them.  It is kept exact under merges by rewriting the keys of the
+// absorbed cluster -- each root carries the list of the clusters it has a key with (entries may
+// name a cluster by any of its former roots; duplicates are harmless), the cluster with the
+// shorter list is the one absorbed, so a key is rewritten O(log n) times.  (Round 3 walked the
+// shorter of two endpoint lists with a find per entry: 140 entries per check on a graph with half
+// of its edges repulsive -- BASELINE config [4] with a random decoder -- 705 ns per edge; this
+// form: see tools/time_mws.py.)  A mutex edge inside one cluster can never matter again (clusters
+// only grow) and is dropped.
 void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N, int32_t *label,
                int64_t *issued) {
     Dsu dsu;
     dsu.parent.resize((size_t)N);
     for (int32_t i = 0; i < N; ++i) dsu.parent[i] = i;
     std::vector<int32_t> cc_of_root((size_t)N, 0);      // component id carried by a root (0: none)
-    std::vector<std::vector<int32_t>> mlist((size_t)N);
+    std::vector<std::vector<int32_t>> nbrs((size_t)N);  // clusters this root has a mutex key with
+    KeySet mutex(1 << 16);
     std::set<int32_t> in_use;                           // ids currently held by some node
     std::vector<int32_t> created;                       // ids in creation order (first issue)
     std::vector<uint8_t> ever;                          // id was issued before (ids are <= N)
     ever.assign((size_t)N + 2, 0);
-    auto has_mutex = [&](int32_t r0, int32_t r1) {
-        const bool first_small = mlist[r0].size() <= mlist[r1].size();
-        const std::vector<int32_t> &small = first_small ? mlist[r0] : mlist[r1];
-        const int32_t other = first_small ? r1 : r0;
-        for (int32_t x : small)
-            if (dsu.find(x) == other) return true;
-        return false;
+    auto key = [](int32_t a, int32_t b) -> uint64_t {
+        const uint32_t lo = (uint32_t)std::min(a, b), hi = (uint32_t)std::max(a, b);
+        return ((uint64_t)lo << 32) | hi;
     };
-    // r_drop's members join r_keep (which stays the root); the longer list survives
-    auto unite = [&](int32_t r_keep, int32_t r_drop) {
-        dsu.parent[r_drop] = r_keep;
-        std::vector<int32_t> &a = mlist[r_keep], &b = mlist[r_drop];
-        if (a.size() < b.size()) a.swap(b);
-        a.insert(a.end(), b.begin(), b.end());
-        std::vector<int32_t>().swap(b);
+    auto has_mutex = [&](int32_t r0, int32_t r1) { return mutex.contains(key(r0, r1)); };
+    // the two clusters become one; returns its root (the one with the longer list)
+    auto unite = [&](int32_t ra, int32_t rb) -> int32_t {
+        int32_t keep = ra, drop = rb;
+        if (nbrs[keep].size() < nbrs[drop].size()) std::swap(keep, drop);
+        std::vector<int32_t> &kl = nbrs[keep], &dl = nbrs[drop];
+        // (find() of the neighbours BEFORE the link: keep and drop are still both roots)
+        for (int32_t x : dl) {
+            const int32_t p = dsu.find(x);
+            if (p == keep || p == drop) continue;          // becomes internal
+            mutex.erase(key(drop, p));
+            if (mutex.insert(key(keep, p))) kl.push_back(p);
+        }
+        mutex.erase(key(keep, drop));
+        std::vector<int32_t>().swap(dl);
+        dsu.parent[drop] = keep;
+        return keep;
     };
+    constexpr int64_t AHEAD = 24;          // the edge list is known: fetch the nodes' entries early
     for (int64_t i = 0; i < n_edges; ++i) {
+        if (i + AHEAD < n_edges) {
+            const int32_t pa = eu[i + AHEAD], pb = ev[i + AHEAD] & 0x7FFFFFFF;
+            __builtin_prefetch(&dsu.parent[pa]);
+            __builtin_prefetch(&dsu.parent[pb]);
+        }
         const int32_t a = eu[i], b = ev[i] & 0x7FFFFFFF;
         const int32_t r0 = dsu.find(a), r1 = dsu.find(b);
         if (ev[i] < 0) {                                  // attractive
@@ -87,26 +155,29 @@ void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N,
             if (c0 == 0 && c1 == 0) {
                 // both unassigned (:36-42): a new component, id = max id in use + 1
                 const int32_t id = (in_use.empty() ? 0 : *in_use.rbegin()) + 1;
-                if (r0 != r1) unite(r0, r1);
-                cc_of_root[r0] = id;
+                const int32_t r = r0 != r1 ? unite(r0, r1) : r0;
+                cc_of_root[r] = id;
                 in_use.insert(id);
                 if (!ever[(size_t)id]) { ever[(size_t)id] = 1; created.push_back(id); }
             } else if (c0 == 0 || c1 == 0) {
                 // the unassigned node joins unless a mutex edge links it to the component (:44-56)
-                const int32_t r_cc = c0 == 0 ? r1 : r0, r_node = c0 == 0 ? r0 : r1;
-                if (!has_mutex(r_cc, r_node)) unite(r_cc, r_node);
+                if (!has_mutex(r0, r1)) {
+                    const int32_t id = c0 == 0 ? c1 : c0;
+                    cc_of_root[unite(r0, r1)] = id;
+                }
             } else if (c0 != c1) {
                 // two components merge into the smaller id unless a mutex edge links them (:57-71)
                 if (!has_mutex(r0, r1)) {
                     const int32_t keep = std::min(c0, c1), drop = std::max(c0, c1);
-                    unite(r0, r1);
-                    cc_of_root[r0] = keep;
+                    cc_of_root[unite(r0, r1)] = keep;
                     in_use.erase(drop);
                 }
             }
         } else if (r0 != r1) {                            // repulsive (:76-77)
-            mlist[r0].push_back(b);
-            mlist[r1].push_back(a);
+            if (mutex.insert(key(r0, r1))) {
+                nbrs[r0].push_back(r1);
+                nbrs[r1].push_back(r0);
+            }
         }
     }
     std::vector<int32_t> label_of_id((size_t)N + 2, 0);

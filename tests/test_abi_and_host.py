@@ -293,3 +293,38 @@ def test_post_steps():
         if l:
             ref[ndimage.binary_dilation(ref == l, iterations=1)] = l
     assert np.array_equal(d, ref)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_native_mws_on_dense_noisy_graphs(seed):
+    """Hundreds of nodes, thousands of edges, half of them repulsive, many tied weights: the regime
+    in which clusters carry long mutex neighbour lists and merge often (what the hash set of root
+    pairs in ppp_host_mws.cpp is for) -- against the oracle's union-find restatement and, on the
+    smaller ones, the literal one."""
+    from oracle import ppp_oracle as orc
+    from oracle import ppp_oracle_scale as ors
+    from patchperpix_amd import backend
+    rng = np.random.default_rng(1000 + seed)
+    shape = (12, 14, 16)
+    n_nodes = int(rng.integers(150, 500))
+    lin = rng.choice(int(np.prod(shape)), size=n_nodes, replace=False)
+    coords = np.stack(np.unravel_index(lin, shape), axis=1).astype(np.uint32)
+    n_rows = int(rng.integers(6 * n_nodes, 14 * n_nodes))
+    a = rng.integers(0, n_nodes, size=n_rows)
+    b = rng.integers(0, n_nodes, size=n_rows)
+    pairs = np.concatenate([coords[a], coords[b]], axis=1)
+    mag = rng.integers(1, 40, size=n_rows) / 64.0
+    sign = np.where(rng.random(n_rows) < (0.5 if seed % 2 else 0.25), -1.0, 1.0)
+    aff = (mag * sign).astype(np.float32)
+    nodes, labels, n_labels = backend.host_mws(pairs, aff, shape)
+    got = {int(np.ravel_multi_index(tuple(int(v) for v in n), shape)): int(l) for n, l in zip(nodes, labels) if l}
+    nodes_o, labels_o, n_ids = ors.mutex_watershed(pairs, aff, shape)
+    assert n_labels == n_ids
+    assert got == {int(n): int(l) for n, l in zip(nodes_o, labels_o) if l}
+    if n_nodes < 260:
+        ccs = orc.mutex_watershed(pairs, aff)
+        lit = {}
+        for k, cc in enumerate(ccs):
+            for n in cc:
+                lit[int(np.ravel_multi_index(n, shape))] = k + 1
+        assert got == lit and n_labels == len(ccs)
