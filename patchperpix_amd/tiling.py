@@ -121,7 +121,18 @@ class TorchDistComm:
         # gloo moves device tensors through the host (tests: several ranks sharing one GPU)
         self.via_host = dist.get_backend(group) == "gloo"
 
+    # element types RCCL reduces / moves (torch's ProcessGroupNCCL maps no 16-bit integer type);
+    # anything else travels as int32 (reductions) or as raw bytes (gathers, point to point)
+    _WIRE_OK = ("torch.int8", "torch.uint8", "torch.int32", "torch.int64", "torch.float16",
+                "torch.bfloat16", "torch.float32", "torch.float64")
+
     def _reduce(self, t, op):
+        if self.world > 1 and str(t.dtype) not in self._WIRE_OK:
+            import torch
+            wide = t.to(torch.int32)
+            self._reduce(wide, op)
+            t.copy_(wide.to(t.dtype))
+            return t
         if self.world > 1:
             if self.via_host and t.is_cuda:
                 h = t.cpu()
@@ -145,6 +156,10 @@ class TorchDistComm:
     def all_gather(self, t):
         """[world, ...] stack of every rank's `t` (same shape everywhere)."""
         import torch
+        if str(t.dtype) not in self._WIRE_OK:
+            # a gather is type-agnostic: send the bytes
+            raw = self.all_gather(t.contiguous().view(torch.uint8))
+            return raw.view(t.dtype).reshape((self.world,) + tuple(t.shape))
         src = t.cpu() if (self.via_host and t.is_cuda) else t.contiguous()
         parts = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(parts, src, group=self.group)
@@ -191,6 +206,12 @@ class TorchDistComm:
         if self.world == 1 or not items:
             return
         host = self.via_host and items[0][1].is_cuda
+        if any(str(t.dtype) not in self._WIRE_OK for _, t in items):
+            wide = [(p, t.to(torch.int32)) for p, t in items]
+            self.neighbour_min(wide)
+            for (_, t), (_, w) in zip(items, wide):
+                t.copy_(w.to(t.dtype))
+            return
         mine = [(p, (t.cpu() if host else t.contiguous())) for p, t in items]
         recv = [torch.empty_like(t) for _, t in mine]
         ops = []

@@ -586,3 +586,46 @@ def test_ranks_provider_local_fields_share_one_gpu(tmp_path, world, ps, flagset)
         z0, z1 = [int(v) for v in np.load(tmp_path / ("range_rank%d.npy" % r))]
         inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
         assert inst.dtype == np.uint32 and np.array_equal(inst, want[z0:z1]), "rank %d differs" % r
+
+
+COMM_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from patchperpix_amd import tiling
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+comm = tiling.TorchDistComm()
+ok = []
+# 16-bit integers and booleans are not element types RCCL moves: they travel as int32 / bytes
+a = torch.tensor([1, -2, 300 * (rank + 1)], dtype=torch.int16)
+ok.append(comm.all_reduce_sum(a.clone()).tolist() == [world, -2 * world, 300 * world * (world + 1) // 2])
+ok.append(comm.all_reduce_max(a.clone()).tolist() == [1, -2, 300 * world])
+b = torch.tensor([rank == 0, True, False])
+g = comm.all_gather(b)
+ok.append(g.dtype == torch.bool and g.shape == (world, 3) and g[:, 0].tolist() == [r == 0 for r in range(world)])
+h = comm.all_gather(torch.arange(4, dtype=torch.int16) + 10 * rank)
+ok.append(h.dtype == torch.int16 and h.tolist() == [[10 * r + i for i in range(4)] for r in range(world)])
+peer = (rank + 1) % world
+t = torch.tensor([5 + rank, 7 - rank], dtype=torch.int16)
+comm.neighbour_min([(peer, t)])
+ok.append(t.tolist() == [5, 7 - (world - 1)])
+vol = torch.zeros((2 * world, 3), dtype=torch.int16)
+vol[2 * rank:2 * rank + 2] = rank + 1
+comm.all_gather_slabs(vol, [(2 * r, 2 * r + 2) for r in range(world)])
+ok.append(vol[:, 0].tolist() == [r + 1 for r in range(world) for _ in range(2)])
+np.save(os.path.join({out!r}, "comm_rank%d.npy" % rank), np.array(ok))
+dist.destroy_process_group()
+"""
+
+
+def test_communicator_moves_types_rccl_has_no_element_type_for(tmp_path):
+    """TorchDistComm: int16 / bool tensors are reduced as int32 and gathered / exchanged as bytes
+    (torch's NCCL = RCCL backend maps no 16-bit integer type); two gloo ranks."""
+    script = tmp_path / "comm_worker.py"
+    script.write_text(COMM_WORKER.format(repo=REPO, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29597", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29597", str(script)], env=env, timeout=300)
+    for r in range(2):
+        assert np.load(tmp_path / ("comm_rank%d.npy" % r)).all(), "rank %d" % r
