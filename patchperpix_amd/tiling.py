@@ -138,6 +138,10 @@ class TorchDistComm:
                 h = t.cpu()
                 self.dist.all_reduce(h, op=op, group=self.group)
                 t.copy_(h)
+            elif not self.via_host and not t.is_cuda:
+                d = t.cuda()                     # (RCCL only moves device memory)
+                self.dist.all_reduce(d, op=op, group=self.group)
+                t.copy_(d)
             else:
                 self.dist.all_reduce(t, op=op, group=self.group)
         return t
@@ -160,7 +164,12 @@ class TorchDistComm:
             # a gather is type-agnostic: send the bytes
             raw = self.all_gather(t.contiguous().view(torch.uint8))
             return raw.view(t.dtype).reshape((self.world,) + tuple(t.shape))
-        src = t.cpu() if (self.via_host and t.is_cuda) else t.contiguous()
+        if self.via_host and t.is_cuda:
+            src = t.cpu()
+        elif not self.via_host and not t.is_cuda:
+            src = t.cuda()                       # (RCCL only moves device memory)
+        else:
+            src = t.contiguous()
         parts = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(parts, src, group=self.group)
         return torch.stack(parts, 0).to(t.device)
