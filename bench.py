@@ -507,7 +507,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from patchperpix_amd import tiling
-        dist.init_process_group("gloo" if one_gpu else "nccl")  # "nccl" = RCCL
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            # "nccl" = RCCL; bound to this rank's device (barriers and object collectives then use it)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:
+                dist.init_process_group("nccl")
         comm = tiling.TorchDistComm()
         # how many ranks the data path's collectives really span: a 1-element SUM all-reduce
         one = torch.ones(1, dtype=torch.int32, device="cpu" if one_gpu else "cuda")
