@@ -17,7 +17,6 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <set>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -115,7 +114,10 @@ void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N,
     std::vector<int32_t> cc_of_root((size_t)N, 0);      // component id carried by a root (0: none)
     std::vector<std::vector<int32_t>> nbrs((size_t)N);  // clusters this root has a mutex key with
     KeySet mutex(1 << 16);
-    std::set<int32_t> in_use;                           // ids currently held by some node
+    // ids currently held by some node: only "the largest one" is ever asked (:37-38), so a flag
+    // per id and a maximum that is walked down lazily when its id dies (amortised O(1), no tree)
+    std::vector<uint8_t> alive((size_t)N + 2, 0);
+    int32_t max_alive = 0;
     std::vector<int32_t> created;                       // ids in creation order (first issue)
     std::vector<uint8_t> ever;                          // id was issued before (ids are <= N)
     ever.assign((size_t)N + 2, 0);
@@ -125,19 +127,25 @@ void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N,
     };
     auto has_mutex = [&](int32_t r0, int32_t r1) { return mutex.contains(key(r0, r1)); };
     // the two clusters become one; returns its root (the one with the longer list)
+    std::vector<int32_t> n_nbrs((size_t)N, 0);          // list lengths, next to each other (the
+                                                        // vector headers are 24 bytes apiece)
     auto unite = [&](int32_t ra, int32_t rb) -> int32_t {
         int32_t keep = ra, drop = rb;
-        if (nbrs[keep].size() < nbrs[drop].size()) std::swap(keep, drop);
-        std::vector<int32_t> &kl = nbrs[keep], &dl = nbrs[drop];
-        // (find() of the neighbours BEFORE the link: keep and drop are still both roots)
-        for (int32_t x : dl) {
-            const int32_t p = dsu.find(x);
-            if (p == keep || p == drop) continue;          // becomes internal
-            mutex.erase(key(drop, p));
-            if (mutex.insert(key(keep, p))) kl.push_back(p);
+        if (n_nbrs[keep] < n_nbrs[drop]) std::swap(keep, drop);
+        if (n_nbrs[drop]) {
+            std::vector<int32_t> &kl = nbrs[keep], &dl = nbrs[drop];
+            // (find() of the neighbours BEFORE the link: keep and drop are still both roots)
+            for (int32_t x : dl) {
+                const int32_t p = dsu.find(x);
+                if (p == keep || p == drop) continue;          // becomes internal
+                mutex.erase(key(drop, p));
+                if (mutex.insert(key(keep, p))) kl.push_back(p);
+            }
+            mutex.erase(key(keep, drop));
+            std::vector<int32_t>().swap(dl);
+            n_nbrs[keep] = (int32_t)kl.size();
+            n_nbrs[drop] = 0;
         }
-        mutex.erase(key(keep, drop));
-        std::vector<int32_t>().swap(dl);
         dsu.parent[drop] = keep;
         return keep;
     };
@@ -154,10 +162,12 @@ void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N,
             const int32_t c0 = cc_of_root[r0], c1 = cc_of_root[r1];
             if (c0 == 0 && c1 == 0) {
                 // both unassigned (:36-42): a new component, id = max id in use + 1
-                const int32_t id = (in_use.empty() ? 0 : *in_use.rbegin()) + 1;
+                while (max_alive > 0 && !alive[(size_t)max_alive]) --max_alive;
+                const int32_t id = max_alive + 1;
                 const int32_t r = r0 != r1 ? unite(r0, r1) : r0;
                 cc_of_root[r] = id;
-                in_use.insert(id);
+                alive[(size_t)id] = 1;
+                max_alive = id;
                 if (!ever[(size_t)id]) { ever[(size_t)id] = 1; created.push_back(id); }
             } else if (c0 == 0 || c1 == 0) {
                 // the unassigned node joins unless a mutex edge links it to the component (:44-56)
@@ -170,13 +180,15 @@ void watershed(const int32_t *eu, const int32_t *ev, int64_t n_edges, int32_t N,
                 if (!has_mutex(r0, r1)) {
                     const int32_t keep = std::min(c0, c1), drop = std::max(c0, c1);
                     cc_of_root[unite(r0, r1)] = keep;
-                    in_use.erase(drop);
+                    alive[(size_t)drop] = 0;
                 }
             }
         } else if (r0 != r1) {                            // repulsive (:76-77)
             if (mutex.insert(key(r0, r1))) {
                 nbrs[r0].push_back(r1);
                 nbrs[r1].push_back(r0);
+                ++n_nbrs[r0];
+                ++n_nbrs[r1];
             }
         }
     }
