@@ -111,6 +111,47 @@ def gather_lists(comm, t):
     return [allp[r, :lens[r]] for r in range(comm.world)]
 
 
+def rows_by_tile(rows, tiles):
+    """{tile number: indices (ascending) of the pair rows whose patch A lies in that tile} in ONE
+    pass over the list -- tile number of A per row (the tiles of a rank are a grid: per-axis
+    position among the sorted cuts), one stable sort by it, a slice per tile -- instead of a scan of
+    the whole list for every tile (6.8 s of 640 scans over 319 M rows at 1024^3).  None when the
+    tiles are not a gap-free grid (the caller scans then)."""
+    import torch
+    dev = rows.device
+    n_rows = int(rows.shape[0])
+    cuts = [sorted(set(t[2 * a] for t in tiles)) for a in range(3)]
+    tile_ends = [max(t[2 * a + 1] for t in tiles) for a in range(3)]
+    grid_index = {}
+    for n_t, t in enumerate(tiles):
+        cell = 0
+        for a in range(3):
+            nxt = cuts[a].index(t[2 * a]) + 1
+            if t[2 * a + 1] != (cuts[a][nxt] if nxt < len(cuts[a]) else tile_ends[a]):
+                return None
+            cell = cell * len(cuts[a]) + nxt - 1
+        grid_index[cell] = n_t
+    if len(grid_index) != len(tiles):
+        return None
+    tid = torch.zeros((n_rows,), dtype=torch.int64, device=dev)
+    inside = torch.ones((n_rows,), dtype=torch.bool, device=dev)
+    for a in range(3):
+        coord = rows[:, a].to(torch.int64)
+        bounds = torch.tensor(cuts[a], dtype=torch.int64, device=dev)
+        pos = torch.searchsorted(bounds, coord, right=True) - 1
+        inside &= (pos >= 0) & (coord < tile_ends[a])
+        tid = tid * len(cuts[a]) + pos.clamp_(min=0)
+        del coord, pos, bounds
+    tid[~inside] = -1
+    order = torch.argsort(tid, stable=True)
+    sorted_tid = tid[order]
+    cells = sorted(grid_index)
+    keys = torch.tensor(cells, dtype=torch.int64, device=dev)
+    seg_a = torch.searchsorted(sorted_tid, keys, right=False).cpu().tolist()
+    seg_b = torch.searchsorted(sorted_tid, keys, right=True).cpu().tolist()
+    return {grid_index[c]: order[a:b] for c, a, b in zip(cells, seg_a, seg_b)}
+
+
 class TorchDistComm:
     """torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU)."""
 
@@ -1159,15 +1200,22 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     # pair affinities, each pair on the rank / tile that owns patch A
     aff = None if state is not None else torch.zeros((n_rows,), dtype=torch.float32, device=dev)
     with backend.host_timer("s5_patch_graph"):
-        for t in (my_tiles if state is None else []):
+        rows_of_tile = None
+        if state is None and len(my_tiles) > 1:
+            with backend.host_timer("s5a_select_rows"):
+                rows_of_tile = rows_by_tile(rows, my_tiles)
+        for n_t, t in enumerate(my_tiles if state is None else []):
             z0, z1, y0, y1, x0, x1 = t
             with backend.host_timer("s5a_select_rows"):
-                own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
-                if ny_t > 1 or nx_t > 1:
-                    own &= (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
-                           (rows[:, 2] >= x0) & (rows[:, 2] < x1)
-                idx = torch.nonzero(own).reshape(-1)
-                del own
+                if rows_of_tile is not None:
+                    idx = rows_of_tile.pop(n_t)
+                else:
+                    own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
+                    if ny_t > 1 or nx_t > 1:
+                        own &= (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
+                               (rows[:, 2] >= x0) & (rows[:, 2] < x1)
+                    idx = torch.nonzero(own).reshape(-1)
+                    del own
                 if idx.numel() == 0:
                     continue
             with backend.host_timer("s5b_consensus"):

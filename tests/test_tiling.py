@@ -629,3 +629,19 @@ def test_communicator_moves_types_rccl_has_no_element_type_for(tmp_path):
                            "--master-addr", "127.0.0.1", "--master-port", "29597", str(script)], env=env, timeout=300)
     for r in range(2):
         assert np.load(tmp_path / ("comm_rank%d.npy" % r)).all(), "rank %d" % r
+
+
+def test_rows_by_tile_equals_a_scan_per_tile():
+    """tiling.rows_by_tile: one sort instead of a scan of the pair list per tile -- same indices,
+    ascending, for a slab x (y, x) grid; None for tiles with gaps (the caller scans then)."""
+    import torch
+    from patchperpix_amd import tiling
+    rng = np.random.default_rng(0)
+    rows = torch.from_numpy(rng.integers(0, [20, 30, 40, 20, 30, 40], size=(5000, 6)).astype(np.int32))
+    tiles = [(z0, z1) + t for (z0, z1) in [(4, 8), (8, 20)] for t in tiling.plan_yx(30, 40, 2, 3)]
+    m = tiling.rows_by_tile(rows, tiles)
+    for n, (z0, z1, y0, y1, x0, x1) in enumerate(tiles):
+        own = (rows[:, 0] >= z0) & (rows[:, 0] < z1) & (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
+              (rows[:, 2] >= x0) & (rows[:, 2] < x1)
+        assert torch.equal(torch.nonzero(own).reshape(-1), m[n])
+    assert tiling.rows_by_tile(rows, [(0, 8, 0, 30, 0, 40), (10, 20, 0, 30, 0, 40)]) is None
