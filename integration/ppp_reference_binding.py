@@ -139,3 +139,51 @@ def computePatchGraph_cuda(pred_affs, consensus_vote_array, selected_patch_pairs
     _check(_lib.ppp_patch_graph(_ptr(pred_affs), PPP_F32, _ptr(consensus_vote_array), _ptr(pairs), None,
                                 n, _ptr(aff), ctypes.byref(P), None))
     return aff
+
+
+# ---- the cuda=False stages (int16 votes, integer ranks, all-pairs graph weights) ------------------
+# The reference's signatures take Python sets / the lookup table; a maintainer keeps the call sites
+# and passes the arrays the sets were made from (pred_affs, foreground): the device kernels form the
+# sets themselves (get_patch_sets.py:32-79), so fillLookup / computeFGBGsets are no longer called.
+def _ref_plane_index(patchshape):
+    """index into the reference's vote array (offset linearised over neighshape,
+    utilVoteInstances.py:36-44) of every plane of the device layout (plane 0 = zero offset)"""
+    ps = [int(p) for p in patchshape]
+    ns1, ns2 = 2 * ps[1], 2 * ps[2]
+    idx = [0]
+    for dz in range(0, ps[0]):
+        for dy in range(-(ps[1] - 1), ps[1]):
+            for dx in range(-(ps[2] - 1), ps[2]):
+                if (dz, dy, dx) > (0, 0, 0):
+                    idx.append(dz * ns1 * ns2 + dy * ns2 + dx)
+    return np.array(idx, dtype=np.int64)
+
+
+def create_consensus_array(pred_affs, foreground, shape, patchshape, neighshape):
+    """consensus_array.py:18-68 -> the reference's array: int16 (prod(neighshape), Z, Y, X) on the
+    host (the offset lists it also returned only fed its own rank_patches)."""
+    P = params_from_flags(shape, patchshape, patch_threshold=create_consensus_array.patch_threshold)
+    _lib.ppp_np_vote_planes.restype = ctypes.c_int64
+    planes = int(_lib.ppp_np_vote_planes(ctypes.byref(P)))
+    fg = torch.as_tensor(np.ascontiguousarray(foreground).astype(np.uint8), device="cuda")
+    votes = torch.empty((planes,) + tuple(shape), dtype=torch.int16, device="cuda")
+    _check(_lib.ppp_np_consensus(_ptr(pred_affs), PPP_F32, _ptr(fg), _ptr(votes), ctypes.byref(P), None))
+    full = np.zeros((int(np.prod(neighshape)),) + tuple(shape), dtype=np.int16)
+    full[_ref_plane_index(patchshape)] = votes.cpu().numpy()
+    return full, votes
+
+
+create_consensus_array.patch_threshold = 0.9       # kwargs['patch_threshold'] at the call site
+
+
+def rank_patches(pred_affs, foreground, votes_dev, all_patches_idx, patchshape):
+    """ranked_patches.py:76-105: [(idx, score), ...] sorted like the reference's list"""
+    shape = tuple(pred_affs.shape[1:])
+    P = params_from_flags(shape, patchshape, patch_threshold=create_consensus_array.patch_threshold)
+    fg = torch.as_tensor(np.ascontiguousarray(foreground).astype(np.uint8), device="cuda")
+    score = torch.empty(shape, dtype=torch.int32, device="cuda")
+    _check(_lib.ppp_np_rank_patches(_ptr(pred_affs), PPP_F32, _ptr(fg), _ptr(votes_dev), _ptr(score),
+                                    ctypes.byref(P), None))
+    s = score.cpu().numpy()
+    ranked = [(np.asarray(idx), int(s[tuple(idx)])) for idx in all_patches_idx]
+    return sorted(ranked, key=lambda x: x[1], reverse=True)
