@@ -145,7 +145,11 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt, const
             if (used(kx, jg + g)) {
                 if constexpr (PPP_S1V3_SPLIT(PX)) {
                     const v2f t2 = bt2[(jg + g) * NC - kx];
+#ifdef PPP_S1_ABL_NOCODEREAD
+                    b[g] = (v4f){t2.x, t2.y, __uint_as_float(0x00010001u), 0.0f};   // (timing experiment: 8 bytes per pair)
+#else
                     b[g] = (v4f){t2.x, t2.y, __uint_as_float(ct[(jg + g) * NC - kx]), 0.0f};
+#endif
                 } else {
 #ifdef PPP_S1_ABL_NOLDS
                     b[g] = (v4f){t.x * 0.9f, t.y * 0.8f, __uint_as_float(0x00010001u), 0.0f};   // (timing experiment)
