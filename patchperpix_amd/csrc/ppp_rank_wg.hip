@@ -66,7 +66,10 @@ namespace ppp {
 #define PPP_RW_ZRUNS(PX) ((PX) == 9)
 #endif
 static constexpr int RW_PAD = 8;
-static constexpr int RW_WAVES = 4;
+#ifndef PPP_RW_WAVES
+#define PPP_RW_WAVES 4
+#endif
+static constexpr int RW_WAVES = PPP_RW_WAVES;     // waves per workgroup (a power of two)
 // Mask words per centre, padded to whole 16-byte loads.  The masks are stored CENTRE-MAJOR,
 // M[centre][word]: a lane reads the 184 bytes of ITS centre with twelve 16-byte loads, and the
 // centres of a wave's chunk (9-runs of x neighbours) cover their cache lines densely.  The earlier
@@ -213,8 +216,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
         return ((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0)) * sX + (c0x + lx - sb.x0);
     };
     // coefficient table: entry e -> four float16 {+2^-5 (P bit), -2^-5 (N bit), 0}
-    {
-        const int e = tid;   // NTHR == 256
+    for (int e = tid; e < 256; e += NTHR) {
         uint32_t h[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[i] = ((e >> i) & 1) ? 0x2800u : (((e >> (4 + i)) & 1) ? 0xA800u : 0u);
