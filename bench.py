@@ -559,6 +559,16 @@ def main():
         backend.HOST_TIMES = None
         warm_done = 1
         planned = t_first * (args.steps + args.warmup)
+        if planned > budget_s and planned < 1.3 * budget_s and args.warmup >= 2:
+            # borderline: the first step also pays first-touch costs (the pooled buffers, library
+            # handles); time a second warm-up step before giving the headline workload up
+            t1 = time.perf_counter()
+            inst = wl.step()
+            barrier()
+            t_second = agree_max(time.perf_counter() - t1)
+            warm_done = 2
+            planned = t_first + t_second * (args.steps + args.warmup - 1)
+            t_first = min(t_first, t_second)
         if planned > budget_s:
             config2 = {
                 "workload": wl.name, "volume": list(wl.gshape), "patchshape": list(wl.ps),
