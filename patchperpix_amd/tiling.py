@@ -1282,12 +1282,31 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 inst_g[z0 - gz0:z1 - gz0] = inst_l[z0 - lo:z1 - lo]
                 del inst_l
         else:
+            # nodes sorted by z once: a tile looks at the nodes of its own z-range (+ radius) only
+            # instead of scanning the whole list (640 tiles x 3.6 M nodes at 1024^3); the painting
+            # keeps the largest label per voxel, so the order of the nodes does not matter
+            if len(my_tiles) > 1 and lab_nodes.shape[0] > 0:
+                z_order = torch.argsort(lab_nodes[:, 0].contiguous(), stable=True)
+                lab_nodes, labels = lab_nodes[z_order].contiguous(), labels[z_order].contiguous()
+                node_z = lab_nodes[:, 0].contiguous()
+                del z_order
+            else:
+                node_z = None
             for t in my_tiles:
                 z0, z1, y0, y1, x0, x1 = t
-                near = (lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)
-                near &= (lab_nodes[:, 1] >= y0 - int(rad[1])) & (lab_nodes[:, 1] < y1 + int(rad[1]))
-                near &= (lab_nodes[:, 2] >= x0 - int(rad[2])) & (lab_nodes[:, 2] < x1 + int(rad[2]))
-                near = torch.nonzero(near).reshape(-1)
+                if node_z is not None:
+                    za = int(torch.searchsorted(node_z, torch.tensor([z0 - rz], dtype=node_z.dtype, device=dev)).item())
+                    zb = int(torch.searchsorted(node_z, torch.tensor([z1 + rz], dtype=node_z.dtype, device=dev)).item())
+                    part = lab_nodes[za:zb]
+                    near = (part[:, 1] >= y0 - int(rad[1])) & (part[:, 1] < y1 + int(rad[1]))
+                    near &= (part[:, 2] >= x0 - int(rad[2])) & (part[:, 2] < x1 + int(rad[2]))
+                    near = torch.nonzero(near).reshape(-1) + za
+                    del part
+                else:
+                    near = (lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)
+                    near &= (lab_nodes[:, 1] >= y0 - int(rad[1])) & (lab_nodes[:, 1] < y1 + int(rad[1]))
+                    near &= (lab_nodes[:, 2] >= x0 - int(rad[2])) & (lab_nodes[:, 2] < x1 + int(rad[2]))
+                    near = torch.nonzero(near).reshape(-1)
                 if near.numel() == 0:
                     continue
                 nxt = next_of(t)
