@@ -115,8 +115,13 @@ def candidate_rows(selected_sorted, overlap_mask, patchshape, include_single):
     ps = np.array([int(p) for p in patchshape])
     ov = overlap_mask[tuple(sel.T)] > 0 if n else np.zeros(0, bool)
     rows = []
+    # the list is sorted by x: partners of r1 end where x exceeds x1 + px (when it really is
+    # sorted -- any other list is scanned to its end)
+    xs = sel[:, 2] if n else np.zeros(0, np.int64)
+    x_sorted = bool(np.all(xs[1:] >= xs[:-1])) if n > 1 else True
     for r1 in range(n):
-        r2 = np.arange(r1 if include_single else r1 + 1, n)
+        end = int(np.searchsorted(xs, xs[r1] + ps[2], side="right")) if x_sorted else n
+        r2 = np.arange(r1 if include_single else r1 + 1, end)
         if len(r2) == 0:
             continue
         keep = ~np.any(np.abs(sel[r2] - sel[r1]) > ps, axis=1)
