@@ -64,26 +64,8 @@ template <int PX> struct PaCfg {
     // (29 % of the issued instructions on the thinned 140^3 volume), and the 11 KB of B-patch
     // bits they reserve cap the CU at 8 workgroups.  One or two waves: 11.6 KB -> 13 per CU, and
     // a register budget without spills.
-#ifndef PPP_PA_THREADS_SMALL9
-#define PPP_PA_THREADS_SMALL9 128
-#endif
-#ifndef PPP_PA_ROWS_SMALL9
-#define PPP_PA_ROWS_SMALL9 128
-#endif
-#ifndef PPP_PA_MINWAVES_SMALL9
-#define PPP_PA_MINWAVES_SMALL9 2
-#endif
-    static constexpr int THREADS_SMALL = PX >= 25 ? 64 : (PX >= 9 ? PPP_PA_THREADS_SMALL9 : 64);
-    static constexpr int MIN_WAVES_SMALL = PX >= 25 ? 1 : (PX >= 9 ? PPP_PA_MINWAVES_SMALL9 : 4);
-    // pair rows per workgroup (<= threads).  Fewer rows than threads: the rows are SPREAD over the
-    // workgroup's waves in contiguous runs (the rows of a patch are sorted by offset, so a run
-    // spans a narrow range of dz / dy and its wave walks a smaller union of candidate rows)
-    static constexpr int ROWS = THREADS;
-    static constexpr int ROWS_SMALL = PX >= 9 && PX < 25 ? PPP_PA_ROWS_SMALL9 : THREADS_SMALL;
-#ifndef PPP_PA_SPREAD
-#define PPP_PA_SPREAD 0
-#endif
-    static constexpr bool SPREAD = PPP_PA_SPREAD != 0;
+    static constexpr int THREADS_SMALL = PX >= 25 ? 64 : (PX >= 9 ? 128 : 64);
+    static constexpr int MIN_WAVES_SMALL = PX >= 25 ? 1 : (PX >= 9 ? 2 : 4);
 };
 static constexpr int PA_PAD = 8;       // floats of slack either side of the staged row (a masked row read overshoots by < PX)
 
@@ -118,18 +100,15 @@ __device__ __forceinline__ AxisMasks axis_masks(int dd, int a, int p) {
     return m;
 }
 
-template <typename T, int PX, bool SMALL>
-__global__ void __launch_bounds__(SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::THREADS,
-                                  SMALL ? PaCfg<PX>::MIN_WAVES_SMALL : PaCfg<PX>::MIN_WAVES)
+template <typename T, int PX, int PA_THREADS>
+__global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ? PaCfg<PX>::MIN_WAVES
+                                                                               : PaCfg<PX>::MIN_WAVES_SMALL)
     patch_graph_pa_kernel(const T *__restrict__ pred, const float *__restrict__ S,
                           const uint32_t *__restrict__ rows, const uint32_t *__restrict__ order,
                           const long long *__restrict__ group_start,
                           const long long *__restrict__ chunk_offsets, const int n_groups,
                           float *__restrict__ aff, const Geo G) {
     extern __shared__ uint32_t lds_raw[];
-    constexpr int PA_THREADS = SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::THREADS;
-    constexpr int PA_ROWS = SMALL ? PaCfg<PX>::ROWS_SMALL : PaCfg<PX>::ROWS;
-    static_assert(PA_ROWS <= PA_THREADS, "a pair row needs a lane");
     const int tid = threadIdx.x, lane = tid & 63;
     const int words = (G.C + 31) / 32;
     const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
@@ -139,7 +118,7 @@ __global__ void __launch_bounds__(SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::
     constexpr int ROW_BUFS = PaCfg<PX>::ROW_BUFS;
     float *rowbuf = reinterpret_cast<float *>(lds_raw);           // [ROW_BUFS][WB]
     uint32_t *faw = lds_raw + ROW_BUFS * WB;                      // [words]
-    uint32_t *fbw = faw + ((words + 3) & ~3);                     // [words][PA_ROWS]
+    uint32_t *fbw = faw + ((words + 3) & ~3);                     // [words][PA_THREADS]
 
     // ---- The range / intersection / stored conditions of a whole (y2o, x2o) candidate plane
     // are evaluated at once as bit masks, bit (y2o - y_first) * PX + x2o, for chunks of RPC rows
@@ -184,19 +163,8 @@ __global__ void __launch_bounds__(SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::
         g = lo;
     }
     const long long gs = group_start[g], ge = group_start[g + 1];
-    // slot = this lane's pair row inside the workgroup's chunk of PA_ROWS rows
-    const long long chunk0 = gs + (long long)(blockIdx.x - chunk_offsets[g]) * PA_ROWS;
-    int slot = tid;
-    bool live = tid < PA_ROWS && chunk0 + tid < ge;
-    if constexpr (PaCfg<PX>::SPREAD && PA_THREADS > 64) {
-        constexpr int NWV = PA_THREADS / 64;
-        const int n_here = (int)min((long long)PA_ROWS, ge - chunk0);
-        const int per = (n_here + NWV - 1) / NWV;          // <= 64
-        slot = (tid >> 6) * per + lane;
-        live = lane < per && slot < n_here;
-    }
-    const long long pos = chunk0 + slot;
-    if (!live) slot = 0;                                   // (reads of idle lanes: any column)
+    const long long pos = gs + (long long)(blockIdx.x - chunk_offsets[g]) * PA_THREADS + tid;
+    const bool live = pos < ge;
     const uint32_t first_row = order[gs];
     const int az = (int)rows[(size_t)first_row * 6 + 0], ay = (int)rows[(size_t)first_row * 6 + 1],
               ax = (int)rows[(size_t)first_row * 6 + 2];
@@ -240,8 +208,10 @@ __global__ void __launch_bounds__(SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::
                                 ldf(pred, (long long)r * G.V + lb) > G.th_gt;
                 bits |= (on ? 1u : 0u) << b;
             }
-            fbw[w * PA_ROWS + slot] = bits;
+            fbw[w * PA_THREADS + tid] = bits;
         }
+    } else {
+        for (int w = 0; w < words; ++w) fbw[w * PA_THREADS + tid] = 0u;
     }
     __syncthreads();
     // the pixels of A that are in F_A are walked in raster order straight off the bit words
@@ -388,9 +358,9 @@ __global__ void __launch_bounds__(SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::
                     {
                         const int nb = c_rows * PX;
                         const int o = (z2o * G.py + c_first) * PX, w0 = o >> 5, sh = o & 31;
-                        const uint32_t lo = fbw[w0 * PA_ROWS + slot];
-                        const uint32_t mi = w0 + 1 < words ? fbw[(w0 + 1) * PA_ROWS + slot] : 0u;
-                        const uint32_t hi = w0 + 2 < words ? fbw[(w0 + 2) * PA_ROWS + slot] : 0u;
+                        const uint32_t lo = fbw[w0 * PA_THREADS + tid];
+                        const uint32_t mi = w0 + 1 < words ? fbw[(w0 + 1) * PA_THREADS + tid] : 0u;
+                        const uint32_t hi = w0 + 2 < words ? fbw[(w0 + 2) * PA_THREADS + tid] : 0u;
                         valid = (M)(((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull));
                         valid &= nb >= (int)(8 * sizeof(M)) ? (M)~(M)0 : (M)(((M)1 << nb) - (M)1);
                     }
@@ -518,38 +488,26 @@ extern "C" void ppp_pa_stats(unsigned long long *out) {
 
 int patch_graph_pa_chunk(const Geo &G, bool small) {
     switch (G.px) {
-    case 3: return small ? PaCfg<3>::ROWS_SMALL : PaCfg<3>::ROWS;
-    case 5: return small ? PaCfg<5>::ROWS_SMALL : PaCfg<5>::ROWS;
-    case 7: return small ? PaCfg<7>::ROWS_SMALL : PaCfg<7>::ROWS;
-    case 9: return small ? PaCfg<9>::ROWS_SMALL : PaCfg<9>::ROWS;
-    case 25: return G.pz == 1 ? (small ? PaCfg<25>::ROWS_SMALL : PaCfg<25>::ROWS) : 0;   // 2-d only
-    }
-    return 0;
-}
-
-static int patch_graph_pa_threads(const Geo &G, bool small) {
-    switch (G.px) {
     case 3: return small ? PaCfg<3>::THREADS_SMALL : PaCfg<3>::THREADS;
     case 5: return small ? PaCfg<5>::THREADS_SMALL : PaCfg<5>::THREADS;
     case 7: return small ? PaCfg<7>::THREADS_SMALL : PaCfg<7>::THREADS;
     case 9: return small ? PaCfg<9>::THREADS_SMALL : PaCfg<9>::THREADS;
-    case 25: return small ? PaCfg<25>::THREADS_SMALL : PaCfg<25>::THREADS;
+    case 25: return G.pz == 1 ? (small ? PaCfg<25>::THREADS_SMALL : PaCfg<25>::THREADS) : 0;   // 2-d only
     }
     return 0;
 }
 
-template <typename T, int PX, bool SMALL>
+template <typename T, int PX, int THREADS>
 static hipError_t launch_pa(const T *pred, const float *S, const uint32_t *rows, const uint32_t *order,
                             const long long *group_start, const long long *chunk_offsets, int n_groups,
                             long long n_blocks, float *aff, const Geo &G, size_t lds, hipStream_t s) {
     // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
-    constexpr int THREADS = SMALL ? PaCfg<PX>::THREADS_SMALL : PaCfg<PX>::THREADS;
     if (lds > 64 * 1024) {
-        hipError_t ea = hipFuncSetAttribute((const void *)patch_graph_pa_kernel<T, PX, SMALL>,
+        hipError_t ea = hipFuncSetAttribute((const void *)patch_graph_pa_kernel<T, PX, THREADS>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return ea;
     }
-    patch_graph_pa_kernel<T, PX, SMALL><<<dim3((unsigned)n_blocks), dim3(THREADS), lds, s>>>(
+    patch_graph_pa_kernel<T, PX, THREADS><<<dim3((unsigned)n_blocks), dim3(THREADS), lds, s>>>(
         pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, G);
     return hipGetLastError();
 }
@@ -559,11 +517,10 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
                                  const long long *chunk_offsets, int n_groups, long long n_blocks,
                                  int chunk, float *aff, const Geo &G, hipStream_t s) {
     if (n_groups <= 0 || n_blocks <= 0) return hipSuccess;
-    // chunk = pair rows per workgroup: one of the two configurations of patch_graph_pa_chunk
-    if (chunk == 0 || (chunk != patch_graph_pa_chunk(G, false) && chunk != patch_graph_pa_chunk(G, true)))
+    const int threads = chunk;
+    if (threads == 0 || (threads != patch_graph_pa_chunk(G, false) && threads != patch_graph_pa_chunk(G, true)))
         return hipErrorNotSupported;
-    const bool small = chunk != patch_graph_pa_chunk(G, false);
-    const int threads = patch_graph_pa_threads(G, small);
+    const bool small = threads != patch_graph_pa_chunk(G, false);
     const int words = (G.C + 31) / 32;
     const int W = (2 * G.pz - 1) * G.wy * G.wx;
     const int WB = (W + 2 * PA_PAD + 3) & ~3;
@@ -573,16 +530,16 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     // candidate planes are handled as ceil(px / (64 / px)) 64-bit chunks of 64 / px rows
     if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;
     const int row_bufs = G.px >= PPP_PA_SINGLE_BUF_FROM ? 1 : 2;
-    const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + ((words * chunk + 1) & ~1)) * 4;
+    const size_t lds = (size_t)(row_bufs * WB + ((words + 3) & ~3) + ((words * threads + 1) & ~1)) * 4;
     if (lds > 80 * 1024 || n_blocks >= (1ll << 31) || grid_too_big((unsigned long long)n_blocks, threads))
         return hipErrorNotSupported;
 #define PPP_PA_CASE(P)                                                                                  \
     case P:                                                                                             \
         if (dtype == PPP_F16)                                                                           \
-            return small ? launch_pa<__half, P, true>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
-                         : launch_pa<__half, P, false>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s); \
-        return small ? launch_pa<float, P, true>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
-                     : launch_pa<float, P, false>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s);
+            return small ? launch_pa<__half, P, PaCfg<P>::THREADS_SMALL>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
+                         : launch_pa<__half, P, PaCfg<P>::THREADS>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s); \
+        return small ? launch_pa<float, P, PaCfg<P>::THREADS_SMALL>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
+                     : launch_pa<float, P, PaCfg<P>::THREADS>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s);
     switch (G.px) {
         PPP_PA_CASE(3)
         PPP_PA_CASE(5)
