@@ -190,6 +190,30 @@ int ppp_patch_graph_by_patch_chunked(const void *d_pred, int pred_dtype, const f
                                      const int64_t *d_group_start, const int64_t *d_chunk_offsets,
                                      int32_t n_groups, int64_t n_blocks, int32_t chunk, float *d_aff,
                                      const ppp_params *p, void *stream);
+/* The thinning decisions of the patch intersection made beforehand (computePatchGraph.cu:75-86:
+ * the pair's LCG advances on every combination of foreground pixels z1 of A, z2 of B that both
+ * lie in the intersection of the two windows; the decisions depend on the two foreground sets and
+ * the pair's seed only).  For pair rows whose windows intersect, ppp_patch_graph_lcg writes, at
+ * uint64 word d_drop_off[pos] of d_drops (pos = position of the row in d_order), the masks of
+ * DROPPED candidates [intersection pixel of A][intersection plane of B][chunk of candidate rows]:
+ * ppp_patch_graph_lcg_words(dz, dy, dx) words for patch offset B - A (0 = no intersection).
+ *   d_lcg_pos   int64 [n_lcg] positions in d_order of the rows to serve (d_drop_off[pos] >= 0;
+ *               rows of similar offset next to each other run with uniform control flow)
+ *   d_drop_off  int64 [rows in d_order], < 0 = no masks for this row
+ * ppp_patch_graph_by_patch_lcg = ppp_patch_graph_by_patch_chunked that reads those masks and
+ * runs the generator itself only for rows without (d_drop_off/d_drops NULL: for all).  Same bits.
+ * ppp_patch_graph_lcg_words is 0 for every offset when the per-patch kernel of this patch width
+ * does not read masks (px > 7: it runs the generator itself). */
+int64_t ppp_patch_graph_lcg_words(int32_t dz, int32_t dy, int32_t dx, const ppp_params *p);
+int ppp_patch_graph_lcg(const void *d_pred, int pred_dtype, const uint32_t *d_pairs,
+                        const uint32_t *d_order, const int64_t *d_lcg_pos, int64_t n_lcg,
+                        const int64_t *d_drop_off, uint64_t *d_drops, const ppp_params *p, void *stream);
+int ppp_patch_graph_by_patch_lcg(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                                 const uint32_t *d_pairs, const uint32_t *d_order,
+                                 const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                                 int32_t n_groups, int64_t n_blocks, int32_t chunk, float *d_aff,
+                                 const int64_t *d_drop_off, const uint64_t *d_drops,
+                                 const ppp_params *p, void *stream);
 int ppp_patch_graph_by_patch(const void *d_pred, int pred_dtype, const float *d_cons_vm,
                              const uint32_t *d_pairs, const uint32_t *d_order,
                              const int64_t *d_group_start, const int64_t *d_chunk_offsets,

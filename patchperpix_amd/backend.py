@@ -109,6 +109,16 @@ _SIGNATURES = {
                                                         ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                                         ctypes.c_int32, ctypes.c_void_p,
                                                         ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_graph_lcg_words": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                   ctypes.POINTER(Params)]),
+    "ppp_patch_graph_lcg": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_patch_graph_by_patch_lcg": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                                    ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_label_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(Params)]),
     "ppp_label_components": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
@@ -594,11 +604,14 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
         if n_live == 0:
             return aff
         keys, order = keys[:n_live], order[:n_live]
+    dkey = keys & 0x1FFFF                         # patch offset B - A
     keys >>= 18                                   # linear index of patch A
     _, counts = torch.unique_consecutive(keys, return_counts=True)
     del keys
     zero = torch.zeros((1,), dtype=torch.int64, device=pred.device)
     group_start = torch.cat([zero, torch.cumsum(counts, 0)])
+    lcg = _lcg_plan(dkey, Pv)
+    del dkey
     chunk = int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv)))
     if chunk <= 0:
         raise RuntimeError("libppp_mi355x: no per-patch kernel for this patch shape")
@@ -612,13 +625,68 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     n_blocks = int(chunk_offsets[-1].item())
     order32 = order.to(torch.int32)
     del order
+    drop_off = drops = None
+    if lcg is not None:
+        lcg_pos, drop_off, n_words = lcg
+        try:
+            drops = torch.empty((n_words,), dtype=torch.int64, device=pred.device)
+        except torch.OutOfMemoryError:
+            drop_off = None                       # the kernel runs the generator itself
+        if drops is not None:
+            with _timed("patch_graph_lcg"):
+                check(lib().ppp_patch_graph_lcg(
+                    _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(order32),
+                    _dev_ptr(lcg_pos), int(lcg_pos.shape[0]), _dev_ptr(drop_off), _dev_ptr(drops),
+                    ctypes.byref(Pv), _stream()))
+            del lcg_pos
     with _timed("patch_graph"):
-        check(lib().ppp_patch_graph_by_patch_chunked(
+        check(lib().ppp_patch_graph_by_patch_lcg(
             _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
             _dev_ptr(order32), _dev_ptr(group_start.contiguous()),
             _dev_ptr(chunk_offsets.contiguous()), n_groups, n_blocks, chunk, _dev_ptr(aff),
-            ctypes.byref(Pv), _stream()))
+            _dev_ptr(drop_off) if drops is not None else None,
+            _dev_ptr(drops) if drops is not None else None, ctypes.byref(Pv), _stream()))
     return aff
+
+
+def lcg_words(dz, dy, dx, P):
+    """uint64 words of precomputed thinning masks for a pair with patch offset (dz, dy, dx)
+    (ppp_patch_graph_lcg_words as array arithmetic; any integer arrays or scalars)."""
+    nz, ny, nx = P.pz - abs(dz), P.py - abs(dy), P.px - abs(dx)
+    rpc = 64 // P.px
+    nch = (P.px + rpc - 1) // rpc
+    inter = (nz > 0) & (ny > 0) & (nx > 0) & (P.px <= 7)
+    return nz * ny * nx * nz * nch * inter
+
+
+def _lcg_plan(dkey, Pv):
+    """Which dispatched pair rows get their thinning decisions made beforehand (ppp_patch_graph_lcg):
+    those whose windows intersect, as long as the masks fit PPP_PA_LCG_BYTES (default 2 GiB; 0 = the
+    per-patch kernel runs the generator itself; so it does for patch widths whose kernel does not
+    read masks: ppp_patch_graph_lcg_words is 0 then).  dkey: offset code of the dispatched rows
+    (ppp_pair_group_keys).  Returns (positions sorted by patch offset, int64 offsets per dispatched row
+    (-1 = none), total words) or None."""
+    torch = _torch()
+    budget = int(os.environ.get("PPP_PA_LCG_BYTES", str(2 << 30))) // 8
+    if budget <= 0 or int(lib().ppp_patch_graph_lcg_words(0, 0, 0, ctypes.byref(Pv))) <= 0:
+        return None
+    wx, wy = 4 * Pv.px + 1, 4 * Pv.py + 1
+    dx = dkey % wx - 2 * Pv.px
+    dy = (dkey // wx) % wy - 2 * Pv.py
+    dz = dkey // (wx * wy) - 2 * Pv.pz
+    words = lcg_words(dz, dy, dx, Pv)
+    del dx, dy, dz
+    ends = torch.cumsum(words, 0)
+    served = (words > 0) & (ends <= budget)       # a prefix of the intersecting rows
+    drop_off = torch.where(served, ends - words, torch.full_like(ends, -1))
+    pos = torch.nonzero(served).reshape(-1)
+    if int(pos.shape[0]) == 0:
+        return None
+    n_words = int(ends[pos[-1]].item())
+    # lanes of a wave = rows of (nearly) the same patch offset
+    pos = pos[torch.argsort(dkey[pos])]
+    note_add("s5_rows_lcg_beforehand", int(pos.shape[0]))
+    return pos.contiguous(), drop_off.contiguous(), n_words
 
 
 def patch_graph_auto(pred, cons_compact, pairs, P):

@@ -281,11 +281,46 @@ int32_t ppp_patch_graph_by_patch_chunk_small(const ppp_params *p) {
     return ppp::patch_graph_pa_chunk(G, true);
 }
 
+int64_t ppp_patch_graph_lcg_words(int32_t dz, int32_t dy, int32_t dx, const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return 0;
+    return ppp::patch_graph_lcg_words(G, dz, dy, dx);
+}
+
+int ppp_patch_graph_lcg(const void *d_pred, int pred_dtype, const uint32_t *d_pairs,
+                        const uint32_t *d_order, const int64_t *d_lcg_pos, int64_t n_lcg,
+                        const int64_t *d_drop_off, uint64_t *d_drops, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (n_lcg <= 0) return PPP_OK;
+    if (!d_pred || !d_pairs || !d_order || !d_lcg_pos || !d_drop_off || !d_drops)
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_patch_graph_lcg(d_pred, pred_dtype, d_pairs, d_order, (const long long *)d_lcg_pos,
+                                               (long long)n_lcg, (const long long *)d_drop_off,
+                                               (unsigned long long *)d_drops, G, (hipStream_t)stream);
+    if (e == hipErrorNotSupported)
+        return fail(PPP_ERR_UNSUPPORTED, "no per-patch kernel for this patch shape");
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph_lcg");
+}
+
 int ppp_patch_graph_by_patch_chunked(const void *d_pred, int pred_dtype, const float *d_cons_vm,
                                      const uint32_t *d_pairs, const uint32_t *d_order,
                                      const int64_t *d_group_start, const int64_t *d_chunk_offsets,
                                      int32_t n_groups, int64_t n_blocks, int32_t chunk, float *d_aff,
                                      const ppp_params *p, void *stream) {
+    return ppp_patch_graph_by_patch_lcg(d_pred, pred_dtype, d_cons_vm, d_pairs, d_order, d_group_start,
+                                        d_chunk_offsets, n_groups, n_blocks, chunk, d_aff, nullptr, nullptr,
+                                        p, stream);
+}
+
+int ppp_patch_graph_by_patch_lcg(const void *d_pred, int pred_dtype, const float *d_cons_vm,
+                                 const uint32_t *d_pairs, const uint32_t *d_order,
+                                 const int64_t *d_group_start, const int64_t *d_chunk_offsets,
+                                 int32_t n_groups, int64_t n_blocks, int32_t chunk, float *d_aff,
+                                 const int64_t *d_drop_off, const uint64_t *d_drops,
+                                 const ppp_params *p, void *stream) {
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     PPP_TRY(check_dtype(pred_dtype));
@@ -294,11 +329,14 @@ int ppp_patch_graph_by_patch_chunked(const void *d_pred, int pred_dtype, const f
         return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
     if (G.layout != PPP_CONS_VOXEL_MAJOR)
         return fail(PPP_ERR_INVALID_ARG, "ppp_patch_graph_by_patch reads the VOXEL_MAJOR layout");
+    if ((d_drop_off == nullptr) != (d_drops == nullptr))
+        return fail(PPP_ERR_INVALID_ARG, "d_drop_off and d_drops go together");
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_patch_graph_pa(d_pred, pred_dtype, d_cons_vm, d_pairs, d_order,
                                               (const long long *)d_group_start,
                                               (const long long *)d_chunk_offsets, n_groups, n_blocks,
-                                              chunk, d_aff, G, (hipStream_t)stream);
+                                              chunk, d_aff, (const long long *)d_drop_off,
+                                              (const unsigned long long *)d_drops, G, (hipStream_t)stream);
     if (e == hipErrorNotSupported)
         return fail(PPP_ERR_UNSUPPORTED, "no per-patch kernel for this patch shape / chunk size");
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph_by_patch");

@@ -57,7 +57,12 @@ int patch_graph_pa_chunk(const Geo &G, bool small = false);
 hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, const uint32_t *rows,
                                  const uint32_t *order, const long long *group_start,
                                  const long long *chunk_offsets, int n_groups, long long n_blocks,
-                                 int chunk, float *aff, const Geo &G, hipStream_t s);
+                                 int chunk, float *aff, const long long *drop_off,
+                                 const unsigned long long *drops, const Geo &G, hipStream_t s);
+long long patch_graph_lcg_words(const Geo &G, int dz, int dy, int dx);
+hipError_t launch_patch_graph_lcg(const void *pred, int dtype, const uint32_t *rows, const uint32_t *order,
+                                  const long long *lcg_pos, long long n, const long long *drop_off,
+                                  unsigned long long *drops, const Geo &G, hipStream_t s);
 hipError_t launch_label(const uint32_t *pairs, const float *aff, uint64_t n,
                         const uint32_t *nodes, uint64_t n_nodes, uint32_t *node_key, void *work,
                         const Geo &G, hipStream_t s);

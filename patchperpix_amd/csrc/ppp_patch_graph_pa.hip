@@ -65,8 +65,17 @@ template <int PX> struct PaCfg {
     // bits they reserve cap the CU at 8 workgroups.  One or two waves: 11.6 KB -> 13 per CU, and
     // a register budget without spills.
     static constexpr int THREADS_SMALL = PX >= 25 ? 64 : (PX >= 9 ? 128 : 64);
-    static constexpr int MIN_WAVES_SMALL = PX >= 25 ? 1 : (PX >= 9 ? 2 : 4);
+#ifndef PPP_PA_MINWAVES_SMALL9
+#define PPP_PA_MINWAVES_SMALL9 2
+#endif
+    static constexpr int MIN_WAVES_SMALL = PX >= 25 ? 1 : (PX >= 9 ? PPP_PA_MINWAVES_SMALL9 : 4);
 };
+// Patch widths whose per-patch kernel reads thinning masks made beforehand (patch_graph_lcg_kernel).
+// 9^3 does not: its kernel sits at 32 KB of LDS / 166 VGPRs (5 workgroups per CU) and every way
+// of getting the masks to the lanes costs more than the generator did -- loads inside the pixel
+// step wait for the row prefetch too (in-order vmcnt): 1219 -> 1286-1485 ms per 256^3 volume;
+// staged through LDS like the row: a workgroup less per CU, 1770-1900 ms (profiles/r04_z[hij]_*).
+static constexpr int PA_MASKS_MAX_PX = 7;
 static constexpr int PA_PAD = 8;       // floats of slack either side of the staged row (a masked row read overshoots by < PX)
 
 // bits b in [0, n) with lo <= b <= hi
@@ -107,7 +116,8 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                           const uint32_t *__restrict__ rows, const uint32_t *__restrict__ order,
                           const long long *__restrict__ group_start,
                           const long long *__restrict__ chunk_offsets, const int n_groups,
-                          float *__restrict__ aff, const Geo G) {
+                          float *__restrict__ aff, const long long *__restrict__ drop_off,
+                          const unsigned long long *__restrict__ drops, const Geo G) {
     extern __shared__ uint32_t lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int words = (G.C + 31) / 32;
@@ -119,15 +129,15 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
     float *rowbuf = reinterpret_cast<float *>(lds_raw);           // [ROW_BUFS][WB]
     uint32_t *faw = lds_raw + ROW_BUFS * WB;                      // [words]
     uint32_t *fbw = faw + ((words + 3) & ~3);                     // [words][PA_THREADS]
+    typedef unsigned long long u64;
+    constexpr int RPC = 64 / PX;                         // candidate rows per 64-bit chunk
+    constexpr int NCH = (PX + RPC - 1) / RPC;            // chunks (the launcher checks py <= NCH * RPC)
 
     // ---- The range / intersection / stored conditions of a whole (y2o, x2o) candidate plane
     // are evaluated at once as bit masks, bit (y2o - y_first) * PX + x2o, for chunks of RPC rows
     // (one chunk unless PX = 9).  Per-axis masks are expanded once per pixel row / pixel: EY*
     // repeat a y bit over the PX bits of its row, RX repeats the x mask in every row.
-    typedef unsigned long long u64;
     constexpr uint32_t RM = (1u << PX) - 1u;
-    constexpr int RPC = 64 / PX;                         // candidate rows per 64-bit chunk
-    constexpr int NCH = (PX + RPC - 1) / RPC;            // chunks (the launcher checks py <= NCH * RPC)
     auto expand_y = [&](uint32_t m, int c) -> u64 {
         u64 e = 0;
         for (int j = 0; j < RPC; ++j) e |= ((m >> (c * RPC + j)) & 1u) ? ((u64)RM << (PX * j)) : 0ull;
@@ -190,7 +200,12 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
     uint32_t row_id = 0;
     int dz = 1 << 20, dy = 1 << 20, dx = 1 << 20;      // idle lanes: every mask comes out empty
     uint32_t rnd = 0;
+    // thinning decisions made beforehand by patch_graph_lcg_kernel (below): position of this
+    // pair's masks in `drops`, < 0 = none (this kernel runs the LCG itself)
+    constexpr bool MASKS = PX <= PA_MASKS_MAX_PX;
+    long long soff = -1;
     if (live) {
+        if (MASKS && drops != nullptr) soff = drop_off[pos];
         row_id = order[pos];
         const uint32_t *rw = rows + (size_t)row_id * 6;
         const int bz = (int)rw[3], by = (int)rw[4], bx = (int)rw[5];
@@ -318,6 +333,14 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
             // (a workgroup table of these masks in LDS, indexed by q0x, was measured: fewer
             // VALU instructions but 4 % slower -- five dependent LDS reads at the head of
             // every pixel step)
+            // this pixel's block of precomputed masks: [i1][plane of the intersection][chunk]
+            long long blk = 0;
+            const bool has_blk = MASKS && soff >= 0 && in_b;
+            if (has_blk) {
+                const int nzl = G.pz - abs(dz), nyl = G.py - abs(dy), nxl = PX - abs(dx);
+                const int i1 = ((z1o - max(dz, 0)) * nyl + (y1o - max(dy, 0))) * nxl + (x1o - max(dx, 0));
+                blk = soff + ((long long)i1 * nzl - max(-dz, 0)) * NCH;   // + z2o * NCH + chunk
+            }
             const AxisMasks mx = axis_masks(dx, x1o, PX);
             const u64 RXf = repeat_x(mx.f), RXbk = repeat_x(mx.bk), RXst = repeat_x(mx.st),
                       RXin = in_b ? repeat_x(mx.in) : 0ull, RXnn = repeat_x(mx.pos | mx.zero),
@@ -364,12 +387,24 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                         valid = (M)(((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull));
                         valid &= nb >= (int)(8 * sizeof(M)) ? (M)~(M)0 : (M)(((M)1 << nb) - (M)1);
                     }
+#ifdef PPP_PA_ABL_NOLCG   // timing experiment only: results are wrong
+                    if (false) {
+#else
                     if (__ballot(inter != (M)0) != 0ull) {
+#endif
                         // thinning inside the patch intersection: the LCG advances on every
-                        // foreground candidate of the intersection, in candidate order
+                        // foreground candidate of the intersection, in candidate order --
+                        // either done beforehand (one mask of dropped candidates per chunk) ...
+                        M lcg_hits = inter & valid;
+                        if (has_blk) {
+                            if (inter != (M)0) valid &= (M) ~((M)drops[blk + z2o * NCH + c] & inter);
+                            lcg_hits = (M)0;
+                        }
+                        // ... or here, for the lanes without precomputed masks
+                        if (__ballot(lcg_hits != (M)0) != 0ull)
                         for (int y2o = ya; y2o <= yb; ++y2o) {
                             const int bp = PX * (y2o - c_first);
-                            const uint32_t hit_row = (uint32_t)((inter & valid) >> bp) & RM;
+                            const uint32_t hit_row = (uint32_t)(lcg_hits >> bp) & RM;
                             if (__ballot(hit_row != 0u) == 0ull) continue;
                             PA_STAT(4, lane == 0 ? 1 : 0);
                             uint32_t drop = 0;
@@ -390,6 +425,10 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                     fg_cnt += sizeof(M) == 8 ? __popcll((u64)(range & valid)) : __popc((uint32_t)(range & valid));
                     const M add = stored & valid;
                     if (__ballot(add != (M)0) == 0ull) return;
+#ifdef PPP_PA_ABL_NOADD   // timing experiment only: results are wrong
+                    if (add != (M)0) acc += 1.0f;
+                    return;
+#endif
                     // this lane's offset into the staged row for candidate (y2o = 0, x2o = 0)
                     const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + q0x;
 // (measured and rejected: 73 -> 79 ms on the thinned list, 540 -> 640 ms on the dense one --
@@ -486,6 +525,180 @@ extern "C" void ppp_pa_stats(unsigned long long *out) {
 }
 #endif
 
+
+// ---- The thinning decisions of the patch intersection, beforehand.
+//
+// computePatchGraph.cu:75-86 advances the pair's LCG (rnd *= 1103515245) on every combination
+// (pixel z1 of A, pixel z2 of B) of foreground pixels that both lie in the intersection of the two
+// windows, in loop order, and drops the combination when rnd / 2^32 > 0.2.  The decisions need
+// the two foreground bit sets and the pair's seed -- not the consensus.  Inside the per-patch
+// kernel above they cost half of its time: ~8 of a wave's 64 pair rows overlap their patch A at
+// all, and the wave walks the union of their candidate rows with nine dependent 32-bit multiplies
+// per row.  Here a lane owns one overlapping pair, the lanes of a wave have (nearly) the same
+// patch offset (the caller sorts them by offset), every lane walks its OWN foreground pixels of A
+// inside the intersection, and the rows of B inside the intersection are the same for the whole
+// wave.  Output per pair: for every intersection pixel i1 of A (raster index inside the
+// intersection box), every plane z2 of the intersection in B's window and every 64-bit chunk of
+// candidate rows of that plane (the chunk layout of the kernel above: bit (y2o - first row) * PX
+// + x2o), the mask of DROPPED candidates.  The kernel above reads one mask per chunk instead of
+// running the generator.
+template <typename T, int PX>
+__global__ void __launch_bounds__(64)
+    patch_graph_lcg_kernel(const T *__restrict__ pred, const uint32_t *__restrict__ rows,
+                           const uint32_t *__restrict__ order, const long long *__restrict__ lcg_pos,
+                           const long long n, const long long *__restrict__ drop_off,
+                           unsigned long long *__restrict__ drops, const Geo G) {
+    typedef unsigned long long u64;
+    extern __shared__ uint32_t lds_raw[];
+    const int lane = threadIdx.x;
+    const int words = (G.C + 31) / 32;
+    uint32_t *fa = lds_raw;                 // [words][64]  F_A inside the intersection (A's window raster)
+    uint32_t *fb = lds_raw + words * 64;    // [words + 2][64]  F_B inside the intersection (B's window raster)
+    constexpr uint32_t RM = (1u << PX) - 1u;
+    constexpr int RPC = 64 / PX;
+    constexpr int NCH = (PX + RPC - 1) / RPC;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    bool live = i < n;
+    long long soff = -1;
+    long long pos = 0;
+    if (live) { pos = lcg_pos[i]; soff = drop_off[pos]; live = soff >= 0; }
+    int az = 0, ay = 0, ax = 0, bz = 0, by = 0, bx = 0;
+    if (live) {
+        const uint32_t *rw = rows + (size_t)order[pos] * 6;
+        az = (int)rw[0]; ay = (int)rw[1]; ax = (int)rw[2];
+        bz = (int)rw[3]; by = (int)rw[4]; bx = (int)rw[5];
+    }
+    const int dz = bz - az, dy = by - ay, dx = bx - ax;
+    // intersection box: n per axis, first window coordinate in A (lo1) and in B (lo2)
+    const int nz = live ? G.pz - abs(dz) : 0, ny = live ? G.py - abs(dy) : 0, nx = live ? PX - abs(dx) : 0;
+    const int z1lo = max(dz, 0), y1lo = max(dy, 0), x1lo = max(dx, 0);
+    const int z2lo = max(-dz, 0), y2lo = max(-dy, 0), x2lo = max(-dx, 0);
+    uint32_t rnd = (uint32_t)(az + G.oz) * (uint32_t)(bz + G.oz) * (uint32_t)(ay + G.oy) *
+                   (uint32_t)(by + G.oy) * (uint32_t)(ax + G.ox) * (uint32_t)(bx + G.ox);
+    for (int w = 0; w < words; ++w) fa[w * 64 + lane] = 0u;
+    for (int w = 0; w < words + 2; ++w) fb[w * 64 + lane] = 0u;
+    {
+        const T *mid = pred + (long long)G.mid * G.V;
+        const long long la = vox(G, az, ay, ax), lb = vox(G, bz, by, bx);
+        const int n_i = nz > 0 && ny > 0 && nx > 0 ? nz * ny * nx : 0;
+        for (int t = 0; t < n_i; ++t) {
+            const int iz = t / (ny * nx), iy = (t / nx) % ny, ix = t % nx;
+            {
+                const int zo = z1lo + iz, yo = y1lo + iy, xo = x1lo + ix;
+                const int r = (zo * G.py + yo) * PX + xo;
+                const bool on = ldf(mid, vox(G, az + zo - G.rz, ay + yo - G.ry, ax + xo - PX / 2)) > G.th_gt &&
+                                ldf(pred, (long long)r * G.V + la) > G.th_gt;
+                if (on) fa[(r >> 5) * 64 + lane] |= 1u << (r & 31);
+            }
+            {
+                const int zo = z2lo + iz, yo = y2lo + iy, xo = x2lo + ix;
+                const int r = (zo * G.py + yo) * PX + xo;
+                const bool on = ldf(mid, vox(G, bz + zo - G.rz, by + yo - G.ry, bx + xo - PX / 2)) > G.th_gt &&
+                                ldf(pred, (long long)r * G.V + lb) > G.th_gt;
+                if (on) fb[(r >> 5) * 64 + lane] |= 1u << (r & 31);
+            }
+        }
+    }
+    // (a lane only touches its own LDS column: no barrier)
+    for (int w = 0; w < words; ++w) {
+        uint32_t m = fa[w * 64 + lane];
+        while (__ballot(m != 0u) != 0ull) {
+            const bool act = m != 0u;
+            const int r1 = w * 32 + (act ? __builtin_ctz(m) : 0);
+            m &= m - 1u;
+            const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
+            const int i1 = ((z1o - z1lo) * ny + (y1o - y1lo)) * nx + (x1o - x1lo);
+            const long long blk = soff + (long long)i1 * nz * NCH;
+            for (int z2o = 0; z2o < G.pz; ++z2o) {
+                const bool inz = act && z2o >= z2lo && z2o < z2lo + nz;
+                if (__ballot(inz) == 0ull) continue;
+#pragma unroll 1
+                for (int c = 0; c < NCH; ++c) {
+                    const int c_first = c * RPC;
+                    const int c_rows = min(RPC, G.py - c_first);
+                    if (c_rows <= 0) break;
+                    u64 hits;
+                    {
+                        const int nb = c_rows * PX;
+                        const int o = (z2o * G.py + c_first) * PX, w0 = o >> 5, sh = o & 31;
+                        const uint32_t lo = fb[w0 * 64 + lane], mi = fb[(w0 + 1) * 64 + lane],
+                                       hi = fb[(w0 + 2) * 64 + lane];
+                        hits = ((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull);
+                        hits &= nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+                        if (!inz) hits = 0ull;
+                    }
+                    u64 drop = 0ull;
+                    if (__ballot(hits != 0ull) != 0ull) {
+                        for (int y = 0; y < c_rows; ++y) {
+                            const uint32_t hit_row = (uint32_t)(hits >> (PX * y)) & RM;
+                            if (__ballot(hit_row != 0u) == 0ull) continue;
+                            uint32_t drow = 0;
+#pragma unroll
+                            for (int t = 0; t < PX; ++t) {
+                                const uint32_t xb = 1u << t;
+                                const uint32_t nxt = rnd * 1103515245U;
+                                const bool hit = (hit_row & xb) != 0u;
+                                rnd = hit ? nxt : rnd;
+                                // (float)nxt / 2^32 > 0.2 in double  <=>  nxt >= 858993441 (see above)
+                                if (hit && nxt >= 858993441u) drow |= xb;
+                            }
+                            drop |= (u64)drow << (PX * y);
+                        }
+                    }
+                    if (inz) drops[blk + (z2o - z2lo) * NCH + c] = drop;
+                }
+            }
+        }
+    }
+}
+
+// u64 words of precomputed masks for a pair with patch offset (dz, dy, dx); 0 = the windows do
+// not intersect
+long long patch_graph_lcg_words(const Geo &G, int dz, int dy, int dx) {
+    const int nz = G.pz - abs(dz), ny = G.py - abs(dy), nx = G.px - abs(dx);
+    if (nz <= 0 || ny <= 0 || nx <= 0 || G.px > PA_MASKS_MAX_PX) return 0;
+    const int rpc = 64 / G.px, nch = (G.px + rpc - 1) / rpc;
+    return (long long)nz * ny * nx * nz * nch;
+}
+
+template <typename T, int PX>
+static hipError_t launch_lcg(const T *pred, const uint32_t *rows, const uint32_t *order, const long long *lcg_pos,
+                             long long n, const long long *drop_off, unsigned long long *drops, const Geo &G,
+                             hipStream_t s) {
+    const int words = (G.C + 31) / 32;
+    const size_t lds = (size_t)(2 * words + 2) * 64 * 4;
+    patch_graph_lcg_kernel<T, PX><<<dim3((unsigned)((n + 63) / 64)), dim3(64), lds, s>>>(
+        pred, rows, order, lcg_pos, n, drop_off, drops, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_patch_graph_lcg(const void *pred, int dtype, const uint32_t *rows, const uint32_t *order,
+                                  const long long *lcg_pos, long long n, const long long *drop_off,
+                                  unsigned long long *drops, const Geo &G, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    // (the shapes the per-patch kernel takes)
+    if (patch_graph_pa_chunk(G, false) == 0 ||
+        G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32)
+        return hipErrorNotSupported;
+    const int words = (G.C + 31) / 32;
+    if ((size_t)(2 * words + 2) * 64 * 4 > 64 * 1024 || grid_too_big((unsigned long long)((n + 63) / 64), 64))
+        return hipErrorNotSupported;
+#define PPP_LCG_CASE(P)                                                                                  \
+    case P:                                                                                              \
+        return dtype == PPP_F16 ? launch_lcg<__half, P>((const __half *)pred, rows, order, lcg_pos, n, drop_off, drops, G, s) \
+                                : launch_lcg<float, P>((const float *)pred, rows, order, lcg_pos, n, drop_off, drops, G, s);
+    switch (G.px) {
+        PPP_LCG_CASE(3)
+        PPP_LCG_CASE(5)
+        PPP_LCG_CASE(7)
+        PPP_LCG_CASE(9)
+        PPP_LCG_CASE(25)
+    default:
+        return hipErrorNotSupported;
+    }
+#undef PPP_LCG_CASE
+}
+
 int patch_graph_pa_chunk(const Geo &G, bool small) {
     switch (G.px) {
     case 3: return small ? PaCfg<3>::THREADS_SMALL : PaCfg<3>::THREADS;
@@ -500,7 +713,8 @@ int patch_graph_pa_chunk(const Geo &G, bool small) {
 template <typename T, int PX, int THREADS>
 static hipError_t launch_pa(const T *pred, const float *S, const uint32_t *rows, const uint32_t *order,
                             const long long *group_start, const long long *chunk_offsets, int n_groups,
-                            long long n_blocks, float *aff, const Geo &G, size_t lds, hipStream_t s) {
+                            long long n_blocks, float *aff, const long long *drop_off,
+                            const unsigned long long *drops, const Geo &G, size_t lds, hipStream_t s) {
     // (dynamic LDS above 64 KB -- the 9^3 rows -- is an opt-in per kernel)
     if (lds > 64 * 1024) {
         hipError_t ea = hipFuncSetAttribute((const void *)patch_graph_pa_kernel<T, PX, THREADS>,
@@ -508,14 +722,15 @@ static hipError_t launch_pa(const T *pred, const float *S, const uint32_t *rows,
         if (ea != hipSuccess) return ea;
     }
     patch_graph_pa_kernel<T, PX, THREADS><<<dim3((unsigned)n_blocks), dim3(THREADS), lds, s>>>(
-        pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, G);
+        pred, S, rows, order, group_start, chunk_offsets, n_groups, aff, drop_off, drops, G);
     return hipGetLastError();
 }
 
 hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, const uint32_t *rows,
                                  const uint32_t *order, const long long *group_start,
                                  const long long *chunk_offsets, int n_groups, long long n_blocks,
-                                 int chunk, float *aff, const Geo &G, hipStream_t s) {
+                                 int chunk, float *aff, const long long *drop_off,
+                                 const unsigned long long *drops, const Geo &G, hipStream_t s) {
     if (n_groups <= 0 || n_blocks <= 0) return hipSuccess;
     const int threads = chunk;
     if (threads == 0 || (threads != patch_graph_pa_chunk(G, false) && threads != patch_graph_pa_chunk(G, true)))
@@ -536,10 +751,10 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
 #define PPP_PA_CASE(P)                                                                                  \
     case P:                                                                                             \
         if (dtype == PPP_F16)                                                                           \
-            return small ? launch_pa<__half, P, PaCfg<P>::THREADS_SMALL>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
-                         : launch_pa<__half, P, PaCfg<P>::THREADS>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s); \
-        return small ? launch_pa<float, P, PaCfg<P>::THREADS_SMALL>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s) \
-                     : launch_pa<float, P, PaCfg<P>::THREADS>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, G, lds, s);
+            return small ? launch_pa<__half, P, PaCfg<P>::THREADS_SMALL>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, drop_off, drops, G, lds, s) \
+                         : launch_pa<__half, P, PaCfg<P>::THREADS>((const __half *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, drop_off, drops, G, lds, s); \
+        return small ? launch_pa<float, P, PaCfg<P>::THREADS_SMALL>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, drop_off, drops, G, lds, s) \
+                     : launch_pa<float, P, PaCfg<P>::THREADS>((const float *)pred, S, rows, order, group_start, chunk_offsets, n_groups, n_blocks, aff, drop_off, drops, G, lds, s);
     switch (G.px) {
         PPP_PA_CASE(3)
         PPP_PA_CASE(5)

@@ -328,3 +328,21 @@ def test_native_mws_on_dense_noisy_graphs(seed):
             for n in cc:
                 lit[int(np.ravel_multi_index(n, shape))] = k + 1
         assert got == lit and n_labels == len(ccs)
+
+
+def test_lcg_mask_words_formula_equals_the_library():
+    """backend.lcg_words (array arithmetic on the device) = ppp_patch_graph_lcg_words: per pair the
+    masks [intersection pixels of A][intersection planes of B][64-bit chunks of a plane]."""
+    import ctypes
+    for ps in [(3, 3, 3), (5, 5, 5), (7, 7, 7), (9, 9, 9), (1, 5, 5), (1, 25, 25), (3, 5, 5)]:
+        P = backend.make_params((40, 60, 60), ps, patch_threshold=0.5)
+        rng = np.random.default_rng(sum(ps))
+        d = rng.integers(-2 * max(ps), 2 * max(ps) + 1, size=(200, 3))
+        d[0] = 0
+        got = backend.lcg_words(d[:, 0], d[:, 1], d[:, 2], P)
+        want = [int(backend.lib().ppp_patch_graph_lcg_words(int(a), int(b), int(c), ctypes.byref(P)))
+                for a, b, c in d]
+        assert got.tolist() == want
+        nch = -(-ps[2] // (64 // ps[2]))
+        # (patch widths above 7: the per-patch kernel runs the generator itself, no masks)
+        assert want[0] == (ps[0] * ps[1] * ps[2] * ps[0] * nch if ps[2] <= 7 else 0)

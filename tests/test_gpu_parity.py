@@ -59,6 +59,15 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
         if P.px in (3, 5, 7, 9) or (P.px == 25 and P.pz == 1):                    # per-patch kernel
             aff4 = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
             assert np.array_equal(out["aff"].view(np.uint32), aff4.view(np.uint32))
+            # ... with the thinning decisions made inside the kernel (no masks beforehand), and
+            # with masks for the first few intersecting rows only
+            for budget in ("0", "4096"):
+                os.environ["PPP_PA_LCG_BYTES"] = budget
+                try:
+                    aff5 = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
+                finally:
+                    del os.environ["PPP_PA_LCG_BYTES"]
+                assert np.array_equal(out["aff"].view(np.uint32), aff5.view(np.uint32)), budget
     return out
 
 
