@@ -651,11 +651,12 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
 
 def lcg_words(dz, dy, dx, P):
     """uint64 words of precomputed thinning masks for a pair with patch offset (dz, dy, dx)
-    (ppp_patch_graph_lcg_words as array arithmetic; any integer arrays or scalars)."""
+    (ppp_patch_graph_lcg_words as array arithmetic, for the patch widths whose kernel reads masks --
+    the library returns 0 for the others; any integer arrays or scalars)."""
     nz, ny, nx = P.pz - abs(dz), P.py - abs(dy), P.px - abs(dx)
     rpc = 64 // P.px
     nch = (P.px + rpc - 1) // rpc
-    inter = (nz > 0) & (ny > 0) & (nx > 0) & (P.px <= 7)
+    inter = (nz > 0) & (ny > 0) & (nx > 0)
     return nz * ny * nx * nz * nch * inter
 
 

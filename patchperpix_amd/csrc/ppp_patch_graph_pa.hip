@@ -70,12 +70,29 @@ template <int PX> struct PaCfg {
 #endif
     static constexpr int MIN_WAVES_SMALL = PX >= 25 ? 1 : (PX >= 9 ? PPP_PA_MINWAVES_SMALL9 : 4);
 };
-// Patch widths whose per-patch kernel reads thinning masks made beforehand (patch_graph_lcg_kernel).
-// 9^3 does not: its kernel sits at 32 KB of LDS / 166 VGPRs (5 workgroups per CU) and every way
-// of getting the masks to the lanes costs more than the generator did -- loads inside the pixel
-// step wait for the row prefetch too (in-order vmcnt): 1219 -> 1286-1485 ms per 256^3 volume;
-// staged through LDS like the row: a workgroup less per CU, 1770-1900 ms (profiles/r04_z[hij]_*).
-static constexpr int PA_MASKS_MAX_PX = 7;
+// Patch widths whose per-patch kernel reads thinning masks made beforehand (patch_graph_lcg_kernel)
+// instead of running the generator: all 3-d widths.  How the masks reach the lanes decides whether
+// that pays (256^3 / 9^3, S5 per volume; profiles/r04_z[h-p]_*): the generator 1219 ms; one 8-byte
+// global load per chunk inside the pixel step 1286-1485 ms -- every s_waitcnt in this kernel is
+// vmcnt(0), so the first mask load of a pixel also waits for the next row's 39 prefetch loads;
+// staged through LDS beside the row (+2.5 KB: one workgroup less per CU) 1770-1900 ms; WITHOUT
+// the register prefetch of the next row (it is loaded after the pixel step: +1.6 % by itself,
+// 39 registers less) and the mask of a chunk requested while the chunk before it is worked on:
+// 1046 + 33 ms for the masks.  7^3 (140^3): 72 -> 48 + 5 ms.  The 25-wide 2-d kernel is not
+// generator-bound (235 -> 230 + 9 ms) and keeps it.
+#ifndef PPP_PA_MASKS_MAX_PX
+#define PPP_PA_MASKS_MAX_PX 9
+#endif
+static constexpr int PA_MASKS_MAX_PX = PPP_PA_MASKS_MAX_PX;
+// experiments: 1 / 0 = the next row loaded after the pixel step / into registers during it for
+// every width (default -1: after the step where masks are read); the mask of a chunk fetched at
+// its use (0) or one chunk ahead (1)
+#ifndef PPP_PA_NO_ROW_PREFETCH
+#define PPP_PA_NO_ROW_PREFETCH -1
+#endif
+#ifndef PPP_PA_MASK_AHEAD
+#define PPP_PA_MASK_AHEAD 1
+#endif
 static constexpr int PA_PAD = 8;       // floats of slack either side of the staged row (a masked row read overshoots by < PX)
 
 // bits b in [0, n) with lo <= b <= hi
@@ -203,6 +220,7 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
     // thinning decisions made beforehand by patch_graph_lcg_kernel (below): position of this
     // pair's masks in `drops`, < 0 = none (this kernel runs the LCG itself)
     constexpr bool MASKS = PX <= PA_MASKS_MAX_PX;
+    constexpr bool NOPF = PPP_PA_NO_ROW_PREFETCH < 0 ? MASKS : PPP_PA_NO_ROW_PREFETCH != 0;
     long long soff = -1;
     if (live) {
         if (MASKS && drops != nullptr) soff = drop_off[pos];
@@ -302,11 +320,13 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
         const bool more = k + 1 < n_u;
         if (more) {
             r_next = next_pixel();
-            const float *src = row_of(r_next);
+            if constexpr (!NOPF) {
+                const float *src = row_of(r_next);
 #pragma unroll
-            for (int i = 0; i < NST; ++i) {
-                const int e = tid + i * PA_THREADS;
-                st[i] = e < W ? src[e] : 0.0f;
+                for (int i = 0; i < NST; ++i) {
+                    const int e = tid + i * PA_THREADS;
+                    st[i] = e < W ? src[e] : 0.0f;
+                }
             }
         }
         // union of the lanes' candidate ranges: -p <= d + b - a <= p (wave-uniform)
@@ -345,16 +365,32 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
             const u64 RXf = repeat_x(mx.f), RXbk = repeat_x(mx.bk), RXst = repeat_x(mx.st),
                       RXin = in_b ? repeat_x(mx.in) : 0ull, RXnn = repeat_x(mx.pos | mx.zero),
                       RXzero = repeat_x(mx.zero);
+#if PPP_PA_MASK_AHEAD
+            // (planes outside the lane's intersection are not fetched)
+            auto fetch = [&](int z, int c) -> u64 {
+                return has_blk && z < G.pz && ((mz.in >> z) & 1u) ? drops[blk + z * NCH + c] : 0ull;
+            };
+            u64 pend = fetch(z_lo, 0);
+#endif
             for (int z2o = z_lo; z2o <= z_hi; ++z2o) {
                 const uint32_t zb = 1u << z2o;
                 const bool z_f = mz.f & zb, z_bk = mz.bk & zb, z_pos = mz.pos & zb, z_zero = mz.zero & zb,
                            z_st = mz.st & zb, z_in = mz.in & zb;
-                if (__ballot(z_f || z_bk || z_in) == 0ull) continue;
+                if (__ballot(z_f || z_bk || z_in) == 0ull) {
+#if PPP_PA_MASK_AHEAD
+                    pend = fetch(z2o + 1, 0);
+#endif
+                    continue;
+                }
                 const int qz = mz.q0 + z2o;
                 // one chunk of candidate rows; M = mask word: 64 bits, or 32 bits for a last
                 // chunk of few rows (9^3: rows 7-8, 18 bits) -- half the mask arithmetic
                 auto chunk = [&](auto mtag, const int c) {
                     using M = decltype(mtag);
+#if PPP_PA_MASK_AHEAD == 1
+                    const u64 dropped = pend;
+                    pend = c + 1 < NCH ? fetch(z2o, c + 1) : fetch(z2o + 1, 0);
+#endif
                     const int c_first = c * RPC;                       // first row of the chunk
                     const int c_rows = min(RPC, G.py - c_first);
                     if (c_rows <= 0) return;
@@ -397,7 +433,11 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                         // either done beforehand (one mask of dropped candidates per chunk) ...
                         M lcg_hits = inter & valid;
                         if (has_blk) {
+#if PPP_PA_MASK_AHEAD == 1
+                            valid &= (M) ~((M)dropped & inter);
+#else
                             if (inter != (M)0) valid &= (M) ~((M)drops[blk + z2o * NCH + c] & inter);
+#endif
                             lcg_hits = (M)0;
                         }
                         // ... or here, for the lanes without precomputed masks
@@ -503,6 +543,14 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
         if (ROW_BUFS == 1) __syncthreads();   // everybody is done reading the only buffer
         if (more) {
             float *dst = rowbuf + (ROW_BUFS == 2 ? ((k + 1) & 1) * WB : 0) + PA_PAD;
+            if constexpr (NOPF) {
+                const float *src = row_of(r_next);
+#pragma unroll
+                for (int i = 0; i < NST; ++i) {
+                    const int e = tid + i * PA_THREADS;
+                    st[i] = e < W ? src[e] : 0.0f;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NST; ++i) {
                 const int e = tid + i * PA_THREADS;
