@@ -203,7 +203,7 @@ int ppp_patch_graph_by_patch_chunked(const void *d_pred, int pred_dtype, const f
  * ppp_patch_graph_by_patch_lcg = ppp_patch_graph_by_patch_chunked that reads those masks and
  * runs the generator itself only for rows without (d_drop_off/d_drops NULL: for all).  Same bits.
  * ppp_patch_graph_lcg_words is 0 for every offset when the per-patch kernel of this patch width
- * does not read masks (px > 7: it runs the generator itself). */
+ * does not read masks (the 25-wide 2-d kernel: it runs the generator itself). */
 int64_t ppp_patch_graph_lcg_words(int32_t dz, int32_t dy, int32_t dx, const ppp_params *p);
 int ppp_patch_graph_lcg(const void *d_pred, int pred_dtype, const uint32_t *d_pairs,
                         const uint32_t *d_order, const int64_t *d_lcg_pos, int64_t n_lcg,

@@ -662,13 +662,14 @@ def lcg_words(dz, dy, dx, P):
 
 def _lcg_plan(dkey, Pv):
     """Which dispatched pair rows get their thinning decisions made beforehand (ppp_patch_graph_lcg):
-    those whose windows intersect, as long as the masks fit PPP_PA_LCG_BYTES (default 2 GiB; 0 = the
-    per-patch kernel runs the generator itself; so it does for patch widths whose kernel does not
+    those whose windows intersect, as long as the masks fit PPP_PA_LCG_BYTES (default 4 GiB -- a tile
+    of the thinned 512^3 / 9^3 cover needs 1.9 GB on average; 0 = the per-patch kernel runs the
+    generator itself; so it does for patch widths whose kernel does not
     read masks: ppp_patch_graph_lcg_words is 0 then).  dkey: offset code of the dispatched rows
     (ppp_pair_group_keys).  Returns (positions sorted by patch offset, int64 offsets per dispatched row
     (-1 = none), total words) or None."""
     torch = _torch()
-    budget = int(os.environ.get("PPP_PA_LCG_BYTES", str(2 << 30))) // 8
+    budget = int(os.environ.get("PPP_PA_LCG_BYTES", str(4 << 30))) // 8
     if budget <= 0 or int(lib().ppp_patch_graph_lcg_words(0, 0, 0, ctypes.byref(Pv))) <= 0:
         return None
     wx, wy = 4 * Pv.px + 1, 4 * Pv.py + 1
