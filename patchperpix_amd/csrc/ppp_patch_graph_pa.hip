@@ -16,9 +16,21 @@
 // for the lexicographic orientation test).  Control flow stays wave-uniform: the (z2o, y2o)
 // candidate rows are walked over the union of the lanes' ranges (the rows of a patch are sorted
 // by offset, so the lanes of a wave have similar ranges), the PX candidates of a row are
-// predicated, and the LCG branch is only entered by waves in which some lane is inside the
-// patch intersection on that row.  The row of the next pixel is fetched into registers while
-// the current one is consumed (two LDS row buffers, one barrier per pixel).
+// predicated.
+//
+// Thinning (computePatchGraph.cu:75-86: inside the intersection of the two windows a candidate is
+// kept with probability 0.2, drawn from the pair's own LCG).  For the 3-d patch widths the
+// decisions are made BEFOREHAND by patch_graph_lcg_kernel (second half of this file: a lane per
+// intersecting pair) and arrive as one 64-bit mask of dropped candidates per chunk of candidate
+// rows; pair rows without masks (2-d 25-wide patches, rows beyond the caller's mask budget) run
+// the generator here, in a branch only entered by waves in which some such lane is inside the
+// intersection on that row.  Same stream, same decisions.
+//
+// The row of the next pixel: where masks are read it is loaded AFTER the pixel step (a global load
+// inside the step waits for everything in flight -- every s_waitcnt here is vmcnt(0) -- so a
+// register prefetch of the row would only move its latency to the first mask load); otherwise it
+// is fetched into registers while the current one is consumed.  One LDS row buffer and two
+// barriers per pixel from 7^3 on, two buffers and one barrier below.
 //
 // The per-pair float sum, the candidate order (r1 raster, then z2o, y2o, x2o ascending) and the
 // LCG stream are exactly those of the reference: results are bit-identical to the other kernels.
