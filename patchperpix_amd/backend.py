@@ -610,8 +610,6 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     del keys
     zero = torch.zeros((1,), dtype=torch.int64, device=pred.device)
     group_start = torch.cat([zero, torch.cumsum(counts, 0)])
-    lcg = _lcg_plan(dkey, Pv)
-    del dkey
     chunk = int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv)))
     if chunk <= 0:
         raise RuntimeError("libppp_mi355x: no per-patch kernel for this patch shape")
@@ -622,30 +620,38 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
         chunk = small
     chunk_offsets = torch.cat([zero, torch.cumsum((counts + chunk - 1) // chunk, 0)])
     n_groups = int(counts.shape[0])
-    n_blocks = int(chunk_offsets[-1].item())
     order32 = order.to(torch.int32)
     del order
-    drop_off = drops = None
-    if lcg is not None:
-        lcg_pos, drop_off, n_words = lcg
+    # thinning masks beforehand: the groups are cut into batches whose masks fit the budget (one
+    # buffer, filled and read batch after batch on the same stream)
+    plan = _lcg_plan(dkey, group_start, Pv)
+    del dkey
+    drops = None
+    if plan is not None:
         try:
-            drops = torch.empty((n_words,), dtype=torch.int64, device=pred.device)
+            drops = torch.empty((plan["buffer_words"],), dtype=torch.int64, device=pred.device)
         except torch.OutOfMemoryError:
-            drop_off = None                       # the kernel runs the generator itself
-        if drops is not None:
-            with _timed("patch_graph_lcg"):
-                check(lib().ppp_patch_graph_lcg(
-                    _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(order32),
-                    _dev_ptr(lcg_pos), int(lcg_pos.shape[0]), _dev_ptr(drop_off), _dev_ptr(drops),
-                    ctypes.byref(Pv), _stream()))
-            del lcg_pos
-    with _timed("patch_graph"):
-        check(lib().ppp_patch_graph_by_patch_lcg(
-            _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
-            _dev_ptr(order32), _dev_ptr(group_start.contiguous()),
-            _dev_ptr(chunk_offsets.contiguous()), n_groups, n_blocks, chunk, _dev_ptr(aff),
-            _dev_ptr(drop_off) if drops is not None else None,
-            _dev_ptr(drops) if drops is not None else None, ctypes.byref(Pv), _stream()))
+            plan = None                           # the kernel runs the generator itself
+    cuts = plan["group_cuts"] if plan is not None else [0, n_groups]
+    for b in range(len(cuts) - 1):
+        g0, g1 = cuts[b], cuts[b + 1]
+        if plan is not None:
+            lo, hi = plan["pos_cuts"][b], plan["pos_cuts"][b + 1]
+            if hi > lo:
+                with _timed("patch_graph_lcg"):
+                    check(lib().ppp_patch_graph_lcg(
+                        _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(order32),
+                        _dev_ptr(plan["pos"][lo:hi]), hi - lo, _dev_ptr(plan["drop_off"]), _dev_ptr(drops),
+                        ctypes.byref(Pv), _stream()))
+        co = chunk_offsets[g0:g1 + 1]
+        n_blocks = int((co[-1] - co[0]).item())
+        with _timed("patch_graph"):
+            check(lib().ppp_patch_graph_by_patch_lcg(
+                _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
+                _dev_ptr(order32), _dev_ptr(group_start[g0:g1 + 1].contiguous()),
+                _dev_ptr((co - co[0]).contiguous()), g1 - g0, n_blocks, chunk, _dev_ptr(aff),
+                _dev_ptr(plan["drop_off"]) if plan is not None else None,
+                _dev_ptr(drops) if plan is not None else None, ctypes.byref(Pv), _stream()))
     return aff
 
 
@@ -660,16 +666,21 @@ def lcg_words(dz, dy, dx, P):
     return nz * ny * nx * nz * nch * inter
 
 
-def _lcg_plan(dkey, Pv):
+def _lcg_plan(dkey, group_start, Pv):
     """Which dispatched pair rows get their thinning decisions made beforehand (ppp_patch_graph_lcg):
-    those whose windows intersect, as long as the masks fit PPP_PA_LCG_BYTES (default 4 GiB -- a tile
-    of the thinned 512^3 / 9^3 cover needs 1.9 GB on average; 0 = the per-patch kernel runs the
-    generator itself; so it does for patch widths whose kernel does not
-    read masks: ppp_patch_graph_lcg_words is 0 then).  dkey: offset code of the dispatched rows
-    (ppp_pair_group_keys).  Returns (positions sorted by patch offset, int64 offsets per dispatched row
-    (-1 = none), total words) or None."""
+    those whose windows intersect.  The groups (patches A) are cut into batches whose masks fit
+    PPP_PA_LCG_BYTES (default 4 GiB -- a tile of the thinned 512^3 / 9^3 cover needs 1.9 GB; 0 = the
+    per-patch kernel runs the generator itself; so it does for patch widths whose kernel does not
+    read masks: ppp_patch_graph_lcg_words is 0 then), at most PPP_PA_LCG_BATCHES (64) of them: rows
+    of later groups keep the generator.  dkey: offset code of the dispatched rows
+    (ppp_pair_group_keys), group_start: int64 [groups + 1].  Returns None or a dict:
+      group_cuts  [batches + 1] group indices, pos_cuts [batches + 1] cuts of `pos`,
+      pos         int64 positions of the served rows, batch after batch, sorted by offset inside
+      drop_off    int64 per dispatched row: word offset inside its batch's masks, -1 = none
+      buffer_words  words of the largest batch"""
     torch = _torch()
     budget = int(os.environ.get("PPP_PA_LCG_BYTES", str(4 << 30))) // 8
+    max_batches = int(os.environ.get("PPP_PA_LCG_BATCHES", "64"))
     if budget <= 0 or int(lib().ppp_patch_graph_lcg_words(0, 0, 0, ctypes.byref(Pv))) <= 0:
         return None
     wx, wy = 4 * Pv.px + 1, 4 * Pv.py + 1
@@ -679,16 +690,48 @@ def _lcg_plan(dkey, Pv):
     words = lcg_words(dz, dy, dx, Pv)
     del dx, dy, dz
     ends = torch.cumsum(words, 0)
-    served = (words > 0) & (ends <= budget)       # a prefix of the intersecting rows
-    drop_off = torch.where(served, ends - words, torch.full_like(ends, -1))
-    pos = torch.nonzero(served).reshape(-1)
-    if int(pos.shape[0]) == 0:
+    total = int(ends[-1].item())
+    if total == 0:
         return None
-    n_words = int(ends[pos[-1]].item())
-    # lanes of a wave = rows of (nearly) the same patch offset
-    pos = pos[torch.argsort(dkey[pos])]
+    n_groups = int(group_start.shape[0]) - 1
+    zero = torch.zeros((1,), dtype=torch.int64, device=dkey.device)
+    ends0 = torch.cat([zero, ends])                       # words before row i
+    g_end = ends0[group_start[1:]]                        # words up to the end of group g
+    g_words = g_end - ends0[group_start[:-1]]
+    # windows of (budget - largest group) words: a batch = the groups that END in one window, so
+    # it holds at most a window plus the part of its first group before the window
+    window = budget - int(g_words.max().item())
+    if window <= 0:
+        return None
+    batch_of_group = torch.clamp(g_end - 1, min=0) // window
+    n_batches = int(batch_of_group[-1].item()) + 1
+    n_served_batches = min(n_batches, max_batches)
+    firsts = torch.searchsorted(batch_of_group, torch.arange(n_served_batches + 1, device=dkey.device))
+    group_cuts = [int(v) for v in firsts.tolist()]
+    if n_served_batches < n_batches:                      # the rest: one more launch, no masks
+        group_cuts_all = group_cuts + [n_groups]
+    else:
+        group_cuts[-1] = n_groups
+        group_cuts_all = group_cuts
+    row_cuts = group_start[torch.tensor(group_cuts, device=dkey.device)]
+    base = ends0[row_cuts]                                # words before each served batch (+ end)
+    n_rows = int(dkey.shape[0])
+    batch_of_row = torch.clamp(torch.searchsorted(row_cuts, torch.arange(n_rows, device=dkey.device),
+                                                  right=True) - 1, max=n_served_batches)
+    served = (words > 0) & (batch_of_row < n_served_batches)
+    drop_off = torch.where(served, ends - words - base[torch.clamp(batch_of_row, max=n_served_batches - 1)],
+                           torch.full_like(ends, -1))
+    pos = torch.nonzero(served).reshape(-1)
+    # batch after batch; inside a batch the lanes of a wave = rows of (nearly) the same offset
+    pos = pos[torch.argsort(batch_of_row[pos] * (1 << 17) + dkey[pos])]
+    pos_cuts = torch.searchsorted(batch_of_row[pos].contiguous(),
+                                  torch.arange(n_served_batches + 1, device=dkey.device)).tolist()
+    buffer_words = int((base[1:] - base[:-1]).max().item())
     note_add("s5_rows_lcg_beforehand", int(pos.shape[0]))
-    return pos.contiguous(), drop_off.contiguous(), n_words
+    note_add("s5_lcg_batches", n_served_batches)
+    return dict(group_cuts=group_cuts_all, pos_cuts=[int(v) for v in pos_cuts] + [int(pos.shape[0])] *
+                (len(group_cuts_all) - len(group_cuts)), pos=pos.contiguous(),
+                drop_off=drop_off.contiguous(), buffer_words=max(buffer_words, 1))
 
 
 def patch_graph_auto(pred, cons_compact, pairs, P):

@@ -348,3 +348,53 @@ def test_lcg_mask_words_formula_equals_the_library():
             assert want[0] == ps[0] * ps[1] * ps[2] * ps[0] * nch
         else:       # the 25-wide 2-d kernel runs the generator itself: no masks
             assert not any(want)
+
+
+@pytest.mark.parametrize("budget_words,max_batches", [(1 << 40, 64), (6000, 64), (6000, 3), (900, 64)])
+def test_lcg_mask_plan_cuts_the_groups_into_batches_that_fit(budget_words, max_batches, monkeypatch):
+    """backend._lcg_plan: every batch's masks fit the budget, the offsets of a batch's rows tile its
+    part of the buffer without overlap, only rows with intersecting windows are served, rows of one
+    group never straddle two batches."""
+    import torch
+    ps = (5, 5, 5)
+    P = backend.make_params((40, 60, 60), ps, patch_threshold=0.5)
+    rng = np.random.default_rng(5)
+    counts = rng.integers(1, 40, size=300)
+    n = int(counts.sum())
+    d = rng.integers(-2 * (ps[0] - 1), 2 * (ps[0] - 1) + 1, size=(n, 3))
+    dkey = ((d[:, 0] + 2 * ps[0]) * (4 * ps[1] + 1) + (d[:, 1] + 2 * ps[1])) * (4 * ps[2] + 1) + d[:, 2] + 2 * ps[2]
+    group_start = np.concatenate([[0], np.cumsum(counts)])
+    words = backend.lcg_words(d[:, 0], d[:, 1], d[:, 2], P)
+    monkeypatch.setenv("PPP_PA_LCG_BYTES", str(8 * budget_words))
+    monkeypatch.setenv("PPP_PA_LCG_BATCHES", str(max_batches))
+    plan = backend._lcg_plan(torch.from_numpy(dkey), torch.from_numpy(group_start), P)
+    if budget_words <= int(max(np.add.reduceat(words, group_start[:-1]))):
+        assert plan is None          # a single group does not fit: the kernel keeps the generator
+        return
+    cuts, pos_cuts = plan["group_cuts"], plan["pos_cuts"]
+    assert cuts[0] == 0 and cuts[-1] == len(counts) and len(cuts) == len(pos_cuts)
+    assert all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+    off, pos = plan["drop_off"].numpy(), plan["pos"].numpy()
+    served = off >= 0
+    assert np.all(words[served] > 0)
+    n_served_batches = min(len(cuts) - 1, max_batches)
+    seen = np.zeros(n, bool)
+    for b in range(len(cuts) - 1):
+        r0, r1 = group_start[cuts[b]], group_start[cuts[b + 1]]
+        rows = pos[pos_cuts[b]:pos_cuts[b + 1]]
+        assert np.all((rows >= r0) & (rows < r1))
+        seen[rows] = True
+        if b >= n_served_batches:
+            assert len(rows) == 0 and not served[r0:r1].any()
+            continue
+        # all intersecting rows of the batch are served, back to back in row order
+        want = np.nonzero(words[r0:r1] > 0)[0] + r0
+        assert sorted(rows.tolist()) == want.tolist()
+        starts, sizes = off[want], words[want]
+        assert starts[0] == 0 and np.array_equal(starts[1:], np.cumsum(sizes)[:-1])
+        assert int(starts[-1] + sizes[-1]) <= min(budget_words, plan["buffer_words"])
+        # inside the batch: sorted by offset code
+        assert np.all(np.diff(dkey[rows]) >= 0)
+    assert np.array_equal(seen, served)
+    if max_batches >= len(cuts) - 1:
+        assert np.array_equal(served, words > 0)

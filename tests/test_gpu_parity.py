@@ -60,8 +60,8 @@ def _stage_outputs(torch, pred_host, overlap_mask, patchshape, kw, pairs=None, f
             aff4 = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
             assert np.array_equal(out["aff"].view(np.uint32), aff4.view(np.uint32))
             # ... with the thinning decisions made inside the kernel (no masks beforehand), and
-            # with masks for the first few intersecting rows only
-            for budget in ("0", "4096"):
+            # with mask budgets that cut the groups into several batches
+            for budget in ("0", "65536", "4194304"):
                 os.environ["PPP_PA_LCG_BYTES"] = budget
                 try:
                     aff5 = backend.patch_graph_by_patch(pred, vm, pd, Pv).cpu().numpy()
