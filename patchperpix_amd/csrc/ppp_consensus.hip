@@ -100,6 +100,10 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     if (G.layout == PPP_CONS_VOXEL_MAJOR) {
         // only the packed two-slice kernel writes the voxel-major rows directly
         if (!consensus_v3_supported(G)) return hipErrorNotSupported;
+        if (consensus_v4_supported(G)) {
+            g_s1_kernel = "consensus_v4_kernel";
+            return launch_consensus_v4(pred, dtype, ov, cons, cnt, G, s);
+        }
         g_s1_kernel = "consensus_v3_kernel";
         return launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
     }
@@ -117,7 +121,10 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     static EnvSwitch generic_sw("PPP_CONSENSUS_GENERIC");
     const bool force_generic = generic_sw.get() != nullptr;
     if (!force_generic) {
-        // packed two-slice kernel (TH = 0.5, normalised product), else the general v2
+        // packed two-slice kernels (TH = 0.5, normalised product): accumulators split over two
+        // waves (px in {5, 7, 9}) or in one wave; else the general v2
+        const hipError_t e4 = launch_consensus_v4(pred, dtype, ov, cons, cnt, G, s);
+        if (e4 != hipErrorNotSupported) { g_s1_kernel = "consensus_v4_kernel"; return e4; }
         const hipError_t e3 = launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
         if (e3 != hipErrorNotSupported) { g_s1_kernel = "consensus_v3_kernel"; return e3; }
         const hipError_t e2 = launch_consensus_v2(pred, dtype, ov, cons, cnt, G, s);

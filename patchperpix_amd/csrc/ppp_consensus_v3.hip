@@ -70,6 +70,10 @@ typedef const volatile __attribute__((address_space(3))) v4f *lds_v4f_cvp;
 #ifndef PPP_S1V3_SPLIT
 #define PPP_S1V3_SPLIT(PX) ((PX) <= 7)
 #endif
+// iterations of the classification whose chains are interleaved
+#ifndef PPP_S1V3_CGROUP
+#define PPP_S1V3_CGROUP 3
+#endif
 typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp;
 typedef const volatile __attribute__((address_space(3))) uint32_t *lds_u32_cvp;
 
@@ -122,7 +126,7 @@ __device__ __forceinline__ uint32_t pack_codes(v2f pos, v2f neg) {
 // processed in groups of GS whose chains are interleaved stage by stage; the LDS reads of the
 // next group are issued before the arithmetic of the current one.
 template <int PX, int NC, bool ROW0, bool EXACT>
-__device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt, const v2f *bt2, const uint32_t *ct,
+__device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v4f_cvp bt, const v2f *bt2, const uint32_t *ct,
                                             const double th2, const double den,
                                             v2f (&acc)[2 * PX - 1], uint32_t (&tc)[2 * PX - 1]) {
     // fl(4/3) and fl(4/3 - fl(4/3)): y = fma(d, c43, d * c43lo) is the correctly rounded d / 0.75
@@ -134,12 +138,12 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt, const
     constexpr int NJG = (PX + GS - 1) / GS;     // groups per kx
     constexpr int NG = PX * NJG;                // groups per tile, n -> kx = PX-1 - n / NJG
     v4f bcur[GS], bnxt[GS];
-    v2f ta, ta_nxt, ga, na;
+    v2f ta, ta_nxt, fa, fa_nxt, ga, na;
     uint32_t ca = 0u;
     auto used = [](int kx, int j) { return j < PX && !(ROW0 && j <= kx); };
-    auto load_group = [&](int n, v4f (&b)[GS], v2f &t) {
+    auto load_group = [&](int n, v4f (&b)[GS], v2f &t, v2f &f) {
         const int kx = PX - 1 - n / NJG, jg = (n % NJG) * GS;
-        if (jg == 0) t = at[kx * NC - kx];
+        if (jg == 0) { t = at[kx * NC - kx]; f = cfp[-kx]; }
 #pragma unroll
         for (int g = 0; g < GS; ++g)
             if (used(kx, jg + g)) {
@@ -159,12 +163,13 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt, const
                 }
             }
     };
-    load_group(0, bcur, ta);
+    load_group(0, bcur, ta, fa);
 #pragma unroll
     for (int n = 0; n < NG; ++n) {
         const int kx = PX - 1 - n / NJG, jg = (n % NJG) * GS;
-        if (n + 1 < NG) load_group(n + 1, bnxt, ta_nxt);
+        if (n + 1 < NG) load_group(n + 1, bnxt, ta_nxt, fa_nxt);
         if (jg == 0) {
+            ta = ta * fa;                                       // centre factor {0, 1}
             if constexpr (!EXACT) {
                 ga = pk_mul_clamp(ta, splat(4.0f));            // [ta > 0]  (|ta| > 0.5 when classified)
                 na = pk_mul_clamp(ta, splat(-4.0f));           // [ta < 0]
@@ -221,10 +226,37 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, lds_v4f_cvp bt, const
         if (n + 1 < NG) {
 #pragma unroll
             for (int g = 0; g < GS; ++g) bcur[g] = bnxt[g];
-            if ((n + 1) % NJG == 0) ta = ta_nxt;
+            if ((n + 1) % NJG == 0) { ta = ta_nxt; fa = fa_nxt; }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// raw buffer loads: scalar base (the resource), 32-bit per-lane byte offset, scalar byte offset.
+// DATA_FORMAT_32 in word 3 (what gfx9 wants of an untyped buffer), num_records = 2^32 - 1.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc buf_rsrc(const void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, -1, 0x00020000);
+}
+// the loaded bits stay as they are (float16: zero-extended) until `widen`: the conversion of a
+// prefetched value belongs to the classification, after the votes the load flies behind
+template <typename T>
+__device__ __forceinline__ unsigned buf_ldraw(BufRsrc r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ unsigned buf_ldraw<float>(BufRsrc r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+template <>
+__device__ __forceinline__ unsigned buf_ldraw<__half>(BufRsrc r, unsigned voff, unsigned soff) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+}
+template <typename T>
+__device__ __forceinline__ float widen(unsigned raw);
+template <>
+__device__ __forceinline__ float widen<float>(unsigned raw) { return __uint_as_float(raw); }
+template <>
+__device__ __forceinline__ float widen<__half>(unsigned raw) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)raw);
 }
 
 template <typename T>
@@ -333,12 +365,10 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
     // tile (element e = it*64 + lane -> channel column j, centre i); the same for both images
     // and both slices:
     //   el_off[it] : byte offset j * V + (line) * X + clamped centre x from the tile's row base
-    //   cf_idx[it] : centre index i (for the centre factor of the "about u" image)
     // and of the (up to two) centres whose factor this lane computes:
     //   cf_off[c]  : byte offset (line) * X + clamped centre x from the centre row of `mid`
     //   cf_st bit c: centre inside the x-interior and its segment exists;  cf_sb bit c: segment B
     unsigned el_off[NIT];
-    unsigned cf_idx[NIT];
     const int ncA = nA + (PX - 1);                    // centres of segment A
     auto centre_x = [&](int i, bool &sb, bool &ok) -> int {
         sb = FLAT && i >= ncA;
@@ -354,7 +384,6 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
         const int j = min(e / K::NC, PX - 1);         // (padding elements repeat the last column)
         bool sb, ok;
         const int cxc = centre_x(i, sb, ok);
-        cf_idx[it] = (unsigned)i;
         el_off[it] = (unsigned)(((long long)j * G.V + cxc) * (long long)sizeof(T));
     }
     unsigned cf_off[2];
@@ -395,34 +424,40 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
                 if (row_a_ok || row_b_ok) return true;
             }
         };
-        float ra[2][NIT], rb[2][NIT], rc[2][2];
+        unsigned ra[2][NIT], rb[2][NIT], rc[2][2];             // loaded bits, [slice]
         bool lz0 = true, lz1 = false, la = true, lb = false;   // flags of the LOADED tile
-        // issue the (independent, unconditional) loads of one tile into registers.  A slice whose
-        // centre slice is not interior reads the other slice's rows (in bounds; its centre
-        // factors are 0).  FLAT: both lines are inside the z-slice (see v2).
+        // issue the (independent, unconditional) loads of one tile into registers: buffer loads
+        // -- a scalar resource per operand image (base = the tile's channel row at the centre
+        // row of slice 0), the lane's 32-bit element offset, the second slice as scalar offset;
+        // no vector instruction per load.  A slice whose centre slice is not interior reads the
+        // other slice's rows (in bounds; its centre factors are 0).  FLAT: both lines are inside
+        // the z-slice (see v2).
         auto load_tile = [&](int z, int y) {
             lz0 = z_ok0; lz1 = z_ok1; la = row_a_ok; lb = row_b_ok;
             const int cz = uz - z + G.rz;
             const long long crow0 = vox(G, z_ok0 ? cz : cz + 1, uy - y + G.ry, 0);
-            const long long crow1 = z_ok1 ? crow0 + (z_ok0 ? slice : 0) : crow0;
+            // (readfirstlane: the scalar offset of a buffer load must be known to be uniform)
+            const unsigned s1 = __builtin_amdgcn_readfirstlane((z_ok1 && z_ok0) ? (unsigned)(slice * (long long)sizeof(T)) : 0u);
             const long long cha = (long long)((z * G.py + y) * PX) * G.V;
             const long long chb = (long long)(((z + dz) * G.py + (y + dy)) * PX) * G.V;
+            const BufRsrc qa = buf_rsrc(pred + cha + crow0), qb = buf_rsrc(pred + chb + crow0),
+                          qc = buf_rsrc(mid + crow0);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
 #ifdef PPP_S1_ABL_NOLOAD
-                ra[0][it] = ra[1][it] = 0.9f + 1e-3f * (float)((el_off[it] + (unsigned)(cha + crow0)) & 15u);   // (timing experiment)
-                rb[0][it] = rb[1][it] = 0.1f + 1e-3f * (float)((el_off[it] + (unsigned)(chb + crow1)) & 15u);
+                ra[0][it] = ra[1][it] = 0x3b00u + ((el_off[it] + (unsigned)(cha + crow0)) & 15u);   // (timing experiment)
+                rb[0][it] = rb[1][it] = 0x2e00u + ((el_off[it] + (unsigned)(chb + crow0)) & 15u);
 #else
-                ra[0][it] = ldf_at3(pred + cha + crow0, el_off[it]);
-                ra[1][it] = ldf_at3(pred + cha + crow1, el_off[it]);
-                rb[0][it] = ldf_at3(pred + chb + crow0, el_off[it]);
-                rb[1][it] = ldf_at3(pred + chb + crow1, el_off[it]);
+                ra[0][it] = buf_ldraw<T>(qa, el_off[it], 0u);
+                ra[1][it] = buf_ldraw<T>(qa, el_off[it], s1);
+                rb[0][it] = buf_ldraw<T>(qb, el_off[it], 0u);
+                rb[1][it] = buf_ldraw<T>(qb, el_off[it], s1);
 #endif
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                rc[0][c] = ldf_at3(mid + crow0, cf_off[c]);
-                rc[1][c] = ldf_at3(mid + crow1, cf_off[c]);
+                rc[0][c] = buf_ldraw<T>(qc, cf_off[c], 0u);
+                rc[1][c] = buf_ldraw<T>(qc, cf_off[c], s1);
             }
         };
         constexpr bool PREFETCH = PPP_S1V3_PREFETCH(PX);
@@ -433,43 +468,62 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
         if (PREFETCH && have) load_tile(kz, ky);
         while (have) {
             if (!PREFETCH) load_tile(kz, ky);
-            // ---- centre factors: foreground && interior (x, y, z) && segment exists
+            // ---- centre factors: foreground && interior (x, y, z) && segment exists; multiplied
+            //      into the "about u" operand when the votes read it
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const bool st = (cf_st >> c) & 1u, sb = (cf_sb >> c) & 1u;
                 const bool rok = st && (sb ? lb : la);
                 v2f f;
-                f.x = (rok && lz0 && rc[0][c] > G.th_gt) ? 1.0f : 0.0f;
-                f.y = (rok && lz1 && rc[1][c] > G.th_gt) ? 1.0f : 0.0f;
+                f.x = (rok && lz0 && widen<T>(rc[0][c]) > G.th_gt) ? 1.0f : 0.0f;
+                f.y = (rok && lz1 && widen<T>(rc[1][c]) > G.th_gt) ? 1.0f : 0.0f;
                 if (lane + 64 * c < K::NC) cf[lane + 64 * c] = f;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             // ---- classify both images of both slices into LDS
             //      t = v (v > 0.5), v - 1 (v < 0.5), 0 (v == 0.5):  g = [v > 0.5], h = [v < 0.5]
-            //      from clamp01((v - 0.5) * 2^26) / clamp01((0.5 - v) * 2^26), t = v*(g + h) - h
+            //      from clamp01((v - 0.5) * 2^26) / clamp01((0.5 - v) * 2^26), t = v*(g + h) - h.
+            //      CG iterations at a time, their chains interleaved stage by stage (a dependent
+            //      packed operation right behind its producer costs a wait state)
             unsigned bigmax = 0u;
-            v2f cf_cur = cf[cf_idx[0]], cf_nxt = cf_cur;
+            constexpr int CG = PPP_S1V3_CGROUP;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int e = it * 64 + lane;
-                if (it + 1 < NIT) cf_nxt = cf[cf_idx[it + 1]];
-                {
-                    const v2f v = {ra[0][it], ra[1][it]};
-                    bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
-                    const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
-                    v2f t = pk_fma(v, g + h, -h);
-                    t = t * cf_cur;
-                    at[e] = t;
-                    cf_cur = cf_nxt;
+            for (int it = 0; it < NIT; ++it)       // (the widening stays here, not next to the load)
+                asm volatile("" : "+v"(ra[0][it]), "+v"(ra[1][it]), "+v"(rb[0][it]), "+v"(rb[1][it]));
+#pragma unroll
+            for (int i0 = 0; i0 < NIT; i0 += CG) {
+                v2f va[CG], vb[CG], ga[CG], ha[CG], gb[CG], hbb[CG], sa[CG], sbb[CG], ta[CG], tb[CG], cc[CG];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) {
+                    va[q] = (v2f){widen<T>(ra[0][i0 + q]), widen<T>(ra[1][i0 + q])};
+                    vb[q] = (v2f){widen<T>(rb[0][i0 + q]), widen<T>(rb[1][i0 + q])};
                 }
-                {
-                    const v2f v = {rb[0][it], rb[1][it]};
-                    bigmax = max(bigmax, max(__float_as_uint(v.x), __float_as_uint(v.y)));
-                    const v2f g = pk_fma_clamp(v, big26, nhb), h = pk_fma_clamp(v, nbig26, hb);
-                    const v2f t = pk_fma(v, g + h, -h);
-                    if constexpr (SPLIT) { bt2[e] = t; ct[e] = pack_codes(g, h); }
-                    else bt[e] = (v4f){t.x, t.y, __uint_as_float(pack_codes(g, h)), 0.0f};
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) ga[q] = pk_fma_clamp(va[q], big26, nhb);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) ha[q] = pk_fma_clamp(va[q], nbig26, hb);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) gb[q] = pk_fma_clamp(vb[q], big26, nhb);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) hbb[q] = pk_fma_clamp(vb[q], nbig26, hb);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) sa[q] = ga[q] + ha[q];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) sbb[q] = gb[q] + hbb[q];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) cc[q] = pk_fma(hbb[q], splat(256.0f), gb[q]);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) ta[q] = pk_fma(va[q], sa[q], -ha[q]);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) tb[q] = pk_fma(vb[q], sbb[q], -hbb[q]);
+#pragma unroll
+                for (int q = 0; q < CG; ++q) if (i0 + q < NIT) {
+                    const int e = (i0 + q) * 64 + lane;
+                    bigmax = max(bigmax, max(max(__float_as_uint(va[q].x), __float_as_uint(va[q].y)),
+                                             max(__float_as_uint(vb[q].x), __float_as_uint(vb[q].y))));
+                    const uint32_t code = (uint32_t)cc[q].x | ((uint32_t)cc[q].y << 16);
+                    at[e] = ta[q];
+                    if constexpr (SPLIT) { bt2[e] = tb[q]; ct[e] = code; }
+                    else bt[e] = (v4f){tb[q].x, tb[q].y, __uint_as_float(code), 0.0f};
                 }
             }
             // a value outside [0, 1] (as an unsigned bit pattern: > 1.0f, negative, inf, nan) sends
@@ -480,15 +534,13 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int e = it * 64 + lane;
-                    const v2f f = cf[cf_idx[it]];
                     v2f ta, tb;
                     unsigned code = 0u;
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const float va = ra[s][it], vb = rb[s][it];
-                        float xa = va > G.th_gt ? va : (va < G.bg_lt ? va - 1.0f : 0.0f);
+                        const float va = widen<T>(ra[s][it]), vb = widen<T>(rb[s][it]);
+                        const float xa = va > G.th_gt ? va : (va < G.bg_lt ? va - 1.0f : 0.0f);
                         const float xb = vb > G.th_gt ? vb : (vb < G.bg_lt ? vb - 1.0f : 0.0f);
-                        if ((s ? f.y : f.x) == 0.0f) xa = 0.0f;
                         if (s) { ta.y = xa; tb.y = xb; } else { ta.x = xa; tb.x = xb; }
                         code |= (xb > 0.0f ? 1u : (xb < 0.0f ? 256u : 0u)) << (16 * s);
                     }
@@ -507,12 +559,13 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             lds_v4f_cvp ib = (lds_v4f_cvp)(bt + (SPLIT ? 0 : pos_l));
             const v2f *ib2 = bt2 + (SPLIT ? pos_l : 0);
             const uint32_t *ic = ct + (SPLIT ? pos_l : 0);
+            const v2f *icf = cf + pos_l;
             if (!any_big) {
-                if (row0) tile_votes3<PX, K::NC, true, false>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
-                else tile_votes3<PX, K::NC, false, false>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
+                if (row0) tile_votes3<PX, K::NC, true, false>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, false>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
             } else {
-                if (row0) tile_votes3<PX, K::NC, true, true>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
-                else tile_votes3<PX, K::NC, false, true>(ia, ib, ib2, ic, G.th2, G.den, acc, tc);
+                if (row0) tile_votes3<PX, K::NC, true, true>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
+                else tile_votes3<PX, K::NC, false, true>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
             }
             if (++n_fold == K::FOLD) {
                 n_fold = 0;
@@ -640,6 +693,11 @@ static hipError_t launch_vm_zero(float *S, const Geo &G, int n_rows, hipStream_t
     PPP_GRID_CHECK((nt + 255) / 256, 256);
     vm_zero_kernel<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s>>>(S, G, n_rows, F);
     return hipGetLastError();
+}
+
+// (also the two-wave kernel's, ppp_consensus_v4.hip)
+hipError_t launch_vm_zero_faces(float *S, const Geo &G, hipStream_t s) {
+    return launch_vm_zero(S, G, (G.pz - 1) * G.wy + G.py, s);
 }
 
 template <typename T, int PX, bool FLAT>

@@ -38,6 +38,9 @@ const char *last_consensus_kernel();
 bool consensus_v3_supported(const Geo &G);
 hipError_t launch_consensus_v3(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s);
+bool consensus_v4_supported(const Geo &G);
+hipError_t launch_consensus_v4(const void *pred, int dtype, const uint8_t *ov, float *cons,
+                               float *cnt, const Geo &G, hipStream_t s);
 hipError_t launch_rank(const void *pred, int dtype, const float *cons, const uint8_t *ov,
                        float *score, const ppp_box &sb, const Geo &G, hipStream_t s);
 hipError_t launch_rank_v2(const void *pred, int dtype, const float *cons, const uint8_t *ov,

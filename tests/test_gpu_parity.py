@@ -737,6 +737,40 @@ def test_consensus_two_slice_packed_kernel_equals_v2(ps, shape, dtype, torch_cud
 
 
 @pytest.mark.parametrize("ps,shape", [((7, 7, 7), (11, 12, 150)), ((5, 5, 5), (9, 11, 97)), ((9, 9, 9), (12, 13, 131)),
+                                      ((5, 9, 9), (9, 19, 40))])
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_consensus_two_wave_kernel_equals_one_wave(ps, shape, dtype, torch_cuda, monkeypatch):
+    """S1 v4 (PPP_S1_V4=1: the accumulators of a run split over the two waves of a workgroup that
+    share one pair of operand images) == S1 v3, bit for bit: compact values and counts, and the
+    voxel-major rows it writes itself; whole volume and a sub-box, flattened and per-line runs."""
+    import torch
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    c = synth.make_case(shape, ps, seed=98, cell=[6, 6, 9], overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    pred = torch.from_numpy(c["pred"].astype(np.float16 if dtype == "f16" else np.float32)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    boxes = [None, (min(1, shape[0] - 1), 2, 9, shape[0], shape[1] - 1, shape[2] - 7)]
+    for box in boxes:
+        P = backend.make_params(shape, ps, cons_box=box, **kw)
+        for flat in ("0", "1"):
+            monkeypatch.setenv("PPP_S1_FLAT", flat)
+            out = {}
+            for v4 in ("0", "1"):
+                monkeypatch.setenv("PPP_S1_V4", v4)
+                backend.reload_env()
+                cons, cnt = backend.consensus(pred, ov, P, want_count=True)
+                name = backend.lib().ppp_consensus_kernel_name().decode()
+                assert name == ("consensus_v4_kernel" if v4 == "1" else "consensus_v3_kernel")
+                rows, _ = backend.consensus_voxel_major(pred, ov, P)
+                out[v4] = (cons.cpu().numpy(), cnt.cpu().numpy(), rows)
+            assert np.array_equal(out["0"][1], out["1"][1]), (box, flat, "counts")
+            assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32)), (box, flat)
+            assert torch.equal(out["0"][2].view(torch.int32), out["1"][2].view(torch.int32)), (box, flat, "rows")
+            assert np.count_nonzero(out["0"][0]) > 1000
+
+
+@pytest.mark.parametrize("ps,shape", [((7, 7, 7), (11, 12, 150)), ((5, 5, 5), (9, 11, 97)), ((9, 9, 9), (12, 13, 131)),
                                       ((1, 5, 5), (1, 30, 90)), ((7, 7, 7), (16, 20, 40))])
 def test_consensus_written_voxel_major_directly(ps, shape, torch_cuda, monkeypatch):
     """S1 writing the symmetric voxel-major rows itself (positive entry, mirrored entry, zero fill
