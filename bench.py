@@ -232,7 +232,7 @@ def set_host_allocator():
     """backend.tune_host_allocator (the package's drivers call the same function); reported in
     the JSON."""
     from patchperpix_amd import backend
-    return backend.tune_host_allocator()
+    return backend.tune_host_allocator(cli=True)
 
 
 class SynthProvider:
@@ -377,6 +377,8 @@ class Workload:
                 extra["_n_slabs"] = args.slabs
             if args.yx:
                 extra["_yx_tiles"] = tuple(args.yx)
+            if args.slabs and os.environ.get("PPP_CONS_CACHE") == "1":
+                extra["_cons_cache"] = True            # (a forced grid skips the memory plan)
                 extra.setdefault("_n_slabs", 1)
 
             def step(flag_kw=kw):
@@ -417,17 +419,20 @@ class Workload:
                 dist.barrier()
             oz0, oz1 = mine[0][0], mine[-1][1]
             reserve = 150.0 * (hi - lo) * shape[1] * shape[2] + 6e9
-            n, ny, nx = tiling.tiles_needed((oz1 - oz0, shape[1], shape[2]), ps, max(free - reserve, 0.25 * free),
-                                            safety=0.92, copies=2.0)
+            # consensus cache: the compact planes of the rank's block (own slices + the pairs halo),
+            # every base voxel computed once, when they fit next to the rows of one tile
+            cz0, cz1 = max(0, oz0 - (ps[0] // 2) - (ps[0] - 1)), min(gshape[0], oz1 + ps[0] // 2)
+            n, ny, nx, use_cache = tiling.plan_tiles((oz1 - oz0, shape[1], shape[2]), ps, max(free - reserve, 0.25 * free),
+                                                     safety=0.92, copies=2.0, cache_shape=(cz1 - cz0, shape[1], shape[2]))
             mine = [(oz0 + a, oz0 + b) for a, b in tiling.plan_slabs(oz1 - oz0, args.slabs or n)]
             yx = tuple(args.yx) if args.yx else (ny, nx)
             self.plan = {"rank": rank, "own_z": [oz0, oz1], "held_z": [lo, hi],
-                         "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx)}
+                         "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx), "cons_cache": bool(use_cache)}
             self.tiles = (len(mine), yx[0], yx[1])
 
             def step(flag_kw=kw):
                 inst, _ = tiling.assemble(self.pred, lo, gshape, fg, fg.clone(), fg, ps, mine,
-                                          comm=comm, _yx_tiles=yx, **dict(flag_kw, **extra))
+                                          comm=comm, _yx_tiles=yx, _cons_cache=use_cache, **dict(flag_kw, **extra))
                 return inst
         self.step = step
         self.fg_fraction = float(fg.float().mean().item())

@@ -138,6 +138,17 @@ int ppp_consensus_writes_voxel_major(const ppp_params *p);
 int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
                        const ppp_params *p, void *stream);
 
+/* The same votes for the base voxels of `part` only (a non-empty sub-box of p->cons_box, which
+ * keeps indexing the output): COMPACT planes or open VOXEL_MAJOR rows, nothing outside `part` is
+ * touched except the mirrored entries S[u + d][-d] of voxel-major rows, which land wherever u + d
+ * lies in cons_box.  What a caller builds with it: a consensus CACHE over a large box filled piece
+ * by piece (every base voxel computed once: consensus_array.py:71-206 run over the whole block,
+ * fillConsensusArray.cu:5-218), from which ppp_cons_planes_to_rows cuts the rows of a tile for the
+ * ranking and, later, for the patch graph -- instead of computing them a second time.  Packed
+ * kernel only (ppp_consensus_writes_voxel_major). */
+int ppp_consensus_part(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
+                       const ppp_params *p, const ppp_box *part, void *stream);
+
 /* --- S2: patch ranking ---------------------------------------------------------------
  * replaces rank_patches_cuda (ranked_patches.py:33-74) + kernel rankPatches
  * (cuda/rankPatches.cu:1-161).  Scores are written for the voxels of `score_box`
@@ -322,6 +333,15 @@ int ppp_cons_to_reference(const float *d_cons_compact, float *d_cons_reference,
 
 /* re-layout a COMPACT consensus (p->cons_box, p->cons_layout ignored) as VOXEL_MAJOR       */
 int ppp_cons_to_voxel_major(const float *d_cons_compact, float *d_cons_voxel_major,
+                            const ppp_params *p, void *stream);
+
+/* VOXEL_MAJOR rows of p->cons_box from COMPACT planes that are indexed by a box of their own,
+ * `planes_box` (it must hold cons_box; same coordinate frame): S[v][+d] = planes[d][v],
+ * S[v][-d] = planes[d][v - d], 0 where v - d lies outside planes_box (an entry nothing reads, as
+ * with ppp_consensus_rows).  ppp_cons_to_voxel_major is the case planes_box == cons_box.
+ * (aff_patch_graph.py:113-187 / ranked_patches.py:33-74 read the consensus array the
+ * reference keeps whole in managed memory; this is how a tile's share of it reaches HBM rows.) */
+int ppp_cons_planes_to_rows(const float *d_planes, const ppp_box *planes_box, float *d_rows,
                             const ppp_params *p, void *stream);
 
 /* --- foreground / patch bit helpers used by the host stages --------------------------

@@ -86,6 +86,11 @@ _SIGNATURES = {
                                      ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_consensus_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_consensus_part": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.POINTER(Params), ctypes.POINTER(Box),
+                                          ctypes.c_void_p]),
+    "ppp_cons_planes_to_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Box), ctypes.c_void_p,
+                                               ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_rank_patches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.POINTER(Box), ctypes.POINTER(Params),
@@ -440,23 +445,35 @@ def counter_calibration(src, n_read, dst, n_write):
 _HOST_ALLOCATOR = None
 
 
-def tune_host_allocator():
+def tune_host_allocator(cli=False):
     """Host allocator of a long-running service: the pipeline's host arrays (masks, instance map:
     a few MB each at 140^3, several dozen per call) would otherwise be mmap'ed, first-touched and
     unmapped again on every call by glibc (~5 ms per step of page faults at 140^3).  Same effect
-    as MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment.  Called once by the
-    drivers (run_ppp, vote_instances.main, stitch_patch_graph.main, bench.py); PPP_MALLOPT=0 (or
-    the older PPP_BENCH_MALLOPT=0) skips it.  Returns what was done."""
+    as MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ in the environment.
+
+    The thresholds are process-wide and keep freed host memory from going back to the OS, so they
+    are set only for a process that IS one of the drivers (`cli=True`: run_ppp / vote_instances /
+    stitch_patch_graph run as a program, bench.py) -- unless PPP_MALLOPT=0 (or the older
+    PPP_BENCH_MALLOPT=0) -- or, for an application that calls main() as a library function, when
+    it opts in with PPP_MALLOPT=1.  Returns what was done (each mallopt call reported on its own:
+    many glibc builds refuse an M_MMAP_THRESHOLD above 32 MiB)."""
     global _HOST_ALLOCATOR
     if _HOST_ALLOCATOR is not None:
         return _HOST_ALLOCATOR
-    if os.environ.get("PPP_MALLOPT", os.environ.get("PPP_BENCH_MALLOPT", "1")) == "0":
-        _HOST_ALLOCATOR = "off"
-        return _HOST_ALLOCATOR
+    want = os.environ.get("PPP_MALLOPT", os.environ.get("PPP_BENCH_MALLOPT"))
+    if want == "0" or (not cli and want != "1"):
+        if cli or want == "0":
+            _HOST_ALLOCATOR = "off"
+        return _HOST_ALLOCATOR or "untouched (library call; PPP_MALLOPT=1 opts in)"
     try:
         libc = ctypes.CDLL("libc.so.6")
-        ok = libc.mallopt(-1, 1 << 30) and libc.mallopt(-3, 1 << 30)   # M_TRIM_ / M_MMAP_THRESHOLD
-        _HOST_ALLOCATOR = "trim/mmap thresholds 1 GiB" if ok else "mallopt refused"
+        trim = bool(libc.mallopt(-1, 1 << 30))             # M_TRIM_THRESHOLD
+        mmap = bool(libc.mallopt(-3, 1 << 30))             # M_MMAP_THRESHOLD
+        if not mmap:
+            mmap32 = bool(libc.mallopt(-3, 32 << 20))      # the largest value older glibc accepts
+        _HOST_ALLOCATOR = "trim threshold 1 GiB: %s; mmap threshold 1 GiB: %s%s" % (
+            "set" if trim else "refused", "set" if mmap else "refused",
+            "" if mmap else (", 32 MiB: %s" % ("set" if mmap32 else "refused")))
     except OSError:
         _HOST_ALLOCATOR = "no libc"
     return _HOST_ALLOCATOR
@@ -624,15 +641,22 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     del order
     # thinning masks beforehand: the groups are cut into batches whose masks fit the budget (one
     # buffer, filled and read batch after batch on the same stream)
-    plan = _lcg_plan(dkey, group_start, Pv)
-    del dkey
-    drops = None
-    if plan is not None:
-        try:
+    # The plan's temporaries (about eight int64 per dispatched row) and the mask buffer are not
+    # part of the tile planner's budget: the mask budget is capped by what is free right now, and
+    # running out of memory anywhere in here falls back to the generator inside the kernel.
+    oom = getattr(torch, "OutOfMemoryError", None) or torch.cuda.OutOfMemoryError
+    plan = drops = None
+    try:
+        plan = _lcg_plan(dkey, group_start, Pv)
+        if plan is not None:
             drops = torch.empty((plan["buffer_words"],), dtype=torch.int64, device=pred.device)
-        except torch.OutOfMemoryError:
-            plan = None                           # the kernel runs the generator itself
+    except oom:
+        plan = drops = None                       # the kernel runs the generator itself
+        torch.cuda.empty_cache()
+    del dkey
     cuts = plan["group_cuts"] if plan is not None else [0, n_groups]
+    co_host = chunk_offsets[torch.tensor(cuts, dtype=torch.int64, device=chunk_offsets.device)].cpu().tolist()
+    co_host = dict(zip(cuts, co_host))            # blocks before each cut: ONE copy for all batches
     for b in range(len(cuts) - 1):
         g0, g1 = cuts[b], cuts[b + 1]
         if plan is not None:
@@ -644,7 +668,7 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
                         _dev_ptr(plan["pos"][lo:hi]), hi - lo, _dev_ptr(plan["drop_off"]), _dev_ptr(drops),
                         ctypes.byref(Pv), _stream()))
         co = chunk_offsets[g0:g1 + 1]
-        n_blocks = int((co[-1] - co[0]).item())
+        n_blocks = int(co_host[g1] - co_host[g0])
         with _timed("patch_graph"):
             check(lib().ppp_patch_graph_by_patch_lcg(
                 _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
@@ -679,7 +703,13 @@ def _lcg_plan(dkey, group_start, Pv):
       drop_off    int64 per dispatched row: word offset inside its batch's masks, -1 = none
       buffer_words  words of the largest batch"""
     torch = _torch()
-    budget = int(os.environ.get("PPP_PA_LCG_BYTES", str(4 << 30))) // 8
+    budget = int(os.environ.get("PPP_PA_LCG_BYTES", str(4 << 30)))
+    if dkey.is_cuda:
+        # never more than a quarter of what is free (+ what torch's allocator holds unused), after
+        # the plan's own temporaries: ~8 int64 per dispatched row
+        free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+        budget = min(budget, max(0, int(0.25 * (free - 64 * int(dkey.shape[0])))))
+    budget //= 8
     max_batches = int(os.environ.get("PPP_PA_LCG_BATCHES", "64"))
     if budget <= 0 or int(lib().ppp_patch_graph_lcg_words(0, 0, 0, ctypes.byref(Pv))) <= 0:
         return None
@@ -704,6 +734,12 @@ def _lcg_plan(dkey, group_start, Pv):
     if window <= 0:
         return None
     batch_of_group = torch.clamp(g_end - 1, min=0) // window
+    n_batches = int(batch_of_group[-1].item()) + 1
+    n_served_batches = min(n_batches, max_batches)
+    # (a group larger than the window leaves windows in which no group ends: number the batches
+    # by the windows that do hold a group end, so that none is empty and PPP_PA_LCG_BATCHES counts
+    # batches with work)
+    _, batch_of_group = torch.unique_consecutive(batch_of_group, return_inverse=True)
     n_batches = int(batch_of_group[-1].item()) + 1
     n_served_batches = min(n_batches, max_batches)
     firsts = torch.searchsorted(batch_of_group, torch.arange(n_served_batches + 1, device=dkey.device))
@@ -982,6 +1018,33 @@ def consensus_voxel_major(pred, overlap, P, out=None, open_rows=False):
     Pc.cons_layout = CONS_COMPACT
     cons = consensus(pred, overlap, Pc)
     return cons_to_voxel_major(cons, Pc)
+
+
+def consensus_part(pred, overlap, P, part, out):
+    """S1 for the base voxels of `part` (z0, y0, x0, z1, y1, x1; inside P.cons_box) written into
+    `out`, a buffer indexed by the whole P.cons_box (COMPACT planes or open VOXEL_MAJOR rows)."""
+    b = Box(*[int(v) for v in part])
+    note_add("s1_base_voxels", int(np.prod(b.shape())))
+    with _timed("consensus"):
+        check(lib().ppp_consensus_part(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap), _dev_ptr(out),
+                                       ctypes.byref(P), ctypes.byref(b), _stream()))
+    note("s1_kernel", lib().ppp_consensus_kernel_name().decode())
+
+
+def cons_planes_to_rows(planes, planes_box, P, out=None):
+    """VOXEL_MAJOR rows of P.cons_box cut from COMPACT planes indexed by `planes_box`
+    (ppp_cons_planes_to_rows).  Returns (tensor [bz, by, bx, W], params with VOXEL_MAJOR)."""
+    Pv = P.copy()
+    Pv.cons_layout = CONS_VOXEL_MAJOR
+    W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
+    shape = Pv.cons_box.shape() + (W,)
+    n_el = int(np.prod(shape))
+    rows = out[:n_el].view(shape) if out is not None and out.numel() >= n_el else _big_empty(shape, planes.device)
+    b = Box(*[int(v) for v in planes_box])
+    with _timed("cons_planes_to_rows"):
+        check(lib().ppp_cons_planes_to_rows(_dev_ptr(planes), ctypes.byref(b), _dev_ptr(rows), ctypes.byref(Pv),
+                                            _stream()))
+    return rows, Pv
 
 
 def cons_to_reference(cons_compact, P):

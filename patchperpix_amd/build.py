@@ -22,8 +22,26 @@ def sources():
         sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
+def _toolchain(hipcc):
+    """what the object stamp records of the compiler: its path and version banner"""
+    try:
+        v = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60).stdout
+        return hipcc + " " + " ".join(v.decode(errors="replace").split())
+    except (OSError, subprocess.SubprocessError):
+        return hipcc
+
+
+def _flags_stamp():
+    return os.path.join(CSRC, "_obj", os.path.basename(LIB), "lib.flags")
+
+
 def is_stale():
     if not os.path.exists(LIB):
+        return True
+    # a library built with other PPP_EXTRA_FLAGS is stale too
+    want = " ".join(os.environ.get("PPP_EXTRA_FLAGS", "").split())
+    have = open(_flags_stamp()).read() if os.path.exists(_flags_stamp()) else ""
+    if want != have:
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
@@ -31,10 +49,11 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, relink=False):
     """Every translation unit is compiled on its own (in parallel, objects under csrc/_obj/),
-    then linked: a full build takes as long as the slowest file instead of their sum."""
-    if not force and not is_stale():
+    then linked: a full build takes as long as the slowest file instead of their sum.
+    force: recompile every object; relink: link again, reusing objects that are up to date."""
+    if not force and not relink and not is_stale():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -46,14 +65,14 @@ def build_library(force=False, verbose=False):
     headers = glob.glob(os.path.join(CSRC, "*.hpp")) + \
         [os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "ppp_mi355x.h")]
     newest_header = max(os.path.getmtime(h) for h in headers)
-    stamp = " ".join(cflags + extra)
+    stamp = " ".join(cflags + extra) + " | " + _toolchain(hipcc)
 
     def compile_one(src):
         # an object is reused when it is newer than its source and every header and was built
         # with the same flags (PPP_EXTRA_FLAGS variants keep their own object directory)
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         flag_file = obj + ".flags"
-        if os.path.exists(obj) and os.path.exists(flag_file) and open(flag_file).read() == stamp and \
+        if not force and os.path.exists(obj) and os.path.exists(flag_file) and open(flag_file).read() == stamp and \
                 os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
             return obj
         cmd = [hipcc] + cflags + extra + ["-c", src, "-o", obj]
@@ -70,8 +89,12 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(_flags_stamp(), "w") as f:
+        f.write(" ".join(extra))
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    # default: rebuild what is out of date and link; --force recompiles everything
+    print(build_library(force="--force" in sys.argv[1:], relink=True, verbose=True))

@@ -88,6 +88,8 @@ int make_geo(const ppp_params *p, ppp::Geo *G) {
     g.bz0 = b.z0; g.by0 = b.y0; g.bx0 = b.x0;
     g.bZ = b.z1 - b.z0; g.bY = b.y1 - b.y0; g.bX = b.x1 - b.x0;
     g.BV = (long long)g.bZ * g.bY * g.bX;
+    g.cz0 = g.bz0; g.cy0 = g.by0; g.cx0 = g.bx0;
+    g.cZ = g.bZ; g.cY = g.bY; g.cX = g.bX;
     g.nsy = 2 * p->py; g.nsx = 2 * p->px;
     g.wy = 2 * p->py - 1; g.wx = 2 * p->px - 1;
     g.n_planes = ((2 * p->pz - 1) * g.wy * g.wx - 1) / 2;
@@ -179,6 +181,28 @@ int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_over
     G.vm_open = 1;
     hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, nullptr, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus_rows");
+}
+
+int ppp_consensus_part(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, float *d_cons,
+                       const ppp_params *p, const ppp_box *part, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_pred || !d_cons || !part) return fail(PPP_ERR_INVALID_ARG, "NULL pred / output / part");
+    if (G.use_overlap && !d_overlap) return fail(PPP_ERR_INVALID_ARG, "use_overlap set but d_overlap is NULL");
+    if ((G.layout != PPP_CONS_VOXEL_MAJOR && G.layout != PPP_CONS_COMPACT) || !ppp::consensus_v3_supported(G))
+        return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus_part writes COMPACT planes or VOXEL_MAJOR rows with the packed "
+                                         "kernel only (see ppp_consensus_writes_voxel_major)");
+    const ppp_box &b = p->cons_box;
+    if (part->z0 < b.z0 || part->y0 < b.y0 || part->x0 < b.x0 || part->z1 > b.z1 || part->y1 > b.y1 ||
+        part->x1 > b.x1 || part->z1 <= part->z0 || part->y1 <= part->y0 || part->x1 <= part->x0)
+        return fail(PPP_ERR_INVALID_ARG, "part must be a non-empty sub-box of cons_box");
+    PPP_TRY(need_device());
+    G.vm_open = 1;
+    G.cz0 = part->z0; G.cy0 = part->y0; G.cx0 = part->x0;
+    G.cZ = part->z1 - part->z0; G.cY = part->y1 - part->y0; G.cX = part->x1 - part->x0;
+    hipError_t e = ppp::launch_consensus_part(d_pred, pred_dtype, d_overlap, d_cons, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus_part");
 }
 
 int ppp_consensus_writes_voxel_major(const ppp_params *p) {
@@ -602,6 +626,21 @@ int ppp_cons_to_voxel_major(const float *d_cons_compact, float *d_cons_voxel_maj
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_cons_to_voxel_major(d_cons_compact, d_cons_voxel_major, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cons_to_voxel_major");
+}
+
+int ppp_cons_planes_to_rows(const float *d_planes, const ppp_box *planes_box, float *d_rows, const ppp_params *p,
+                            void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    if (!d_planes || !d_rows || !planes_box) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.layout != PPP_CONS_VOXEL_MAJOR) return fail(PPP_ERR_INVALID_ARG, "params must describe the VOXEL_MAJOR rows");
+    const ppp_box &b = p->cons_box, &q = *planes_box;
+    if (q.z1 <= q.z0 || q.y1 <= q.y0 || q.x1 <= q.x0 || b.z0 < q.z0 || b.y0 < q.y0 || b.x0 < q.x0 || b.z1 > q.z1 ||
+        b.y1 > q.y1 || b.x1 > q.x1)
+        return fail(PPP_ERR_INVALID_ARG, "the planes' box must hold cons_box (the rows' box)");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_cons_planes_to_rows(d_planes, q, d_rows, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cons_planes_to_rows");
 }
 
 int ppp_patch_bits(const void *d_pred, int pred_dtype, const uint32_t *d_centres, uint64_t n,

@@ -35,6 +35,9 @@ struct Geo {
     int n_planes;       // compact: ((2pz-1)(2py-1)(2px-1)-1)/2
     int oz, oy, ox;     // global coordinate of local voxel (0,0,0)
     int vm_open;        // voxel-major output: entries with a source outside the box stay undefined
+    // S1 only: the base voxels a launch COMPUTES (a sub-box of the cons box, which stays the
+    // box the output buffer is indexed by); the whole cons box unless ppp_consensus_part asks
+    int cz0, cy0, cx0, cZ, cY, cX;
 };
 
 // A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch

@@ -141,6 +141,13 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     return hipGetLastError();
 }
 
+// S1 for a sub-box of the cons box (G.c*): the packed kernel only
+hipError_t launch_consensus_part(const void *pred, int dtype, const uint8_t *ov, float *cons, const Geo &G,
+                                 hipStream_t s) {
+    g_s1_kernel = "consensus_v3_kernel";
+    return launch_consensus_v3(pred, dtype, ov, cons, nullptr, G, s);
+}
+
 // ---- compact -> reference layout ------------------------------------------------------
 __global__ void cons_expand_kernel(const float *__restrict__ compact, float *__restrict__ ref,
                                    const Geo G) {
@@ -176,9 +183,13 @@ hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo 
 // i.e. the consensus between voxel v and voxel v+q.  The patch-graph kernel reads, for a
 // fixed pixel z1, a run of consecutive L -- contiguous in this layout.  64x64 LDS transpose:
 // coalesced reads along the voxel axis, coalesced writes along L.
+// The planes may be indexed by a box of their own (sz0 ... sX: a cache of compact planes over a
+// larger box, ppp_cons_planes_to_rows): the rows' box lies inside it; a negative entry whose
+// earlier voxel lies outside the PLANES' box is 0 (nothing reads it, see ppp_consensus_rows).
+struct PlaneBox { int z0, y0, x0, Y, X; long long V; };
 __global__ void __launch_bounds__(256)
     cons_voxel_major_kernel(const float *__restrict__ compact, float *__restrict__ S, const Geo G,
-                            const int W) {
+                            const int W, const PlaneBox Q) {
     __shared__ float tile[64][65];
     const int Lc = (W - 1) / 2;
     const long long v0 = (long long)blockIdx.x * 64;
@@ -205,12 +216,14 @@ __global__ void __launch_bounds__(256)
             const int q2 = t2 / G.wx;
             const int qy = q2 % G.wy - (G.py - 1);
             const int qz = q2 / G.wy;
+            // (coordinates in the planes' box)
+            const int sz = bz + G.bz0 - Q.z0, sy = by + G.by0 - Q.y0, sx = bx + G.bx0 - Q.x0;
             if (!neg) {
-                val = compact[(long long)(Ls - 1) * G.BV + v];
+                val = compact[(long long)(Ls - 1) * Q.V + ((long long)sz * Q.Y + sy) * Q.X + sx];
             } else {
-                const int ez = bz - qz, ey = by - qy, ex = bx - qx;  // earlier voxel v + q
-                if (ez >= 0 && ey >= 0 && ey < G.bY && ex >= 0 && ex < G.bX)
-                    val = compact[(long long)(Ls - 1) * G.BV + ((long long)ez * G.bY + ey) * G.bX + ex];
+                const int ez = sz - qz, ey = sy - qy, ex = sx - qx;  // earlier voxel v + q
+                if (ez >= 0 && ey >= 0 && ey < Q.Y && ex >= 0 && ex < Q.X)
+                    val = compact[(long long)(Ls - 1) * Q.V + ((long long)ez * Q.Y + ey) * Q.X + ex];
             }
         }
         tile[i][lane] = val;
@@ -228,7 +241,19 @@ hipError_t launch_cons_to_voxel_major(const float *compact, float *S, const Geo 
     const int W = (2 * G.pz - 1) * G.wy * G.wx;
     PPP_GRID_CHECK((G.BV + 63) / 64, 256);
     const dim3 grid((unsigned)((G.BV + 63) / 64), (unsigned)((W + 63) / 64));
-    cons_voxel_major_kernel<<<grid, dim3(256), 0, s>>>(compact, S, G, W);
+    const PlaneBox Q = {G.bz0, G.by0, G.bx0, G.bY, G.bX, G.BV};
+    cons_voxel_major_kernel<<<grid, dim3(256), 0, s>>>(compact, S, G, W, Q);
+    return hipGetLastError();
+}
+
+hipError_t launch_cons_planes_to_rows(const float *planes, const ppp_box &pb, float *S, const Geo &G,
+                                      hipStream_t s) {
+    const int W = (2 * G.pz - 1) * G.wy * G.wx;
+    PPP_GRID_CHECK((G.BV + 63) / 64, 256);
+    const dim3 grid((unsigned)((G.BV + 63) / 64), (unsigned)((W + 63) / 64));
+    const PlaneBox Q = {pb.z0, pb.y0, pb.x0, pb.y1 - pb.y0, pb.x1 - pb.x0,
+                        (long long)(pb.z1 - pb.z0) * (pb.y1 - pb.y0) * (pb.x1 - pb.x0)};
+    cons_voxel_major_kernel<<<grid, dim3(256), 0, s>>>(planes, S, G, W, Q);
     return hipGetLastError();
 }
 

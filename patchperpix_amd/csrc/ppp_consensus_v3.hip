@@ -302,24 +302,26 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
     const int xr = (int)(run % runs_per_line);
     run /= runs_per_line;
     int uy, uz, ux0, nA;
+    // (base voxels are enumerated over the COMPUTE box c*, a sub-box of the cons box b* that
+    // indexes the output)
     if (FLAT) {
         const int flat0 = xr * 64;
-        uy = G.by0 + flat0 / G.bX;
-        uz = G.bz0 + 2 * (int)run;
-        ux0 = G.bx0 + flat0 % G.bX;
-        nA = min(64, G.bX - flat0 % G.bX);
+        uy = G.cy0 + flat0 / G.cX;
+        uz = G.cz0 + 2 * (int)run;
+        ux0 = G.cx0 + flat0 % G.cX;
+        nA = min(64, G.cX - flat0 % G.cX);
     } else {
-        uy = G.by0 + (int)(run % G.bY);
-        uz = G.bz0 + 2 * (int)(run / G.bY);
-        ux0 = G.bx0 + xr * 64;
+        uy = G.cy0 + (int)(run % G.cY);
+        uz = G.cz0 + 2 * (int)(run / G.cY);
+        ux0 = G.cx0 + xr * 64;
         nA = 64;
     }
-    const bool have_s1 = uz + 1 < G.bz0 + G.bZ;                    // slice 1 exists (wave-uniform)
+    const bool have_s1 = uz + 1 < G.cz0 + G.cZ;                    // slice 1 exists (wave-uniform)
     const bool in_b = FLAT && lane >= nA;                          // this lane sits on line B
-    const bool have_b = FLAT && nA < 64 && uy + 1 < G.by0 + G.bY;  // (wave-uniform)
-    const int ux = in_b ? G.bx0 + (lane - nA) : ux0 + lane;
+    const bool have_b = FLAT && nA < 64 && uy + 1 < G.cy0 + G.cY;  // (wave-uniform)
+    const int ux = in_b ? G.cx0 + (lane - nA) : ux0 + lane;
     const int uy_l = in_b ? uy + 1 : uy;
-    const bool lane_ok = in_b ? have_b : ux < G.bx0 + G.bX;
+    const bool lane_ok = in_b ? have_b : ux < G.cx0 + G.cX;
     const int pos_l = lane + (PX - 1) + (in_b ? PX - 1 : 0);       // image column of the lane's centre at kx = PX-1
     const int wy = uy + dy;                                        // (line A; line B: wy + 1)
     const bool wy_ok_a = wy >= 0 && wy < G.Y;
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
         const bool wz_ok = s ? wz_ok1 : wz_ok0;
         for (int i = lane; i < K::NT; i += 64) {
             const bool sb = FLAT && i >= ntA;
-            const int x = sb ? G.bx0 - (PX - 1) + (i - ntA) : ux0 - (PX - 1) + i;
+            const int x = sb ? G.cx0 - (PX - 1) + (i - ntA) : ux0 - (PX - 1) + i;
             const int yy = sb ? uy + 1 : uy, wyy = sb ? wy + 1 : wy;
             bool vu = false, vw = false;
             if (s_ok && x >= 0 && x < G.X && (!sb || have_b)) {
@@ -373,7 +375,7 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
     auto centre_x = [&](int i, bool &sb, bool &ok) -> int {
         sb = FLAT && i >= ncA;
         const int iseg = sb ? i - ncA : i;
-        const int cx = (sb ? G.bx0 : ux0) - (PX - 1) + K::RX + iseg;
+        const int cx = (sb ? G.cx0 : ux0) - (PX - 1) + K::RX + iseg;
         ok = cx >= K::RX && cx < G.X - K::RX && (!sb || have_b);
         return min(max(cx, 0), G.X - 1) + (sb ? G.X : 0);
     };
@@ -704,9 +706,9 @@ template <typename T, int PX, bool FLAT>
 static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, float *cnt,
                              const Geo &G, hipStream_t s) {
     const int n_rows = (G.pz - 1) * G.wy + G.py;
-    const int runs_per_line = FLAT ? (int)(((long long)G.bX * G.bY + 63) / 64) : (G.bX + 63) / 64;
-    const int bZ2 = (G.bZ + 1) / 2;
-    const long long n_waves = (long long)runs_per_line * (FLAT ? 1 : G.bY) * bZ2 * n_rows;
+    const int runs_per_line = FLAT ? (int)(((long long)G.cX * G.cY + 63) / 64) : (G.cX + 63) / 64;
+    const int bZ2 = (G.cZ + 1) / 2;
+    const long long n_waves = (long long)runs_per_line * (FLAT ? 1 : G.cY) * bZ2 * n_rows;
     constexpr int V3_WAVES = PPP_S1V3_WAVES(PX);
     const long long n_blocks = (n_waves + V3_WAVES - 1) / V3_WAVES;
     if (n_blocks >= (1ll << 31)) return hipErrorInvalidValue;
@@ -726,9 +728,9 @@ static hipError_t launch_v3(const T *pred, const uint8_t *ov, float *cons, float
                             const Geo &G, hipStream_t s) {
     static EnvSwitch sw("PPP_S1_FLAT");        // same rule as v2
     const char *e = sw.get();
-    bool flat = G.bX >= 64 && G.bX % 64 != 0 && G.py >= 3 && G.bY > 1;
+    bool flat = G.cX >= 64 && G.cX % 64 != 0 && G.py >= 3 && G.cY > 1;
     if (e && e[0] == '0') flat = false;
-    if (e && e[0] == '1' && G.bX >= 64 && G.py >= 3) flat = true;
+    if (e && e[0] == '1' && G.cX >= 64 && G.py >= 3) flat = true;
     return flat ? launch_v3f<T, PX, true>(pred, ov, cons, cnt, G, s)
                 : launch_v3f<T, PX, false>(pred, ov, cons, cnt, G, s);
 }

@@ -38,6 +38,8 @@ const char *last_consensus_kernel();
 bool consensus_v3_supported(const Geo &G);
 hipError_t launch_consensus_v3(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s);
+hipError_t launch_consensus_part(const void *pred, int dtype, const uint8_t *ov, float *cons, const Geo &G,
+                                 hipStream_t s);
 bool consensus_v4_supported(const Geo &G);
 hipError_t launch_consensus_v4(const void *pred, int dtype, const uint8_t *ov, float *cons,
                                float *cnt, const Geo &G, hipStream_t s);
@@ -106,6 +108,8 @@ hipError_t launch_paint(const void *pred, int dtype, const uint32_t *nodes,
                         const uint32_t *labels, uint64_t n, uint32_t *inst, const Geo &G,
                         hipStream_t s);
 hipError_t launch_cons_to_voxel_major(const float *compact, float *S, const Geo &G,
+                                      hipStream_t s);
+hipError_t launch_cons_planes_to_rows(const float *planes, const ppp_box &pb, float *S, const Geo &G,
                                       hipStream_t s);
 hipError_t launch_cons_to_reference(const float *compact, float *ref, const Geo &G,
                                     hipStream_t s);

@@ -32,6 +32,7 @@ use local coordinates; ``ppp_params.origin_z`` carries the global offset (the pe
 of the patch-graph kernel is the only thing that depends on absolute coordinates).
 """
 import logging
+import ctypes
 import os
 
 import numpy as np
@@ -420,6 +421,27 @@ class DeviceOps:
             return None
         W = (2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1)
         return backend._big_empty((int(n_voxels) * W,), self.device)
+
+    # -- consensus cache: COMPACT planes over a rank's whole block, every base voxel computed once
+    def cons_cache_alloc(self, P):
+        """None when S1 cannot fill a cache for these parameters (packed kernel only)"""
+        if not backend.direct_voxel_major(P):
+            return None
+        Pc = P.copy()
+        Pc.cons_layout = backend.CONS_COMPACT
+        n = int(backend.lib().ppp_cons_elems(ctypes.byref(Pc)))
+        return backend._big_empty((n,), self.device)
+
+    def cons_cache_fill(self, pred, ov, P, part, cache):
+        Pc = P.copy()
+        Pc.cons_layout = backend.CONS_COMPACT
+        backend.consensus_part(pred, ov if P.use_overlap else None, Pc, part, cache)
+
+    def cons_from_cache(self, cache, cache_box, P, out=None):
+        """the layout ranking and patch graph read (voxel-major rows of P.cons_box)"""
+        if out is not None and os.environ.get("PPP_VM_POISON") == "1":
+            out.fill_(float("nan"))
+        return backend.cons_planes_to_rows(cache, cache_box, P, out=out)
 
     def patch_bits(self, pred, centres, thresh, P, scratch=None):
         return backend.patch_bits(pred, centres, thresh, P, scratch=scratch)
@@ -876,6 +898,43 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             return ops.consensus_voxel_major(fr.pred, fr.ov, P, **({"out": pool} if pool is not None else {}))
         return ops.consensus(fr.pred, fr.ov, P), P
 
+    # ---- consensus cache (`_cons_cache`, decided by the caller's memory plan: plan_tiles).
+    # Several tiles and a resident prediction: the COMPACT planes of the rank's whole block (every
+    # tile's pairs box) are computed ONCE, tile by tile, into one array; the voxel-major rows a tile
+    # needs -- for its scores now, for its pair rows after the global stage -- are cut from it by a
+    # transpose.  S1 then runs over 1.0 x the block (+ the rank's z-halo) instead of scores pass
+    # (tile + radius) + pairs pass (tile + radius + p - 1): 2.5 x at 512^3 / 9^3.
+    cache = cache_box = None
+    if kw.get("_cons_cache") and not keep_cons and len(my_tiles) > 1 and whole is not None and contiguous \
+            and hasattr(ops, "cons_cache_alloc") \
+            and (not hasattr(ops, "rank_on_voxel_major") or ops.rank_on_voxel_major(params(whole))):
+        boxes = [bases_for_pairs(t) for t in my_tiles]
+        cache_box = tuple(f(b[i] for b in boxes) for i, f in enumerate((min, max) * 3))
+        Pc = params(whole, cache_box)
+        cache = ops.cons_cache_alloc(Pc)
+        if cache is None:
+            cache_box = None
+        else:
+            def to_frame(b):
+                o = whole.origin
+                return (b[0] - o[0], b[2] - o[1], b[4] - o[2], b[1] - o[0], b[3] - o[1], b[5] - o[2])
+            with backend.host_timer("s1_consensus"):
+                for t in my_tiles:
+                    # a tile fills its own voxels; tiles on the rim of the rank's block also the rim
+                    part = list(t)
+                    for a in range(3):
+                        lo_a, hi_a = (oz0, oz1) if a == 0 else (0, dims[a])
+                        if t[2 * a] == lo_a:
+                            part[2 * a] = cache_box[2 * a]
+                        if t[2 * a + 1] == hi_a:
+                            part[2 * a + 1] = cache_box[2 * a + 1]
+                    ops.cons_cache_fill(whole.pred, whole.ov, Pc, to_frame(part), cache)
+            backend.note("cons_cache_gb", round(cache.numel() * 4 / 1e9, 2))
+
+    def rows_from_cache(fr, cbox, pool):
+        with backend.host_timer("cons_rows"):
+            return ops.cons_from_cache(cache, to_frame(cache_box), params(fr, cbox), **({"out": pool} if pool is not None else {}))
+
     # ---- stage A: consensus + scores per tile ----------------------------------------------
     # several tiles: ONE consensus buffer, sized for the largest box of either pass, serves all
     # of them (allocated first, while the allocator's address space is still unfragmented)
@@ -902,8 +961,11 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         fr = frame_for(scores_frame_box(t), scores_frame_box(my_tiles[ti + 1]) if ti + 1 < len(my_tiles) else None)
         o = fr.origin
         P = params(fr, cbox)
-        with backend.host_timer("s1_consensus"):
-            cons, P = consensus_of(fr, P, pool)
+        if cache is not None:
+            cons, P = rows_from_cache(fr, cbox, pool)
+        else:
+            with backend.host_timer("s1_consensus"):
+                cons, P = consensus_of(fr, P, pool)
         with backend.host_timer("s2_rank"):
             same = fr.shape == (Zf, Y, X) and o == (flo, 0, 0)
             sc = ops.rank_patches(fr.pred, cons, fr.ov, P, (z0 - o[0], y0 - o[1], x0 - o[2], z1 - o[0], y1 - o[1], x1 - o[2]),
@@ -1124,6 +1186,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             cons, P, fr = kept.pop(t)
             return fr, cons, P
         cbox = bases_for_pairs(t)
+        if cache is not None:
+            cons, P = rows_from_cache(whole, cbox, pool)
+            return whole, cons, P
         nxt = next_of(t)
         fr = frame_for(pairs_frame_box(t), pairs_frame_box(nxt) if nxt is not None else None)
         cons, P = consensus_of(fr, params(fr, cbox), pool)
@@ -1226,7 +1291,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
                 aff[idx] = a
             del cons, idx, a, fr
     kept.clear()
-    pool = scratch = None
+    pool = scratch = cache = None
     if state is None:
         comm.all_reduce_sum(aff)
     if want_inter:
@@ -1405,6 +1470,41 @@ def tiles_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
     if best is None:
         return Z, min(Y, 64), min(X, 64)
     return best[1], best[2], best[3]
+
+
+def pairs_box_voxels(shape, patchshape, n, ny, nx):
+    """base voxels of the largest pairs box (tile + radius + p - 1 below in z, on both sides in
+    y / x, clipped to the volume) of an n x ny x nx grid of tiles"""
+    big = 1
+    for ext, k, p, both in zip(shape, (n, ny, nx), patchshape, (False, True, True)):
+        r, g = int(p) // 2, int(p) - 1
+        big *= max(min(int(ext), b + r + (g if both else 0)) - max(0, a - r - g) for a, b in plan_slabs(int(ext), k))
+    return big
+
+
+def cons_cache_bytes(box_shape, patchshape):
+    """bytes of the COMPACT consensus planes over a box of base voxels"""
+    pz, py, px = [int(p) for p in patchshape]
+    planes = ((2 * pz - 1) * (2 * py - 1) * (2 * px - 1) - 1) // 2
+    return 4.0 * planes * float(np.prod([int(v) for v in box_shape]))
+
+
+def plan_tiles(own_shape, patchshape, free_bytes, safety=0.6, copies=3.0, cache_shape=None, min_pool=10e9):
+    """(n_slabs, ny, nx, use_cache).  With `cache_shape` -- the box of base voxels a consensus cache
+    would span: the rank's own block grown by the pairs halo, clipped -- the cache is taken when its
+    planes fit and at least `min_pool` bytes remain for the rows of one tile; the tile grid is then
+    planned for what is left.  PPP_CONS_CACHE=0 / 1 overrides the memory rule (1: taken whenever a
+    grid still fits)."""
+    mode = os.environ.get("PPP_CONS_CACHE", "auto")
+    budget = safety * free_bytes
+    whole_fits = tiles_needed(own_shape, patchshape, free_bytes, safety=safety, copies=copies) == (1, 1, 1)
+    if cache_shape is not None and mode != "0" and not whole_fits:
+        left = budget - cons_cache_bytes(cache_shape, patchshape)
+        if left >= (min_pool if mode != "1" else 1e9):
+            n, ny, nx = tiles_needed(own_shape, patchshape, left, safety=1.0, copies=copies)
+            if float(copies) * cons_cache_bytes((1, 1, 1), patchshape) * pairs_box_voxels(own_shape, patchshape, n, ny, nx) <= left:
+                return n, ny, nx, True       # (tiles_needed's last resort may not fit)
+    return tiles_needed(own_shape, patchshape, free_bytes, safety=safety, copies=copies) + (False,)
 
 
 def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,

@@ -127,7 +127,7 @@ def main(pred_file, result_folder='.', **kwargs):
     Output datasets and dtypes follow the reference: ``vote_instances``, ``vote_foreground``,
     ``vote_instances_masked`` (uint16)."""
     from patchperpix_amd import backend as _backend
-    _backend.tune_host_allocator()
+    _backend.tune_host_allocator(cli=__name__ == "__main__")
     if kwargs.pop("blockwise_semantics", "whole_volume") == "reference":
         # the reference's own function of the input: per-block cover, block graphs on disk,
         # inter-block edges, one global labelling (patchperpix_amd/blockwise.py)

@@ -192,9 +192,13 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         # (ranked lists, cover / sort work space: ~70 bytes per voxel) and the pair rows of the
         # patch-graph stage must fit next to it
         reserve = 70.0 * float(np.prod(shape)) + 4e9
-        n_slabs, ny_t, nx_t = tiling.tiles_needed(shape, patchshape, max(avail - reserve, 0.25 * avail),
-                                                  safety=float(os.environ.get("PPP_TILE_SAFETY", "0.92")),
-                                                  copies=2.0 if direct else 3.0)
+        # (a consensus cache -- every base voxel computed once, tiling.assemble -- is taken when its
+        # planes fit next to the rows of one tile; only the packed S1 kernel fills one)
+        n_slabs, ny_t, nx_t, use_cache = tiling.plan_tiles(
+            shape, patchshape, max(avail - reserve, 0.25 * avail),
+            safety=float(os.environ.get("PPP_TILE_SAFETY", "0.92")), copies=2.0 if direct else 3.0,
+            cache_shape=shape if direct and torch.is_tensor(pred_affs) else None)
+        kwargs.setdefault("_cons_cache", use_cache)
         if yx_tiles is None and (ny_t > 1 or nx_t > 1):
             yx_tiles = (ny_t, nx_t)
     # With nothing to store or load between the stages, the single-slab case takes the same
@@ -409,7 +413,7 @@ def main(**kwargs):
     """Whole-volume driver (vote_instances.py:557-604): command-line arguments overridden by
     keyword arguments; ``affinities`` is one prediction file or a directory of ``*.hdf``
     files, otherwise ``<basedir>/<mode>/processed/<checkpoint>/*.hdf``."""
-    backend.tune_host_allocator()
+    backend.tune_host_allocator(cli=__name__ == "__main__")
     from_cli = not kwargs
     required = kwargs['check_required'] if 'check_required' in kwargs else True
     args = vars(get_arguments(check_required=required, argv=None if from_cli else []))

@@ -45,6 +45,33 @@ class OracleOps:
         pos = orc.positive_planes(full, ps)[:, b.z0:b.z1, b.y0:b.y1, b.x0:b.x1]
         return torch.from_numpy(np.ascontiguousarray(pos))
 
+    # -- consensus cache (same contract as DeviceOps: COMPACT planes over the cache's box, filled
+    #    part by part; a tile's share handed out in the layout rank_patches / patch_graph read)
+    def cons_cache_alloc(self, P):
+        n_planes = ((2 * P.pz - 1) * (2 * P.py - 1) * (2 * P.px - 1) - 1) // 2
+        return torch.full((n_planes,) + P.cons_box.shape(), float("nan"), dtype=torch.float32)
+
+    def cons_cache_fill(self, pred, ov, P, part, cache):
+        z0, y0, x0, z1, y1, x1 = [int(v) for v in part]
+        b = P.cons_box
+        assert b.z0 <= z0 < z1 <= b.z1 and b.y0 <= y0 < y1 <= b.y1 and b.x0 <= x0 < x1 <= b.x1
+        key = (pred.data_ptr(), tuple(pred.shape))
+        if getattr(self, "_cache_full_key", None) != key:
+            full = orc.consensus(pred.numpy().astype(np.float32), ov.numpy(), self._ps(P), **self.kw)
+            self._cache_full = orc.positive_planes(full, self._ps(P))
+            self._cache_full_key = key
+        piece = self._cache_full[:, z0:z1, y0:y1, x0:x1]
+        view = cache[:, z0 - b.z0:z1 - b.z0, y0 - b.y0:y1 - b.y0, x0 - b.x0:x1 - b.x0]
+        assert bool(torch.isnan(view).all()), "a base voxel of the cache is filled twice"
+        view.copy_(torch.from_numpy(np.ascontiguousarray(piece)))
+
+    def cons_from_cache(self, cache, cache_box, P, out=None):
+        cz0, cy0, cx0 = [int(v) for v in cache_box[:3]]
+        b = P.cons_box
+        piece = cache[:, b.z0 - cz0:b.z1 - cz0, b.y0 - cy0:b.y1 - cy0, b.x0 - cx0:b.x1 - cx0]
+        assert not bool(torch.isnan(piece).any()), "a base voxel of the cache was never filled"
+        return piece.contiguous(), P
+
     def rank_patches(self, pred, cons, ov, P, score_box):
         full = self._ref_layout(cons, P)
         s = orc.rank(pred.numpy().astype(np.float32), full, ov.numpy(), self._ps(P), **self.kw)

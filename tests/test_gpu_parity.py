@@ -910,6 +910,81 @@ def test_open_rows_never_reach_a_result(ps, shape, cell, torch_cuda, monkeypatch
     assert np.array_equal(want, got) and want.max() > 5
 
 
+@pytest.mark.parametrize("ps,shape,cell,flags", [((7, 7, 7), (48, 52, 56), 18, "shipped"), ((9, 9, 9), (44, 48, 60), 24, "shipped"),
+                                                 ((5, 5, 5), (40, 44, 48), 12, "cc"), ((5, 9, 9), (30, 50, 70), 20, "cc")])
+def test_consensus_cache_equals_recomputation(ps, shape, cell, flags, torch_cuda, monkeypatch):
+    """Tiled path with the consensus cache (`_cons_cache`: ppp_consensus_part fills COMPACT planes
+    over the whole block once, ppp_cons_planes_to_rows cuts every tile's rows from them, in both
+    passes) against the tiled path that computes every tile's rows itself: pair rows, pair affinities
+    (bit patterns) and instance map are the same; the row buffer is poisoned with NaN before every
+    cut, so an entry the transpose leaves unwritten would show."""
+    from patchperpix_amd import backend, synth
+    from patchperpix_amd import flags as F
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    kw = dict(F.FLYLIGHT if flags == "shipped" else F.FLYLIGHT_CC, _instances_dtype=np.uint32)
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, [cell] * 3, seed=6)
+    pred = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=6, f16=True)
+    fg = lab != 0
+    args = lambda: (fg.copy(), fg.copy(), fg.astype(np.uint8), list(ps))     # noqa: E731
+    for grid in (dict(_n_slabs=2, _yx_tiles=(2, 2)), dict(_n_slabs=3, _yx_tiles=(1, 2))):
+        want = vi.to_instance_seg(pred, *args(), **dict(kw, _cons_cache=False, **grid))[0]
+        want_pairs, want_aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, _cons_cache=False, **grid))
+        monkeypatch.setenv("PPP_VM_POISON", "1")
+        backend.NOTES.pop("cons_cache_gb", None)
+        got = vi.to_instance_seg(pred, *args(), **dict(kw, _cons_cache=True, **grid))[0]
+        # (a shape without a voxel-major ranking kernel keeps the two-pass path: same result)
+        assert ("cons_cache_gb" in backend.NOTES) == (ps[0] == ps[1] == ps[2])
+        got_pairs, got_aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, _cons_cache=True, **grid))
+        monkeypatch.delenv("PPP_VM_POISON")
+        assert np.array_equal(want_pairs, got_pairs)
+        assert not np.isnan(got_aff).any()
+        assert np.array_equal(_bits(want_aff), _bits(got_aff))
+        assert np.array_equal(want, got) and want.max() > 5
+
+
+def test_consensus_part_and_planes_to_rows(torch_cuda):
+    """ppp_consensus_part: COMPACT planes / open VOXEL_MAJOR rows of a box filled in pieces equal the
+    one-launch result; ppp_cons_planes_to_rows from a larger planes box equals the rows S1 writes for
+    the sub-box (wherever both define an entry: sources inside the sub-box)."""
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    torch = torch_cuda
+    for ps, shape in (((9, 9, 9), (21, 30, 140)), ((7, 7, 7), (20, 33, 90)), ((5, 5, 5), (16, 20, 70))):
+        c = synth.make_case(shape, ps, seed=99, cell=[7, 8, 9], overlap_frac=0.02)
+        kw = dict(FLYLIGHT)
+        pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+        ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+        box = (1, 2, 3, shape[0] - 1, shape[1] - 2, shape[2] - 5)
+        P = backend.make_params(shape, ps, cons_box=box, **kw)
+        whole = backend.consensus(pred, ov, P)
+        # the same planes from four pieces (cut in z at an odd slice, in y and in x)
+        zc, yc, xc = box[0] + 5, box[1] + 11, box[2] + 70
+        parts = [(box[0], box[1], box[2], zc, box[4], box[5]), (zc, box[1], box[2], box[3], yc, box[5]),
+                 (zc, yc, box[2], box[3], box[4], xc), (zc, yc, xc, box[3], box[4], box[5])]
+        pieces = torch.full_like(whole, float("nan"))
+        for part in parts:
+            backend.consensus_part(pred, ov, P, part, pieces)
+        assert torch.equal(pieces.view(torch.int32), whole.view(torch.int32)), ps
+        # rows of a sub-box cut from the planes == rows S1 writes for that sub-box, where the source
+        # voxel of an entry lies inside the sub-box (elsewhere S1's open rows are undefined)
+        sub = (box[0] + 2, box[1] + 3, box[2] + 9, box[3] - 1, box[4] - 2, box[5] - 4)
+        Ps = backend.make_params(shape, ps, cons_box=sub, **kw)
+        rows_cut, Pv = backend.cons_planes_to_rows(whole, box, Ps)
+        Pz = Ps.copy()
+        Pz.cons_layout = backend.CONS_VOXEL_MAJOR
+        rows_s1 = backend.consensus(pred, ov, Pz)                    # zero-filled rows (not open)
+        W = rows_s1.shape[-1]
+        Lc = (W - 1) // 2
+        assert torch.equal(rows_cut[..., Lc:].view(torch.int32), rows_s1[..., Lc:].view(torch.int32)), ps
+        # negative entries: equal wherever S1's are not the zero fill of a missing source
+        inner = (slice(ps[0] - 1, None), slice(ps[1] - 1, rows_s1.shape[1] - (ps[1] - 1)),
+                 slice(ps[2] - 1, rows_s1.shape[2] - (ps[2] - 1)))
+        assert torch.equal(rows_cut[inner].view(torch.int32), rows_s1[inner].view(torch.int32)), ps
+        assert int(torch.count_nonzero(rows_cut[inner])) > 1000
+
+
 def test_resume_from_a_saved_consensus(torch_cuda, tmp_path):
     """Kernel path: `save_consensus` writes the reference-layout array (consensus_array.py:202-206);
     a later call with `consensus=<that file>` (:213-218) loads it instead of running S1 -- same

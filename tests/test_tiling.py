@@ -16,6 +16,15 @@ from patchperpix_amd import synth, tiling
 from patchperpix_amd.flags import FLYLIGHT_NOTHIN_CC as FLYLIGHT
 
 
+def _free_port():
+    """a TCP port nobody listens on right now (fixed rendezvous ports collide when two launches
+    overlap: parametrised cases under pytest-xdist, two suites on one box)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def make_case(seed=61, shape=(44, 12, 13), ps=(3, 3, 3)):
     c = synth.make_case(shape, ps, seed=seed, cell=[5, 5, 5], overlap_frac=0.02)
     if os.environ.get("PPP_TEST_EMPTY_TOP") == "1":
@@ -82,6 +91,52 @@ def test_yx_tiles_equal_whole_volume_cpu(n_slabs, yx):
     assert np.array_equal(inst, ref["instances"]) and inst.any()
 
 
+@pytest.mark.parametrize("n_slabs,yx,thin", [(2, (2, 2), False), (3, (1, 2), True), (4, (1, 1), False)])
+def test_consensus_cache_equals_whole_volume_cpu(n_slabs, yx, thin):
+    """`_cons_cache`: every base voxel's consensus computed once into a cache over the block (each
+    voxel filled exactly once -- the stand-in ops check that), the tiles' shares cut from it in
+    both passes: same pair affinities, same instance map."""
+    import torch
+    from oracle_ops import OracleOps
+    from patchperpix_amd import backend
+    c, ps, kw = make_case(seed=64, shape=(20, 17, 19))
+    kw["skipThinCover"] = not thin
+    ref = whole_volume(c, ps, kw)
+    ops = OracleOps(**kw)
+    slabs = tiling.plan_slabs(c["pred"].shape[1], n_slabs)
+    backend.NOTES.pop("cons_cache_gb", None)
+    pairs, aff = tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                                 c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                                 slabs, ops=ops, return_intermediates=True, _yx_tiles=yx, _cons_cache=True, **kw)
+    assert "cons_cache_gb" in backend.NOTES          # the cache path ran
+    assert np.array_equal(pairs, ref["pairs"])
+    assert np.array_equal(aff.view(np.uint32), ref["aff"].view(np.uint32))
+    inst, fg = tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape,
+                               c["foreground"].copy(), c["foreground"].copy(), c["numinst"], ps,
+                               slabs, ops=OracleOps(**kw), _yx_tiles=yx, _cons_cache=True, **kw)
+    assert np.array_equal(inst, ref["instances"]) and inst.any()
+
+
+def test_plan_tiles_takes_the_cache_when_it_fits(monkeypatch):
+    monkeypatch.delenv("PPP_CONS_CACHE", raising=False)
+    ps = (9, 9, 9)
+    # 256^3 / 9^3 next to its prediction on a 288 GB device: the planes (165 GB) fit beside a tile
+    n, ny, nx, cache = tiling.plan_tiles((256, 256, 256), ps, 258e9, safety=0.92, copies=2.0, cache_shape=(256, 256, 256))
+    assert cache and n * ny * nx > 1
+    left = 0.92 * 258e9 - tiling.cons_cache_bytes((256, 256, 256), ps)
+    assert 2.0 * ((17 ** 3 - 1) // 2) * 4 * tiling.pairs_box_voxels((256, 256, 256), ps, n, ny, nx) <= left
+    # 512^3: 1.3 TB of planes do not fit -- no cache, the usual grid
+    n5 = tiling.plan_tiles((512, 512, 512), ps, 90e9, safety=0.92, copies=2.0, cache_shape=(512, 512, 512))
+    assert n5 == tiling.tiles_needed((512, 512, 512), ps, 90e9, safety=0.92, copies=2.0) + (False,)
+    # a rank's 64 slices of 512^3 (+ 16 halo slices): 206 GB of planes, 12 GB left for tiles
+    n8 = tiling.plan_tiles((64, 512, 512), ps, 237e9, safety=0.92, copies=2.0, cache_shape=(80, 512, 512))
+    assert n8[3]
+    # a volume that fits whole needs none; PPP_CONS_CACHE=0 switches it off
+    assert tiling.plan_tiles((64, 64, 64), ps, 200e9, cache_shape=(64, 64, 64)) == (1, 1, 1, False)
+    monkeypatch.setenv("PPP_CONS_CACHE", "0")
+    assert not tiling.plan_tiles((256, 256, 256), ps, 258e9, safety=0.92, copies=2.0, cache_shape=(256, 256, 256))[3]
+
+
 def test_tiles_needed():
     # fits whole: one tile
     assert tiling.tiles_needed((140, 140, 140), (7, 7, 7), 250e9) == (1, 1, 1)
@@ -120,17 +175,19 @@ np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 from patchperpix_amd import backend
 np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
         np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
-                  backend.NOTES.get("cover_p2p", 0)]))
+                  backend.NOTES.get("cover_p2p", 0), 1 if "cons_cache_gb" in backend.NOTES else 0]))
 dist.destroy_process_group()
 """
 
 
 # 2 slabs per rank / one slab per rank (kept consensus) / three ranks (a rank with two
-# neighbours) / several cover passes (pixel thresholds 10, 0) with thinning
+# neighbours) / several cover passes (pixel thresholds 10, 0) with thinning / consensus cache
 @pytest.mark.parametrize("n_slabs,world,extra", [
     (4, 2, {}), (2, 2, {}), (3, 3, {}),
     (2, 2, {"select_patches_for_sparse_data": False, "skipThinCover": False}),
-    (2, 2, {"_empty_top": True})])
+    (2, 2, {"_empty_top": True}),
+    # every rank fills a consensus cache over its own block + halo (two tiles per rank)
+    (4, 2, {"_cons_cache": True})])
 def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypatch):
     import json
     extra = dict(extra)
@@ -141,17 +198,19 @@ def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypa
     ref = whole_volume(c, ps, kw)
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(repo=REPO, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", OMP_NUM_THREADS="1",
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
                PPP_TEST_SLABS=str(n_slabs), PPP_TEST_KW=json.dumps(extra))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
-                           "--master-port", "29591", str(script)], env=env, timeout=900)
+                           "--master-port", _port, str(script)], env=env, timeout=900)
     for r in range(world):
         inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
         assert np.array_equal(inst, ref["instances"]), "rank %d differs" % r
         # the cover ran sharded (z-halo exchange per round), the labels were merged
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
         assert notes[0] == world and notes[1] > 0
+        assert notes[3] == (1 if extra.get("_cons_cache") else 0)
 
 
 @pytest.mark.gpu
@@ -331,12 +390,13 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
                                  c["numinst"].copy(), list(ps), **dict(FLYLIGHT, _n_slabs=1))
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29593", OMP_NUM_THREADS="1",
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
                PPP_TEST_EMPTY_TOP="1" if empty_top else "0", PPP_TEST_FLAGSET=flagset,
                PPP_COVER_P2P=p2p)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
-                           "--master-port", "29593", str(script)], env=env, timeout=900)
+                           "--master-port", _port, str(script)], env=env, timeout=900)
     assert want.any()
     for r in range(world):
         inst = np.load(tmp_path / ("inst_rank%d.npy" % r))
@@ -385,11 +445,11 @@ def test_two_ranks_over_rccl(tmp_path):
                                  c["numinst"].copy(), list(ps), **dict(flagsets.FLYLIGHT, _n_slabs=1))
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_WORKER.format(repo=REPO, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29597", OMP_NUM_THREADS="1",
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                           "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
-                           "29597", str(script)], env=env, timeout=900)
+                           "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", _port, str(script)], env=env, timeout=900)
     assert want.any()
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / ("inst_rank%d.npy" % r)), want), "rank %d differs" % r
@@ -487,11 +547,12 @@ def test_ranks_gloo_provider_local_fields(tmp_path, world, extra, gather, monkey
     ref = whole_volume(c, ps, kw)
     script = tmp_path / "worker.py"
     script.write_text(WORKER_SHARDED.format(repo=REPO, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29595", OMP_NUM_THREADS="1",
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
                PPP_TEST_KW=json.dumps(extra), PPP_TEST_GATHER="1" if gather else "0")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
-                           "--master-port", "29595", str(script)], env=env, timeout=900)
+                           "--master-port", _port, str(script)], env=env, timeout=900)
     assert ref["instances"].any()
     n_ranked = 0
     for r in range(world):
@@ -576,11 +637,12 @@ def test_ranks_provider_local_fields_share_one_gpu(tmp_path, world, ps, flagset)
                                  **dict(flagsets.FLAG_SETS[flagset], _n_slabs=1))
     script = tmp_path / "gpu_worker_sharded.py"
     script.write_text(GPU_WORKER_SHARDED.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29599", OMP_NUM_THREADS="1",
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
                PPP_TEST_FLAGSET=flagset)
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
-                           "--master-port", "29599", str(script)], env=env, timeout=900)
+                           "--master-port", _port, str(script)], env=env, timeout=900)
     assert want.any()
     for r in range(world):
         z0, z1 = [int(v) for v in np.load(tmp_path / ("range_rank%d.npy" % r))]
@@ -624,9 +686,10 @@ def test_communicator_moves_types_rccl_has_no_element_type_for(tmp_path):
     (torch's NCCL = RCCL backend maps no 16-bit integer type); two gloo ranks."""
     script = tmp_path / "comm_worker.py"
     script.write_text(COMM_WORKER.format(repo=REPO, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29597", OMP_NUM_THREADS="1")
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29597", str(script)], env=env, timeout=300)
+                           "--master-addr", "127.0.0.1", "--master-port", _port, str(script)], env=env, timeout=300)
     for r in range(2):
         assert np.load(tmp_path / ("comm_rank%d.npy" % r)).all(), "rank %d" % r
 

@@ -15,5 +15,7 @@ backend.lib().ppp_pa_stats(out)
 steps, planes, rows, useful, lcg, live = [int(v) for v in out[:6]]
 print("wave-steps %d  planes/step %.2f  rows/step %.2f  lcg rows/step %.2f" %
       (steps, planes / steps, rows / steps, lcg / steps))
+wl = [a for a in sys.argv if a in bench.WORKLOADS]
+px = bench.WORKLOADS[wl[0]][1][2] if wl else 7          # patch width of the workload (7: the default one)
 print("useful slots / (rows*64*px) = %.3f   live lanes = %.3f" %
-      (useful / (rows * 64.0 * bench.WORKLOADS[[a for a in sys.argv if a in bench.WORKLOADS][0]][1][2] if [a for a in sys.argv if a in bench.WORKLOADS] else 7.0), live / (steps * 64.0)))
+      (useful / (rows * 64.0 * px), live / (steps * 64.0)))
