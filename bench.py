@@ -621,7 +621,7 @@ def main():
     # space) -- the maximum over the ranks
     peak_gb = agree_max(torch.cuda.max_memory_allocated() / 1e9)
     value = float(np.prod(gshape)) * args.steps / dt / 1e6
-    roofline = None
+    roofline = roofline_valu = None
     if ev.get("consensus"):
         s1_kernel = notes.get("s1_kernel", "consensus_v3_kernel")
         roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C, kernel=s1_kernel)
@@ -636,6 +636,13 @@ def main():
                 "writes = the consensus output (symmetric voxel-major rows, 2x the stored planes); "
                 "reads = the f16 prediction (re-read across the offset rows of a run) + the "
                 "read-for-ownership of partially written lines")
+        # "bound" keeps the contract's vocabulary and the north star's figure (HBM-read fraction);
+        # what limits the kernel is vector-instruction issue: roofline_valu below
+        roofline["limited_by"] = "valu-issue (see roofline_valu)"
+        n_l = max(1, len(ev["consensus"]))
+        fgf = float(getattr(wl, "fg_fraction", 1.0))
+        roofline_valu = valu_roofline(s1_kernel, wl.name, float(np.sum(ev["consensus"])) / n_l,
+                                      C * (C - 1) / 2.0 * fgf * notes.get("s1_base_voxels", 0) / n_l)
     # Secondary figures for the other two big kernels.  S2 (ranking): the voxel-major consensus
     # rows it reads once + the prediction block once: 4 (2p-1)^3 + 2 C bytes per base voxel.
     # S5 (patch graph): both patches' channel vectors per dispatched pair row, SURVEY 8(d)'s
@@ -730,6 +737,7 @@ def main():
                        "plan": plan,
                        "host_allocator": allocator},
             "roofline": roofline,
+            "roofline_valu": roofline_valu,
             "roofline_other_kernels": roofline_other,
             "step_ms": [round(v, 1) for v in step_ms],
             **({"stage_lists_ms": {k: [1e3 * x for x in v] for k, v in (host_times or {}).items()}}
@@ -785,6 +793,76 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+VALU_CLOCK_GHZ = 2.4          # MI355X_MICROARCH.md: peak engine clock; a wave64 vector instruction issues in 4 cycles
+N_SIMD = 256 * 4
+
+
+def pmc_sq(kernel, workload):
+    """SQ counters of `kernel` per launch from the committed passes of THIS workload and THESE kernel
+    sources (profiles/*_pmc_sq.txt next to the same .meta.json as the FETCH / WRITE passes;
+    tools/profile_round.sh): {counter: mean per launch} or {} when none matches."""
+    import glob
+    sha = source_sha16()
+    found = None
+    for meta_f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*.meta.json"))):
+        try:
+            meta = json.load(open(meta_f))
+        except ValueError:
+            continue
+        f = meta_f.replace(".meta.json", "_pmc_sq.txt")
+        if meta.get("workload", FALLBACK_WORKLOAD) == workload and meta.get("src_sha16") == sha and os.path.exists(f):
+            found = f
+    if found is None:
+        return {}
+    out = {"source": os.path.relpath(found, ROOT)}
+    for ln in open(found):
+        if kernel not in ln:
+            continue
+        parts = ln.split()
+        for i, tok in enumerate(parts):
+            if tok.startswith(("SQ_", "GRBM_")) and i + 1 < len(parts):
+                try:
+                    out[tok] = float(parts[i + 1])
+                except ValueError:
+                    pass
+    return out
+
+
+def valu_roofline(kernel, workload, launch_ms, pair_votes_per_launch):
+    """The S1 kernel against the bound that actually holds for it, vector-instruction issue.
+    chain floor: the vote chain is 8 packed instructions per PAIR of votes (two z-slices per lane),
+    64 lanes per instruction, one instruction per 4 cycles and SIMD, 1024 SIMDs; `instr_per_launch`
+    (SQ_INSTS_VALU) and the busy cycles come from the committed SQ pass of these sources."""
+    chain_instr = pair_votes_per_launch / 2.0 * 8.0 / 64.0
+    floor_ms = chain_instr * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e3
+    out = {"kernel": kernel, "bound": "valu-issue", "launch_ms": launch_ms,
+           "chain_instr_per_launch": chain_instr, "chain_floor_ms": floor_ms,
+           "achieved_over_floor": floor_ms / launch_ms if launch_ms else None,
+           "clock_ghz_assumed": VALU_CLOCK_GHZ,
+           "chain": "x = ta*tb; dp = clamp(x*ga - 1/4); dn = clamp(-x - 1/4); d = dp - dn; q = d*lo(4/3); "
+                    "y = fma(d, hi(4/3), q); acc += y; cnt = mad_u16(ca, cb, cnt)"}
+    sq = pmc_sq(kernel, workload)
+    if sq.get("SQ_INSTS_VALU"):
+        instr = sq["SQ_INSTS_VALU"]
+        out.update(instr_per_launch=instr, chain_share_of_instr=chain_instr / instr,
+                   instr_floor_ms=instr * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e3,
+                   issue_frac=instr * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e3 / launch_ms if launch_ms else None,
+                   sq_source=sq["source"])
+        if sq.get("SQ_BUSY_CYCLES"):
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines: cycles of the launch = / 32
+            cyc = sq["SQ_BUSY_CYCLES"] / 32.0
+            out.update(issue_frac_profiled_clock=instr * 4.0 / (N_SIMD * cyc),
+                       clock_ghz_profiled=cyc / (launch_ms * 1e-3) / 1e9 if launch_ms else None)
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_INSTS_LDS",
+                  "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+            if k in sq:
+                out[k] = sq[k]
+    else:
+        out["instr_per_launch"] = None
+        out["sq_note"] = "no SQ pass of %s from these kernel sources is committed (tools/profile_round.sh)" % workload
+    return out
 
 
 def pmc_traffic(kernel, workload, read_width="pred"):

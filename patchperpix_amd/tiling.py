@@ -698,10 +698,12 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     # to_instance_seg -- applies skeletonize_foreground to the mask before it gets here)
     for opt in ("skipConsensus", "skipRanking", "termAfterThinCover", "termAfterPatchGraph",
                 "save_consensus", "graphToInst", "debug", "isbiHack", "pad_with_ps",
-                "mark_close_neighboorhood", "select_patches_overlap_neighborhood",
                 "one_instance_per_channel", "no_overlap_per_channel", "sparse_labels"):
         if kw.get(opt, False):
             raise NotImplementedError("%s is not supported by the tiled / multi-rank assembly" % opt)
+    # the two optional branches of the greedy cover (foreground_cover.py:53-85, 141-168) leave marks
+    # anywhere in a slice: a sequential walk of the ranked list -- served on ONE rank (below)
+    seq_cover = bool(kw.get("mark_close_neighboorhood", False) or kw.get("select_patches_overlap_neighborhood", False))
     if kw.get("aff_graph") is not None:
         raise NotImplementedError("aff_graph input is not supported by the tiled assembly")
     if kw.get("max_total_patch_distance_in_ps_multiples", 2) > 2:
@@ -710,6 +712,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     if not my_slabs:
         raise ValueError("this rank owns no z-slab (more ranks than slabs)")
     comm = comm or LocalComm()
+    if seq_cover and comm.world > 1:
+        raise NotImplementedError("mark_close_neighboorhood / select_patches_overlap_neighborhood walk the ranked "
+                                  "list sequentially: one rank only")
     ops = ops or DeviceOps()
     dev = ops.device
     Z, Y, X = [int(s) for s in shape]
@@ -1091,10 +1096,26 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             lin_t, rscores_t = ops.rank_order(score_f, fg_d, ps)
         if debug_crc:
             backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
+        scores_host = score_f.cpu().numpy() if seq_cover and kw.get("select_patches_overlap_neighborhood") else None
         del score_f
         coords_t = coords_of(lin_t)
         if kw.get("skipSelection", False):
             sel_coords = coords_t.cpu().numpy()
+        elif seq_cover:
+            # ---- sequential native cover with marks (one rank; the ranked list goes to the host,
+            # the patch bits of a chunk of centres come from wherever the prediction lives)
+            from .vote_instances.ranked_patches import PatchList
+            with backend.host_timer("s3_cover"):
+                radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
+
+                def bits_of(coords):
+                    c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.int32)).to(dev)
+                    return gathered_bits(c, kw["fc_threshold"]).cpu().numpy().view(np.uint32)
+                ranked_h = PatchList(coords_t.cpu().numpy(), rscores_t.cpu().numpy())
+                sel_list, _ = fc.cover_sequential(ov_d.cpu().numpy(), mask_d.cpu().numpy() != 0, ps, ranked_h, radslice,
+                                                  bits_of, scores_host, **kw)
+                sel_coords = np.ascontiguousarray(sel_list.coords, dtype=np.int32).reshape(-1, 3)
+            del ranked_h, scores_host
         else:
             # sharded over the ranks when every rank owns one contiguous z-range
             # (PPP_COVER_SHARDED=0: every rank runs the whole cover; "force": also with one rank)

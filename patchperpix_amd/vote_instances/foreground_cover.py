@@ -43,15 +43,26 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
             and not near_overlap:
         return _cover_on_device(overlap_mask, mask_to_cover, patchshape, ranked, radslice,
                                 pred_affs, P, silent, **kwargs)
+    return cover_sequential(overlap_mask, mask_to_cover, patchshape, ranked, radslice,
+                            lambda coords: _bits_for(pred_affs, coords, kwargs["fc_threshold"], P),
+                            scores_array, silent=silent, **kwargs)
+
+
+def cover_sequential(overlap_mask, mask_to_cover, patchshape, ranked, radslice, bits_of, scores_array,
+                     silent=True, **kwargs):
+    """The sequential native cover (ppp_host_cover_pass[_marked]) with the reference's two optional
+    branches, `mark_close_neighboorhood` (foreground_cover.py:141-143, 162-168) and
+    `select_patches_overlap_neighborhood` (:53-85).  bits_of(coords [m, 3]) -> uint32 [m, words]:
+    the patch bits of a chunk of centres (from the prediction, wherever it lives: the stage path
+    packs them from the resident block, the tiled assembly from its frames).  Host arrays in,
+    (selected PatchList, count) out."""
+    mark = bool(kwargs.get("mark_close_neighboorhood", False))
+    near_overlap = bool(kwargs.get("select_patches_overlap_neighborhood", False))
     running, _owner = backend.padded_mask(mask_to_cover)
     overlap = np.ascontiguousarray(np.asarray(overlap_mask) > 0).astype(np.uint8)
     selected = np.zeros(len(ranked), dtype=np.uint8)
     marked = np.zeros(running.shape, dtype=np.uint8) if mark else None
-    if kwargs["select_patches_for_sparse_data"]:
-        pix_ths = [0]
-    else:
-        mid = int(np.prod(patchshape) / 2)
-        pix_ths = [t for t in [500, 100, 50, 10, 0] if t < mid]
+    pix_ths = _pix_thresholds(patchshape, kwargs)
     thr = kwargs.get("score_threshold", False)
     thr = thr if isinstance(thr, float) else None
     lin = ranked.lin(running.shape)
@@ -64,7 +75,7 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
             if remaining <= 0:
                 break
             e = min(len(ranked), s + COVER_CHUNK)
-            bits = _bits_for(pred_affs, ranked.coords[s:e], kwargs["fc_threshold"], P)
+            bits = bits_of(ranked.coords[s:e])
             remaining, stopped = backend.host_cover_pass(
                 running, overlap, patchshape, lin[s:e], ranked.scores[s:e], bits, pix_th, thr,
                 selected[s:e], remaining, marked=marked)
@@ -74,7 +85,7 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
             break
     if near_overlap:
         return _select_near_overlap(overlap_mask, mask_to_cover, patchshape, ranked, selected, radslice,
-                                    pred_affs, P, pix_th, thr, marked, scores_array, **kwargs)
+                                    bits_of, pix_th, thr, marked, scores_array, **kwargs)
     sel = ranked[np.flatnonzero(selected)]
     if len(sel) and not silent:
         logger.info("num patches to cover foreground: %s best score: %s, worst score: %s, "
@@ -82,7 +93,7 @@ def computeForegroundCover(overlap_mask, mask_to_cover, patchshape, ranked_patch
     return sel, len(sel)
 
 
-def _select_near_overlap(overlap_mask, mask_to_cover, patchshape, ranked, selected, radslice, pred_affs, P,
+def _select_near_overlap(overlap_mask, mask_to_cover, patchshape, ranked, selected, radslice, bits_of,
                          pix_th, thr, marked, scores_array, **kwargs):
     """foreground_cover.py:53-85 (`select_patches_overlap_neighborhood`): a second cover of the
     foreground ring between 2 and 5 dilations of the overlap voxels, by the not yet selected
@@ -111,7 +122,7 @@ def _select_near_overlap(overlap_mask, mask_to_cover, patchshape, ranked, select
             if remaining <= 0:
                 break
             e = min(len(sub), s + COVER_CHUNK)
-            bits = _bits_for(pred_affs, sub.coords[s:e], kwargs["fc_threshold"], P)
+            bits = bits_of(sub.coords[s:e])
             remaining, stopped = backend.host_cover_pass(running, ov8, patchshape, lin[s:e], sub.scores[s:e], bits,
                                                          pix_th, thr, sel2[s:e], remaining, marked=marked)
             if stopped:

@@ -210,9 +210,7 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
         and not any(kwargs.get(k) for k in ("skipConsensus", "skipRanking",
                                             "termAfterThinCover", "termAfterPatchGraph",
                                             "save_consensus", "blockwise",
-                                            "one_instance_per_channel", "no_overlap_per_channel",
-                                            # (sequential native cover: stage path only)
-                                            "mark_close_neighboorhood", "select_patches_overlap_neighborhood")) \
+                                            "one_instance_per_channel", "no_overlap_per_channel")) \
         and os.environ.get("PPP_PIPELINE", "fused") != "stages"
     if n_slabs and (n_slabs > 1 or yx_tiles or plain) and not kwargs.get("graphToInst") \
             and kwargs.get("aff_graph") is None and not kwargs.get("pad_with_ps", False):

@@ -985,6 +985,22 @@ def test_consensus_part_and_planes_to_rows(torch_cuda):
         assert int(torch.count_nonzero(rows_cut[inner])) > 1000
 
 
+@pytest.mark.parametrize("name", ["c2d_p5_mark", "c3d_p3_mark_nosparse", "c3d_p3_near_overlap"])
+def test_marked_cover_options_tiled(name, torch_cuda):
+    """The two optional branches of the greedy cover (foreground_cover.py:53-85, 141-168) through the
+    tiled assembly (y/x tiles, z-slabs where the case has slices): the reference's instances."""
+    from conftest import Golden
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    g = Golden(name)
+    kw = dict(g.kw, debug=False, isbiHack=False, save_no_intermediates=True, sample=1.0,
+              result_folder="/tmp", affinities="x.zarr")
+    for grid in (dict(_n_slabs=1), dict(_n_slabs=2 if g.foreground.shape[0] > 1 else 1, _yx_tiles=(2, 2))):
+        inst, fg = vi.to_instance_seg(g.pred.copy(), g.foreground.copy(), g.foreground.copy(), g.numinst.copy(),
+                                      g.patchshape, **dict(kw, **grid))
+        assert np.array_equal(inst, g["instances"]) and inst.any(), grid
+        assert np.array_equal(fg, g["foreground_out"])
+
+
 def test_resume_from_a_saved_consensus(torch_cuda, tmp_path):
     """Kernel path: `save_consensus` writes the reference-layout array (consensus_array.py:202-206);
     a later call with `consensus=<that file>` (:213-218) loads it instead of running S1 -- same

@@ -117,6 +117,28 @@ def test_consensus_cache_equals_whole_volume_cpu(n_slabs, yx, thin):
     assert np.array_equal(inst, ref["instances"]) and inst.any()
 
 
+@pytest.mark.parametrize("name", ["c2d_p5_mark", "c3d_p3_mark_nosparse", "c3d_p3_near_overlap"])
+def test_marked_cover_options_in_the_tiled_assembly_cpu(name):
+    """`mark_close_neighboorhood` / `select_patches_overlap_neighborhood` (foreground_cover.py:53-85,
+    141-168) in the tiled assembly on one rank: the sequential native cover walks the ranked list
+    with the patch bits taken from the tiles' frames -- the reference's own result (goldens)."""
+    import torch
+    from conftest import Golden
+    from oracle_ops import OracleOps
+    g = Golden(name)
+    kw = dict(g.kw)
+    shape = g.foreground.shape
+    slabs = tiling.plan_slabs(shape[0], 2 if shape[0] > 1 else 1)
+    inst, fg = tiling.assemble(torch.from_numpy(g.pred), 0, shape, g.foreground.copy(), g.foreground.copy(),
+                               g.numinst.copy(), g.patchshape, slabs, ops=OracleOps(**kw), _yx_tiles=(2, 2), **kw)
+    assert np.array_equal(inst, g["instances"]) and inst.any()
+    with pytest.raises(NotImplementedError, match="one rank only"):
+        class Two(tiling.LocalComm):
+            world = 2
+        tiling.assemble(torch.from_numpy(g.pred), 0, shape, g.foreground.copy(), g.foreground.copy(),
+                        g.numinst.copy(), g.patchshape, slabs, ops=OracleOps(**kw), comm=Two(), **kw)
+
+
 def test_plan_tiles_takes_the_cache_when_it_fits(monkeypatch):
     monkeypatch.delenv("PPP_CONS_CACHE", raising=False)
     ps = (9, 9, 9)

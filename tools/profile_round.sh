@@ -23,6 +23,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-variants > $out/bench_pmc_$c.json 2>> $out/bench.err
 done
 unset PPP_BENCH_CALIBRATE
+# SQ counters of the same command (two more passes: instruction counts / issue, waits + LDS)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/pmc_sq1 -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-variants > /dev/null 2>> $out/bench.err
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $out/pmc_sq2 -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-variants > /dev/null 2>> $out/bench.err
+python3 - <<PY
+import glob, os, shutil, sys
+sys.path.insert(0, "tools")
+import summarize_prof
+tmp = "$out/pmc_sq_all"
+os.makedirs(tmp, exist_ok=True)
+for i, d in enumerate(["$out/pmc_sq1", "$out/pmc_sq2"]):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        shutil.copy(f, os.path.join(tmp, "%d_%s" % (i, os.path.basename(f))))
+summarize_prof.main(tmp, "$out/pmc_sq.txt")
+PY
+rm -rf $out/pmc_sq_all $out/pmc_sq1 $out/pmc_sq2
 python3 - <<PY
 import glob, json, os, shutil, sys
 sys.path.insert(0, "tools"); sys.path.insert(0, ".")
