@@ -152,8 +152,12 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
     const int words = (G.C + 31) / 32;
     const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
     const int WB = (W + 2 * PA_PAD + 3) & ~3;                     // floats per row buffer
-    // staged floats per thread (the launcher checks W <= NST * PA_THREADS)
-    constexpr int NST = ((2 * PX - 1) * (2 * PX - 1) * (2 * PX - 1) + PA_THREADS - 1) / PA_THREADS;
+    // staged floats per thread (the launcher checks W <= NST * PA_THREADS): a (2 PX - 1)^3 row --
+    // for the wide kernel (25 x 25: 2-d patches only) a (2 PX - 1)^2 one.  (Sized for a cube it was
+    // 1 839 floats per thread at PX = 25 with 64 threads: the staging array lived in scratch and
+    // every pixel step walked 1 839 predicated iterations to move 38 floats -- what the "mask
+    // algebra" of profiles/r04_zy_s5_p25_ablations.txt really was.)
+    constexpr int NST = ((PX > 16 ? 1 : 2 * PX - 1) * (2 * PX - 1) * (2 * PX - 1) + PA_THREADS - 1) / PA_THREADS;
     constexpr int ROW_BUFS = PaCfg<PX>::ROW_BUFS;
     float *rowbuf = reinterpret_cast<float *>(lds_raw);           // [ROW_BUFS][WB]
     uint32_t *faw = lds_raw + ROW_BUFS * WB;                      // [words]
@@ -395,6 +399,64 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
                     continue;
                 }
                 const int qz = mz.q0 + z2o;
+                if constexpr (PX > 16) {
+                    // ---- wide windows (the 25 x 25 2-d patches): ONE candidate row per step.  A row
+                    // of PX <= 32 candidates is one 32-bit word; the y conditions are single bits of
+                    // the per-axis masks, so a row costs a dozen 32-bit operations -- the chunk
+                    // form below expands six y masks into 64-bit words for every two rows (13 chunks
+                    // per plane and pixel at 25 x 25: what this kernel spent its time on,
+                    // profiles/r04_zy_s5_p25_ablations.txt).  Same candidates, same order (rows
+                    // ascending, x ascending inside a row), same LCG stream.
+                    const int idx0 = Lc + (qz * G.wy + my.q0) * G.wx + q0x;
+                    const uint32_t xin = in_b ? mx.in : 0u;
+#pragma unroll 1
+                    for (int y2o = y_lo; y2o <= y_hi; ++y2o) {
+                        const uint32_t yb1 = 1u << y2o;
+                        const bool y_pos = my.pos & yb1, y_zero = my.zero & yb1;
+                        const uint32_t fwd = z_pos ? RM : (z_zero ? (y_pos ? RM : (y_zero ? (mx.pos | mx.zero) : 0u)) : 0u);
+                        const uint32_t range = ((z_f && (my.f & yb1)) ? (mx.f & fwd) : 0u) |
+                                               ((z_bk && (my.bk & yb1)) ? (mx.bk & ~fwd & RM) : 0u);
+                        const uint32_t inter = (z_in && (my.in & yb1)) ? xin : 0u;
+                        if (__ballot((range | inter) != 0u) == 0ull) continue;
+                        PA_STAT(1, lane == 0 ? 1 : 0);
+                        uint32_t stored = (z_st && (my.st & yb1)) ? (mx.st & range) : 0u;
+                        if (z_zero && y_zero) stored &= ~mx.zero;
+                        // foreground bits of patch B on this candidate row
+                        uint32_t valid;
+                        {
+                            const int o = (z2o * G.py + y2o) * PX, w0 = o >> 5, sh = o & 31;
+                            const uint32_t lo = fbw[w0 * PA_THREADS + tid];
+                            const uint32_t hi = w0 + 1 < words ? fbw[(w0 + 1) * PA_THREADS + tid] : 0u;
+                            valid = (uint32_t)(((((u64)hi) << 32) | lo) >> sh) & RM;
+                        }
+                        const uint32_t hit_row = inter & valid;
+                        if (__ballot(hit_row != 0u) != 0ull) {
+                            PA_STAT(4, lane == 0 ? 1 : 0);
+                            uint32_t drop = 0;
+#pragma unroll
+                            for (int t = 0; t < PX; ++t) {
+                                const uint32_t xb = 1u << t;
+                                const uint32_t nxt = rnd * 1103515245U;
+                                const bool hit = (hit_row & xb) != 0u;
+                                rnd = hit ? nxt : rnd;
+                                if (hit && nxt >= 858993441u) drop |= xb;      // (see the chunk form)
+                            }
+                            valid &= ~drop;
+                        }
+                        fg_cnt += __popc(range & valid);
+                        const uint32_t rb = stored & valid;
+                        if (__ballot(rb != 0u) == 0ull) continue;
+                        PA_STAT(2, lane == 0 ? 1 : 0);
+                        PA_STAT(3, __popc(rb));
+                        const float *rowq = cur + (rb != 0u ? idx0 + y2o * G.wx : 0);
+#pragma unroll
+                        for (int t = 0; t < PX; ++t) {
+                            const int sel = ((int)(rb << (31 - t))) >> 31;
+                            acc += __int_as_float(__float_as_int(rowq[t]) & sel);
+                        }
+                    }
+                    continue;
+                }
                 // one chunk of candidate rows; M = mask word: 64 bits, or 32 bits for a last
                 // chunk of few rows (9^3: rows 7-8, 18 bits) -- half the mask arithmetic
                 auto chunk = [&](auto mtag, const int c) {
@@ -799,8 +861,8 @@ hipError_t launch_patch_graph_pa(const void *pred, int dtype, const float *S, co
     const int words = (G.C + 31) / 32;
     const int W = (2 * G.pz - 1) * G.wy * G.wx;
     const int WB = (W + 2 * PA_PAD + 3) & ~3;
-    // the per-thread staging registers are sized for a (2px-1)^3 row
-    const int cube = (2 * G.px - 1) * (2 * G.px - 1) * (2 * G.px - 1);
+    // the per-thread staging registers are sized for a (2px-1)^3 row ((2px-1)^2 for the wide 2-d kernel)
+    const int cube = (G.px > 16 ? 1 : 2 * G.px - 1) * (2 * G.px - 1) * (2 * G.px - 1);
     if (W > (cube + threads - 1) / threads * threads) return hipErrorNotSupported;
     // candidate planes are handled as ceil(px / (64 / px)) 64-bit chunks of 64 / px rows
     if (G.py > (G.px + 64 / G.px - 1) / (64 / G.px) * (64 / G.px) || G.pz > 32) return hipErrorNotSupported;

@@ -960,7 +960,7 @@ def test_consensus_part_and_planes_to_rows(torch_cuda):
         P = backend.make_params(shape, ps, cons_box=box, **kw)
         whole = backend.consensus(pred, ov, P)
         # the same planes from four pieces (cut in z at an odd slice, in y and in x)
-        zc, yc, xc = box[0] + 5, box[1] + 11, box[2] + 70
+        zc, yc, xc = box[0] + 5, box[1] + 11, box[2] + (box[5] - box[2]) // 2 + 3
         parts = [(box[0], box[1], box[2], zc, box[4], box[5]), (zc, box[1], box[2], box[3], yc, box[5]),
                  (zc, yc, box[2], box[3], box[4], xc), (zc, yc, xc, box[3], box[4], box[5])]
         pieces = torch.full_like(whole, float("nan"))
