@@ -379,6 +379,8 @@ class Workload:
                 extra["_yx_tiles"] = tuple(args.yx)
             if args.slabs and os.environ.get("PPP_CONS_CACHE") == "1":
                 extra["_cons_cache"] = True            # (a forced grid skips the memory plan)
+            if args.slabs and os.environ.get("PPP_RING_Z"):
+                extra["_ring_z"] = int(os.environ["PPP_RING_Z"])
                 extra.setdefault("_n_slabs", 1)
 
             def step(flag_kw=kw):
@@ -424,15 +426,23 @@ class Workload:
             cz0, cz1 = max(0, oz0 - (ps[0] // 2) - (ps[0] - 1)), min(gshape[0], oz1 + ps[0] // 2)
             n, ny, nx, use_cache = tiling.plan_tiles((oz1 - oz0, shape[1], shape[2]), ps, max(free - reserve, 0.25 * free),
                                                      safety=0.92, copies=2.0, cache_shape=(cz1 - cz0, shape[1], shape[2]))
+            ring_z = 0
+            if not use_cache and not args.slabs and not args.yx:
+                ring = tiling.plan_ring((oz1 - oz0, shape[1], shape[2]), ps, max(free - reserve, 0.25 * free),
+                                        safety=0.92, copies=2.0)
+                if ring is not None:
+                    n, ny, nx, ring_z = ring
             mine = [(oz0 + a, oz0 + b) for a, b in tiling.plan_slabs(oz1 - oz0, args.slabs or n)]
             yx = tuple(args.yx) if args.yx else (ny, nx)
             self.plan = {"rank": rank, "own_z": [oz0, oz1], "held_z": [lo, hi],
-                         "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx), "cons_cache": bool(use_cache)}
+                         "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx), "cons_cache": bool(use_cache),
+                         "ring_z": ring_z}
             self.tiles = (len(mine), yx[0], yx[1])
 
             def step(flag_kw=kw):
                 inst, _ = tiling.assemble(self.pred, lo, gshape, fg, fg.clone(), fg, ps, mine,
-                                          comm=comm, _yx_tiles=yx, _cons_cache=use_cache, **dict(flag_kw, **extra))
+                                          comm=comm, _yx_tiles=yx, _cons_cache=use_cache, _ring_z=ring_z,
+                                          **dict(flag_kw, **extra))
                 return inst
         self.step = step
         self.fg_fraction = float(fg.float().mean().item())

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define PPP_ABI_VERSION 3
+#define PPP_ABI_VERSION 4
 
 enum ppp_error {
     PPP_OK = 0,
@@ -93,6 +93,15 @@ typedef struct ppp_params {
                               buffers hold a sub-volume (slab of a larger volume); only the
                               per-pair LCG seed of ppp_patch_graph depends on absolute
                               coordinates (computePatchGraph.cu:24-27)                          */
+    int32_t ring_z;        /* 0, or -- VOXEL_MAJOR rows only -- the number of z-slices of a RING the
+                              row buffer holds: the row of voxel (z, y, x) lives in slice
+                              (z + origin_z) mod ring_z of a [ring_z][by][bx][W] buffer, cons_box
+                              (at most ring_z slices thick) says which slices are current.  A caller
+                              that sweeps a column of tiles upwards computes every base voxel once
+                              (ppp_consensus_part over the new slices) and keeps the rows its next
+                              tile still needs; read by ppp_rank_patches_vm and
+                              ppp_patch_graph_by_patch*.  (The reference holds the whole array in
+                              managed memory: consensus_array.py:99-106.)                         */
 } ppp_params;
 
 /* --- library / device ------------------------------------------------------------- */

@@ -17,7 +17,7 @@ F32, F16 = 0, 1
 BG_INV_TH, BG_HALF_TH, BG_LESS_THAN_TH = 0, 1, 2
 VAL_COUNT, VAL_PROB_PRODUCT, VAL_NORM_PROB_PRODUCT = 0, 1, 2
 CONS_COMPACT, CONS_REFERENCE, CONS_VOXEL_MAJOR = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 NONE_KEY = 0xFFFFFFFF
 NONE_KEY64 = 1 << 62      # PPP_LABEL_NONE_KEY (streaming labels, int64 keys)
 PAIR_KEY_FAR = 0x7FFFFFFFFFFFFFFF   # PPP_PAIR_KEY_FAR
@@ -41,7 +41,7 @@ class Params(ctypes.Structure):
                 ("norm_aff", ctypes.c_int32), ("cons_layout", ctypes.c_int32),
                 ("cons_box", Box),
                 ("origin_z", ctypes.c_int32), ("origin_y", ctypes.c_int32),
-                ("origin_x", ctypes.c_int32)]
+                ("origin_x", ctypes.c_int32), ("ring_z", ctypes.c_int32)]
 
     @property
     def shape(self):

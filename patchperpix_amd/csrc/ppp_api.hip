@@ -94,6 +94,9 @@ int make_geo(const ppp_params *p, ppp::Geo *G) {
     g.wy = 2 * p->py - 1; g.wx = 2 * p->px - 1;
     g.n_planes = ((2 * p->pz - 1) * g.wy * g.wx - 1) / 2;
     g.oz = p->origin_z; g.oy = p->origin_y; g.ox = p->origin_x;
+    if (p->ring_z < 0 || (p->ring_z > 0 && (g.layout != PPP_CONS_VOXEL_MAJOR || g.bZ > p->ring_z || p->origin_z < 0)))
+        return fail(PPP_ERR_INVALID_ARG, "ring_z: VOXEL_MAJOR rows only, cons_box at most ring_z slices thick");
+    g.ring = p->ring_z;
     *G = g;
     return PPP_OK;
 }
@@ -162,6 +165,7 @@ int ppp_consensus(const void *d_pred, int pred_dtype, const uint8_t *d_overlap, 
     if (G.layout == PPP_CONS_VOXEL_MAJOR && (!ppp::consensus_v3_supported(G) || d_count || !d_cons))
         return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus writes VOXEL_MAJOR only with the packed kernel (TH = 0.5, normalised "
                                          "product, px in {3,5,7,9}; no counts): see ppp_consensus_writes_voxel_major");
+    if (G.ring) return fail(PPP_ERR_UNSUPPORTED, "ring_z: rows of a ring are written by ppp_consensus_part");
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, d_count, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_consensus");
@@ -177,6 +181,7 @@ int ppp_consensus_rows(const void *d_pred, int pred_dtype, const uint8_t *d_over
     if (G.layout != PPP_CONS_VOXEL_MAJOR || !ppp::consensus_v3_supported(G))
         return fail(PPP_ERR_UNSUPPORTED, "ppp_consensus_rows writes VOXEL_MAJOR rows with the packed kernel only "
                                          "(see ppp_consensus_writes_voxel_major)");
+    if (G.ring) return fail(PPP_ERR_UNSUPPORTED, "ring_z: rows of a ring are written by ppp_consensus_part");
     PPP_TRY(need_device());
     G.vm_open = 1;
     hipError_t e = ppp::launch_consensus(d_pred, pred_dtype, d_overlap, d_cons, nullptr, G, (hipStream_t)stream);
@@ -271,6 +276,8 @@ int ppp_rank_patches_vm(const void *d_pred, int pred_dtype, const float *d_cons_
     if (!ppp::rank_vm_supported(G))
         return fail(PPP_ERR_UNSUPPORTED, "ppp_rank_patches_vm: VOXEL_MAJOR layout, cubic patches of 3/5/7/9, "
                                          "no count_pos_neg (use ppp_rank_patches otherwise)");
+    if (G.ring && !ppp::rank_wg_supported(G))
+        return fail(PPP_ERR_UNSUPPORTED, "ring_z: only the workgroup-per-tile ranking kernel reads a ring of rows");
     ppp_box sb;
     PPP_TRY(rank_box(score_box, p, G, &sb));
     PPP_TRY(need_device());
@@ -288,6 +295,7 @@ int ppp_patch_graph(const void *d_pred, int pred_dtype, const float *d_cons,
     if (n_pairs == 0) return PPP_OK;
     if (n_pairs >= (1ull << 32)) return fail(PPP_ERR_UNSUPPORTED, "more than 2^32-1 pair rows");
     if (!d_pred || !d_cons || !d_pairs || !d_aff) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    if (G.ring) return fail(PPP_ERR_UNSUPPORTED, "ring_z: only ppp_patch_graph_by_patch reads a ring of rows");
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_patch_graph(d_pred, pred_dtype, d_cons, d_pairs, d_order, n_pairs, d_aff, G, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_patch_graph");
@@ -633,7 +641,7 @@ int ppp_cons_planes_to_rows(const float *d_planes, const ppp_box *planes_box, fl
     ppp::Geo G;
     PPP_TRY(make_geo(p, &G));
     if (!d_planes || !d_rows || !planes_box) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
-    if (G.layout != PPP_CONS_VOXEL_MAJOR) return fail(PPP_ERR_INVALID_ARG, "params must describe the VOXEL_MAJOR rows");
+    if (G.layout != PPP_CONS_VOXEL_MAJOR || G.ring) return fail(PPP_ERR_INVALID_ARG, "params must describe VOXEL_MAJOR rows of a plain box");
     const ppp_box &b = p->cons_box, &q = *planes_box;
     if (q.z1 <= q.z0 || q.y1 <= q.y0 || q.x1 <= q.x0 || b.z0 < q.z0 || b.y0 < q.y0 || b.x0 < q.x0 || b.z1 > q.z1 ||
         b.y1 > q.y1 || b.x1 > q.x1)

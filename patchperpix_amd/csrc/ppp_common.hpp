@@ -38,6 +38,7 @@ struct Geo {
     // S1 only: the base voxels a launch COMPUTES (a sub-box of the cons box, which stays the
     // box the output buffer is indexed by); the whole cons box unless ppp_consensus_part asks
     int cz0, cy0, cx0, cZ, cY, cX;
+    int ring;           // voxel-major rows in a ring of `ring` z-slices (0: the plain box), ppp_params.ring_z
 };
 
 // A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch
@@ -78,6 +79,11 @@ __device__ __forceinline__ long long cons_at(const Geo &G, int dz, int dy, int d
     }
     const long long plane = ((long long)dz * G.wy + dy) * G.wx + dx - 1;
     return plane * G.BV + ((long long)(z - G.bz0) * G.bY + (y - G.by0)) * G.bX + (x - G.bx0);
+}
+// slice of the voxel-major row buffer that holds the rows of (local) slice z: box-relative, or
+// (z + origin) mod ring when the buffer is a ring
+__device__ __forceinline__ int row_slice(const Geo &G, int z) {
+    return G.ring ? (z + G.oz) % G.ring : z - G.bz0;
 }
 // value of one vote from the float product x = v1*v2 or v1*(1-v2)
 // (fillConsensusArray.cu:104-110,127-133): normalisation in double, rounded to float.

@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             // Entries whose source voxel lies outside the box are zeroed by vm_zero_kernel.
             const int W = (2 * G.pz - 1) * G.wy * G.wx, Lc = (W - 1) / 2;
             const int L0 = (dz * G.wy + dy) * G.wx;
-            const long long vu = ((long long)(uz + s - G.bz0) * G.bY + (uy_l - G.by0)) * G.bX + (ux - G.bx0);
+            const long long vu = ((long long)row_slice(G, uz + s) * G.bY + (uy_l - G.by0)) * G.bX + (ux - G.bx0);
             float *pos = cons + vu * W + Lc + L0 - (PX - 1);     // entry of dx = -(PX-1)
             if (row0) {
                 pos[PX - 1] = 0.0f;                              // offset 0
@@ -631,7 +631,8 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             }
             const int wz = uz + s + dz, wy2 = uy_l + dy;
             if (wz < G.bz0 + G.bZ && wy2 >= G.by0 && wy2 < G.by0 + G.bY) {
-                const long long vw0 = vu + ((long long)dz * G.bY + dy) * G.bX;
+                // (the slice of w: a ring may wrap between u and w)
+                const long long vw0 = ((long long)row_slice(G, wz) * G.bY + (wy2 - G.by0)) * G.bX + (ux - G.bx0);
 #pragma unroll
                 for (int i = 0; i < K::NACC; ++i) {
                     const int dx = i - (PX - 1);

@@ -597,7 +597,7 @@ bool consensus_v4_supported(const Geo &G) {
     static EnvSwitch sw("PPP_S1_V4");
     const char *e = sw.get();
     if (!e || e[0] != '1') return false;
-    return consensus_v3_supported(G) && (G.px == 5 || G.px == 7 || G.px == 9);
+    return consensus_v3_supported(G) && (G.px == 5 || G.px == 7 || G.px == 9) && !G.ring;
 }
 
 hipError_t launch_vm_zero_faces(float *S, const Geo &G, hipStream_t s);   // ppp_consensus_v3.hip

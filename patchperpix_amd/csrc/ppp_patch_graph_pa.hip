@@ -292,12 +292,12 @@ __global__ void __launch_bounds__(PA_THREADS, PA_THREADS == PaCfg<PX>::THREADS ?
     const bool wave_live = dz_lo <= dz_hi;
 
     const long long sY = G.bX, sZ = (long long)G.bX * G.bY;
-    const long long baseA = ((long long)(az - G.bz0) * G.bY + (ay - G.by0)) * G.bX + (ax - G.bx0);
+    const long long baseA = ((long long)(ay - G.by0)) * G.bX + (ax - G.bx0);        // (the slice is added per pixel)
     // (pixel indices are workgroup-uniform scalars: the row address arithmetic stays on the
     // scalar unit and the staging loads take the saddr + voffset form)
     auto row_of = [&](int r1) -> const float * {
         const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
-        return S + (baseA + (long long)(z1o - G.rz) * sZ + (long long)(y1o - G.ry) * sY + (x1o - PX / 2)) * W;
+        return S + (baseA + (long long)row_slice(G, az + z1o - G.rz) * sZ + (long long)(y1o - G.ry) * sY + (x1o - PX / 2)) * W;
     };
     float acc = 0.0f;
     unsigned fg_cnt = 0;

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     };
     auto row_src = [&](int k) -> const float * {
         const int uz = uz0 + k / (nuy * nux), uy = uy0 + (k / nux) % nuy, ux = ux0 + k % nux;
-        return S + (((long long)(uz - G.bz0) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
+        return S + (((long long)row_slice(G, uz) * rsZ + (long long)(uy - G.by0) * rsY + (ux - G.bx0)) * W);
     };
     float st[NST];
     int uk = __builtin_amdgcn_readfirstlane(next_valid(0));

@@ -443,6 +443,14 @@ class DeviceOps:
             out.fill_(float("nan"))
         return backend.cons_planes_to_rows(cache, cache_box, P, out=out)
 
+    # -- rows in a ring of z-slices (ppp_params.ring_z): the new slices of a tile written into the
+    #    buffer the previous tile of the column left its upper rows in
+    def ring_fill(self, pred, ov, P, part, pool):
+        if os.environ.get("PPP_VM_POISON") == "1" and getattr(self, "_ring_poison", None) is not pool:
+            pool.fill_(float("nan"))               # (test switch: once per buffer, not per tile)
+            self._ring_poison = pool
+        backend.consensus_part(pred, ov if P.use_overlap else None, P, part, pool)
+
     def patch_bits(self, pred, centres, thresh, P, scratch=None):
         return backend.patch_bits(pred, centres, thresh, P, scratch=scratch)
 
@@ -940,6 +948,54 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         with backend.host_timer("cons_rows"):
             return ops.cons_from_cache(cache, to_frame(cache_box), params(fr, cbox), **({"out": pool} if pool is not None else {}))
 
+    # ---- z-sweep with the rows in a RING (`_ring_z`, decided by the caller's memory plan: plan_ring).
+    # The tiles of a (y, x) column are visited bottom-up; the row buffer is a ring of `_ring_z`
+    # slices (row of slice z in slot z mod ring).  A tile computes only the base slices its
+    # predecessor in the column has not (ppp_consensus_part) -- the rows it shares with it are still
+    # in the ring, and the mirrored entries S[u + d][-d] its predecessor's last bases wrote into
+    # rows ABOVE their own box wait there ("spill": the box of a launch reaches p - 1 slices past
+    # its last base).  So neither pass pays a z-halo: S1 runs over (tile + radius in y / x) per
+    # pass instead of (tile + radius) and (tile + radius + p - 1) in all three axes.
+    ring_z = int(kw.get("_ring_z") or 0)
+    if ring_z and (keep_cons or cache is not None or whole is None or not hasattr(ops, "ring_fill")
+                   or not ops.rank_on_voxel_major(params(whole))):
+        ring_z = 0
+    if ring_z:
+        thick = max(t[1] - t[0] for t in my_tiles)
+        if ring_z < thick + 2 * int(rad[0]) + 2 * (ps[0] - 1) + 4 or thick < ps[0] - 1:
+            raise ValueError("_ring_z = %d is too small for tiles of %d slices (or the tiles are thinner than "
+                             "p - 1)" % (ring_z, thick))
+        # column-major order: all z-tiles of one (y, x) column, bottom-up, then the next column
+        my_tiles.sort(key=lambda t: (t[2], t[4], t[0]))
+        backend.note("ring_z", ring_z)
+    ring_state = {}
+
+    def ring_rows(fr, t, pairs_pass, pool):
+        """S1 for the new base slices of tile t into the ring; returns (pool, params of the rows the
+        consumers of t read: slices [z0 - rad, z1 + rad), the column's y / x box)."""
+        ybox = bases_for_pairs(t) if pairs_pass else bases_for_scores(t)
+        r0, r1 = bases_for_scores(t)[:2]                          # rows the consumers read
+        col = (pairs_pass,) + tuple(ybox[2:])
+        hi = ring_state.get("hi") if ring_state.get("col") == col else None
+        if hi is None or hi < r0:
+            # first tile of the column: for the pair rows also the p - 1 source slices below
+            part0 = max(bases_for_pairs(t)[0], 0) if pairs_pass else r0
+        else:
+            part0 = hi
+        o = fr.origin
+        top = min(fr.shape[0] + o[0], dims[0], r1 + ps[0] - 1)     # spill rows (inside the frame)
+        if part0 < r1:
+            P1 = params(fr, (min(part0, r0), top) + tuple(ybox[2:]))
+            P1.cons_layout = backend.CONS_VOXEL_MAJOR
+            P1.ring_z = ring_z
+            part = (part0 - o[0], ybox[2] - o[1], ybox[4] - o[2], r1 - o[0], ybox[3] - o[1], ybox[5] - o[2])
+            ops.ring_fill(fr.pred, fr.ov, P1, part, pool)
+        ring_state.update(col=col, hi=r1)
+        Pr = params(fr, (r0, r1) + tuple(ybox[2:]))
+        Pr.cons_layout = backend.CONS_VOXEL_MAJOR
+        Pr.ring_z = ring_z
+        return pool, Pr
+
     # ---- stage A: consensus + scores per tile ----------------------------------------------
     # several tiles: ONE consensus buffer, sized for the largest box of either pass, serves all
     # of them (allocated first, while the allocator's address space is still unfragmented)
@@ -947,6 +1003,8 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     if not keep_cons and my_tiles and hasattr(ops, "voxel_major_pool"):
         biggest = max(int(np.prod([b[2 * a + 1] - b[2 * a] for a in range(3)]))
                       for b in (bases_for_pairs(t) for t in my_tiles))
+        if ring_z:
+            biggest = ring_z * max((b[3] - b[2]) * (b[5] - b[4]) for b in (bases_for_pairs(t) for t in my_tiles))
         fr0 = whole if whole is not None else _Frame(None, None, (0, 0, 0), (2 * ps[0], 2 * ps[1], 2 * ps[2]))
         P0 = params(fr0)
         if ops.rank_on_voxel_major(P0):
@@ -968,6 +1026,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         P = params(fr, cbox)
         if cache is not None:
             cons, P = rows_from_cache(fr, cbox, pool)
+        elif ring_z:
+            with backend.host_timer("s1_consensus"):
+                cons, P = ring_rows(fr, t, False, pool)
         else:
             with backend.host_timer("s1_consensus"):
                 cons, P = consensus_of(fr, P, pool)
@@ -1209,6 +1270,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         cbox = bases_for_pairs(t)
         if cache is not None:
             cons, P = rows_from_cache(whole, cbox, pool)
+            return whole, cons, P
+        if ring_z:
+            cons, P = ring_rows(whole, t, True, pool)
             return whole, cons, P
         nxt = next_of(t)
         fr = frame_for(pairs_frame_box(t), pairs_frame_box(nxt) if nxt is not None else None)
@@ -1526,6 +1590,70 @@ def plan_tiles(own_shape, patchshape, free_bytes, safety=0.6, copies=3.0, cache_
             if float(copies) * cons_cache_bytes((1, 1, 1), patchshape) * pairs_box_voxels(own_shape, patchshape, n, ny, nx) <= left:
                 return n, ny, nx, True       # (tiles_needed's last resort may not fit)
     return tiles_needed(own_shape, patchshape, free_bytes, safety=safety, copies=copies) + (False,)
+
+
+def consensus_work(shape, patchshape, n, ny, nx, ring=False):
+    """base voxels S1 computes for an n x ny x nx grid of tiles, both passes (scores: tile + radius;
+    pairs: tile + radius + p - 1 below in z and on both sides in y / x; clipped to the volume).
+    ring: the z-sweep with the rows in a ring -- no z-halo, only the p - 1 source slices below the
+    first tile of a column in the pairs pass."""
+    ext = []
+    for e, k, p, both in zip(shape, (n, ny, nx), patchshape, (False, True, True)):
+        r, g = int(p) // 2, int(p) - 1
+        sc = pa = 0
+        for a, b in plan_slabs(int(e), k):
+            sc += min(int(e), b + r) - max(0, a - r)
+            pa += min(int(e), b + r + (g if both else 0)) - max(0, a - r - g)
+        ext.append((sc, pa))
+    if ring:
+        z_sc = z_pa = int(shape[0])        # (the first tile starts at slice 0 of the block: nothing below it)
+    else:
+        z_sc, z_pa = ext[0]
+    return float(z_sc) * ext[1][0] * ext[2][0] + float(z_pa) * ext[1][1] * ext[2][1]
+
+
+def plan_ring(own_shape, patchshape, free_bytes, safety=0.6, copies=2.0, min_thick=16, gain=0.95):
+    """(n_slabs, ny, nx, ring_z) for the z-sweep with a ring of rows (tiling.assemble, `_ring_z`), or
+    None when it does not pay: columns of ny x nx tiles in y / x, the ring as many slices as the
+    budget holds of a column's pairs box, tiles a multiple of 8 slices thick (the ranking kernel's
+    tiles of centres are 8 thick) with ring >= thick + 28; taken when S1's work falls below `gain`
+    x that of the best plain grid.  PPP_RING=0 switches it off."""
+    if os.environ.get("PPP_RING", "1") == "0":
+        return None
+    pz, py, px = [int(p) for p in patchshape]
+    Z, Y, X = [int(v) for v in own_shape]
+    row_bytes = float(copies) * cons_cache_bytes((1, 1, 1), patchshape)
+    budget = safety * free_bytes
+    plain = tiles_needed(own_shape, patchshape, free_bytes, safety=safety, copies=copies)
+    if plain == (1, 1, 1) or pz < 3:
+        return None
+    def rank_tail(n, ny, nx):
+        """how well a ranking launch of one tile fills the chip: workgroups of 8 x 8 x 16 centres,
+        four resident per CU -- a launch of 1.5 x 1024 workgroups takes as long as one of 2 x 1024"""
+        wgs = max(-(-(b - a) // 8) for a, b in plan_slabs(Z, n)) * -(-(-(-Y // ny)) // 8) * -(-(-(-X // nx)) // 16)
+        return wgs / (-(-wgs // 1024) * 1024.0)
+
+    def cost(n, ny, nx, ring):
+        # S1 work per voxel of both passes + the ranking's share (11.0 of 25.9 s at 512^3 / 9^3,
+        # profiles/r04_zv: 1.1 x the cost of one S1 pass per voxel) over how well its launches fill
+        return consensus_work(own_shape, patchshape, n, ny, nx, ring=ring) / float(Z * Y * X) + 1.1 / rank_tail(n, ny, nx)
+
+    best = None
+    for ny in range(1, min(Y, 8) + 1):
+        for nx in range(1, min(X, 8) + 1):
+            area = pairs_box_voxels((1, Y, X), (1, py, px), 1, ny, nx)
+            slices = int(budget // (row_bytes * area))
+            top = min((slices - 28) // 8 * 8, -(-Z // 8) * 8)
+            for thick in range(top, max(min_thick, pz - 1, 8) - 1, -8):
+                n = -(-Z // thick)
+                if n < 2:
+                    continue
+                key = (cost(n, ny, nx, True), n * ny * nx)
+                if best is None or key < best[0]:
+                    best = (key, n, ny, nx, max(b - a for a, b in plan_slabs(Z, n)) + 28)
+    if best is None or best[0][0] > gain * cost(*plain, False):
+        return None
+    return best[1], best[2], best[3], best[4]
 
 
 def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,

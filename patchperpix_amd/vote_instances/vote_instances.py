@@ -199,6 +199,13 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
             safety=float(os.environ.get("PPP_TILE_SAFETY", "0.92")), copies=2.0 if direct else 3.0,
             cache_shape=shape if direct and torch.is_tensor(pred_affs) else None)
         kwargs.setdefault("_cons_cache", use_cache)
+        if not use_cache and direct and torch.is_tensor(pred_affs) and "_ring_z" not in kwargs:
+            # neither whole nor cached: sweep the columns of tiles bottom-up with the rows in a ring
+            # (no z-halo in either S1 pass) where that is less work than the plain grid
+            ring = tiling.plan_ring(shape, patchshape, max(avail - reserve, 0.25 * avail),
+                                    safety=float(os.environ.get("PPP_TILE_SAFETY", "0.92")), copies=2.0)
+            if ring is not None:
+                n_slabs, ny_t, nx_t, kwargs["_ring_z"] = ring
         if yx_tiles is None and (ny_t > 1 or nx_t > 1):
             yx_tiles = (ny_t, nx_t)
     # With nothing to store or load between the stages, the single-slab case takes the same

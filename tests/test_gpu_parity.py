@@ -944,6 +944,41 @@ def test_consensus_cache_equals_recomputation(ps, shape, cell, flags, torch_cuda
         assert np.array_equal(want, got) and want.max() > 5
 
 
+@pytest.mark.parametrize("ps,shape,cell,flags", [((9, 9, 9), (70, 48, 60), 24, "shipped"), ((7, 7, 7), (64, 52, 56), 18, "shipped"),
+                                                 ((5, 5, 5), (50, 44, 48), 12, "cc")])
+def test_ring_sweep_equals_plain_tiles(ps, shape, cell, flags, torch_cuda, monkeypatch):
+    """Tiled path with the rows in a ring (`_ring_z`: the tiles of a column bottom-up, every base
+    slice computed once per pass by ppp_consensus_part, ranking and patch-graph kernels addressing
+    the ring) against the plain tiled path: pair rows, pair affinities (bit patterns), instance map.
+    The ring is poisoned with NaN once, so a row entry nobody wrote would show."""
+    from patchperpix_amd import backend, synth
+    from patchperpix_amd import flags as F
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    kw = dict(F.FLYLIGHT if flags == "shipped" else F.FLYLIGHT_CC, _instances_dtype=np.uint32, _cons_cache=False)
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, [cell] * 3, seed=7)
+    pred = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=7, f16=True)
+    fg = lab != 0
+    args = lambda: (fg.copy(), fg.copy(), fg.astype(np.uint8), list(ps))     # noqa: E731
+    thick = max(8, ps[0] - 1)
+    n = -(-shape[0] // thick)
+    for grid in (dict(_n_slabs=n, _yx_tiles=(2, 2)), dict(_n_slabs=n, _yx_tiles=(1, 1))):
+        want = vi.to_instance_seg(pred, *args(), **dict(kw, **grid))[0]
+        want_pairs, want_aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, **grid))
+        ring = -(-shape[0] // n) + 28
+        monkeypatch.setenv("PPP_VM_POISON", "1")
+        backend.NOTES.pop("ring_z", None)
+        got = vi.to_instance_seg(pred, *args(), **dict(kw, _ring_z=ring, **grid))[0]
+        assert backend.NOTES.get("ring_z") == ring
+        got_pairs, got_aff = vi.to_instance_seg(pred, *args(), **dict(kw, return_intermediates=True, _ring_z=ring, **grid))
+        monkeypatch.delenv("PPP_VM_POISON")
+        assert np.array_equal(want_pairs, got_pairs)
+        assert not np.isnan(got_aff).any()
+        assert np.array_equal(_bits(want_aff), _bits(got_aff))
+        assert np.array_equal(want, got) and want.max() > 5
+
+
 def test_consensus_part_and_planes_to_rows(torch_cuda):
     """ppp_consensus_part: COMPACT planes / open VOXEL_MAJOR rows of a box filled in pieces equal the
     one-launch result; ppp_cons_planes_to_rows from a larger planes box equals the rows S1 writes for

@@ -159,6 +159,26 @@ def test_plan_tiles_takes_the_cache_when_it_fits(monkeypatch):
     assert not tiling.plan_tiles((256, 256, 256), ps, 258e9, safety=0.92, copies=2.0, cache_shape=(256, 256, 256))[3]
 
 
+def test_plan_ring(monkeypatch):
+    monkeypatch.delenv("PPP_RING", raising=False)
+    ps = (9, 9, 9)
+    # 512^3 / 9^3 next to the resident prediction: columns of 2 x 2, tiles 16 thick, less S1 work
+    r = tiling.plan_ring((512, 512, 512), ps, 80e9, safety=0.92, copies=2.0)
+    plain = tiling.tiles_needed((512, 512, 512), ps, 80e9, safety=0.92, copies=2.0)
+    assert r is not None
+    n, ny, nx, ring = r
+    thick = max(b - a for a, b in tiling.plan_slabs(512, n))
+    assert ring >= thick + 28 and thick % 8 == 0
+    # the ring of the column's pairs box fits the budget
+    assert 2.0 * tiling.cons_cache_bytes((1, 1, 1), ps) * ring * tiling.pairs_box_voxels((1, 512, 512), (1, 9, 9), 1, ny, nx) <= 0.92 * 80e9
+    assert tiling.consensus_work((512,) * 3, ps, n, ny, nx, ring=True) < 0.9 * tiling.consensus_work((512,) * 3, ps, *plain)
+    # a volume that fits whole, or one whose plain grid is as good, takes none; PPP_RING=0 switches it off
+    assert tiling.plan_ring((140, 140, 140), (7, 7, 7), 250e9, safety=0.92, copies=2.0) is None
+    assert tiling.plan_ring((256, 256, 256), ps, 240e9, safety=0.92, copies=2.0) is None
+    monkeypatch.setenv("PPP_RING", "0")
+    assert tiling.plan_ring((512, 512, 512), ps, 80e9, safety=0.92, copies=2.0) is None
+
+
 def test_tiles_needed():
     # fits whole: one tile
     assert tiling.tiles_needed((140, 140, 140), (7, 7, 7), 250e9) == (1, 1, 1)
