@@ -873,7 +873,7 @@ int ppp_cover_step(int32_t what, const uint32_t *d_bits, int32_t pix_th, int32_t
     hipError_t e;
     if (what == PPP_COVER_COUNT) e = ppp::cover_step_count(d_bits, pix_th, d_state, d_work, G, (hipStream_t)stream);
     else if (what == PPP_COVER_FILTER) e = ppp::cover_step_filter(d_work, G, (hipStream_t)stream);
-    else if (what == PPP_COVER_SELECT) e = ppp::cover_step_select(d_bits, d_state, d_cleared, d_work, global_z, G, (hipStream_t)stream);
+    else if (what == PPP_COVER_SELECT) e = ppp::cover_step_select(d_bits, pix_th, d_state, d_cleared, d_work, global_z, G, (hipStream_t)stream);
     else return fail(PPP_ERR_INVALID_ARG, "unknown cover step %d", what);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_step");
 }

@@ -232,6 +232,15 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v
     }
 }
 
+// Prefetch loads: global loads (scalar base + 32-bit per-lane offset), NOT raw buffer loads.
+// Buffer loads need no vector instruction per load (the global form spends a v_mov per load on
+// the offset) and are 4 % faster on volumes whose channel offsets stay below 2 GB (9^3 slab of a
+// 48 x 512 x 512 volume: 252 vs 264 ms) -- but with the 512^3 block resident (channel stride
+// 268 MB, per-lane offsets up to 2.1 GB) the same launch takes 309 ms with buffer loads against
+// 281 ms with global loads and 291 ms for round 4's kernel (profiles/r05_l_s1_tile.txt).
+#ifndef PPP_S1V3_BUFLOAD
+#define PPP_S1V3_BUFLOAD 0
+#endif
 // raw buffer loads: scalar base (the resource), 32-bit per-lane byte offset, scalar byte offset.
 // DATA_FORMAT_32 in word 3 (what gfx9 wants of an untyped buffer), num_records = 2^32 - 1.
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
@@ -249,6 +258,19 @@ __device__ __forceinline__ unsigned buf_ldraw<float>(BufRsrc r, unsigned voff, u
 template <>
 __device__ __forceinline__ unsigned buf_ldraw<__half>(BufRsrc r, unsigned voff, unsigned soff) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, (int)soff, 0);
+}
+// (experiment switch PPP_S1V3_BUFLOAD=0: the same bits by global loads, saddr + 32-bit voffset)
+template <typename T>
+__device__ __forceinline__ unsigned glb_ldraw(const T *base, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ unsigned glb_ldraw<float>(const float *base, unsigned voff, unsigned soff) {
+    asm volatile("" : "+v"(voff));
+    return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(base) + soff + voff);
+}
+template <>
+__device__ __forceinline__ unsigned glb_ldraw<__half>(const __half *base, unsigned voff, unsigned soff) {
+    asm volatile("" : "+v"(voff));
+    return (unsigned)*reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(base) + soff + voff);
 }
 template <typename T>
 __device__ __forceinline__ float widen(unsigned raw);
@@ -450,10 +472,17 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
                 ra[0][it] = ra[1][it] = 0x3b00u + ((el_off[it] + (unsigned)(cha + crow0)) & 15u);   // (timing experiment)
                 rb[0][it] = rb[1][it] = 0x2e00u + ((el_off[it] + (unsigned)(chb + crow0)) & 15u);
 #else
+#if PPP_S1V3_BUFLOAD
                 ra[0][it] = buf_ldraw<T>(qa, el_off[it], 0u);
                 ra[1][it] = buf_ldraw<T>(qa, el_off[it], s1);
                 rb[0][it] = buf_ldraw<T>(qb, el_off[it], 0u);
                 rb[1][it] = buf_ldraw<T>(qb, el_off[it], s1);
+#else
+                ra[0][it] = glb_ldraw<T>(pred + cha + crow0, el_off[it], 0u);
+                ra[1][it] = glb_ldraw<T>(pred + cha + crow0, el_off[it], s1);
+                rb[0][it] = glb_ldraw<T>(pred + chb + crow0, el_off[it], 0u);
+                rb[1][it] = glb_ldraw<T>(pred + chb + crow0, el_off[it], s1);
+#endif
 #endif
             }
 #pragma unroll

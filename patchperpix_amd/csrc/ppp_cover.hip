@@ -44,10 +44,11 @@ struct CoverWork {
     int32_t *counters;                   // [COVER_BATCH]
     int32_t *loc_vol;                    // [V] sharded cover only: index into the rank's own
                                          // state / cleared / bits tables, -1 off the own centres
-    uint8_t *witness;                    // [V] pix_th == 0: a window row (dz * py + dy) on which
-                                         // the patch centred here still covered a voxel at its
-                                         // last recount; 0xFF = none known
+    uint16_t *witness;                   // [V] pix_th == 0: ONE voxel of the window that the patch
+                                         // centred here still covered at its last recount: window
+                                         // row (dz * py + dy) | x offset << 7; 0xFFFF = none known
 };
+static constexpr uint16_t WIT_NONE = 0xFFFFu;
 
 // words per row of the bit mask: one spare word so a window may be read as two words
 __host__ __device__ __forceinline__ int row_words(const Geo &G) { return (G.X + 31) / 32 + 1; }
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
     cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                        uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
-                       const int32_t *__restrict__ loc_vol, uint8_t *__restrict__ witness,
+                       const int32_t *__restrict__ loc_vol, uint16_t *__restrict__ witness,
                        const long long bits_vox, const Geo G) {
     __shared__ uint16_t s_list[COUNT_THREADS];
     __shared__ int s_n;
@@ -128,8 +129,29 @@ __global__ void __launch_bounds__(COUNT_THREADS)
         // only the own centres are worked on, through their local table index
         if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
         const bool alive = k != RANK_NONE;
-        const bool marked = in && dirty[v] != 0;
-        if (marked) dirty[v] = 0;
+        // pix_th == 0 ("does the patch still cover ANY voxel"): a patch stays undecided as long as
+        // its witness voxel is uncovered -- one bit of the running mask (16 MB at 512^3: cache
+        // resident) decides it, no patch bits are read and no dirty marks are needed; only a patch
+        // whose witness was cleared (or that has none yet) is recounted.  On a dense volume a patch
+        // is looked at in hundreds of rounds and nearly always survives.
+        const bool use_wit = pix_th == 0 && witness != nullptr;
+        bool marked;
+        if (use_wit) {
+            bool wit_ok = false;
+            if (alive) {
+                const unsigned w = witness[v];
+                if (w != WIT_NONE) {
+                    const int wr = (int)(w & 0x7Fu), xo = (int)(w >> 7);
+                    const long long row = v / G.X + (long long)(wr / G.py - G.rz) * G.Y + (wr % G.py - G.ry);
+                    const int x = (int)(v % G.X) - G.rx + xo;
+                    wit_ok = ((mbits[row * row_words(G) + (x >> 5)] >> (x & 31)) & 1u) != 0u;
+                }
+            }
+            marked = alive && !wit_ok;
+        } else {
+            marked = in && dirty[v] != 0;
+            if (marked) dirty[v] = 0;
+        }
         const unsigned long long m = __ballot(alive && marked);
         if (m != 0ull) {
             const int lane = threadIdx.x & 63;
@@ -157,23 +179,8 @@ __global__ void __launch_bounds__(COUNT_THREADS)
         const int start = cx - G.rx, wi = start >> 5, sh = start & 31;
         const bool two = sh + G.px > 32;
         const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
-        // pix_th == 0: "does the patch still cover ANY voxel" -- a patch is recounted every time a
-        // neighbour within p-1 is selected (hundreds of times on a dense volume) and nearly always
-        // survives: first look at the window row that held a hit last time (one row instead of a
-        // plane of rows); only when that row is exhausted is the window scanned again, and the
-        // first row with a hit becomes the new witness.
         const bool use_wit = pix_th == 0 && witness != nullptr;
-        if (use_wit) {
-            const int wr = witness[v];
-            if (wr != 0xFF) {
-                const uint32_t *row = mbits + ((long long)(cz + wr / G.py - G.rz) * G.Y + (cy + wr % G.py - G.ry)) * XW;
-                if (bit_window(row, start, G.px, XW) & bit_window(b, wr * G.px, G.px, words)) {
-                    *n_alive = 1;
-                    continue;
-                }
-            }
-        }
-        int wit_new = 0xFF;
+        unsigned wit_new = WIT_NONE;      // first covered voxel found: row | x offset << 7
         // sliding 64-bit window over the patch's bit string
         unsigned long long win = b[0] | ((unsigned long long)(words > 1 ? b[1] : 0u) << 32);
         int have = 64, next = 2, hits = 0;
@@ -195,8 +202,9 @@ __global__ void __launch_bounds__(COUNT_THREADS)
                 for (int dy = 0; dy < MAXPY; ++dy) {
                     if (dy < G.py) {
                         const unsigned long long mw = lo[dy] | ((unsigned long long)hi[dy] << 32);
-                        const int rh = __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
-                        if (rh && wit_new == 0xFF) wit_new = dz * G.py + dy;
+                        const uint32_t hm = (uint32_t)(mw >> sh) & (uint32_t)win & pmask;
+                        const int rh = __popc(hm);
+                        if (rh && wit_new == WIT_NONE) wit_new = (unsigned)(dz * G.py + dy) | ((unsigned)__builtin_ctz(hm) << 7);
                         hits += rh;
                         win >>= G.px;
                         have -= G.px;
@@ -211,8 +219,9 @@ __global__ void __launch_bounds__(COUNT_THREADS)
                 for (int dy = 0; dy < G.py; ++dy, row += XW) {
                     unsigned long long mw = row[0];
                     if (two) mw |= (unsigned long long)row[1] << 32;
-                    const int rh = __popc((uint32_t)(mw >> sh) & (uint32_t)win & pmask);
-                    if (rh && wit_new == 0xFF) wit_new = dz * G.py + dy;
+                    const uint32_t hm = (uint32_t)(mw >> sh) & (uint32_t)win & pmask;
+                    const int rh = __popc(hm);
+                    if (rh && wit_new == WIT_NONE) wit_new = (unsigned)(dz * G.py + dy) | ((unsigned)__builtin_ctz(hm) << 7);
                     hits += rh;
                     win >>= G.px;
                     have -= G.px;
@@ -228,7 +237,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
             state[k] = 2;
             rank_vol[v] = RANK_NONE;
         } else {
-            if (use_wit && wit_new < 0xFF) witness[v] = (uint8_t)wit_new;
+            if (use_wit) witness[v] = (uint16_t)wit_new;
             *n_alive = 1;
         }
     }
@@ -329,7 +338,7 @@ __global__ void __launch_bounds__(256)
                         const int32_t *__restrict__ nbr_min, int32_t *__restrict__ state,
                         int32_t *__restrict__ rank_vol, int32_t *__restrict__ cleared_interior,
                         uint8_t *__restrict__ dirty, const int32_t *__restrict__ loc_vol,
-                        const int gZ, const long long bits_vox, const Geo G) {
+                        const int gZ, const long long bits_vox, const int mark_dirty, const Geo G) {
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int k = v < G.V ? rank_vol[v] : RANK_NONE;
@@ -369,7 +378,8 @@ __global__ void __launch_bounds__(256)
         const int y0 = max(cy - (G.py - 1), 0), y1 = min(cy + G.py - 1, G.Y - 1);
         const int x0 = max(cx - (G.px - 1), 0), x1 = min(cx + G.px - 1, G.X - 1);
         const int ny = y1 - y0 + 1, nx = x1 - x0 + 1;
-        const int rows = (z1 - z0 + 1) * ny;
+        // (pix_th == 0: the count step asks every undecided patch's witness voxel instead)
+        const int rows = mark_dirty ? (z1 - z0 + 1) * ny : 0;
         for (int row = lane; row < rows; row += 64) {
             uint8_t *d = dirty + vox(G, z0 + row / ny, y0 + row % ny, x0);
             for (int x = 0; x < nx; ++x) d[x] = 1;
@@ -386,7 +396,7 @@ static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 size_t cover_workspace_bytes(long long n, const Geo &G) {
     (void)n;
-    return 4 * up256((size_t)G.V * 4) + 2 * up256((size_t)G.V) +
+    return 4 * up256((size_t)G.V * 4) + up256((size_t)G.V) + up256((size_t)G.V * 2) +
            up256((size_t)G.Z * G.Y * row_words(G) * 4) + 256;
 }
 
@@ -400,7 +410,7 @@ static CoverWork carve(void *work, const Geo &G) {
     W.mbits = (uint32_t *)p;   p += up256((size_t)G.Z * G.Y * row_words(G) * 4);
     W.counters = (int32_t *)p; p += 256;
     W.loc_vol = (int32_t *)p;  p += up256((size_t)G.V * 4);
-    W.witness = (uint8_t *)p;
+    W.witness = (uint16_t *)p;
     return W;
 }
 
@@ -415,7 +425,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
     hipError_t e;
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;   // count everything once
-    if ((e = hipMemsetAsync(W.witness, 0xFF, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.witness, 0xFF, (size_t)G.V * 2, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
     const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
     const long long n_words = (long long)G.Z * G.Y * row_words(G);
@@ -431,7 +441,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
             minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
-                                                        W.dirty, nullptr, G.Z + G.oz, bits_vox, G);
+                                                        W.dirty, nullptr, G.Z + G.oz, bits_vox, pix_th != 0 ? 1 : 0, G);
         }
         *rounds += COVER_BATCH;
         // "any patch undecided" at the start of the batch's last round; if none, that round
@@ -774,7 +784,7 @@ hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.rank_vol, RANK_NONE, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetD32Async((hipDeviceptr_t)W.loc_vol, 0xFFFFFFFF, (size_t)G.V, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(W.witness, 0xFF, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.witness, 0xFF, (size_t)G.V * 2, s)) != hipSuccess) return e;
     if (n && (e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
     const dim3 block(256);
@@ -802,11 +812,11 @@ hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t cover_step_select(const uint32_t *bits, int32_t *state, int32_t *cleared, void *work,
+hipError_t cover_step_select(const uint32_t *bits, int pix_th, int32_t *state, int32_t *cleared, void *work,
                              int gZ, const Geo &G, hipStream_t s) {
     CoverWork W = carve(work, G);
     cover_select_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
-        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, -1ll, G);
+        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, -1ll, pix_th != 0 ? 1 : 0, G);
     return hipGetLastError();
 }
 

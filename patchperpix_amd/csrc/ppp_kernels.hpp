@@ -152,7 +152,7 @@ hipError_t cover_open(const uint8_t *mask, const long long *lin, const int32_t *
 hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, void *work,
                             const Geo &G, hipStream_t s);
 hipError_t cover_step_filter(void *work, const Geo &G, hipStream_t s);
-hipError_t cover_step_select(const uint32_t *bits, int32_t *state, int32_t *cleared, void *work,
+hipError_t cover_step_select(const uint32_t *bits, int pix_th, int32_t *state, int32_t *cleared, void *work,
                              int gZ, const Geo &G, hipStream_t s);
 hipError_t cover_alive(void *work, const Geo &G, int32_t *alive, hipStream_t s);
 hipError_t cover_close(uint8_t *mask, void *work, const Geo &G, hipStream_t s);

@@ -617,7 +617,7 @@ def sharded_cover_own(ops, comm, shape, ps, my_range, ranges, mask_ab, a, remain
                 shard.step(shard.COUNT, pix_th)
                 exchange(True)
                 shard.step(shard.FILTER)
-                shard.step(shard.SELECT)
+                shard.step(shard.SELECT, pix_th)
                 exchange(False)
             total_rounds += COVER_BATCH
             flag = torch.tensor([1 if shard.alive() else 0], dtype=torch.int32, device=dev)
