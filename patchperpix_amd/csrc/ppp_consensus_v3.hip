@@ -140,6 +140,16 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v
     v4f bcur[GS], bnxt[GS];
     v2f ta, ta_nxt, fa, fa_nxt, ga, na;
     uint32_t ca = 0u;
+    // (experiment PPP_S1V3_ADDRREGS=1: the reads of a group through address registers of their own)
+#ifndef PPP_S1V3_ADDRREGS
+#define PPP_S1V3_ADDRREGS 0
+#endif
+    lds_v4f_cvp btg[GS];
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
+        btg[g] = bt;
+        if (PPP_S1V3_ADDRREGS) asm volatile("" : "+v"(btg[g]));
+    }
     auto used = [](int kx, int j) { return j < PX && !(ROW0 && j <= kx); };
     auto load_group = [&](int n, v4f (&b)[GS], v2f &t, v2f &f) {
         const int kx = PX - 1 - n / NJG, jg = (n % NJG) * GS;
@@ -158,7 +168,7 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v
 #ifdef PPP_S1_ABL_NOLDS
                     b[g] = (v4f){t.x * 0.9f, t.y * 0.8f, __uint_as_float(0x00010001u), 0.0f};   // (timing experiment)
 #else
-                    b[g] = bt[(jg + g) * NC - kx];
+                    b[g] = btg[g][(jg + g) * NC - kx];
 #endif
                 }
             }
@@ -262,6 +272,11 @@ __device__ __forceinline__ unsigned buf_ldraw<__half>(BufRsrc r, unsigned voff, 
 // (experiment switch PPP_S1V3_BUFLOAD=0: the same bits by global loads, saddr + 32-bit voffset)
 template <typename T>
 __device__ __forceinline__ unsigned glb_ldraw(const T *base, unsigned voff, unsigned soff);
+// (an empty asm pins a COPY of the offset per load: it keeps the zero extension next to the load --
+// hoisted out of the tile loop it would turn every load into a 64-bit VGPR address computation
+// instead of saddr + voffset.  One copy shared by the four loads of an element saves 39 v_mov per
+// tile and is SLOWER: 312 vs 281 ms on the 512^3 tile, 263 vs 252 on the small slab
+// (profiles/r05_n_s1_tile.txt) -- like the buffer loads, which share the offset register too.)
 template <>
 __device__ __forceinline__ unsigned glb_ldraw<float>(const float *base, unsigned voff, unsigned soff) {
     asm volatile("" : "+v"(voff));

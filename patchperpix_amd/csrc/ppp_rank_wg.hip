@@ -337,6 +337,17 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             for (int w = 0; w < W16; ++w) mw[w] = active ? mw[w] : 0u;
             float acc = active ? accs[cl] : 0.0f;
             lds_f32_cvp2 row = (lds_f32_cvp2)(rowbuf + RW_PAD + LCP - (az * SZP + ay * WX + ax));
+            // (experiment PPP_RW_ADDRREGS=1: the four reads of a group through address registers of
+            // their own instead of one register + immediate offsets)
+#ifndef PPP_RW_ADDRREGS
+#define PPP_RW_ADDRREGS 0
+#endif
+            lds_f32_cvp2 rowc[4];
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                rowc[i2] = row;
+                if (PPP_RW_ADDRREGS) asm volatile("" : "+v"(rowc[i2]));
+            }
             const int aw = a >> 4;
             // b in P counts only for b > a: P bits of the partners <= a go (N bits stay)
             const uint32_t above16 = ~((2u << (a & 15)) - 1u) & 0xFFFFu;
@@ -367,7 +378,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
 #ifdef PPP_RW_ABL_NOLDS
                         if (b < C) r[i2] = __builtin_bit_cast(float, 0x3F800000u + (uint32_t)(lane + b));   // (timing experiment)
 #else
-                        if (b < C) r[i2] = row[(b / (PY * PX)) * SZP + ((b / PX) % PY) * WX + b % PX];
+                        if (b < C) r[i2] = rowc[i2][(b / (PY * PX)) * SZP + ((b / PX) % PY) * WX + b % PX];
 #endif
                     }
                 };
