@@ -397,23 +397,33 @@ Z = shape[0]
 slabs = tiling.plan_slabs(Z, world)
 mine = tiling.slabs_of_rank(slabs, rank, world)
 lo, hi = tiling.local_range(mine, Z, ps)
+import json
+sub = int(os.environ.get("PPP_TEST_SUBSLABS", "1"))        # the rank's range cut into several tiles
+if sub > 1:
+    a0 = mine[0][0]
+    mine = [(a0 + a, a0 + b) for a, b in tiling.plan_slabs(mine[-1][1] - a0, sub)]
+kw.update(json.loads(os.environ.get("PPP_TEST_KW", "{{}}")))
 pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi])).cuda()
 inst, fg = tiling.assemble(pred_local, lo, shape, c["foreground"].copy(), c["foreground"].copy(),
                            c["numinst"], list(ps), mine, comm=tiling.TorchDistComm(), **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
         np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
-                  backend.NOTES.get("cover_p2p", 0)]))
+                  backend.NOTES.get("cover_p2p", 0), backend.NOTES.get("ring_z", 0),
+                  1 if "cons_cache_gb" in backend.NOTES else 0]))
 dist.destroy_process_group()
 """
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,empty_top,ps,flagset,p2p", [
-    (2, False, (5, 5, 5), "nothin_cc", "1"), (3, False, (5, 5, 5), "nothin_cc", "1"),
-    (2, True, (5, 5, 5), "nothin_cc", "1"), (2, False, (7, 7, 7), "shipped", "1"),
-    (3, False, (7, 7, 7), "cc", "1"), (3, False, (5, 5, 5), "nothin_cc", "0")])
-def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps, flagset, p2p):
+@pytest.mark.parametrize("world,empty_top,ps,flagset,p2p,sub,extra", [
+    (2, False, (5, 5, 5), "nothin_cc", "1", 1, {}), (3, False, (5, 5, 5), "nothin_cc", "1", 1, {}),
+    (2, True, (5, 5, 5), "nothin_cc", "1", 1, {}), (2, False, (7, 7, 7), "shipped", "1", 1, {}),
+    (3, False, (7, 7, 7), "cc", "1", 1, {}), (3, False, (5, 5, 5), "nothin_cc", "0", 1, {}),
+    # a rank's range cut into three tiles: rows in a ring / a consensus cache over the rank's block
+    (2, False, (5, 5, 5), "shipped", "1", 3, {"_ring_z": 40}), (2, False, (5, 5, 5), "cc", "1", 3, {"_cons_cache": True}),
+    (2, False, (7, 7, 7), "shipped", "1", 3, {"_ring_z": 40, "_yx_tiles": [1, 2]})])
+def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps, flagset, p2p, sub, extra):
     """The multi-rank path with the REAL kernels: `world` processes on the one GPU of the box,
     gloo as the transport (RCCL needs one device per rank): sharded cover with z-halo exchange,
     per-rank pair rows, merged label forests -- same instance map as one process.  The slab
@@ -435,7 +445,7 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
     _port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
                PPP_TEST_EMPTY_TOP="1" if empty_top else "0", PPP_TEST_FLAGSET=flagset,
-               PPP_COVER_P2P=p2p)
+               PPP_COVER_P2P=p2p, PPP_TEST_SUBSLABS=str(sub), PPP_TEST_KW=__import__("json").dumps(extra))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                            "--master-port", _port, str(script)], env=env, timeout=900)
@@ -445,6 +455,7 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
         assert np.array_equal(inst, want), "rank %d differs" % r
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
         assert notes[0] == world and notes[1] > 0 and notes[2] == int(p2p)
+        assert notes[3] == extra.get("_ring_z", 0) and notes[4] == (1 if extra.get("_cons_cache") else 0)
 
 
 RCCL_WORKER = r"""
