@@ -32,6 +32,16 @@
 //     registers for the p rows of an x-run: a ninth of the mask loads, which are 60 % of this
 //     kernel's 482 GB of fetches): 402 ms -- one 12-wave workgroup per CU does one chunk per
 //     barrier interval and nothing overlaps the row publication.
+// Round 5, designed and not built: the masks are 60 % of the fetches and, by the
+// constant-mask ablation, 39 % of the time, and every chunk waits for its twelve mask loads before
+// its chain can start.  A walk along x-lines with lanes bound to (centre line, slot = cx mod 9)
+// keeps a centre's masks and accumulator in registers for its nine rows (a ninth of the loads);
+// with four waves a line's <= 64 centre lines need ~2.3 groups, i.e. the rows of the line staged
+// 2.3 x (from L2) -- the bytes the masks save -- so what it can win is the LATENCY: only if the
+// masks of the ONE centre per line that enters at the next row are prefetched (28 x 192 B per row
+// and group) by a fifth, helper wave into a 10 KB LDS double buffer while the four compute waves
+// run the current row.  Rows that are skipped (no valid voxel) make several centres enter at once:
+// those lanes load directly, as every lane does today.
 // What holds the kernel back is neither unit alone (VALU 24 %, LDS 54 % busy of which half bank
 // conflicts, 2.35 TB/s of fetches) but the stalls of its dependent chains at 16 waves per CU.
 #include <stdlib.h>
