@@ -267,8 +267,11 @@ __global__ void __launch_bounds__(256)
 // x and y passes of the running minimum in one kernel: a block owns 8 rows x 64 columns of one
 // z-slice, stages them with their (ry, rx) apron in LDS, takes the minimum along x into a second
 // LDS array and then along y (one launch and one volume round trip less per round).
-static constexpr int MF_TY = 8, MF_TX = 64;
-template <typename T>
+// (rows per block by element size: 32 rows of int32 / 16 of int64 -- with the (ry, rx) apron a block
+// reads (TY + 2 ry)(64 + 2 rx) elements for TY * 64 results: 1.9 x at 32 rows, 3.75 x at 8)
+static constexpr int MF_TX = 64;
+template <typename T> struct MfRows { static constexpr int value = sizeof(T) == 4 ? 32 : 16; };
+template <typename T, int MF_TY>
 __global__ void __launch_bounds__(256)
     cover_minfilter_xy_kernel(const T *__restrict__ in, T *__restrict__ out, const Geo G,
                               const int rx, const int ry) {
@@ -309,11 +312,14 @@ __global__ void __launch_bounds__(256)
 template <typename T>
 static void minfilter_xy(const T *in, T *scratch, T *out, const Geo &G, hipStream_t s) {
     const int rx = G.px - 1, ry = G.py - 1;
-    const dim3 grid((unsigned)((G.X + MF_TX - 1) / MF_TX), (unsigned)((G.Y + MF_TY - 1) / MF_TY), (unsigned)G.Z);
-    const size_t lds = (size_t)((MF_TY + 2 * ry) * (MF_TX + 2 * rx) + (MF_TY + 2 * ry) * MF_TX) * sizeof(T);
+    constexpr int TYB = MfRows<T>::value, TYS = 8;      // rows per block: the tall tile where it fits LDS
+    auto lds_of = [&](int ty) { return (size_t)((ty + 2 * ry) * (MF_TX + 2 * rx) + (ty + 2 * ry) * MF_TX) * sizeof(T); };
+    auto grid_of = [&](int ty) { return dim3((unsigned)((G.X + MF_TX - 1) / MF_TX), (unsigned)((G.Y + ty - 1) / ty), (unsigned)G.Z); };
     const dim3 vgrid((unsigned)((G.V + 255) / 256)), block(256);
-    if (lds <= 48 * 1024 && G.Y <= 65535 * MF_TY && G.Z <= 65535) {
-        cover_minfilter_xy_kernel<T><<<grid, block, lds, s>>>(in, out, G, rx, ry);
+    if (lds_of(TYB) <= 48 * 1024 && G.Z <= 65535) {
+        cover_minfilter_xy_kernel<T, TYB><<<grid_of(TYB), block, lds_of(TYB), s>>>(in, out, G, rx, ry);
+    } else if (lds_of(TYS) <= 48 * 1024 && G.Y <= 65535 * TYS && G.Z <= 65535) {
+        cover_minfilter_xy_kernel<T, TYS><<<grid_of(TYS), block, lds_of(TYS), s>>>(in, out, G, rx, ry);
     } else {
         cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(in, scratch, G.V, G.X, 1, rx);
         cover_minfilter_kernel<T><<<vgrid, block, 0, s>>>(scratch, out, G.V, G.Y, G.X, ry);
