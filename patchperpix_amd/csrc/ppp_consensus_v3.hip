@@ -173,11 +173,19 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v
                 }
             }
     };
+    // PPP_S1V3_DEPTH = 2 (experiment): the LDS reads run TWO groups ahead of the arithmetic
+#ifndef PPP_S1V3_DEPTH
+#define PPP_S1V3_DEPTH 1
+#endif
+    constexpr int DEPTH = (PPP_S1V3_DEPTH == 2 && NJG >= 2) ? 2 : 1;    // (one new kx per two groups at most)
+    v4f bnx2[GS];
     load_group(0, bcur, ta, fa);
+    if (DEPTH == 2 && NG > 1) load_group(1, bnxt, ta_nxt, fa_nxt);
 #pragma unroll
     for (int n = 0; n < NG; ++n) {
         const int kx = PX - 1 - n / NJG, jg = (n % NJG) * GS;
-        if (n + 1 < NG) load_group(n + 1, bnxt, ta_nxt, fa_nxt);
+        if (DEPTH == 1) { if (n + 1 < NG) load_group(n + 1, bnxt, ta_nxt, fa_nxt); }
+        else if (n + 2 < NG) load_group(n + 2, bnx2, ta_nxt, fa_nxt);
         if (jg == 0) {
             ta = ta * fa;                                       // centre factor {0, 1}
             if constexpr (!EXACT) {
@@ -235,7 +243,7 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v
         }
         if (n + 1 < NG) {
 #pragma unroll
-            for (int g = 0; g < GS; ++g) bcur[g] = bnxt[g];
+            for (int g = 0; g < GS; ++g) { bcur[g] = bnxt[g]; if (DEPTH == 2) bnxt[g] = bnx2[g]; }
             if ((n + 1) % NJG == 0) { ta = ta_nxt; fa = fa_nxt; }
         }
         __builtin_amdgcn_sched_barrier(0);
