@@ -132,7 +132,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
     rank_masks_il_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, const ppp_box sb,
                          uint32_t *__restrict__ M, uint32_t *__restrict__ info,
-                         float *__restrict__ score, const Geo G) {
+                         float *__restrict__ score, const int *__restrict__ any_e, const Geo G) {
+    if (any_e && *any_e == 0) return;         // (the one-bit masks serve this launch)
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
     const long long sbV = (long long)sX * sY * sZ;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,6 +174,64 @@ __global__ void __launch_bounds__(256)
     info[t] = inf;
 }
 
+// ---- one bit per partner (round 5) ----------------------------------------------------------
+// The consensus entry S[u][q] is 0 whenever u or u + q is not a valid foreground voxel (the votes
+// skip such pixels: fillConsensusArray.cu:45-57, 75-83), so a term with an invalid partner adds
+// +-0 to the running sum -- which never changes it (the sum is never -0).  The masks therefore need
+// no validity, and with the background rule "v < TH" (the shipped one) a partner that is not in P
+// is in N unless its value EQUALS the threshold: ONE bit per partner (P' = v > TH), 92 bytes per
+// centre instead of 184 -- half the mask fetches, half the mask registers.  A launch in which any
+// centre has a valid partner with v == TH (or a NaN) falls back to the two-bit masks: the pre-pass
+// raises `any_e`, the one-bit main kernel returns at once and the two-bit pre-pass + kernel, launched
+// behind it, run (they return at once otherwise).
+static constexpr int rw_p1_words(int C) { return (((C + 31) / 32) + 3) & ~3; }
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rank_masks_p1_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, const ppp_box sb,
+                         uint32_t *__restrict__ M, uint32_t *__restrict__ info, int *__restrict__ any_e,
+                         float *__restrict__ score, const Geo G) {
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    const long long sbV = (long long)sX * sY * sZ;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sbV) return;
+    const int cx = sb.x0 + (int)(t % sX), cy = sb.y0 + (int)((t / sX) % sY), cz = sb.z0 + (int)(t / ((long long)sX * sY));
+    const long long lc = vox(G, cz, cy, cx);
+    const T *mid = pred + (long long)G.mid * G.V;
+    uint32_t inf = 0;
+    if (!interior(G, cz, cy, cx)) {
+        score[lc] = G.norm_rank ? -1.0f : -9999999.0f;
+    } else if (!(ldf(mid, lc) > G.th_gt)) {
+        score[lc] = 0.0f;   // the reference leaves the allocation's zero
+    } else {
+        const int words = (G.C + 31) / 32, wp = rw_p1_words(G.C);
+        unsigned nP = 0, nV = 0;
+        bool e = false;
+        int r = 0;
+        for (int w = 0; w < words; ++w) {
+            uint32_t p = 0;
+            for (int b = 0; b < 32 && r < G.C; ++b, ++r) {
+                const int z = cz + r / (G.py * G.px) - G.rz, y = cy + (r / G.px) % G.py - G.ry,
+                          x = cx + r % G.px - G.rx;
+                const long long lz = vox(G, z, y, x);
+                const bool valid = ldf(mid, lz) > G.th_gt && (!G.use_overlap || ov[lz] == 0);
+                const float val = ldf(pred, (long long)r * G.V + lc);
+                const bool isp = val > G.th_gt;
+                if (valid) ++nV;
+                if (valid && isp) ++nP;
+                if (valid && !isp && !(val < G.bg_lt)) e = true;     // neither P nor N: needs the two-bit masks
+                if (isp) p |= 1u << b;
+            }
+            M[t * (long long)wp + w] = p;
+        }
+        for (int w = words; w < wp; ++w) M[t * (long long)wp + w] = 0u;
+        if (e) *any_e = 1;
+        const unsigned fg_cnt = nP ? nP * (nV - 1u) - nP * (nP - 1u) / 2u : 0u;
+        inf = 0x80000000u | fg_cnt;
+        if (nP == 0) score[lc] = 0.0f;
+    }
+    info[t] = inf;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
     rank_valid2_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov, uint8_t *__restrict__ valid,
@@ -183,14 +242,17 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---- main kernel ---------------------------------------------------------------------------
-template <int PZ, int PY, int PX, int TZ, int TY, int TX>
+template <int PZ, int PY, int PX, int TZ, int TY, int TX, bool P1>
 __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     rank_wg_kernel(const float *__restrict__ S, const uint32_t *__restrict__ M,
                    const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
-                   const int tiles_x, const int n_tiles) {
+                   const int tiles_x, const int n_tiles, const int *__restrict__ any_e) {
+    // (one launch of each form per call when the one-bit masks are possible: the pre-pass decides)
+    if (any_e && (*any_e != 0) == P1) return;
     constexpr int C = PZ * PY * PX, W16 = (C + 15) / 16, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
-    constexpr int W16P = rw_mask_words(C);
+    constexpr int W16P = P1 ? rw_p1_words(C) : rw_mask_words(C);   // mask words per centre in M
+    constexpr int NMW = P1 ? (C + 31) / 32 : W16;                  // ... that hold bits
     constexpr int WZ = 2 * PZ - 1, WY = 2 * PY - 1, WX = 2 * PX - 1, W = WZ * WY * WX, LC = (W - 1) / 2;
     constexpr int NTHR = 64 * RW_WAVES;
     constexpr int NST = (W + NTHR - 1) / NTHR;
@@ -285,8 +347,57 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     }
     __syncthreads();
     int turn = 0;   // rotates the wave that takes the first chunk of a row
+    // geometry of a row (which pixels a of voxel u have their centre in the tile) and of the item a
+    // lane takes in chunk i0 of it -- functions of the row index, so that the masks of the NEXT
+    // chunk (of this row or of the next) can be requested ahead
+    struct RowG { int uz, uy, ux, az0, ay0, ax0, nz, ny, nx, n_box; };
+    struct ItemG { bool in; int cl, a, az, ay, ax; long long t; };
+    auto row_geom = [&](int k) -> RowG {
+        RowG r;
+        r.uz = uz0 + k / (nuy * nux); r.uy = uy0 + (k / nux) % nuy; r.ux = ux0 + k % nux;
+        r.az0 = max(0, r.uz + RZ - (c0z + tz - 1));
+        r.ay0 = max(0, r.uy + RY - (c0y + ty - 1));
+        r.ax0 = max(0, r.ux + RX - (c0x + tx - 1));
+        r.nz = min(PZ - 1, r.uz + RZ - c0z) - r.az0 + 1;
+        r.ny = min(PY - 1, r.uy + RY - c0y) - r.ay0 + 1;
+        r.nx = min(PX - 1, r.ux + RX - c0x) - r.ax0 + 1;
+        r.n_box = (r.nz <= 0 || r.ny <= 0 || r.nx <= 0) ? 0 : r.nz * r.ny * r.nx;
+        return r;
+    };
+    auto item_geom = [&](const RowG &r, int i0) -> ItemG {
+        ItemG g;
+        const int i = i0 + lane;
+        g.in = i < r.n_box;
+        const int ii = g.in ? i : 0;
+        g.ax = r.ax0 + ii % r.nx;
+        g.ay = PPP_RW_ZRUNS(PX) ? r.ay0 + ii / (r.nx * r.nz) : r.ay0 + (ii / r.nx) % r.ny;
+        g.az = PPP_RW_ZRUNS(PX) ? r.az0 + (ii / r.nx) % r.nz : r.az0 + ii / (r.nx * r.ny);
+        const int lz = r.uz + RZ - g.az - c0z, ly = r.uy + RY - g.ay - c0y, lx = r.ux + RX - g.ax - c0x;
+        g.cl = (lz * TY + ly) * TX + lx;
+        g.a = (g.az * PY + g.ay) * PX + g.ax;
+        g.t = sb_index(lz, ly, lx);
+        return g;
+    };
+    // one-bit masks: the first PFQ 16-byte pieces of a centre's words + the word with P'[a], requested
+    // one chunk ahead (PPP_RW_PREFETCH=0: every chunk loads its masks when it starts, as the two-bit form)
+#ifndef PPP_RW_PREFETCH
+#define PPP_RW_PREFETCH 1
+#endif
+    constexpr bool PF = PPP_RW_PREFETCH != 0;
+    constexpr int PFQ = (W16P / 4) / 2;
+    uint4 pfa[PFQ > 0 ? PFQ : 1];
+    uint32_t pfw = 0u;
+    bool pf_have = false;
+    auto prefetch = [&](const RowG &r, int i0) {
+        const ItemG g = item_geom(r, i0);
+        const uint32_t *mrow = M + g.t * (long long)W16P;
+        pfw = mrow[g.a >> 5];
+        const uint4 *mc = reinterpret_cast<const uint4 *>(mrow);
+#pragma unroll
+        for (int q = 0; q < PFQ; ++q) pfa[q] = mc[q];
+    };
+    (void)prefetch; (void)pf_have; (void)pfw;
     while (uk < nu) {
-        const int uz = uz0 + uk / (nuy * nux), uy = uy0 + (uk / nux) % nuy, ux = ux0 + uk % nux;
         const int uk_next = __builtin_amdgcn_readfirstlane(next_valid(uk + 1));
         if (uk_next < nu) {
             const float *src = row_src(uk_next);
@@ -301,50 +412,86 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             }
         }
         // pixels a of this voxel whose centre c = u + R - a lies in the tile
-        const int az0 = max(0, uz + RZ - (c0z + tz - 1)), az1 = min(PZ - 1, uz + RZ - c0z);
-        const int ay0 = max(0, uy + RY - (c0y + ty - 1)), ay1 = min(PY - 1, uy + RY - c0y);
-        const int ax0 = max(0, ux + RX - (c0x + tx - 1)), ax1 = min(PX - 1, ux + RX - c0x);
-        const int nz = az1 - az0 + 1, ny = ay1 - ay0 + 1, nx = ax1 - ax0 + 1;
-        const int n_box = (nz <= 0 || ny <= 0 || nx <= 0) ? 0 : nz * ny * nx;
+        const RowG R = row_geom(uk);
+        const int n_box = R.n_box;
         const int first = (wave + RW_WAVES - turn) & (RW_WAVES - 1);
         turn = (turn + ((n_box + 63) >> 6)) & (RW_WAVES - 1);
+        if constexpr (P1 && PF) {
+            // (the first chunk of a row is normally prefetched at the end of the row before)
+            if (!pf_have && 64 * first < n_box) prefetch(R, 64 * first);
+            pf_have = false;
+        }
         for (int i0 = 64 * first; i0 < n_box; i0 += NTHR) {
-            const int i = i0 + lane;
-            const bool in = i < n_box;
-            const int ii = in ? i : 0;
-            const int ax = ax0 + ii % nx;
-            const int ay = PPP_RW_ZRUNS(PX) ? ay0 + ii / (nx * nz) : ay0 + (ii / nx) % ny;
-            const int az = PPP_RW_ZRUNS(PX) ? az0 + (ii / nx) % nz : az0 + ii / (nx * ny);
-            const int lz = uz + RZ - az - c0z, ly = uy + RY - ay - c0y, lx = ux + RX - ax - c0x;
-            const int cl = (lz * TY + ly) * TX + lx;
-            const int a = (az * PY + ay) * PX + ax;
-            const long long t = sb_index(lz, ly, lx);
-            bool active = in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
-            // is a in P?  P bit of partner s: bit 8 (s >> 2 & 3) + (s & 3) of word s >> 4
-            if (active) active = ((M[t * (long long)W16P + (a >> 4)] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
+            const ItemG it = item_geom(R, i0);
+            const bool in = it.in;
+            const int ax = it.ax, ay = it.ay, az = it.az, cl = it.cl, a = it.a;
+            const long long t = it.t;
+            (void)in;
+            bool active = it.in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
+            uint32_t mw[NMW];
+            if constexpr (P1 && PF) {
+                // ---- one-bit masks, software pipelined: the first half of this chunk's words and the
+                // word that holds P'[a] were requested a chunk ago; the second half is requested now
+                // and arrives behind the first half of the chain; then the next chunk's first half
+                // (this row's next chunk of the wave, or the first chunk of the next row)
+                const uint32_t aword = pfw;
+#pragma unroll
+                for (int q = 0; q < PFQ; ++q) {
+                    if (4 * q < NMW) mw[4 * q] = pfa[q].x;
+                    if (4 * q + 1 < NMW) mw[4 * q + 1] = pfa[q].y;
+                    if (4 * q + 2 < NMW) mw[4 * q + 2] = pfa[q].z;
+                    if (4 * q + 3 < NMW) mw[4 * q + 3] = pfa[q].w;
+                }
+                const uint4 *mc = reinterpret_cast<const uint4 *>(M + t * (long long)W16P);
+#pragma unroll
+                for (int q = PFQ; q < W16P / 4; ++q) {
+                    const uint4 v = mc[q];
+                    if (4 * q < NMW) mw[4 * q] = v.x;
+                    if (4 * q + 1 < NMW) mw[4 * q + 1] = v.y;
+                    if (4 * q + 2 < NMW) mw[4 * q + 2] = v.z;
+                    if (4 * q + 3 < NMW) mw[4 * q + 3] = v.w;
+                }
+                if (i0 + NTHR < n_box) {
+                    prefetch(R, i0 + NTHR);
+                } else if (uk_next < nu) {
+                    const RowG Rn = row_geom(uk_next);
+                    const int first_n = (wave + RW_WAVES - turn) & (RW_WAVES - 1);
+                    if (64 * first_n < Rn.n_box) { prefetch(Rn, 64 * first_n); pf_have = true; }
+                }
+                if (active) active = ((aword >> (a & 31)) & 1u) != 0;
+                if (__ballot(active) == 0) continue;
+            } else {
+            // is a in P?  P bit of partner s: bit 8 (s >> 2 & 3) + (s & 3) of word s >> 4 (two-bit
+            // masks), bit s & 31 of word s >> 5 (one-bit masks)
+            if (active) {
+                if constexpr (P1) active = ((M[t * (long long)W16P + (a >> 5)] >> (a & 31)) & 1u) != 0;
+                else active = ((M[t * (long long)W16P + (a >> 4)] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
+            }
             if (__ballot(active) == 0) continue;
-            uint32_t mw[W16];
             // (unconditional loads -- t is a centre of the tile for every lane -- then one select
             // per word: a predicated load is a branch per word)
 #ifdef PPP_RW_ABL_NOMASK
             // (timing experiment: no mask loads -- every partner in P)
 #pragma unroll
-            for (int w = 0; w < W16; ++w) mw[w] = 0x0F0F0F0Fu + (uint32_t)(t & 0);
+            for (int w = 0; w < NMW; ++w) mw[w] = (P1 ? 0xFFFFFFFFu : 0x0F0F0F0Fu) + (uint32_t)(t & 0);
 #else
             {
                 const uint4 *mc = reinterpret_cast<const uint4 *>(M + t * (long long)W16P);
 #pragma unroll
                 for (int q = 0; q < W16P / 4; ++q) {
                     const uint4 v = mc[q];
-                    if (4 * q < W16) mw[4 * q] = v.x;
-                    if (4 * q + 1 < W16) mw[4 * q + 1] = v.y;
-                    if (4 * q + 2 < W16) mw[4 * q + 2] = v.z;
-                    if (4 * q + 3 < W16) mw[4 * q + 3] = v.w;
+                    if (4 * q < NMW) mw[4 * q] = v.x;
+                    if (4 * q + 1 < NMW) mw[4 * q + 1] = v.y;
+                    if (4 * q + 2 < NMW) mw[4 * q + 2] = v.z;
+                    if (4 * q + 3 < NMW) mw[4 * q + 3] = v.w;
                 }
             }
 #endif
+            }
+            if constexpr (!P1) {
 #pragma unroll
-            for (int w = 0; w < W16; ++w) mw[w] = active ? mw[w] : 0u;
+                for (int w = 0; w < W16; ++w) mw[w] = active ? mw[w] : 0u;
+            }
             float acc = active ? accs[cl] : 0.0f;
             lds_f32_cvp2 row = (lds_f32_cvp2)(rowbuf + RW_PAD + LCP - (az * SZP + ay * WX + ax));
             // (experiment PPP_RW_ADDRREGS=1: the four reads of a group through address registers of
@@ -367,7 +514,22 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             // offset at run time)
             StaticFor<0, W16>::run([&](auto wc) {
                 constexpr int w = decltype(wc)::value;
-                const uint32_t m = mw[w] & (w < aw ? 0xF0F0F0F0u : (w > aw ? 0xFFFFFFFFu : keep_a));
+                uint32_t m;
+                if constexpr (P1) {
+                    // the two-bit word of these 16 partners from their P' bits: P counts for b > a,
+                    // N = not P' for every b != a (partners beyond C do not exist)
+                    constexpr uint32_t last = (w == W16 - 1 && (C & 15)) ? ((1u << (C & 15)) - 1u) : 0xFFFFu;
+                    const uint32_t pw = (mw[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
+                    const uint32_t pos = pw & (w < aw ? 0u : (w > aw ? 0xFFFFu : above16));
+                    const uint32_t neg = ~pw & (w == aw ? ~(1u << (a & 15)) : 0xFFFFFFFFu) & last;
+                    auto spread = [](uint32_t x) -> uint32_t {      // nibble j of x -> low nibble of byte j
+                        x = (x | (x << 8)) & 0x00FF00FFu;
+                        return (x | (x << 4)) & 0x0F0F0F0Fu;
+                    };
+                    m = active ? (spread(pos) | (spread(neg) << 4)) : 0u;
+                } else {
+                    m = mw[w] & (w < aw ? 0xF0F0F0F0u : (w > aw ? 0xFFFFFFFFu : keep_a));
+                }
                 if (__ballot(m != 0u) == 0) return;
                 // table reads of the word first; then the four groups of four partners, the row
                 // values of the next group in flight while the current chain runs
@@ -450,7 +612,7 @@ bool rank_wg_supported(const Geo &G) {
 size_t rank_wg_workspace_bytes(const ppp_box &sb, const Geo &G) {
     const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
     const size_t words16 = (size_t)rw_mask_words(G.C);
-    return up256w(words16 * sbV * 4) + up256w(sbV * 4) + up256w((size_t)G.V);
+    return up256w(words16 * sbV * 4) + up256w(sbV * 4) + up256w((size_t)G.V) + 256;
 }
 
 template <typename T>
@@ -462,7 +624,8 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     char *p = (char *)work;
     uint32_t *M = (uint32_t *)p;    p += up256w(words16 * sbV * 4);
     uint32_t *info = (uint32_t *)p; p += up256w(sbV * 4);
-    uint8_t *valid = (uint8_t *)p;
+    uint8_t *valid = (uint8_t *)p;  p += up256w((size_t)G.V);
+    int *any_e = (int *)p;          // one-bit masks: "a partner equals the threshold somewhere"
     if (G.bz0 > (sb.z0 - G.rz > 0 ? sb.z0 - G.rz : 0) || G.by0 > (sb.y0 - G.ry > 0 ? sb.y0 - G.ry : 0) ||
         G.bx0 > (sb.x0 - G.rx > 0 ? sb.x0 - G.rx : 0) ||
         G.bz0 + G.bZ < (sb.z1 + G.rz < G.Z ? sb.z1 + G.rz : G.Z) ||
@@ -472,7 +635,21 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     PPP_GRID_CHECK((G.V + 255) / 256, 256);
     PPP_GRID_CHECK((sbV + 255) / 256, 256);
     rank_valid2_kernel<T><<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(pred, ov, valid, G);
-    rank_masks_il_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, M, info, score, G);
+    // one bit per partner where N is the complement of P up to values that equal the threshold
+    // (background rule "v < TH": bg_lt >= th_gt) -- only with PPP_RANK_P1=1: it halves the mask
+    // fetches and, with the prefetch, takes their latency off the chain's start, and is SLOWER
+    // (112 x 176 x 176 / 9^3: 285 ms, 272 ms without the prefetch, against 254 ms for the two-bit masks;
+    // 140^3 / 7^3: 72 vs 62 ms; profiles/r05_x_s2_one_bit_masks.txt): the 12 vector instructions that
+    // rebuild a two-bit word from 16 mask bits cost more than the fetches they save -- the kernel is
+    // not waiting for its masks.
+    static EnvSwitch p1_sw("PPP_RANK_P1");
+    const bool p1 = G.bg_lt >= G.th_gt && p1_sw.get() && p1_sw.get()[0] == '1';
+    if (p1) {
+        hipError_t em = hipMemsetAsync(any_e, 0, 4, s);
+        if (em != hipSuccess) return em;
+        rank_masks_p1_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, M, info, any_e,
+                                                                                          score, G);
+    }
     // Tile of centres per workgroup: 8 x 16 x 16 when that still gives every CU four workgroups
     // (a row is then staged 4.5 times per centre at 9^3), else 8 x 8 x 16 (6 times).
     // PPP_RANK_WG_TILE=8x8x16 | 8x16x16 overrides.
@@ -490,23 +667,36 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64 * RW_WAVES);
+#define PPP_RW_LAUNCH1(A_, D_, E_, F_, P1_)                                                                 \
+    rank_wg_kernel<A_, A_, A_, D_, E_, F_, P1_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>(    \
+        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr)
 #define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
-    rank_wg_kernel<A_, A_, A_, D_, E_, F_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>(         \
-        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles)
+    do {                                                                                                    \
+        if (p1 && pass == 0) PPP_RW_LAUNCH1(A_, D_, E_, F_, true);                                          \
+        else PPP_RW_LAUNCH1(A_, D_, E_, F_, false);                                                         \
+    } while (0)
 #define PPP_RW_CASE(P)                                                                                      \
     case P:                                                                                                 \
         if (tall) PPP_RW_LAUNCH(P, 16, 8, 16);                                                              \
         else if (big) PPP_RW_LAUNCH(P, 8, 16, 16);                                                          \
         else PPP_RW_LAUNCH(P, 8, 8, 16);                                                                    \
         break;
-    switch (G.px) {
-        PPP_RW_CASE(5)
-        PPP_RW_CASE(7)
-        PPP_RW_CASE(9)
-    default:
-        return hipErrorNotSupported;
+    // pass 0: the one-bit form (when possible); then the two-bit pre-pass and kernel -- both return
+    // at once unless the one-bit pre-pass found a partner that equals the threshold
+    for (int pass = p1 ? 0 : 1; pass < 2; ++pass) {
+        if (pass == 1)
+            rank_masks_il_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, M, info, score,
+                                                                                              p1 ? any_e : nullptr, G);
+        switch (G.px) {
+            PPP_RW_CASE(5)
+            PPP_RW_CASE(7)
+            PPP_RW_CASE(9)
+        default:
+            return hipErrorNotSupported;
+        }
     }
 #undef PPP_RW_LAUNCH
+#undef PPP_RW_LAUNCH1
 #undef PPP_RW_CASE
     return hipGetLastError();
 }

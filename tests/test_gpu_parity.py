@@ -979,6 +979,39 @@ def test_ring_sweep_equals_plain_tiles(ps, shape, cell, flags, torch_cuda, monke
         assert np.array_equal(want, got) and want.max() > 5
 
 
+@pytest.mark.parametrize("ps,shape", [((9, 9, 9), (20, 30, 44)), ((7, 7, 7), (18, 26, 40)), ((5, 5, 5), (14, 20, 36))])
+def test_rank_one_bit_masks_equal_two_bit(ps, shape, torch_cuda, monkeypatch):
+    """S2 with ONE mask bit per partner (PPP_RANK_P1=1; P' = v > TH; N = not P': the rows already hold 0
+    for invalid partners; measured slower, kept as a second implementation) == the two-bit masks, bit for bit -- also when some values EQUAL the threshold (neither
+    P nor N: the launch then takes the two-bit kernel by itself) and with an overlap mask."""
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    torch = torch_cuda
+    c = synth.make_case(shape, ps, seed=77, cell=[7, 9, 11], overlap_frac=0.03)
+    kw = dict(FLYLIGHT)
+    base = c["pred"].astype(np.float16)
+    with_eq = base.copy()
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, with_eq.size, size=200)
+    with_eq.reshape(-1)[idx] = np.float16(0.5)                       # values that are neither P nor N
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    P = backend.make_params(shape, ps, **kw)
+    for name, arr in (("plain", base), ("with values == TH", with_eq)):
+        pred = torch.from_numpy(arr).cuda()
+        rows, Pv = backend.consensus_voxel_major(pred, ov, P)
+        out = {}
+        for p1 in ("1", "0"):
+            monkeypatch.setenv("PPP_RANK_P1", p1)
+            backend.reload_env()
+            out[p1] = backend.rank_patches(pred, rows, ov, Pv).cpu().numpy()
+        assert np.array_equal(_bits(out["1"]), _bits(out["0"])), name
+        assert np.count_nonzero(out["1"] > 0) > 100
+        # ... and both equal the gather kernel on the compact planes
+        cons = backend.consensus(pred, ov, P)
+        want = backend.rank_patches(pred, cons, ov, P).cpu().numpy()
+        assert np.array_equal(_bits(out["1"]), _bits(want)), name
+
+
 def test_consensus_part_and_planes_to_rows(torch_cuda):
     """ppp_consensus_part: COMPACT planes / open VOXEL_MAJOR rows of a box filled in pieces equal the
     one-launch result; ppp_cons_planes_to_rows from a larger planes box equals the rows S1 writes for
