@@ -79,7 +79,10 @@ static constexpr int RW_PAD = 8;
 #ifndef PPP_RW_WAVES
 #define PPP_RW_WAVES 4
 #endif
-static constexpr int RW_WAVES = PPP_RW_WAVES;     // waves per workgroup (a power of two)
+#ifndef PPP_RW_REVREADS
+#define PPP_RW_REVREADS 1
+#endif
+static constexpr int RW_WAVES = PPP_RW_WAVES;     // waves per workgroup
 // Mask words per centre, padded to whole 16-byte loads.  The masks are stored CENTRE-MAJOR,
 // M[centre][word]: a lane reads the 184 bytes of ITS centre with twelve 16-byte loads, and the
 // centres of a wave's chunk (9-runs of x neighbours) cover their cache lines densely.  The earlier
@@ -89,6 +92,23 @@ static constexpr int RW_WAVES = PPP_RW_WAVES;     // waves per workgroup (a powe
 // XCD share a 4 MB L2, most of those lines came over the fabric (the kernel ran at the fabric's
 // bandwidth: profiles/r04_b_s2_ablations.txt -- 205 ms, 126 ms without the mask loads).
 static constexpr int rw_mask_words(int C) { return (((C + 15) / 16) + 3) & ~3; }
+// Round 5: the two-bit masks in ROWS OF 16 X-NEIGHBOURS, M[row][quad of words][centre in row][4 words]:
+// the 16-byte load of quad q by the nine x-neighbours of a run touches 144 contiguous bytes (two or
+// three lines) instead of nine lines 184 bytes apart -- the bytes fetched stay the same, the
+// addresses the vector cache has to look up per load fall to a quarter.  PPP_RW_MASKBLK=0: centre-major.
+#ifndef PPP_RW_MASKBLK
+#define PPP_RW_MASKBLK 1
+#endif
+// index (in 16-byte units) of quad 0 of the centre at x of line zy (score-box coordinates)
+__host__ __device__ __forceinline__ long long rw_mask_quad0(long long zy, int x, int sX, int quads) {
+    if (!PPP_RW_MASKBLK) return (zy * sX + x) * quads;
+    return ((zy * ((sX + 15) >> 4) + (x >> 4)) * quads) * 16 + (x & 15);
+}
+static constexpr int RW_QSTRIDE = PPP_RW_MASKBLK ? 16 : 1;      // 16-byte units between a centre's quads
+static size_t rw_mask_bytes(int sZ, int sY, int sX, int C) {
+    const size_t cols = PPP_RW_MASKBLK ? (size_t)((sX + 15) >> 4) * 16 : (size_t)sX;
+    return (size_t)sZ * sY * cols * rw_mask_words(C) * 4;
+}
 typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp2;
 
 // acc + r * c with c a float16 in the low / high half of a register: the compiler selects
@@ -148,6 +168,7 @@ __global__ void __launch_bounds__(256)
         score[lc] = 0.0f;   // the reference leaves the allocation's zero
     } else {
         const int words16 = (G.C + 15) / 16;
+        const long long q0 = rw_mask_quad0(t / sX, (int)(t % sX), sX, rw_mask_words(G.C) / 4);
         unsigned nP = 0, nV = 0;
         int r = 0;
         for (int w = 0; w < words16; ++w) {
@@ -162,10 +183,10 @@ __global__ void __launch_bounds__(256)
                 if (valid && val > G.th_gt) p |= 1u << b;
                 if (valid && val < G.bg_lt) n |= 1u << b;
             }
-            M[t * (long long)rw_mask_words(G.C) + w] = interleave16(p, n);
+            M[(q0 + (long long)(w >> 2) * RW_QSTRIDE) * 4 + (w & 3)] = interleave16(p, n);
             nP += __popc(p);
         }
-        for (int w = words16; w < rw_mask_words(G.C); ++w) M[t * (long long)rw_mask_words(G.C) + w] = 0u;
+        for (int w = words16; w < rw_mask_words(G.C); ++w) M[(q0 + (long long)(w >> 2) * RW_QSTRIDE) * 4 + (w & 3)] = 0u;
         // fgCnt = |P| (|V| - 1) - |P| (|P| - 1) / 2   (rankPatches.cu:139, see ppp_rank_v2.hip)
         const unsigned fg_cnt = nP ? nP * (nV - 1u) - nP * (nP - 1u) / 2u : 0u;
         inf = 0x80000000u | fg_cnt;
@@ -351,7 +372,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     // lane takes in chunk i0 of it -- functions of the row index, so that the masks of the NEXT
     // chunk (of this row or of the next) can be requested ahead
     struct RowG { int uz, uy, ux, az0, ay0, ax0, nz, ny, nx, n_box; };
-    struct ItemG { bool in; int cl, a, az, ay, ax; long long t; };
+    struct ItemG { bool in; int cl, a, az, ay, ax; long long t, q0; };
     auto row_geom = [&](int k) -> RowG {
         RowG r;
         r.uz = uz0 + k / (nuy * nux); r.uy = uy0 + (k / nux) % nuy; r.ux = ux0 + k % nux;
@@ -376,6 +397,8 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
         g.cl = (lz * TY + ly) * TX + lx;
         g.a = (g.az * PY + g.ay) * PX + g.ax;
         g.t = sb_index(lz, ly, lx);
+        // (two-bit masks: quad 0 of the centre, in 16-byte units)
+        g.q0 = rw_mask_quad0((long long)(c0z + lz - sb.z0) * sY + (c0y + ly - sb.y0), c0x + lx - sb.x0, sX, W16P / 4);
         return g;
     };
     // one-bit masks: the first PFQ 16-byte pieces of a centre's words + the word with P'[a], requested
@@ -414,8 +437,8 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
         // pixels a of this voxel whose centre c = u + R - a lies in the tile
         const RowG R = row_geom(uk);
         const int n_box = R.n_box;
-        const int first = (wave + RW_WAVES - turn) & (RW_WAVES - 1);
-        turn = (turn + ((n_box + 63) >> 6)) & (RW_WAVES - 1);
+        const int first = (wave + RW_WAVES - turn) % RW_WAVES;
+        turn = (turn + ((n_box + 63) >> 6)) % RW_WAVES;
         if constexpr (P1 && PF) {
             // (the first chunk of a row is normally prefetched at the end of the row before)
             if (!pf_have && 64 * first < n_box) prefetch(R, 64 * first);
@@ -425,8 +448,8 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             const ItemG it = item_geom(R, i0);
             const bool in = it.in;
             const int ax = it.ax, ay = it.ay, az = it.az, cl = it.cl, a = it.a;
-            const long long t = it.t;
-            (void)in;
+            const long long t = it.t, q0 = it.q0;
+            (void)in; (void)q0;
             bool active = it.in && ((act_bits[cl >> 5] >> (cl & 31)) & 1u) != 0;
             uint32_t mw[NMW];
             if constexpr (P1 && PF) {
@@ -455,7 +478,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
                     prefetch(R, i0 + NTHR);
                 } else if (uk_next < nu) {
                     const RowG Rn = row_geom(uk_next);
-                    const int first_n = (wave + RW_WAVES - turn) & (RW_WAVES - 1);
+                    const int first_n = (wave + RW_WAVES - turn) % RW_WAVES;
                     if (64 * first_n < Rn.n_box) { prefetch(Rn, 64 * first_n); pf_have = true; }
                 }
                 if (active) active = ((aword >> (a & 31)) & 1u) != 0;
@@ -465,7 +488,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             // masks), bit s & 31 of word s >> 5 (one-bit masks)
             if (active) {
                 if constexpr (P1) active = ((M[t * (long long)W16P + (a >> 5)] >> (a & 31)) & 1u) != 0;
-                else active = ((M[t * (long long)W16P + (a >> 4)] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
+                else active = ((M[(q0 + (long long)(a >> 6) * RW_QSTRIDE) * 4 + ((a >> 4) & 3)] >> (8 * ((a >> 2) & 3) + (a & 3))) & 1u) != 0;
             }
             if (__ballot(active) == 0) continue;
             // (unconditional loads -- t is a centre of the tile for every lane -- then one select
@@ -476,10 +499,10 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             for (int w = 0; w < NMW; ++w) mw[w] = (P1 ? 0xFFFFFFFFu : 0x0F0F0F0Fu) + (uint32_t)(t & 0);
 #else
             {
-                const uint4 *mc = reinterpret_cast<const uint4 *>(M + t * (long long)W16P);
+                const uint4 *mc = reinterpret_cast<const uint4 *>(M) + (P1 ? t * (long long)(W16P / 4) : q0);
 #pragma unroll
                 for (int q = 0; q < W16P / 4; ++q) {
-                    const uint4 v = mc[q];
+                    const uint4 v = mc[q * (P1 ? 1 : RW_QSTRIDE)];
                     if (4 * q < NMW) mw[4 * q] = v.x;
                     if (4 * q + 1 < NMW) mw[4 * q + 1] = v.y;
                     if (4 * q + 2 < NMW) mw[4 * q + 2] = v.z;
@@ -543,9 +566,14 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
                     if (w * 16 + j * 4 < C) cf[j] = coefT[(m >> (8 * j)) & 0xFFu];
 #endif
                 float rv[2][4];
+                // (the reads of a group are issued LAST ELEMENT FIRST: the LDS returns in order, so the
+                // wait of the group's first term covers the other three -- one s_waitcnt per group
+                // instead of one per term, and an s_waitcnt costs its wave an issue slot like any
+                // instruction; PPP_RW_REVREADS=0: first element first)
                 auto load_rows = [&](int j, float (&r)[4]) {
 #pragma unroll
-                    for (int i2 = 0; i2 < 4; ++i2) {
+                    for (int i3 = 0; i3 < 4; ++i3) {
+                        const int i2 = PPP_RW_REVREADS ? 3 - i3 : i3;
                         const int b = w * 16 + j * 4 + i2;
 #ifdef PPP_RW_ABL_NOLDS
                         if (b < C) r[i2] = __builtin_bit_cast(float, 0x3F800000u + (uint32_t)(lane + b));   // (timing experiment)
@@ -611,8 +639,7 @@ bool rank_wg_supported(const Geo &G) {
 
 size_t rank_wg_workspace_bytes(const ppp_box &sb, const Geo &G) {
     const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
-    const size_t words16 = (size_t)rw_mask_words(G.C);
-    return up256w(words16 * sbV * 4) + up256w(sbV * 4) + up256w((size_t)G.V) + 256;
+    return up256w(rw_mask_bytes(sb.z1 - sb.z0, sb.y1 - sb.y0, sb.x1 - sb.x0, G.C)) + up256w(sbV * 4) + up256w((size_t)G.V) + 256;
 }
 
 template <typename T>
@@ -620,9 +647,8 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
                              const ppp_box &sb, void *work, const Geo &G, hipStream_t s) {
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
     const size_t sbV = (size_t)sX * sY * sZ;
-    const size_t words16 = (size_t)rw_mask_words(G.C);
     char *p = (char *)work;
-    uint32_t *M = (uint32_t *)p;    p += up256w(words16 * sbV * 4);
+    uint32_t *M = (uint32_t *)p;    p += up256w(rw_mask_bytes(sZ, sY, sX, G.C));
     uint32_t *info = (uint32_t *)p; p += up256w(sbV * 4);
     uint8_t *valid = (uint8_t *)p;  p += up256w((size_t)G.V);
     int *any_e = (int *)p;          // one-bit masks: "a partner equals the threshold somewhere"
