@@ -1386,8 +1386,21 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     with backend.host_timer("s6_label_paint"):
         if kw.get("mws") and kw.get("selected_patch_pairs") is None and hasattr(ops, "mws_labels"):
             # the library's own pair list never repeats a node pair: edge order and |aff| sort on
-            # the device, only the sequential loop on the host (replicated on every rank)
-            lab_all, n_labels = ops.mws_labels(rows, aff, nodes_dev, Pg)
+            # the device, only the sequential loop on the host -- on rank 0 alone (the loop is one
+            # host thread; N copies of it on one node's memory system run slower than one), the
+            # labels reach the others as one SUM all-reduce of 4 bytes per selected patch
+            if comm.world > 1 and os.environ.get("PPP_MWS_RANK0", "1") != "0":
+                if comm.rank == 0:
+                    lab_all, n_labels = ops.mws_labels(rows, aff, nodes_dev, Pg)
+                    lab_all = torch.cat([lab_all.to(torch.int32),
+                                         torch.tensor([n_labels], dtype=torch.int32, device=dev)])
+                else:
+                    lab_all = torch.zeros((len(nodes) + 1,), dtype=torch.int32, device=dev)
+                comm.all_reduce_sum(lab_all)
+                n_labels = int(lab_all[-1].item())
+                lab_all = lab_all[:-1]
+            else:
+                lab_all, n_labels = ops.mws_labels(rows, aff, nodes_dev, Pg)
             held = lab_all > 0
             lab_nodes, labels = nodes_dev[held], lab_all[held]
             del lab_all, held
