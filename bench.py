@@ -840,6 +840,9 @@ def pmc_sq(kernel, workload):
     return out
 
 
+PK_F32_ISSUE_CYCLES = 4.7
+
+
 def valu_roofline(kernel, workload, launch_ms, pair_votes_per_launch):
     """The S1 kernel against the bound that actually holds for it, vector-instruction issue.
     chain floor: the vote chain is 8 packed instructions per PAIR of votes (two z-slices per lane),
@@ -847,9 +850,15 @@ def valu_roofline(kernel, workload, launch_ms, pair_votes_per_launch):
     (SQ_INSTS_VALU) and the busy cycles come from the committed SQ pass of these sources."""
     chain_instr = pair_votes_per_launch / 2.0 * 8.0 / 64.0
     floor_ms = chain_instr * 4.0 / (N_SIMD * VALU_CLOCK_GHZ * 1e9) * 1e3
+    # measured issue cost of a packed float32 instruction at 4 waves per SIMD (tools/ubench/valu_rate2.hip,
+    # profiles/r05_zf_issue_costs.txt: v_pk_fma / mul / add_f32 4.5-4.8 cycles per SIMD, v_fma_f32 2.9):
+    # the floor with THAT cost instead of the nominal 4 cycles
+    floor_measured_ms = floor_ms * PK_F32_ISSUE_CYCLES / 4.0
     out = {"kernel": kernel, "bound": "valu-issue", "launch_ms": launch_ms,
            "chain_instr_per_launch": chain_instr, "chain_floor_ms": floor_ms,
            "achieved_over_floor": floor_ms / launch_ms if launch_ms else None,
+           "pk_f32_issue_cycles_measured": PK_F32_ISSUE_CYCLES, "chain_floor_measured_issue_ms": floor_measured_ms,
+           "achieved_over_measured_floor": floor_measured_ms / launch_ms if launch_ms else None,
            "clock_ghz_assumed": VALU_CLOCK_GHZ,
            "chain": "x = ta*tb; dp = clamp(x*ga - 1/4); dn = clamp(-x - 1/4); d = dp - dn; q = d*lo(4/3); "
                     "y = fma(d, hi(4/3), q); acc += y; cnt = mad_u16(ca, cb, cnt)"}

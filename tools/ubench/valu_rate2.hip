@@ -61,6 +61,23 @@ DEFK(k_cvt_f16, I8("v_cvt_f32_f16", F1))
 DEFK64(k_lshr64, "v_lshrrev_b64 %0, %4, %0\n v_lshrrev_b64 %1, %4, %1\n v_lshrrev_b64 %2, %4, %2\n v_lshrrev_b64 %3, %4, %3\n v_lshrrev_b64 %0, %4, %0\n v_lshrrev_b64 %1, %4, %1\n v_lshrrev_b64 %2, %4, %2\n v_lshrrev_b64 %3, %4, %3")
 DEFK64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %1\n v_lshl_add_u64 %1, %1, 1, %2\n v_lshl_add_u64 %2, %2, 1, %3\n v_lshl_add_u64 %3, %3, 1, %0\n v_lshl_add_u64 %0, %0, 1, %1\n v_lshl_add_u64 %1, %1, 1, %2\n v_lshl_add_u64 %2, %2, 1, %3\n v_lshl_add_u64 %3, %3, 1, %0")
 
+// packed float32 (operands are aligned register pairs): S1's vote chain
+#define DEFKPK(NAME, ASM8)                                                                     \
+    __global__ void __launch_bounds__(1024) NAME(float *out, int iters) {                      \
+        double a0 = threadIdx.x * 3 + 1, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 1.5, c = 0.25; \
+        for (int it = 0; it < iters; ++it) {                                                   \
+            REP8(asm volatile(ASM8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)  \
+        }                                                                                      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3);                \
+    }
+DEFKPK(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5")
+DEFKPK(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4")
+DEFKPK(k_pk_add_f32, "v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4")
+DEFKPK(k_pk_add_clamp, "v_pk_add_f32 %0, %0, %4 clamp\n v_pk_add_f32 %1, %1, %4 clamp\n v_pk_add_f32 %2, %2, %4 clamp\n v_pk_add_f32 %3, %3, %4 clamp\n v_pk_add_f32 %0, %0, %4 clamp\n v_pk_add_f32 %1, %1, %4 clamp\n v_pk_add_f32 %2, %2, %4 clamp\n v_pk_add_f32 %3, %3, %4 clamp")
+DEFK(k_fma_f32, I8("v_fma_f32", F3))
+DEFK(k_fma_mix, "v_fma_mix_f32 %0, %0, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %1, %1, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %2, %2, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %3, %3, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %4, %4, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %5, %5, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %6, %6, %8, %9 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %7, %7, %8, %9 op_sel_hi:[0,1,0]")
+DEFK(k_pk_mad_u16, I8("v_pk_mad_u16", F3))
+
 typedef void (*kern_t)(float *, int);
 static void run(const char *name, kern_t k, float *out, bool pair) {
     const int iters = 2000, wps = 4, threads = 1024, blocks = 256;
@@ -77,11 +94,13 @@ static void run(const char *name, kern_t k, float *out, bool pair) {
 }
 #define RUN(n) run(#n, n, out, false)
 int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
     float *out; (void)hipMalloc(&out, 256 * 1024 * 4);
     RUN(k_mov); RUN(k_add_u32); RUN(k_mul_f32); RUN(k_sub_f32); RUN(k_fmac); RUN(k_lshl32); RUN(k_ashr);
     RUN(k_max_i32); RUN(k_bfi); RUN(k_bfe_u); RUN(k_or3); RUN(k_and_or); RUN(k_lshl_add); RUN(k_add3);
     RUN(k_bcnt); RUN(k_perm); RUN(k_cvt_ubyte); RUN(k_cvt_f16); RUN(k_and_sdwa);
     RUN(k_cmp_vcc); RUN(k_cmp_sgpr); RUN(k_cndmask_vcc); RUN(k_cndmask_sgpr); RUN(k_addc);
+    RUN(k_fma_f32); RUN(k_fma_mix); RUN(k_pk_fma_f32); RUN(k_pk_mul_f32); RUN(k_pk_add_f32); RUN(k_pk_add_clamp); RUN(k_pk_mad_u16);
     RUN(k_mul_lo); RUN(k_mul_hi); RUN(k_mul_u24); RUN(k_mad_u24); RUN(k_lshr64); RUN(k_lshl_add_u64);
     return 0;
 }
