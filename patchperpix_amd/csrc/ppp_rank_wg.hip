@@ -109,7 +109,11 @@ static size_t rw_mask_bytes(int sZ, int sY, int sX, int C) {
     const size_t cols = PPP_RW_MASKBLK ? (size_t)((sX + 15) >> 4) * 16 : (size_t)sX;
     return (size_t)sZ * sY * cols * rw_mask_words(C) * 4;
 }
+#ifndef PPP_RW_NOVOLATILE
 typedef const volatile __attribute__((address_space(3))) float *lds_f32_cvp2;
+#else
+typedef const __attribute__((address_space(3))) float *lds_f32_cvp2;
+#endif
 
 // acc + r * c with c a float16 in the low / high half of a register: the compiler selects
 // v_fma_mix_f32 (op_sel picks the half; the float16 -> float32 conversion is exact and part of the
