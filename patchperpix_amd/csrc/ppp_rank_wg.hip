@@ -697,8 +697,11 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64 * RW_WAVES);
+    // (occupancy experiment: PPP_RANK_WG_DYNLDS=<bytes> of unused dynamic LDS per workgroup)
+    static EnvSwitch dyn_sw("PPP_RANK_WG_DYNLDS");
+    const unsigned dyn_lds = dyn_sw.get() ? (unsigned)atoi(dyn_sw.get()) : 0u;
 #define PPP_RW_LAUNCH1(A_, D_, E_, F_, P1_)                                                                 \
-    rank_wg_kernel<A_, A_, A_, D_, E_, F_, P1_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), 0, s>>>(    \
+    rank_wg_kernel<A_, A_, A_, D_, E_, F_, P1_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), dyn_lds, s>>>( \
         S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr)
 #define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
     do {                                                                                                    \
