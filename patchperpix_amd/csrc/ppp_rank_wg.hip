@@ -266,13 +266,61 @@ __global__ void __launch_bounds__(256)
     valid[v] = (ldf(pred, (long long)G.mid * G.V + v) > G.th_gt && (!G.use_overlap || ov[v] == 0)) ? 1 : 0;
 }
 
+// ---- heavy tiles first (round 5) -----------------------------------------------------------
+// A launch ends with its slowest workgroup, and the tiles of centres differ: by the valid voxels
+// of their grown box (rows walked) and by their foreground centres (items with work).  On a 264^2
+// column one round of 1 024 workgroups takes 146 ms, every further round 64 ms
+// (profiles/r05_zl_s2_rounds.txt) -- the dispatcher hands out blocks in index order, so with the
+// tiles in spatial order the heavy ones of the LAST round decide the end.  Launches of up to
+// RW_ORDER_MAX tiles are therefore dealt heaviest first: weight = active centres of the tile, eight
+// weight classes; every XCD keeps its contiguous range of tiles (neighbours share rows in its L2)
+// and walks it class by class.  order[slot] = tile, or -1 for the padding slots.
+static constexpr int RW_ORDER_MAX = 16384;
+__global__ void __launch_bounds__(256)
+    rank_tile_weight_kernel(const uint32_t *__restrict__ info, const ppp_box sb, const int TZ, const int TY,
+                            const int TX, const int tiles_y, const int tiles_x, int32_t *__restrict__ weight) {
+    const int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
+    const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
+    int c = 0;
+    for (int cl = threadIdx.x; cl < TZ * TY * TX; cl += blockDim.x) {
+        const int z = tz_i * TZ + cl / (TX * TY), y = ty_i * TY + (cl / TX) % TY, x = tx_i * TX + cl % TX;
+        if (z < sZ && y < sY && x < sX) c += (int)(info[((long long)z * sY + y) * sX + x] >> 31);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) weight[bid] = part[0] + part[1] + part[2] + part[3];
+}
+// one workgroup per XCD range
+__global__ void __launch_bounds__(256)
+    rank_tile_order_kernel(const int32_t *__restrict__ weight, const int n_tiles, const int per_xcd, const int nt,
+                           int32_t *__restrict__ order) {
+    __shared__ int cnt[8], base[8], fill[8];
+    const int lo = blockIdx.x * per_xcd, hi = min(lo + per_xcd, n_tiles);
+    if (threadIdx.x < 8) { cnt[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
+    __syncthreads();
+    auto cls = [&](int w) -> int { return 7 - min(7, (int)((long long)w * 8 / (nt + 1))); };   // 0 = heaviest
+    for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) atomicAdd(&cnt[cls(weight[t])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < 8; ++b) { base[b] = a; a += cnt[b]; } }
+    __syncthreads();
+    for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+        const int b = cls(weight[t]);
+        order[lo + base[b] + atomicAdd(&fill[b], 1)] = t;
+    }
+    for (int t = max(hi, lo) + threadIdx.x; t < lo + per_xcd; t += blockDim.x) order[t] = -1;
+}
+
 // ---- main kernel ---------------------------------------------------------------------------
 template <int PZ, int PY, int PX, int TZ, int TY, int TX, bool P1>
 __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     rank_wg_kernel(const float *__restrict__ S, const uint32_t *__restrict__ M,
                    const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
-                   const int tiles_x, const int n_tiles, const int *__restrict__ any_e) {
+                   const int tiles_x, const int n_tiles, const int *__restrict__ any_e,
+                   const int32_t *__restrict__ order) {
     // (one launch of each form per call when the one-bit masks are possible: the pre-pass decides)
     if (any_e && (*any_e != 0) == P1) return;
     constexpr int C = PZ * PY * PX, W16 = (C + 15) / 16, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
@@ -302,8 +350,10 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     // of tiles so that x-neighbours (which share a third of their rows) meet in one L2
     const int n_blocks = gridDim.x;
     const int per_xcd = (n_blocks + 7) / 8;
-    const int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (bid >= n_tiles) return;
+    const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    // (heavy tiles first within the XCD's range when the launcher made an order)
+    const int bid = order ? order[slot] : slot;
+    if (bid < 0 || bid >= n_tiles) return;
     const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
     const int c0z = sb.z0 + tz_i * TZ, c0y = sb.y0 + ty_i * TY, c0x = sb.x0 + tx_i * TX;
     const int tz = min(TZ, sb.z1 - c0z), ty = min(TY, sb.y1 - c0y), tx = min(TX, sb.x1 - c0x);
@@ -643,7 +693,8 @@ bool rank_wg_supported(const Geo &G) {
 
 size_t rank_wg_workspace_bytes(const ppp_box &sb, const Geo &G) {
     const size_t sbV = (size_t)(sb.x1 - sb.x0) * (sb.y1 - sb.y0) * (sb.z1 - sb.z0);
-    return up256w(rw_mask_bytes(sb.z1 - sb.z0, sb.y1 - sb.y0, sb.x1 - sb.x0, G.C)) + up256w(sbV * 4) + up256w((size_t)G.V) + 256;
+    return up256w(rw_mask_bytes(sb.z1 - sb.z0, sb.y1 - sb.y0, sb.x1 - sb.x0, G.C)) + up256w(sbV * 4) + up256w((size_t)G.V) + 256 +
+           2 * (size_t)RW_ORDER_MAX * 4;
 }
 
 template <typename T>
@@ -697,12 +748,16 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;
     const long long n_blocks = (n_tiles + 7) / 8 * 8;
     PPP_GRID_CHECK(n_blocks, 64 * RW_WAVES);
+    // heavy tiles first (PPP_RANK_ORDER=0: spatial order)
+    static EnvSwitch order_sw("PPP_RANK_ORDER");
+    int32_t *weight = (int32_t *)((char *)any_e + 256), *order = weight + RW_ORDER_MAX;
+    if (n_tiles > RW_ORDER_MAX || (order_sw.get() && order_sw.get()[0] == '0')) order = nullptr;
     // (occupancy experiment: PPP_RANK_WG_DYNLDS=<bytes> of unused dynamic LDS per workgroup)
     static EnvSwitch dyn_sw("PPP_RANK_WG_DYNLDS");
     const unsigned dyn_lds = dyn_sw.get() ? (unsigned)atoi(dyn_sw.get()) : 0u;
 #define PPP_RW_LAUNCH1(A_, D_, E_, F_, P1_)                                                                 \
     rank_wg_kernel<A_, A_, A_, D_, E_, F_, P1_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), dyn_lds, s>>>( \
-        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr)
+        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr, order)
 #define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
     do {                                                                                                    \
         if (p1 && pass == 0) PPP_RW_LAUNCH1(A_, D_, E_, F_, true);                                          \
@@ -720,6 +775,10 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
         if (pass == 1)
             rank_masks_il_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, M, info, score,
                                                                                               p1 ? any_e : nullptr, G);
+        if (order && pass == (p1 ? 0 : 1)) {      // (`info` is the same from either pre-pass)
+            rank_tile_weight_kernel<<<dim3((unsigned)n_tiles), dim3(256), 0, s>>>(info, sb, TZ, TY, TX, tiles_y, tiles_x, weight);
+            rank_tile_order_kernel<<<dim3(8), dim3(256), 0, s>>>(weight, (int)n_tiles, (int)(n_blocks / 8), TZ * TY * TX, order);
+        }
         switch (G.px) {
             PPP_RW_CASE(5)
             PPP_RW_CASE(7)

@@ -969,6 +969,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         my_tiles.sort(key=lambda t: (t[2], t[4], t[0]))
         backend.note("ring_z", ring_z)
     ring_state = {}
+    # the scores pass keeps a column's rows on a smaller (y, x) box than the pairs pass the pool is
+    # sized for (tile + radius instead of tile + radius + p - 1 per side): its ring is as many slices
+    # as the same pool holds of THAT box (44 -> 49 at 512^3 / 9^3 with 256^2 columns)
+    ring_sc = {"z": ring_z}
 
     def ring_rows(fr, t, pairs_pass, pool):
         """S1 for the new base slices of tile t into the ring; returns (pool, params of the rows the
@@ -984,16 +988,17 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
             part0 = hi
         o = fr.origin
         top = min(fr.shape[0] + o[0], dims[0], r1 + ps[0] - 1)     # spill rows (inside the frame)
+        ring_len = ring_z if pairs_pass else ring_sc["z"]
         if part0 < r1:
             P1 = params(fr, (min(part0, r0), top) + tuple(ybox[2:]))
             P1.cons_layout = backend.CONS_VOXEL_MAJOR
-            P1.ring_z = ring_z
+            P1.ring_z = ring_len
             part = (part0 - o[0], ybox[2] - o[1], ybox[4] - o[2], r1 - o[0], ybox[3] - o[1], ybox[5] - o[2])
             ops.ring_fill(fr.pred, fr.ov, P1, part, pool)
         ring_state.update(col=col, hi=r1)
         Pr = params(fr, (r0, r1) + tuple(ybox[2:]))
         Pr.cons_layout = backend.CONS_VOXEL_MAJOR
-        Pr.ring_z = ring_z
+        Pr.ring_z = ring_len
         return pool, Pr
 
     # ---- stage A: consensus + scores per tile ----------------------------------------------
@@ -1009,6 +1014,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         P0 = params(fr0)
         if ops.rank_on_voxel_major(P0):
             pool = ops.voxel_major_pool(P0, biggest)
+        if ring_z and pool is not None and os.environ.get("PPP_RING_SCORES", "1") != "0":
+            area_sc = max((b[3] - b[2]) * (b[5] - b[4]) for b in (bases_for_scores(t) for t in my_tiles))
+            ring_sc["z"] = max(ring_z, int(biggest // area_sc))
     # scores in the field frame; with a provider also the patch bits of every own voxel (the
     # cover candidates), packed while the tile's prediction exists
     score_f = torch.zeros((Zf, Y, X), dtype=torch.float32, device=dev)
@@ -1017,6 +1025,21 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         bits_own = torch.zeros(((oz1 - oz0) * plane, words), dtype=torch.int32, device=dev)
     def scores_frame_box(t):
         return grow(bases_for_pairs(t) if keep_cons else bases_for_scores(t), 2 * rad)
+
+    # Ring sweep: ONE ranking launch serves as many consecutive tiles of a column as the ring holds
+    # rows for (their slices + the radius on both sides + the p - 1 slices S1 reaches past its last
+    # base).  A launch is as long as its slowest workgroup (the tiles of centres differ in valid
+    # rows and foreground pixels: 146 ms for one round of 1 024 workgroups, + 64 ms for every further
+    # round on a 264 x 264 column, profiles/r05_zl_s2_rounds.txt) -- a launch of 2 048 workgroups
+    # costs 0.72 of two launches of 1 024.  PPP_RANK_GROUP=1: one launch per tile.
+    rank_group = 1
+    if ring_z:
+        thick = max(t[1] - t[0] for t in my_tiles)
+        rank_group = max(1, (ring_sc["z"] - 2 * int(rad[0]) - (ps[0] - 1)) // thick)
+        rank_group = max(1, min(rank_group, int(os.environ.get("PPP_RANK_GROUP", rank_group))))
+        backend.note("rank_group", rank_group)
+        backend.note("ring_z_scores", ring_sc["z"])
+    pending = []          # tiles of the current column whose rows are in the ring, not ranked yet
 
     for ti, t in enumerate(my_tiles):
         z0, z1, y0, y1, x0, x1 = t
@@ -1029,6 +1052,19 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         elif ring_z:
             with backend.host_timer("s1_consensus"):
                 cons, P = ring_rows(fr, t, False, pool)
+            if rank_group > 1:
+                pending.append(t)
+                nxt = my_tiles[ti + 1] if ti + 1 < len(my_tiles) else None
+                if len(pending) < rank_group and nxt is not None and nxt[2:] == t[2:] and nxt[0] == t[1]:
+                    del cons, fr
+                    continue                       # ranked together with the next tile of the column
+                # the rows of every pending tile: [first z0 - rad, last z1 + rad) of the column's box
+                z0 = pending[0][0]
+                rb = bases_for_scores((z0, z1) + tuple(t[2:]))
+                P = params(fr, rb)
+                P.cons_layout = backend.CONS_VOXEL_MAJOR
+                P.ring_z = ring_sc["z"]
+                pending = []
         else:
             with backend.host_timer("s1_consensus"):
                 cons, P = consensus_of(fr, P, pool)

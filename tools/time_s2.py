@@ -8,7 +8,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CASES = {"140p7": ((140, 140, 140), (7, 7, 7), (20, 20, 20)), "96p9": ((96, 96, 96), (9, 9, 9), (24, 24, 24)),
-         "128p9": ((128, 128, 128), (9, 9, 9), (24, 24, 24)), "176p9": ((112, 176, 176), (9, 9, 9), (24, 24, 24))}
+         "128p9": ((128, 128, 128), (9, 9, 9), (24, 24, 24)), "176p9": ((112, 176, 176), (9, 9, 9), (24, 24, 24)),
+         # one / two / four rounds of workgroups (1024 / 2048 / 4096 tiles of 8 x 8 x 16 centres)
+         "wg1024": ((24, 264, 264), (9, 9, 9), (24, 24, 24)), "wg2048": ((40, 264, 264), (9, 9, 9), (24, 24, 24)),
+         "wg4096": ((72, 264, 264), (9, 9, 9), (24, 24, 24))}
 
 
 def main():
