@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default="140p7")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--burst", type=int, default=1, help="launches between the two events of a repetition")
     args = ap.parse_args()
     import torch
     import bench
@@ -33,7 +34,8 @@ def main():
     for r in range(args.reps + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(torch.cuda.current_stream())
-        sc = backend.rank_patches(pred, vm, ov, Pv)
+        for _ in range(args.burst):
+            sc = backend.rank_patches(pred, vm, ov, Pv)
         b.record(torch.cuda.current_stream())
         torch.cuda.synchronize()
         if r:
@@ -41,6 +43,7 @@ def main():
         else:
             crc = int(sc.view(torch.int32).sum(dtype=torch.int64).item()) & 0xFFFFFFFF
     print(json.dumps({"case": args.case, "lib": os.path.basename(backend.library_path()),
+                      "burst": args.burst,
                       "ms": [round(t, 2) for t in times], "min_ms": round(min(times), 2), "checksum": crc}))
 
 
