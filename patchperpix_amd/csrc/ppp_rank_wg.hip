@@ -44,6 +44,21 @@
 // those lanes load directly, as every lane does today.
 // What holds the kernel back is neither unit alone (VALU 24 %, LDS 54 % busy of which half bank
 // conflicts, 2.35 TB/s of fetches) but the stalls of its dependent chains at 16 waves per CU.
+//
+// Round 5, measured (profiles/r05_z*; DESIGN.md section 7 has the numbers):
+//   * kept: the four reads of a group are issued last element first (one s_waitcnt per group); the
+//     two-bit masks lie in rows of 16 x-neighbours (a quad load of an x-run touches 144 contiguous
+//     bytes); the tiles of a launch are dealt HEAVIEST FIRST inside every XCD's range (a launch ends
+//     with its slowest workgroup: one round of 1 024 workgroups 146 ms, every further round 64 ms);
+//   * dropped, all bit-identical: TWO x-neighbouring centres per lane sharing their row reads
+//     (0.58 reads per term, two independent chains: 476 vs 253 ms -- five chunks of double work per
+//     row for four waves, and the second mask set costs a wave per SIMD); three waves per workgroup;
+//     ds_read2_b32 through a non-volatile pointer; 8 x 8 x 8 tiles; staggered starts of the first round;
+//   * the instruction cache serves 100 % hits and s_waitcnt / s_nop cost next to nothing
+//     (tools/ubench/issue_mix.hip); v_fma_mix_f32 issues in 4.6-5.0 cycles per SIMD against 2.9 for
+//     v_fma_f32; a conflict-free ds_read_b32 costs the CU 2.6 cycles; with 1 / 2 / 3 / 4 resident
+//     workgroups per CU the 112 x 176 x 176 launch takes 579 / 348 / 279 / 248 ms (a fifth would
+//     give ~6 %); without masks, table and row reads at all it takes 180 ms.
 #include <stdlib.h>
 #include <string.h>
 
@@ -272,45 +287,67 @@ __global__ void __launch_bounds__(256)
 // column one round of 1 024 workgroups takes 146 ms, every further round 64 ms
 // (profiles/r05_zl_s2_rounds.txt) -- the dispatcher hands out blocks in index order, so with the
 // tiles in spatial order the heavy ones of the LAST round decide the end.  Launches of up to
-// RW_ORDER_MAX tiles are therefore dealt heaviest first: weight = active centres of the tile, eight
-// weight classes; every XCD keeps its contiguous range of tiles (neighbours share rows in its L2)
-// and walks it class by class.  order[slot] = tile, or -1 for the padding slots.
+// RW_ORDER_MAX tiles are therefore dealt heaviest first; every XCD keeps its contiguous range of
+// tiles (neighbours share rows in its L2) and walks it in descending order of weight.
+// order[slot] = tile, or -1 for the padding slots.
 static constexpr int RW_ORDER_MAX = 16384;
+// weight of a tile = the chunks of 64 items its workgroup walks: over the VALID voxels u of the tile
+// grown by the radius, ceil(items of u / 64) (+ 1 for the row's staging and barriers); 0 without an
+// active centre (the workgroup leaves at once).  PPP_RANK_ORDER=centres: the active centres instead.
 __global__ void __launch_bounds__(256)
-    rank_tile_weight_kernel(const uint32_t *__restrict__ info, const ppp_box sb, const int TZ, const int TY,
-                            const int TX, const int tiles_y, const int tiles_x, int32_t *__restrict__ weight) {
+    rank_tile_weight_kernel(const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid, const ppp_box sb,
+                            const int TZ, const int TY, const int TX, const int tiles_y, const int tiles_x,
+                            const int by_centres, int32_t *__restrict__ weight, const Geo G) {
     const int bid = blockIdx.x;
     const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
-    int c = 0;
+    int c = 0, w = 0;
     for (int cl = threadIdx.x; cl < TZ * TY * TX; cl += blockDim.x) {
         const int z = tz_i * TZ + cl / (TX * TY), y = ty_i * TY + (cl / TX) % TY, x = tx_i * TX + cl % TX;
         if (z < sZ && y < sY && x < sX) c += (int)(info[((long long)z * sY + y) * sX + x] >> 31);
     }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    __shared__ int part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) weight[bid] = part[0] + part[1] + part[2] + part[3];
-}
-// one workgroup per XCD range
-__global__ void __launch_bounds__(256)
-    rank_tile_order_kernel(const int32_t *__restrict__ weight, const int n_tiles, const int per_xcd, const int nt,
-                           int32_t *__restrict__ order) {
-    __shared__ int cnt[8], base[8], fill[8];
-    const int lo = blockIdx.x * per_xcd, hi = min(lo + per_xcd, n_tiles);
-    if (threadIdx.x < 8) { cnt[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
-    __syncthreads();
-    auto cls = [&](int w) -> int { return 7 - min(7, (int)((long long)w * 8 / (nt + 1))); };   // 0 = heaviest
-    for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) atomicAdd(&cnt[cls(weight[t])], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < 8; ++b) { base[b] = a; a += cnt[b]; } }
-    __syncthreads();
-    for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-        const int b = cls(weight[t]);
-        order[lo + base[b] + atomicAdd(&fill[b], 1)] = t;
+    if (!by_centres) {
+        const int c0z = sb.z0 + tz_i * TZ, c0y = sb.y0 + ty_i * TY, c0x = sb.x0 + tx_i * TX;
+        const int tz = min(TZ, sb.z1 - c0z), ty = min(TY, sb.y1 - c0y), tx = min(TX, sb.x1 - c0x);
+        const int uz0 = max(c0z - G.rz, G.bz0), uz1 = min(c0z + tz - 1 + G.rz, G.bz0 + G.bZ - 1);
+        const int uy0 = max(c0y - G.ry, G.by0), uy1 = min(c0y + ty - 1 + G.ry, G.by0 + G.bY - 1);
+        const int ux0 = max(c0x - G.rx, G.bx0), ux1 = min(c0x + tx - 1 + G.rx, G.bx0 + G.bX - 1);
+        const int nuy = uy1 - uy0 + 1, nux = ux1 - ux0 + 1, nu = (uz1 - uz0 + 1) * nuy * nux;
+        for (int k = threadIdx.x; k < nu; k += blockDim.x) {
+            const int uz = uz0 + k / (nuy * nux), uy = uy0 + (k / nux) % nuy, ux = ux0 + k % nux;
+            if (!valid[vox(G, uz, uy, ux)]) continue;
+            const int nz = min(G.pz - 1, uz + G.rz - c0z) - max(0, uz + G.rz - (c0z + tz - 1)) + 1;
+            const int ny = min(G.py - 1, uy + G.ry - c0y) - max(0, uy + G.ry - (c0y + ty - 1)) + 1;
+            const int nx = min(G.px - 1, ux + G.rx - c0x) - max(0, ux + G.rx - (c0x + tx - 1)) + 1;
+            if (nz > 0 && ny > 0 && nx > 0) w += (nz * ny * nx + 63) / 64 + 1;
+        }
     }
-    for (int t = max(hi, lo) + threadIdx.x; t < lo + per_xcd; t += blockDim.x) order[t] = -1;
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); w += __shfl_xor(w, o); }
+    __shared__ int part[2][4];
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = c; part[1][threadIdx.x >> 6] = w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int cs = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        const int ws = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        weight[bid] = by_centres ? cs : (cs ? ws : 0);
+    }
+}
+// one workgroup per XCD range: its tiles in descending order of weight (position = the number of tiles
+// of the range that come before: heavier, or as heavy with a smaller index)
+__global__ void __launch_bounds__(256)
+    rank_tile_order_kernel(const int32_t *__restrict__ weight, const int n_tiles, const int per_xcd,
+                           int32_t *__restrict__ order) {
+    __shared__ int32_t w[RW_ORDER_MAX / 8 + 8];
+    const int lo = blockIdx.x * per_xcd, hi = min(lo + per_xcd, n_tiles), n = max(hi - lo, 0);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = weight[lo + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int wi = w[i];
+        int before = 0;
+        for (int j = 0; j < n; ++j) before += (w[j] > wi || (w[j] == wi && j < i)) ? 1 : 0;
+        order[lo + before] = lo + i;
+    }
+    for (int t = lo + n + threadIdx.x; t < lo + per_xcd; t += blockDim.x) order[t] = -1;
 }
 
 // ---- main kernel ---------------------------------------------------------------------------
@@ -752,6 +789,7 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     static EnvSwitch order_sw("PPP_RANK_ORDER");
     int32_t *weight = (int32_t *)((char *)any_e + 256), *order = weight + RW_ORDER_MAX;
     if (n_tiles > RW_ORDER_MAX || (order_sw.get() && order_sw.get()[0] == '0')) order = nullptr;
+    const bool by_centres = order_sw.get() && order_sw.get()[0] == 'c';
     // (occupancy experiment: PPP_RANK_WG_DYNLDS=<bytes> of unused dynamic LDS per workgroup)
     static EnvSwitch dyn_sw("PPP_RANK_WG_DYNLDS");
     const unsigned dyn_lds = dyn_sw.get() ? (unsigned)atoi(dyn_sw.get()) : 0u;
@@ -776,8 +814,9 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
             rank_masks_il_kernel<T><<<dim3((unsigned)((sbV + 255) / 256)), dim3(256), 0, s>>>(pred, ov, sb, M, info, score,
                                                                                               p1 ? any_e : nullptr, G);
         if (order && pass == (p1 ? 0 : 1)) {      // (`info` is the same from either pre-pass)
-            rank_tile_weight_kernel<<<dim3((unsigned)n_tiles), dim3(256), 0, s>>>(info, sb, TZ, TY, TX, tiles_y, tiles_x, weight);
-            rank_tile_order_kernel<<<dim3(8), dim3(256), 0, s>>>(weight, (int)n_tiles, (int)(n_blocks / 8), TZ * TY * TX, order);
+            rank_tile_weight_kernel<<<dim3((unsigned)n_tiles), dim3(256), 0, s>>>(info, valid, sb, TZ, TY, TX, tiles_y, tiles_x,
+                                                                                  by_centres ? 1 : 0, weight, G);
+            rank_tile_order_kernel<<<dim3(8), dim3(256), 0, s>>>(weight, (int)n_tiles, (int)(n_blocks / 8), order);
         }
         switch (G.px) {
             PPP_RW_CASE(5)
