@@ -1015,6 +1015,30 @@ def test_rank_one_bit_masks_equal_two_bit(ps, shape, torch_cuda, monkeypatch):
         assert np.array_equal(_bits(out["1"]), _bits(want)), name
 
 
+@pytest.mark.parametrize("ps,shape", [((9, 9, 9), (28, 44, 76)), ((7, 7, 7), (26, 40, 70))])
+def test_rank_tile_order_does_not_change_scores(ps, shape, torch_cuda, monkeypatch):
+    """S2 deals the tiles of a launch heaviest first inside every XCD's range (weight = the chunks of
+    a tile's valid rows; PPP_RANK_ORDER=c: its active centres; =0: spatial order): which workgroup
+    takes which tile when must not show in the scores."""
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    torch = torch_cuda
+    c = synth.make_case(shape, ps, seed=31, cell=[8, 10, 12], overlap_frac=0.02)
+    pred = torch.from_numpy(c["pred"].astype(np.float16)).cuda()
+    ov = torch.from_numpy((c["numinst"] > 1).astype(np.uint8)).cuda()
+    P = backend.make_params(shape, ps, **dict(FLYLIGHT))
+    rows, Pv = backend.consensus_voxel_major(pred, ov, P)
+    out = {}
+    for mode in ("1", "c", "0"):
+        monkeypatch.setenv("PPP_RANK_ORDER", mode)
+        backend.reload_env()
+        out[mode] = backend.rank_patches(pred, rows, ov, Pv).cpu().numpy()
+    monkeypatch.delenv("PPP_RANK_ORDER")
+    backend.reload_env()
+    assert np.count_nonzero(out["0"] > 0) > 100
+    assert np.array_equal(_bits(out["1"]), _bits(out["0"])) and np.array_equal(_bits(out["c"]), _bits(out["0"]))
+
+
 def test_consensus_part_and_planes_to_rows(torch_cuda):
     """ppp_consensus_part: COMPACT planes / open VOXEL_MAJOR rows of a box filled in pieces equal the
     one-launch result; ppp_cons_planes_to_rows from a larger planes box equals the rows S1 writes for
