@@ -110,60 +110,87 @@ __global__ void __launch_bounds__(256)
 // others idled -- a few per cent of the voxels are dirty candidates, scattered.  (A global list
 // costs a same-address atomic per wave: 4x slower than no compaction at all.)
 static constexpr int COUNT_THREADS = 1024;
+static constexpr int COUNT_VPT = 4;     // voxels per thread of the cover's count sweep
 __global__ void __launch_bounds__(COUNT_THREADS)
     cover_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                        uint8_t *__restrict__ dirty, const int pix_th, int32_t *__restrict__ state,
                        int32_t *__restrict__ rank_vol, int32_t *__restrict__ n_alive,
                        const int32_t *__restrict__ loc_vol, uint16_t *__restrict__ witness,
                        const long long bits_vox, const Geo G) {
-    __shared__ uint16_t s_list[COUNT_THREADS];
+    // COUNT_VPT voxels per thread (v = block base + j * 1024 + thread: every pass stays coalesced).  The
+    // sweep is a chain of dependent loads per voxel -- rank, then witness, then one word of the mask --
+    // and its time was their latency (1.17 ms for the 134 M voxels of 512^3 with one voxel per thread:
+    // 0.8 TB/s); the loads of a thread's voxels are issued pass by pass, four in flight each.
+    __shared__ uint16_t s_list[COUNT_THREADS * COUNT_VPT];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const long long v0 = blockIdx.x * (long long)blockDim.x;
+    const long long v0 = blockIdx.x * (long long)(COUNT_THREADS * COUNT_VPT);
     {
-        const long long v = v0 + threadIdx.x;
-        const bool in = v < G.V;
-        int k = in ? rank_vol[v] : RANK_NONE;
+        const bool use_wit = pix_th == 0 && witness != nullptr;
+        long long vv[COUNT_VPT];
+        int kk[COUNT_VPT];
+        bool alive[COUNT_VPT], marked[COUNT_VPT];
+        unsigned wv[COUNT_VPT];
+#pragma unroll
+        for (int j = 0; j < COUNT_VPT; ++j) {
+            vv[j] = v0 + j * COUNT_THREADS + threadIdx.x;
+            kk[j] = vv[j] < G.V ? rank_vol[vv[j]] : RANK_NONE;
+        }
         // sharded: rank_vol holds GLOBAL ranks (also of the neighbour's patches in the halo);
         // only the own centres are worked on, through their local table index
-        if (loc_vol && in && k != RANK_NONE) { const int l = loc_vol[v]; k = l < 0 ? RANK_NONE : l; }
-        const bool alive = k != RANK_NONE;
+        if (loc_vol) {
+#pragma unroll
+            for (int j = 0; j < COUNT_VPT; ++j)
+                if (kk[j] != RANK_NONE) { const int l = loc_vol[vv[j]]; kk[j] = l < 0 ? RANK_NONE : l; }
+        }
         // pix_th == 0 ("does the patch still cover ANY voxel"): a patch stays undecided as long as
         // its witness voxel is uncovered -- one bit of the running mask (16 MB at 512^3: cache
         // resident) decides it, no patch bits are read and no dirty marks are needed; only a patch
         // whose witness was cleared (or that has none yet) is recounted.  On a dense volume a patch
         // is looked at in hundreds of rounds and nearly always survives.
-        const bool use_wit = pix_th == 0 && witness != nullptr;
-        bool marked;
+#pragma unroll
+        for (int j = 0; j < COUNT_VPT; ++j) {
+            alive[j] = kk[j] != RANK_NONE;
+            wv[j] = WIT_NONE;
+            if (use_wit) { if (alive[j]) wv[j] = witness[vv[j]]; }
+            else { marked[j] = vv[j] < G.V && dirty[vv[j]] != 0; if (marked[j]) dirty[vv[j]] = 0; }
+        }
         if (use_wit) {
-            bool wit_ok = false;
-            if (alive) {
-                const unsigned w = witness[v];
-                if (w != WIT_NONE) {
-                    const int wr = (int)(w & 0x7Fu), xo = (int)(w >> 7);
-                    const long long row = v / G.X + (long long)(wr / G.py - G.rz) * G.Y + (wr % G.py - G.ry);
-                    const int x = (int)(v % G.X) - G.rx + xo;
-                    wit_ok = ((mbits[row * row_words(G) + (x >> 5)] >> (x & 31)) & 1u) != 0u;
+            uint32_t mw[COUNT_VPT];
+            int xb[COUNT_VPT];
+#pragma unroll
+            for (int j = 0; j < COUNT_VPT; ++j) {
+                mw[j] = 0u; xb[j] = 0;
+                if (alive[j] && wv[j] != WIT_NONE) {
+                    const int wr = (int)(wv[j] & 0x7Fu), xo = (int)(wv[j] >> 7);
+                    const long long row = vv[j] / G.X + (long long)(wr / G.py - G.rz) * G.Y + (wr % G.py - G.ry);
+                    const int x = (int)(vv[j] % G.X) - G.rx + xo;
+                    mw[j] = mbits[row * row_words(G) + (x >> 5)];
+                    xb[j] = x & 31;
                 }
             }
-            marked = alive && !wit_ok;
-        } else {
-            marked = in && dirty[v] != 0;
-            if (marked) dirty[v] = 0;
+#pragma unroll
+            for (int j = 0; j < COUNT_VPT; ++j) marked[j] = alive[j] && ((mw[j] >> xb[j]) & 1u) == 0u;
         }
-        const unsigned long long m = __ballot(alive && marked);
-        if (m != 0ull) {
-            const int lane = threadIdx.x & 63;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
-            base = __shfl(base, 0);
-            if (alive && marked) s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        bool rest = false;
+#pragma unroll
+        for (int j = 0; j < COUNT_VPT; ++j) {
+            const unsigned long long m = __ballot(alive[j] && marked[j]);
+            if (m != 0ull) {
+                const int lane = threadIdx.x & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_n, __popcll(m));
+                base = __shfl(base, 0);
+                if (alive[j] && marked[j])
+                    s_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(j * COUNT_THREADS + threadIdx.x);
+            }
+            rest = rest || (alive[j] && !marked[j]);
         }
         // "is any patch still undecided" AFTER this step: a plain store of the same value from
         // every wave that has one that is not recounted now (same-address atomics from ~V/64
         // waves would dominate the kernel); the recounted ones report below if they survive
-        if (__ballot(alive && !marked) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
+        if (__ballot(rest) != 0 && (threadIdx.x & 63) == 0) *n_alive = 1;
     }
     __syncthreads();
     const int n = s_n;
@@ -457,7 +484,7 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
     int32_t n_alive = 1;
     while (n_alive > 0) {
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
-        const dim3 cgrid((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), cblock(COUNT_THREADS);
+        const dim3 cgrid((unsigned)((G.V + COUNT_THREADS * COUNT_VPT - 1) / (COUNT_THREADS * COUNT_VPT))), cblock(COUNT_THREADS);
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<cgrid, cblock, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
                                                        W.counters + r, nullptr, W.witness, bits_vox, G);
@@ -824,7 +851,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
     CoverWork W = carve(work, G);
     hipError_t e;
     if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
-    cover_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
+    cover_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS * COUNT_VPT - 1) / (COUNT_THREADS * COUNT_VPT))), dim3(COUNT_THREADS), 0, s>>>(
         W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, W.witness, -1ll, G);
     return hipGetLastError();
 }
