@@ -602,14 +602,22 @@ def pair_order(pairs, P):
     return torch.argsort(keys).to(torch.int32)
 
 
-def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
-    """S5 with one workgroup per patch A (ppp_patch_graph_by_patch): groups the rows by A
-    (inside a group by patch offset, so neighbouring lanes do similar work), then launches."""
+def patch_graph_prepare(pred, pairs, Pv, ahead=False):
+    """The part of S5 (patch_graph_by_patch) that needs no consensus: the rows grouped by patch A
+    (inside a group by patch offset, so neighbouring lanes do similar work), the plan of the thinning
+    masks and their buffers.  ahead=True: the masks of the first batch are launched at once, on a
+    side stream -- the caller prepares tile t + 1 before it runs tile t, so the mask kernel (a few
+    hundred one-wave workgroups whose pairs differ in work by the volume of their window
+    intersection: 848 waves per launch at 512^3, the longest four times the average, 16 ms during
+    which the chip is nearly empty) runs beside the per-patch kernel of the tile before.
+    Pv: parameters of the FRAME `pred` and the rows live in (consensus box and ring do not matter)."""
+    import types
     torch = _torch()
     n = int(pairs.shape[0])
-    aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
+    job = types.SimpleNamespace(n=n, n_live=0, plan=None, bufs=[None, None], ev_lcg={}, overlap=False, side=None)
+    job.aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
     if n == 0:
-        return aff
+        return job
     with host_timer("s5e_group_sort"):
         keys = torch.empty((n,), dtype=torch.int64, device=pairs.device)
         check(lib().ppp_pair_group_keys(_dev_ptr(pairs), n, _dev_ptr(keys), ctypes.byref(Pv), _stream()))
@@ -618,15 +626,16 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
         n_live = int(torch.searchsorted(keys, torch.tensor([PAIR_KEY_FAR], dtype=torch.int64,
                                                            device=keys.device)).item())
         note_add("s5_rows_dispatched", n_live)
+        job.n_live = n_live
         if n_live == 0:
-            return aff
+            return job
         keys, order = keys[:n_live], order[:n_live]
     dkey = keys & 0x1FFFF                         # patch offset B - A
     keys >>= 18                                   # linear index of patch A
     _, counts = torch.unique_consecutive(keys, return_counts=True)
     del keys
     zero = torch.zeros((1,), dtype=torch.int64, device=pred.device)
-    group_start = torch.cat([zero, torch.cumsum(counts, 0)])
+    job.group_start = torch.cat([zero, torch.cumsum(counts, 0)])
     chunk = int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv)))
     if chunk <= 0:
         raise RuntimeError("libppp_mi355x: no per-patch kernel for this patch shape")
@@ -635,48 +644,122 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv):
     mode = os.environ.get("PPP_PA_CHUNK", "auto")
     if mode == "small" or (mode == "auto" and n_live <= 1.5 * small * int(counts.shape[0])):
         chunk = small
-    chunk_offsets = torch.cat([zero, torch.cumsum((counts + chunk - 1) // chunk, 0)])
-    n_groups = int(counts.shape[0])
-    order32 = order.to(torch.int32)
+    job.chunk = chunk
+    job.chunk_offsets = torch.cat([zero, torch.cumsum((counts + chunk - 1) // chunk, 0)])
+    job.n_groups = int(counts.shape[0])
+    job.order32 = order.to(torch.int32)
     del order
     # thinning masks beforehand: the groups are cut into batches whose masks fit the budget (one
-    # buffer, filled and read batch after batch on the same stream)
-    # The plan's temporaries (about eight int64 per dispatched row) and the mask buffer are not
+    # buffer, filled and read batch after batch; a second buffer when a batch's masks are made
+    # beside the per-patch kernel of the batch before)
+    # The plan's temporaries (about eight int64 per dispatched row) and the mask buffers are not
     # part of the tile planner's budget: the mask budget is capped by what is free right now, and
     # running out of memory anywhere in here falls back to the generator inside the kernel.
     oom = getattr(torch, "OutOfMemoryError", None) or torch.cuda.OutOfMemoryError
     plan = drops = None
     try:
-        plan = _lcg_plan(dkey, group_start, Pv)
+        plan = _lcg_plan(dkey, job.group_start, Pv)
         if plan is not None:
             drops = torch.empty((plan["buffer_words"],), dtype=torch.int64, device=pred.device)
     except oom:
         plan = drops = None                       # the kernel runs the generator itself
         torch.cuda.empty_cache()
     del dkey
-    cuts = plan["group_cuts"] if plan is not None else [0, n_groups]
-    co_host = chunk_offsets[torch.tensor(cuts, dtype=torch.int64, device=chunk_offsets.device)].cpu().tolist()
-    co_host = dict(zip(cuts, co_host))            # blocks before each cut: ONE copy for all batches
-    for b in range(len(cuts) - 1):
+    job.plan = plan
+    job.cuts = plan["group_cuts"] if plan is not None else [0, job.n_groups]
+    co_host = job.chunk_offsets[torch.tensor(job.cuts, dtype=torch.int64, device=pred.device)].cpu().tolist()
+    job.co_host = dict(zip(job.cuts, co_host))    # blocks before each cut: ONE copy for all batches
+    job.bufs = [drops, drops]
+    can_overlap = plan is not None and pred.is_cuda and os.environ.get("PPP_PA_LCG_OVERLAP", "1") != "0"
+    if can_overlap and len(job.cuts) > 2:
+        # several batches: the masks of batch b + 1 beside the per-patch kernel of batch b
+        try:
+            job.bufs = [drops, torch.empty_like(drops)]
+            job.overlap = True
+        except oom:
+            torch.cuda.empty_cache()
+    if can_overlap and (ahead or job.overlap):
+        job.side = _side_stream(pred.device)
+        job.side.wait_stream(torch.cuda.current_stream())     # (the plan and the row order were made here)
+        _pa_masks(job, pred, pairs, Pv, 0, on_side=True)
+    return job
+
+
+def _pa_masks(job, pred, pairs, Pv, b, on_side=False, after=None):
+    """the thinning masks of batch b into its buffer; on_side: on the job's side stream (after the
+    event `after`: the per-patch kernel that read this buffer), an event marks their completion"""
+    torch = _torch()
+    n_b = len(job.cuts) - 1
+    if job.plan is None or b >= n_b or b in job.ev_lcg:
+        return
+
+    def launch():
+        lo, hi = job.plan["pos_cuts"][b], job.plan["pos_cuts"][b + 1]
+        if hi > lo:
+            with _timed("patch_graph_lcg"):
+                check(lib().ppp_patch_graph_lcg(
+                    _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(job.order32),
+                    _dev_ptr(job.plan["pos"][lo:hi]), hi - lo, _dev_ptr(job.plan["drop_off"]),
+                    _dev_ptr(job.bufs[b % 2]), ctypes.byref(Pv), _stream()))
+
+    if on_side:
+        with torch.cuda.stream(job.side):
+            if after is not None:
+                job.side.wait_event(after)
+            launch()
+            job.ev_lcg[b] = job.side.record_event()
+    else:
+        launch()
+        job.ev_lcg[b] = None
+
+
+def patch_graph_by_patch(pred, cons_vm, pairs, Pv, job=None):
+    """S5 with one workgroup per patch A (ppp_patch_graph_by_patch).  job: what patch_graph_prepare
+    made for these rows (None: made here)."""
+    torch = _torch()
+    if job is None:
+        job = patch_graph_prepare(pred, pairs, Pv)
+    aff = job.aff
+    if job.n == 0 or job.n_live == 0:
+        return aff
+    plan, cuts = job.plan, job.cuts
+    n_b = len(cuts) - 1
+    main = torch.cuda.current_stream() if pred.is_cuda else None
+    ev_pa = [None] * n_b
+    for b in range(n_b):
         g0, g1 = cuts[b], cuts[b + 1]
-        if plan is not None:
-            lo, hi = plan["pos_cuts"][b], plan["pos_cuts"][b + 1]
-            if hi > lo:
-                with _timed("patch_graph_lcg"):
-                    check(lib().ppp_patch_graph_lcg(
-                        _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(order32),
-                        _dev_ptr(plan["pos"][lo:hi]), hi - lo, _dev_ptr(plan["drop_off"]), _dev_ptr(drops),
-                        ctypes.byref(Pv), _stream()))
-        co = chunk_offsets[g0:g1 + 1]
-        n_blocks = int(co_host[g1] - co_host[g0])
+        if job.side is not None:
+            if job.overlap:                       # (two buffers: the next batch's masks beside this batch's kernel)
+                _pa_masks(job, pred, pairs, Pv, b + 1, on_side=True, after=ev_pa[b - 1] if b >= 1 else None)
+            _pa_masks(job, pred, pairs, Pv, b, on_side=False)      # (one buffer, later batches: here, in order)
+            if job.ev_lcg.get(b) is not None:
+                main.wait_event(job.ev_lcg[b])
+        elif plan is not None:
+            _pa_masks(job, pred, pairs, Pv, b)
+        co = job.chunk_offsets[g0:g1 + 1]
+        n_blocks = int(job.co_host[g1] - job.co_host[g0])
         with _timed("patch_graph"):
             check(lib().ppp_patch_graph_by_patch_lcg(
                 _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(cons_vm), _dev_ptr(pairs),
-                _dev_ptr(order32), _dev_ptr(group_start[g0:g1 + 1].contiguous()),
-                _dev_ptr((co - co[0]).contiguous()), g1 - g0, n_blocks, chunk, _dev_ptr(aff),
+                _dev_ptr(job.order32), _dev_ptr(job.group_start[g0:g1 + 1].contiguous()),
+                _dev_ptr((co - co[0]).contiguous()), g1 - g0, n_blocks, job.chunk, _dev_ptr(aff),
                 _dev_ptr(plan["drop_off"]) if plan is not None else None,
-                _dev_ptr(drops) if plan is not None else None, ctypes.byref(Pv), _stream()))
+                _dev_ptr(job.bufs[b % 2]) if plan is not None else None, ctypes.byref(Pv), _stream()))
+        if job.side is not None:
+            ev_pa[b] = main.record_event()
     return aff
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """one extra stream per device for work that runs beside the library's stream"""
+    torch = _torch()
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)     # (high: its few waves take the slots that free up)
+    return _SIDE_STREAMS[key]
 
 
 def lcg_words(dz, dy, dx, P):
@@ -770,7 +853,17 @@ def _lcg_plan(dkey, group_start, Pv):
                 drop_off=drop_off.contiguous(), buffer_words=max(buffer_words, 1))
 
 
-def patch_graph_auto(pred, cons_compact, pairs, P):
+def patch_graph_ahead(pred, pairs, P):
+    """patch_graph_prepare(ahead=True) when the per-patch kernel will serve these rows (else None):
+    what patch_graph_auto(..., job=...) of the NEXT tile can be handed while this tile is running.
+    P: parameters of the frame."""
+    if os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and os.environ.get("PPP_PA_LCG_OVERLAP", "1") != "0" and \
+            pred.is_cuda and int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(P))) > 0 and max(P.pz, P.py) <= P.px:
+        return patch_graph_prepare(pred, pairs, P, ahead=True)
+    return None
+
+
+def patch_graph_auto(pred, cons_compact, pairs, P, job=None):
     """S5 from a COMPACT consensus: re-layout to voxel-major, then the workgroup-per-patch
     kernel (consensus rows staged once per patch in LDS; 0.3 TB instead of 5.4 TB of HBM reads
     on the 140^3 benchmark).  PPP_PATCH_GRAPH=pairs selects the pair-per-lane gather kernel
@@ -786,7 +879,7 @@ def patch_graph_auto(pred, cons_compact, pairs, P):
     if os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and \
             int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(Pv))) > 0 and \
             max(P.pz, P.py) <= P.px:
-        return patch_graph_by_patch(pred, vm, pairs, Pv)
+        return patch_graph_by_patch(pred, vm, pairs, Pv, job=job)
     return patch_graph(pred, vm, pairs, Pv, order=pair_order(pairs, Pv))
 
 
