@@ -774,6 +774,126 @@ __global__ void __launch_bounds__(64)
     }
 }
 
+// ---- the same masks, a WAVE per pair (round 5).
+//
+// With a lane per pair a launch is a few hundred waves whose time is their heaviest pair's (the
+// work of a pair grows with the square of its window intersection: 848 waves per launch at 512^3,
+// the longest four times the average, 16 ms with the chip nearly empty), and every lane walks all
+// 81 x 9 candidate positions of a pixel of A with a dependent multiply each.  The generator's state
+// before A's j-th foreground pixel is seed * g^j with g = a^nB (nB = B's foreground pixels inside
+// the intersection: every one of them advances it once), so A's pixels are INDEPENDENT: here the
+// 64 lanes of a wave take 64 foreground pixels of A at a time, the two bit sets are gathered by
+// the whole wave, B's candidates -- the same for every lane -- are walked set bit by set bit
+// (one multiply per foreground pixel of B, none for the others), and a launch is one wave per
+// pair: tens of thousands of waves of similar length.  Same masks, bit for bit.
+__device__ __forceinline__ uint32_t lcg_pow(uint32_t base, uint32_t e) {      // base^e mod 2^32
+    uint32_t r = 1u;
+    while (e) { if (e & 1u) r *= base; base *= base; e >>= 1; }
+    return r;
+}
+static constexpr int LCGW_WAVES = 4;
+template <typename T, int PX>
+__global__ void __launch_bounds__(64 * LCGW_WAVES)
+    patch_graph_lcg_wave_kernel(const T *__restrict__ pred, const uint32_t *__restrict__ rows,
+                                const uint32_t *__restrict__ order, const long long *__restrict__ lcg_pos,
+                                const long long n, const long long *__restrict__ drop_off,
+                                unsigned long long *__restrict__ drops, const Geo G) {
+    typedef unsigned long long u64;
+    extern __shared__ uint32_t lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int words = (G.C + 31) / 32;
+    uint32_t *fa = lds_raw + wave * (2 * words + 2);      // F_A inside the intersection (A's window raster)
+    uint32_t *fb = fa + words;                            // [words + 2]  F_B (B's window raster)
+    constexpr int RPC = 64 / PX;
+    constexpr int NCH = (PX + RPC - 1) / RPC;
+    const long long i = (long long)blockIdx.x * LCGW_WAVES + wave;
+    if (i >= n) return;                                   // (whole waves: no workgroup barrier below)
+    const long long pos = lcg_pos[i];
+    const long long soff = drop_off[pos];
+    if (soff < 0) return;
+    const uint32_t *rw = rows + (size_t)order[pos] * 6;
+    const int az = (int)rw[0], ay = (int)rw[1], ax = (int)rw[2], bz = (int)rw[3], by = (int)rw[4], bx = (int)rw[5];
+    const int dz = bz - az, dy = by - ay, dx = bx - ax;
+    const int nz = G.pz - abs(dz), ny = G.py - abs(dy), nx = PX - abs(dx);
+    if (nz <= 0 || ny <= 0 || nx <= 0) return;
+    const int z1lo = max(dz, 0), y1lo = max(dy, 0), x1lo = max(dx, 0);
+    const int z2lo = max(-dz, 0), y2lo = max(-dy, 0), x2lo = max(-dx, 0);
+    const uint32_t seed = (uint32_t)(az + G.oz) * (uint32_t)(bz + G.oz) * (uint32_t)(ay + G.oy) *
+                          (uint32_t)(by + G.oy) * (uint32_t)(ax + G.ox) * (uint32_t)(bx + G.ox);
+    for (int w = lane; w < 2 * words + 2; w += 64) fa[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    {
+        const T *mid = pred + (long long)G.mid * G.V;
+        const long long la = vox(G, az, ay, ax), lb = vox(G, bz, by, bx);
+        const int n_i = nz * ny * nx;
+        for (int t = lane; t < n_i; t += 64) {
+            const int iz = t / (ny * nx), iy = (t / nx) % ny, ix = t % nx;
+            const int ra = ((z1lo + iz) * G.py + (y1lo + iy)) * PX + (x1lo + ix);
+            const int rb = ((z2lo + iz) * G.py + (y2lo + iy)) * PX + (x2lo + ix);
+            const float ma = ldf(mid, vox(G, az + z1lo + iz - G.rz, ay + y1lo + iy - G.ry, ax + x1lo + ix - PX / 2));
+            const float pa = ldf(pred, (long long)ra * G.V + la);
+            const float mb = ldf(mid, vox(G, bz + z2lo + iz - G.rz, by + y2lo + iy - G.ry, bx + x2lo + ix - PX / 2));
+            const float pb = ldf(pred, (long long)rb * G.V + lb);
+            if (ma > G.th_gt && pa > G.th_gt) atomicOr(&fa[ra >> 5], 1u << (ra & 31));
+            if (mb > G.th_gt && pb > G.th_gt) atomicOr(&fb[rb >> 5], 1u << (rb & 31));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int nA = 0, nB = 0;
+    for (int w = 0; w < words; ++w) { nA += __popc(fa[w]); nB += __popc(fb[w]); }
+    const uint32_t g = lcg_pow(1103515245U, (uint32_t)nB);
+    for (int j0 = 0; j0 < nA; j0 += 64) {
+        const int j = j0 + lane;
+        const bool act = j < nA;
+        // A's j-th foreground pixel (window raster order)
+        int r1 = 0;
+        {
+            int left = act ? j : 0;
+            for (int w = 0; w < words; ++w) {
+                const uint32_t m = fa[w];
+                const int c = __popc(m);
+                if (left < c) {
+                    uint32_t mm = m;
+                    for (int k = 0; k < left; ++k) mm &= mm - 1u;
+                    r1 = w * 32 + __builtin_ctz(mm);
+                    break;
+                }
+                left -= c;
+            }
+        }
+        const int z1o = r1 / (G.py * PX), y1o = (r1 / PX) % G.py, x1o = r1 % PX;
+        const int i1 = ((z1o - z1lo) * ny + (y1o - y1lo)) * nx + (x1o - x1lo);
+        const long long blk = soff + (long long)i1 * nz * NCH;
+        uint32_t rnd = seed * lcg_pow(g, (uint32_t)(act ? j : 0));
+        for (int z2o = z2lo; z2o < z2lo + nz; ++z2o) {
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                const int c_first = c * RPC;
+                const int c_rows = min(RPC, G.py - c_first);
+                if (c_rows <= 0) break;
+                const int nb = c_rows * PX;
+                const int o = (z2o * G.py + c_first) * PX, w0 = o >> 5, sh = o & 31;
+                const uint32_t lo = fb[w0], mi = fb[w0 + 1], hi = fb[w0 + 2];
+                u64 hits = ((((u64)mi << 32) | lo) >> sh) | (sh ? ((u64)hi << (64 - sh)) : 0ull);
+                hits &= nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+                hits = (u64)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)hits) |
+                       ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(hits >> 32)) << 32);
+                u64 drop = 0ull;
+                while (hits) {                              // (the same bits for every lane)
+                    const int b = __builtin_ctzll(hits);
+                    hits &= hits - 1ull;
+                    rnd *= 1103515245U;
+                    // (float)rnd / 2^32 > 0.2 in double  <=>  rnd >= 858993441 (see above)
+                    if (rnd >= 858993441u) drop |= 1ull << b;
+                }
+                if (act) drops[blk + (z2o - z2lo) * NCH + c] = drop;
+            }
+        }
+    }
+}
+
 // u64 words of precomputed masks for a pair with patch offset (dz, dy, dx); 0 = the windows do
 // not intersect
 long long patch_graph_lcg_words(const Geo &G, int dz, int dy, int dx) {
@@ -789,6 +909,15 @@ static hipError_t launch_lcg(const T *pred, const uint32_t *rows, const uint32_t
                              hipStream_t s) {
     const int words = (G.C + 31) / 32;
     const size_t lds = (size_t)(2 * words + 2) * 64 * 4;
+    // a wave per pair (PPP_PA_LCG_WAVE=0: a lane per pair)
+    static EnvSwitch wave_sw("PPP_PA_LCG_WAVE");
+    if (!(wave_sw.get() && wave_sw.get()[0] == '0') &&
+        !grid_too_big((unsigned long long)((n + LCGW_WAVES - 1) / LCGW_WAVES), 64 * LCGW_WAVES)) {
+        const size_t ldsw = (size_t)(2 * words + 2) * LCGW_WAVES * 4;
+        patch_graph_lcg_wave_kernel<T, PX><<<dim3((unsigned)((n + LCGW_WAVES - 1) / LCGW_WAVES)), dim3(64 * LCGW_WAVES), ldsw, s>>>(
+            pred, rows, order, lcg_pos, n, drop_off, drops, G);
+        return hipGetLastError();
+    }
     patch_graph_lcg_kernel<T, PX><<<dim3((unsigned)((n + 63) / 64)), dim3(64), lds, s>>>(
         pred, rows, order, lcg_pos, n, drop_off, drops, G);
     return hipGetLastError();
