@@ -670,7 +670,11 @@ def patch_graph_prepare(pred, pairs, Pv, ahead=False):
     co_host = job.chunk_offsets[torch.tensor(job.cuts, dtype=torch.int64, device=pred.device)].cpu().tolist()
     job.co_host = dict(zip(job.cuts, co_host))    # blocks before each cut: ONE copy for all batches
     job.bufs = [drops, drops]
-    can_overlap = plan is not None and pred.is_cuda and os.environ.get("PPP_PA_LCG_OVERLAP", "1") != "0"
+    # (PPP_PA_LCG_OVERLAP=1: the masks on a side stream, beside the per-patch kernel of the batch -- or,
+    # with ahead=True, of the tile -- before.  It paid while the mask kernel was a few hundred waves
+    # with the chip nearly empty (stage wall 7.22 -> 6.90 s at 512^3); with a wave per pair the masks
+    # of a 512^3 step take 0.14 s and running them beside the per-patch kernel only slows that one.)
+    can_overlap = plan is not None and pred.is_cuda and os.environ.get("PPP_PA_LCG_OVERLAP", "0") == "1"
     if can_overlap and len(job.cuts) > 2:
         # several batches: the masks of batch b + 1 beside the per-patch kernel of batch b
         try:
@@ -851,16 +855,6 @@ def _lcg_plan(dkey, group_start, Pv):
     return dict(group_cuts=group_cuts_all, pos_cuts=[int(v) for v in pos_cuts] + [int(pos.shape[0])] *
                 (len(group_cuts_all) - len(group_cuts)), pos=pos.contiguous(),
                 drop_off=drop_off.contiguous(), buffer_words=max(buffer_words, 1))
-
-
-def patch_graph_ahead(pred, pairs, P):
-    """patch_graph_prepare(ahead=True) when the per-patch kernel will serve these rows (else None):
-    what patch_graph_auto(..., job=...) of the NEXT tile can be handed while this tile is running.
-    P: parameters of the frame."""
-    if os.environ.get("PPP_PATCH_GRAPH", "patch") != "pairs" and os.environ.get("PPP_PA_LCG_OVERLAP", "1") != "0" and \
-            pred.is_cuda and int(lib().ppp_patch_graph_by_patch_chunk(ctypes.byref(P))) > 0 and max(P.pz, P.py) <= P.px:
-        return patch_graph_prepare(pred, pairs, P, ahead=True)
-    return None
 
 
 def patch_graph_auto(pred, cons_compact, pairs, P, job=None):

@@ -458,13 +458,8 @@ class DeviceOps:
         return backend.device_patch_pairs(sorted_zyx, P, max_ps_dist=max_ps_dist,
                                           include_single=include_single)
 
-    def patch_graph(self, pred, cons, rows, P, job=None):
-        return backend.patch_graph_auto(pred, cons, rows, P, job=job)
-
-    def patch_graph_ahead(self, pred, rows, P):
-        """the consensus-free part of patch_graph for the rows of the NEXT tile (thinning masks on a
-        side stream, beside this tile's kernels); None when there is nothing to prepare"""
-        return backend.patch_graph_ahead(pred, rows, P)
+    def patch_graph(self, pred, cons, rows, P):
+        return backend.patch_graph_auto(pred, cons, rows, P)
 
     # streaming pair rows / labels: the rows of a tile exist only while the tile is worked on
     def pair_counts(self, sorted_zyx, subset, P, max_ps_dist):
@@ -1395,58 +1390,27 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         if state is None and len(my_tiles) > 1:
             with backend.host_timer("s5a_select_rows"):
                 rows_of_tile = rows_by_tile(rows, my_tiles)
-        def rows_of(n_t, t):
+        for n_t, t in enumerate(my_tiles if state is None else []):
             z0, z1, y0, y1, x0, x1 = t
-            if rows_of_tile is not None:
-                return rows_of_tile.pop(n_t)
-            own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
-            if ny_t > 1 or nx_t > 1:
-                own &= (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
-                       (rows[:, 2] >= x0) & (rows[:, 2] < x1)
-            return torch.nonzero(own).reshape(-1)
-
-        # With the prediction resident (one frame for every tile) the consensus-free part of tile
-        # t + 1 -- row order, mask plan, thinning masks -- is made while tile t runs: its mask kernel
-        # on a side stream, beside this tile's S1 and per-patch kernel (backend.patch_graph_prepare).
-        todo = list(enumerate(my_tiles)) if state is None else []
-        ahead = whole is not None and hasattr(ops, "patch_graph_ahead") and len(todo) > 1
-        prepared = {}                                  # tile number -> (idx, local rows, job)
-
-        def prepare(k):
-            if k >= len(todo) or k in prepared:
-                return
-            n_t, t = todo[k]
             with backend.host_timer("s5a_select_rows"):
-                idx = rows_of(n_t, t)
-            if idx.numel() == 0:
-                prepared[k] = (idx, None, None)
-                return
-            local = to_local(rows[idx], whole, 2) if whole is not None else None
-            job = None
-            if ahead and k > 0:
-                # (no stage timer from here to the launch of the running tile's kernel: a timer
-                # synchronises the device, which would wait for the masks just launched)
-                job = ops.patch_graph_ahead(whole.pred, local, params(whole))
-            prepared[k] = (idx, local, job)
-
-        for k, (n_t, t) in enumerate(todo):
-            prepare(k)
-            idx, local, job = prepared.pop(k)
-            if idx.numel() == 0:
-                continue
+                if rows_of_tile is not None:
+                    idx = rows_of_tile.pop(n_t)
+                else:
+                    own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
+                    if ny_t > 1 or nx_t > 1:
+                        own &= (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
+                               (rows[:, 2] >= x0) & (rows[:, 2] < x1)
+                    idx = torch.nonzero(own).reshape(-1)
+                    del own
+                if idx.numel() == 0:
+                    continue
             with backend.host_timer("s5b_consensus"):
                 fr, cons, P = tile_consensus(t)
             with backend.host_timer("s5c_patch_graph"):
-                if local is None:
-                    local = to_local(rows[idx], fr, 2)
-                if job is None and ahead:
-                    job = ops.patch_graph_ahead(fr.pred, local, params(whole))    # (first tile: made here)
-                if ahead:
-                    prepare(k + 1)                     # (its masks run beside this tile's kernel)
-                a = ops.patch_graph(fr.pred, cons, local, P, **({"job": job} if job is not None else {}))
+                a = ops.patch_graph(fr.pred, cons, to_local(rows[idx], fr, 2), P)
             with backend.host_timer("s5d_scatter"):
                 aff[idx] = a
-            del cons, idx, a, fr, local, job
+            del cons, idx, a, fr
     kept.clear()
     pool = scratch = cache = None
     if state is None:
