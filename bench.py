@@ -377,11 +377,11 @@ class Workload:
                 extra["_n_slabs"] = args.slabs
             if args.yx:
                 extra["_yx_tiles"] = tuple(args.yx)
+                extra.setdefault("_n_slabs", 1)        # (a forced y/x grid without --slabs: one z-slab)
             if args.slabs and os.environ.get("PPP_CONS_CACHE") == "1":
                 extra["_cons_cache"] = True            # (a forced grid skips the memory plan)
             if args.slabs and os.environ.get("PPP_RING_Z"):
                 extra["_ring_z"] = int(os.environ["PPP_RING_Z"])
-                extra.setdefault("_n_slabs", 1)
 
             def step(flag_kw=kw):
                 # foreground / mask / numinst are inputs like the prediction: resident in HBM

@@ -605,16 +605,15 @@ def pair_order(pairs, P):
 def patch_graph_prepare(pred, pairs, Pv, ahead=False):
     """The part of S5 (patch_graph_by_patch) that needs no consensus: the rows grouped by patch A
     (inside a group by patch offset, so neighbouring lanes do similar work), the plan of the thinning
-    masks and their buffers.  ahead=True: the masks of the first batch are launched at once, on a
-    side stream -- the caller prepares tile t + 1 before it runs tile t, so the mask kernel (a few
-    hundred one-wave workgroups whose pairs differ in work by the volume of their window
-    intersection: 848 waves per launch at 512^3, the longest four times the average, 16 ms during
-    which the chip is nearly empty) runs beside the per-patch kernel of the tile before.
+    masks and their buffers.  (`ahead` is accepted and ignored: rounds 4-5 ran the masks of tile t + 1
+    on a side stream beside tile t's per-patch kernel; with a wave per pair the masks of a 512^3 step
+    take 0.14 s and running them beside that kernel only slowed it -- 6.24 s in line, 6.70 s beside,
+    DESIGN.md section 4 -- so the side stream is gone.)
     Pv: parameters of the FRAME `pred` and the rows live in (consensus box and ring do not matter)."""
     import types
     torch = _torch()
     n = int(pairs.shape[0])
-    job = types.SimpleNamespace(n=n, n_live=0, plan=None, bufs=[None, None], ev_lcg={}, overlap=False, side=None)
+    job = types.SimpleNamespace(n=n, n_live=0, plan=None, bufs=[None, None], masks_done=set())
     job.aff = torch.zeros((n,), dtype=torch.float32, device=pred.device)
     if n == 0:
         return job
@@ -670,57 +669,27 @@ def patch_graph_prepare(pred, pairs, Pv, ahead=False):
     co_host = job.chunk_offsets[torch.tensor(job.cuts, dtype=torch.int64, device=pred.device)].cpu().tolist()
     job.co_host = dict(zip(job.cuts, co_host))    # blocks before each cut: ONE copy for all batches
     job.bufs = [drops, drops]
-    # (PPP_PA_LCG_OVERLAP=1: the masks on a side stream, beside the per-patch kernel of the batch -- or,
-    # with ahead=True, of the tile -- before.  It paid while the mask kernel was a few hundred waves
-    # with the chip nearly empty (stage wall 7.22 -> 6.90 s at 512^3); with a wave per pair the masks
-    # of a 512^3 step take 0.14 s and running them beside the per-patch kernel only slows that one.)
-    can_overlap = plan is not None and pred.is_cuda and os.environ.get("PPP_PA_LCG_OVERLAP", "0") == "1"
-    if can_overlap and len(job.cuts) > 2:
-        # several batches: the masks of batch b + 1 beside the per-patch kernel of batch b
-        try:
-            job.bufs = [drops, torch.empty_like(drops)]
-            job.overlap = True
-        except oom:
-            torch.cuda.empty_cache()
-    if can_overlap and (ahead or job.overlap):
-        job.side = _side_stream(pred.device)
-        job.side.wait_stream(torch.cuda.current_stream())     # (the plan and the row order were made here)
-        _pa_masks(job, pred, pairs, Pv, 0, on_side=True)
     return job
 
 
-def _pa_masks(job, pred, pairs, Pv, b, on_side=False, after=None):
-    """the thinning masks of batch b into its buffer; on_side: on the job's side stream (after the
-    event `after`: the per-patch kernel that read this buffer), an event marks their completion"""
-    torch = _torch()
+def _pa_masks(job, pred, pairs, Pv, b):
+    """the thinning masks of batch b into the buffer (filled and read batch after batch)"""
     n_b = len(job.cuts) - 1
-    if job.plan is None or b >= n_b or b in job.ev_lcg:
+    if job.plan is None or b >= n_b or b in job.masks_done:
         return
-
-    def launch():
-        lo, hi = job.plan["pos_cuts"][b], job.plan["pos_cuts"][b + 1]
-        if hi > lo:
-            with _timed("patch_graph_lcg"):
-                check(lib().ppp_patch_graph_lcg(
-                    _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(job.order32),
-                    _dev_ptr(job.plan["pos"][lo:hi]), hi - lo, _dev_ptr(job.plan["drop_off"]),
-                    _dev_ptr(job.bufs[b % 2]), ctypes.byref(Pv), _stream()))
-
-    if on_side:
-        with torch.cuda.stream(job.side):
-            if after is not None:
-                job.side.wait_event(after)
-            launch()
-            job.ev_lcg[b] = job.side.record_event()
-    else:
-        launch()
-        job.ev_lcg[b] = None
+    lo, hi = job.plan["pos_cuts"][b], job.plan["pos_cuts"][b + 1]
+    if hi > lo:
+        with _timed("patch_graph_lcg"):
+            check(lib().ppp_patch_graph_lcg(
+                _dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(pairs), _dev_ptr(job.order32),
+                _dev_ptr(job.plan["pos"][lo:hi]), hi - lo, _dev_ptr(job.plan["drop_off"]),
+                _dev_ptr(job.bufs[b % 2]), ctypes.byref(Pv), _stream()))
+    job.masks_done.add(b)
 
 
 def patch_graph_by_patch(pred, cons_vm, pairs, Pv, job=None):
     """S5 with one workgroup per patch A (ppp_patch_graph_by_patch).  job: what patch_graph_prepare
     made for these rows (None: made here)."""
-    torch = _torch()
     if job is None:
         job = patch_graph_prepare(pred, pairs, Pv)
     aff = job.aff
@@ -728,17 +697,9 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv, job=None):
         return aff
     plan, cuts = job.plan, job.cuts
     n_b = len(cuts) - 1
-    main = torch.cuda.current_stream() if pred.is_cuda else None
-    ev_pa = [None] * n_b
     for b in range(n_b):
         g0, g1 = cuts[b], cuts[b + 1]
-        if job.side is not None:
-            if job.overlap:                       # (two buffers: the next batch's masks beside this batch's kernel)
-                _pa_masks(job, pred, pairs, Pv, b + 1, on_side=True, after=ev_pa[b - 1] if b >= 1 else None)
-            _pa_masks(job, pred, pairs, Pv, b, on_side=False)      # (one buffer, later batches: here, in order)
-            if job.ev_lcg.get(b) is not None:
-                main.wait_event(job.ev_lcg[b])
-        elif plan is not None:
+        if plan is not None:
             _pa_masks(job, pred, pairs, Pv, b)
         co = job.chunk_offsets[g0:g1 + 1]
         n_blocks = int(job.co_host[g1] - job.co_host[g0])
@@ -749,21 +710,7 @@ def patch_graph_by_patch(pred, cons_vm, pairs, Pv, job=None):
                 _dev_ptr((co - co[0]).contiguous()), g1 - g0, n_blocks, job.chunk, _dev_ptr(aff),
                 _dev_ptr(plan["drop_off"]) if plan is not None else None,
                 _dev_ptr(job.bufs[b % 2]) if plan is not None else None, ctypes.byref(Pv), _stream()))
-        if job.side is not None:
-            ev_pa[b] = main.record_event()
     return aff
-
-
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    """one extra stream per device for work that runs beside the library's stream"""
-    torch = _torch()
-    key = str(device)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)     # (high: its few waves take the slots that free up)
-    return _SIDE_STREAMS[key]
 
 
 def lcg_words(dz, dy, dx, P):

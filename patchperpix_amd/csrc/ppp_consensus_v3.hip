@@ -187,7 +187,11 @@ __device__ __forceinline__ void tile_votes3(const v2f *at, const v2f *cfp, lds_v
         if (DEPTH == 1) { if (n + 1 < NG) load_group(n + 1, bnxt, ta_nxt, fa_nxt); }
         else if (n + 2 < NG) load_group(n + 2, bnx2, ta_nxt, fa_nxt);
         if (jg == 0) {
-            ta = ta * fa;                                       // centre factor {0, 1}
+            // centre factor {0, 1}.  EXACT (a value outside [0, 1] in the tile): select, so that an
+            // infinite prediction at a centre that votes nothing contributes 0 like the reference's
+            // skipped centre (fillConsensusArray.cu:25-32), not inf * 0 = nan
+            if constexpr (EXACT) ta = (v2f){fa.x != 0.0f ? ta.x : 0.0f, fa.y != 0.0f ? ta.y : 0.0f};
+            else ta = ta * fa;
             if constexpr (!EXACT) {
                 ga = pk_mul_clamp(ta, splat(4.0f));            // [ta > 0]  (|ta| > 0.5 when classified)
                 na = pk_mul_clamp(ta, splat(-4.0f));           // [ta < 0]

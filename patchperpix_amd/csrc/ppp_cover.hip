@@ -46,9 +46,13 @@ struct CoverWork {
                                          // state / cleared / bits tables, -1 off the own centres
     uint16_t *witness;                   // [V] pix_th == 0: ONE voxel of the window that the patch
                                          // centred here still covered at its last recount: window
-                                         // row (dz * py + dy) | x offset << 7; 0xFFFF = none known
+                                         // row (dz * py + dy) << 5 | x offset (px <= 32: five bits; the row
+                                         // keeps eleven, witness_ok); 0xFFFF = none known
 };
 static constexpr uint16_t WIT_NONE = 0xFFFFu;
+// the 16-bit witness holds a window row in eleven bits (0x7FF | 31 would read as WIT_NONE); taller
+// windows run without witnesses: dirty marks + windowed recounts, as the pix_th > 0 passes do
+static inline bool witness_ok(const Geo &G) { return G.pz * G.py < 2047 && G.px <= 32; }
 
 // words per row of the bit mask: one spare word so a window may be read as two words
 __host__ __device__ __forceinline__ int row_words(const Geo &G) { return (G.X + 31) / 32 + 1; }
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
             for (int j = 0; j < COUNT_VPT; ++j) {
                 mw[j] = 0u; xb[j] = 0;
                 if (alive[j] && wv[j] != WIT_NONE) {
-                    const int wr = (int)(wv[j] & 0x7Fu), xo = (int)(wv[j] >> 7);
+                    const int wr = (int)(wv[j] >> 5), xo = (int)(wv[j] & 0x1Fu);
                     const long long row = vv[j] / G.X + (long long)(wr / G.py - G.rz) * G.Y + (wr % G.py - G.ry);
                     const int x = (int)(vv[j] % G.X) - G.rx + xo;
                     mw[j] = mbits[row * row_words(G) + (x >> 5)];
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
         const bool two = sh + G.px > 32;
         const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
         const bool use_wit = pix_th == 0 && witness != nullptr;
-        unsigned wit_new = WIT_NONE;      // first covered voxel found: row | x offset << 7
+        unsigned wit_new = WIT_NONE;      // first covered voxel found: row << 5 | x offset
         // sliding 64-bit window over the patch's bit string
         unsigned long long win = b[0] | ((unsigned long long)(words > 1 ? b[1] : 0u) << 32);
         int have = 64, next = 2, hits = 0;
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
                         const unsigned long long mw = lo[dy] | ((unsigned long long)hi[dy] << 32);
                         const uint32_t hm = (uint32_t)(mw >> sh) & (uint32_t)win & pmask;
                         const int rh = __popc(hm);
-                        if (rh && wit_new == WIT_NONE) wit_new = (unsigned)(dz * G.py + dy) | ((unsigned)__builtin_ctz(hm) << 7);
+                        if (rh && wit_new == WIT_NONE) wit_new = ((unsigned)(dz * G.py + dy) << 5) | (unsigned)__builtin_ctz(hm);
                         hits += rh;
                         win >>= G.px;
                         have -= G.px;
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
                     if (two) mw |= (unsigned long long)row[1] << 32;
                     const uint32_t hm = (uint32_t)(mw >> sh) & (uint32_t)win & pmask;
                     const int rh = __popc(hm);
-                    if (rh && wit_new == WIT_NONE) wit_new = (unsigned)(dz * G.py + dy) | ((unsigned)__builtin_ctz(hm) << 7);
+                    if (rh && wit_new == WIT_NONE) wit_new = ((unsigned)(dz * G.py + dy) << 5) | (unsigned)__builtin_ctz(hm);
                     hits += rh;
                     win >>= G.px;
                     have -= G.px;
@@ -487,11 +491,11 @@ hipError_t run_cover_pass(uint8_t *mask, const uint32_t *bits, long long bits_vo
         const dim3 cgrid((unsigned)((G.V + COUNT_THREADS * COUNT_VPT - 1) / (COUNT_THREADS * COUNT_VPT))), cblock(COUNT_THREADS);
         for (int r = 0; r < COVER_BATCH; ++r) {
             cover_count_kernel<<<cgrid, cblock, 0, s>>>(W.mbits, bits, W.dirty, pix_th, state, W.rank_vol,
-                                                       W.counters + r, nullptr, W.witness, bits_vox, G);
+                                                       W.counters + r, nullptr, witness_ok(G) ? W.witness : nullptr, bits_vox, G);
             // x, y, z; radius p-1: two windows overlap iff |dc| <= p-1 on every axis
             minfilter_xy<int32_t>(W.rank_vol, W.tmp, W.nbr_min, G, s);
             cover_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared,
-                                                        W.dirty, nullptr, G.Z + G.oz, bits_vox, pix_th != 0 ? 1 : 0, G);
+                                                        W.dirty, nullptr, G.Z + G.oz, bits_vox, (pix_th != 0 || !witness_ok(G)) ? 1 : 0, G);
         }
         *rounds += COVER_BATCH;
         // "any patch undecided" at the start of the batch's last round; if none, that round
@@ -852,7 +856,7 @@ hipError_t cover_step_count(const uint32_t *bits, int pix_th, int32_t *state, vo
     hipError_t e;
     if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
     cover_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS * COUNT_VPT - 1) / (COUNT_THREADS * COUNT_VPT))), dim3(COUNT_THREADS), 0, s>>>(
-        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, W.witness, -1ll, G);
+        W.mbits, bits, W.dirty, pix_th, state, W.rank_vol, W.counters, W.loc_vol, witness_ok(G) ? W.witness : nullptr, -1ll, G);
     return hipGetLastError();
 }
 
@@ -866,7 +870,7 @@ hipError_t cover_step_select(const uint32_t *bits, int pix_th, int32_t *state, i
                              int gZ, const Geo &G, hipStream_t s) {
     CoverWork W = carve(work, G);
     cover_select_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
-        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, -1ll, pix_th != 0 ? 1 : 0, G);
+        W.mbits, bits, W.nbr_min, state, W.rank_vol, cleared, W.dirty, W.loc_vol, gZ, -1ll, (pix_th != 0 || !witness_ok(G)) ? 1 : 0, G);
     return hipGetLastError();
 }
 

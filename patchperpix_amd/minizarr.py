@@ -5,15 +5,18 @@ lacks (reference: experiments/flylight/setups/setup01/predict_no_gp.py:243-257 w
 shuffle=Blosc.BITSHUFFLE)``; PatchPerPix/vote_instances/stitch_patch_graph.py:36 uses the same
 compressor for its block graphs; utilVoteInstances.py:136-322 and io_hdflike.py read them).
 
-Supported: C-order arrays of any fixed-size dtype; compressors ``null``, ``zlib`` and ``blosc``
+Supported: C-order arrays of any fixed-size dtype; compressors ``null``, ``zlib``, ``gzip`` and ``blosc``
 (Blosc-1 frames with the zstd, lz4 / lz4hc or zlib codec, no / byte / bit shuffle, split or
 unsplit blocks, memcpy'ed frames); nested groups; ``.zattrs``; both chunk-key separators.
 Decompression calls the system ``libzstd`` / ``liblz4`` through ctypes (they release the GIL, so
 chunks are decoded by a thread pool) and zlib from the standard library.  Writing produces
 Blosc-1 frames a stock numcodecs decodes (one stream per block, "do not split" flag set).
 
-PINNING: there is no Blosc implementation in this container to produce reference frames, and
-the reference tree holds no zarr data.  The frame layout follows c-blosc's README_HEADER.rst
+PINNING: the reference tree holds ONE store written by a real zarr / numcodecs -- the example
+experiments/flylight/JRC_SS05008-20160318_24_B2_crop.zip (gzip chunks); its metadata and chunks are
+a data fixture (tests/golden/ref_zarr_fixture, tests/test_minizarr.py::test_reference_example_store)
+and pin the metadata / chunk-grid / edge-chunk / gzip side of this reader.  There is no Blosc
+implementation in this container to produce reference frames, and the tree holds no Blosc data.  The frame layout follows c-blosc's README_HEADER.rst
 (format version 2) and bitshuffle's element/bit order as documented there; the tests round-trip
 writer -> reader and decode hand-assembled frames (split streams, memcpy'ed, byte shuffle).
 Parity against files written by a real numcodecs is UNPINNED and says so in DESIGN.md.
@@ -299,6 +302,10 @@ class Array:
             data = blosc_decode(raw)
         elif c["id"] == "zlib":
             data = np.frombuffer(zlib.decompress(raw), dtype=np.uint8)
+        elif c["id"] == "gzip":
+            # numcodecs.GZip (the compressor of the reference's own example store,
+            # experiments/flylight/JRC_SS05008-20160318_24_B2_crop.zip): a gzip member per chunk
+            data = np.frombuffer(zlib.decompress(raw, 16 + zlib.MAX_WBITS), dtype=np.uint8)
         else:
             raise NotImplementedError("zarr compressor %r" % c["id"])
         return data.view(self.dtype).reshape(self.chunks)
@@ -317,6 +324,9 @@ class Array:
                                 blocksize=c.get("blocksize") or None)
         if c["id"] == "zlib":
             return zlib.compress(arr.tobytes(), int(c.get("level", 1)))
+        if c["id"] == "gzip":
+            import gzip
+            return gzip.compress(arr.tobytes(), int(c.get("level", 1)), mtime=0)   # (numcodecs writes mtime 0 too)
         raise NotImplementedError("zarr compressor %r" % c["id"])
 
     # ---- selections

@@ -91,7 +91,7 @@ def decode(args, config):
 
 def main(argv=None):
     from patchperpix_amd import backend as _backend
-    _backend.tune_host_allocator(cli=__name__ == "__main__")
+    _backend.tune_host_allocator(cli=True)     # (main(argv) IS the program, also behind a console script)
     ap = argparse.ArgumentParser()
     ap.add_argument("-c", "--config", action="append", required=True)
     ap.add_argument("-a", "--app", default="flylight")

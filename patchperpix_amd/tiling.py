@@ -962,7 +962,7 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         ring_z = 0
     if ring_z:
         thick = max(t[1] - t[0] for t in my_tiles)
-        if ring_z < thick + 2 * int(rad[0]) + 2 * (ps[0] - 1) + 4 or thick < ps[0] - 1:
+        if ring_z < thick + ring_margin(ps[0]) or thick < ps[0] - 1:
             raise ValueError("_ring_z = %d is too small for tiles of %d slices (or the tiles are thinner than "
                              "p - 1)" % (ring_z, thick))
         # column-major order: all z-tiles of one (y, x) column, bottom-up, then the next column
@@ -1661,12 +1661,20 @@ def consensus_work(shape, patchshape, n, ny, nx, ring=False):
     return float(z_sc) * ext[1][0] * ext[2][0] + float(z_pa) * ext[1][1] * ext[2][1]
 
 
+def ring_margin(pz):
+    """Slices a ring of rows needs beyond a tile's thickness: the radius on both sides, the pairs
+    pass's p - 1 source slices below and p - 1 mirrored slices above, four spare."""
+    pz = int(pz)
+    return 2 * (pz // 2) + 2 * (pz - 1) + 4
+
+
 def plan_ring(own_shape, patchshape, free_bytes, safety=0.6, copies=2.0, min_thick=16, gain=0.95):
     """(n_slabs, ny, nx, ring_z) for the z-sweep with a ring of rows (tiling.assemble, `_ring_z`), or
     None when it does not pay: columns of ny x nx tiles in y / x, the ring as many slices as the
     budget holds of a column's pairs box, tiles a multiple of 8 slices thick (the ranking kernel's
-    tiles of centres are 8 thick) with ring >= thick + 28; taken when S1's work falls below `gain`
-    x that of the best plain grid.  PPP_RING=0 switches it off."""
+    tiles of centres are 8 thick) with ring >= thick + ring_margin(pz) (28 at pz = 9: what
+    assemble() asks of `_ring_z`); taken when S1's work falls below `gain` x that of the best plain
+    grid.  PPP_RING=0 switches it off."""
     if os.environ.get("PPP_RING", "1") == "0":
         return None
     pz, py, px = [int(p) for p in patchshape]
@@ -1688,18 +1696,19 @@ def plan_ring(own_shape, patchshape, free_bytes, safety=0.6, copies=2.0, min_thi
         return consensus_work(own_shape, patchshape, n, ny, nx, ring=ring) / float(Z * Y * X) + 1.1 / rank_tail(n, ny, nx)
 
     best = None
+    margin = ring_margin(pz)
     for ny in range(1, min(Y, 8) + 1):
         for nx in range(1, min(X, 8) + 1):
             area = pairs_box_voxels((1, Y, X), (1, py, px), 1, ny, nx)
             slices = int(budget // (row_bytes * area))
-            top = min((slices - 28) // 8 * 8, -(-Z // 8) * 8)
+            top = min((slices - margin) // 8 * 8, -(-Z // 8) * 8)
             for thick in range(top, max(min_thick, pz - 1, 8) - 1, -8):
                 n = -(-Z // thick)
                 if n < 2:
                     continue
                 key = (cost(n, ny, nx, True), n * ny * nx)
                 if best is None or key < best[0]:
-                    best = (key, n, ny, nx, max(b - a for a, b in plan_slabs(Z, n)) + 28)
+                    best = (key, n, ny, nx, max(b - a for a, b in plan_slabs(Z, n)) + margin)
     if best is None or best[0][0] > gain * cost(*plain, False):
         return None
     return best[1], best[2], best[3], best[4]

@@ -418,8 +418,8 @@ def main(**kwargs):
     """Whole-volume driver (vote_instances.py:557-604): command-line arguments overridden by
     keyword arguments; ``affinities`` is one prediction file or a directory of ``*.hdf``
     files, otherwise ``<basedir>/<mode>/processed/<checkpoint>/*.hdf``."""
-    backend.tune_host_allocator(cli=__name__ == "__main__")
     from_cli = not kwargs
+    backend.tune_host_allocator(cli=from_cli or __name__ == "__main__")   # (no kwargs: argv drives it)
     required = kwargs['check_required'] if 'check_required' in kwargs else True
     args = vars(get_arguments(check_required=required, argv=None if from_cli else []))
     if kwargs:

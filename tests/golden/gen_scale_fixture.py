@@ -29,6 +29,11 @@ CASES = {
     "s96_p9": ((96, 96, 96), (9, 9, 9), (24, 24, 24)),
     # BASELINE config [1]'s patch and generator at 64^3
     "s64_p7": ((64, 64, 64), (7, 7, 7), (18, 18, 18)),
+    # BASELINE config [1] AT ITS STATED SIZE: 140^3, 7^3 (bench.py's flylight140_p7; round 6)
+    "f140_p7": ((140, 140, 140), (7, 7, 7), (18, 18, 18)),
+    # BASELINE config [0]'s image AT ITS STATED SIZE: one 696 x 520 image, 25 x 25 patches, kernel
+    # semantics (bench.py's worm2d_p25; round 6)
+    "w696x520_p25": ((1, 520, 696), (1, 25, 25), (1, 40, 40)),
 }
 
 

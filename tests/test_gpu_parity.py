@@ -390,10 +390,11 @@ def test_device_cover_matches_reference_goldens(golden, torch_cuda, monkeypatch)
         assert np.array_equal(sel.coords, g["cover_coords"]), mode
 
 
-@pytest.mark.parametrize("variant", ["sparse", "passes", "score_threshold", "p7"])
+@pytest.mark.parametrize("variant", ["sparse", "passes", "score_threshold", "p7", "tall_window"])
 def test_device_cover_matches_sequential_loop(variant, torch_cuda, monkeypatch):
     """Larger volumes and every rule of the loop: several pixel-threshold passes, overlap
-    centres, the score threshold break and the stop rule."""
+    centres, the score threshold break and the stop rule.  `tall_window`: pz * py = 143 window
+    rows -- more than the seven bits the 16-bit witness voxel of round 5 gave the row."""
     from patchperpix_amd import synth
     from patchperpix_amd.vote_instances import foreground_cover as fc
     from tests_flags import FLYLIGHT
@@ -405,6 +406,8 @@ def test_device_cover_matches_sequential_loop(variant, torch_cuda, monkeypatch):
         kw["score_threshold"] = 0.55
     elif variant == "p7":
         shape, ps, skw = (30, 44, 52), (7, 7, 7), dict(seed=62, cell=[12, 12, 12], noise=0.25)
+    elif variant == "tall_window":
+        shape, ps, skw = (36, 38, 20), (13, 11, 3), dict(seed=64, cell=[12, 11, 5], overlap_frac=0.02)
     c = synth.make_case(shape, ps, **skw)
     pred, overlap, mask, ranked, radslice, rad, _score = _cover_inputs(
         torch_cuda, c["pred"], c["foreground"], c["numinst"], ps, kw)
@@ -518,6 +521,20 @@ def test_consensus_out_of_range_operands_take_exact_divisions(torch_cuda):
     ov = 1 * (c["numinst"] > 1)
     cons_ref = orc.consensus(pred, ov, ps, **kw)
     o = _stage_outputs(torch_cuda, pred, ov, ps, kw)
+    assert np.array_equal(_bits(o["cons"]), _bits(orc.positive_planes(cons_ref, ps)))
+    # an INFINITE value at a centre that votes nothing (outside the interior / not foreground): the
+    # reference skips the centre (fillConsensusArray.cu:25-32); the exact path must select its
+    # centre factor, not multiply by it (inf * 0 = nan would poison the accumulators)
+    mid = int(np.prod(ps)) // 2
+    others = [r for r in range(pred.shape[0]) if r != mid]
+    pred[others[3], 0, 5, 10:30] = np.inf              # z = 0: never an interior centre
+    pred[others[7], 6, 0, 20:50] = np.inf              # y = 0
+    bgz, bgy, bgx = np.nonzero(pred[mid, 2:-2, 2:-2, 2:-2] < 0.5)
+    if len(bgz):                                       # interior, but not foreground
+        pred[others[11], bgz[0] + 2, bgy[0] + 2, bgx[0] + 2] = np.inf
+    cons_ref = orc.consensus(pred, ov, ps, **kw)
+    o = _stage_outputs(torch_cuda, pred, ov, ps, kw)
+    assert not np.isnan(o["cons"]).any()
     assert np.array_equal(_bits(o["cons"]), _bits(orc.positive_planes(cons_ref, ps)))
 
 

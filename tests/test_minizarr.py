@@ -16,7 +16,7 @@ from patchperpix_amd import minizarr as mz
                                                 (np.float32, (3, 7, 5), (3, 7, 5)),
                                                 (np.uint8, (100,), (32,)),
                                                 (np.uint32, (4, 6), (3, 4))])
-@pytest.mark.parametrize("compressor", ["default", None, {"id": "zlib", "level": 1},
+@pytest.mark.parametrize("compressor", ["default", None, {"id": "zlib", "level": 1}, {"id": "gzip", "level": 1},
                                         {"id": "blosc", "cname": "zstd", "clevel": 1, "shuffle": 1},
                                         {"id": "blosc", "cname": "zlib", "clevel": 1, "shuffle": 0}])
 def test_round_trip(tmp_path, dtype, shape, chunks, compressor):
@@ -198,3 +198,32 @@ def test_zarr_provider_works_ahead(tmp_path):
                               tiling.plan_slabs(a.shape[1], 1), ops=OracleOps(**kw), **kw)
     assert prov.boxes_prefetched >= 3 and np.asarray(want).max() > 1
     assert np.array_equal(np.asarray(got), np.asarray(want))
+
+
+def test_reference_example_store():
+    """The reference's own example store (experiments/flylight/JRC_SS05008-20160318_24_B2_crop.zip:
+    zarr v2 written by a real zarr / numcodecs, gzip level-1 chunks, `|u1` and `<u2`, an edge chunk on
+    the channel axis) -- the one file in its tree that pins the reader of SURVEY 8(f) row 2
+    (io_hdflike.py:111-120).  tests/golden/ref_zarr_fixture/ holds its metadata and six of its eight
+    chunks as DATA (tests/golden/gen_ref_zarr_fixture.py); shape / dtype / CRC-32 / sums were
+    computed there with Python's gzip module.  The chunks left out read as the fill value."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_zarr_fixture")
+    with open(os.path.join(here, "expected.json")) as f:
+        expected = json.load(f)
+    root = mz.open(os.path.join(here, "crop.zarr"), "r")
+    for key, want in expected.items():
+        a = root[key]
+        assert a.compressor == want["compressor"] == {"id": "gzip", "level": 1}
+        assert list(a.shape) == want["shape"] and a.dtype == np.dtype(want["dtype"]) and list(a.chunks) == want["chunks"]
+        full = np.array(a)
+        assert zlib.crc32(np.ascontiguousarray(full).tobytes()) == want["crc32"]
+        assert int(np.count_nonzero(full)) == want["nonzero"] and int(full.max()) == want["max"]
+        assert int(full.astype(np.int64).sum()) == want["sum"]
+        # a partial read across the chunk border on the channel axis, and read_into a caller's buffer
+        part = a[1:3, 10:40, 5:45, 0:50]
+        assert np.array_equal(part, full[1:3, 10:40, 5:45, 0:50])
+    # through the reference-named container (io_hdflike.py:111-120 opens zarr stores by suffix)
+    from patchperpix_amd.vote_instances import io_hdflike
+    with io_hdflike.open_container(os.path.join(here, "crop.zarr"), "r") as f:
+        gt = np.array(f["volumes/gt_instances"])
+    assert gt.shape == (3, 50, 50, 50) and gt.dtype == np.uint8 and set(np.unique(gt)) <= {0, 1, 2, 3}

@@ -168,7 +168,14 @@ def test_plan_ring(monkeypatch):
     assert r is not None
     n, ny, nx, ring = r
     thick = max(b - a for a, b in tiling.plan_slabs(512, n))
-    assert ring >= thick + 28 and thick % 8 == 0
+    assert ring >= thick + 28 and thick % 8 == 0 and tiling.ring_margin(9) == 28
+    # wider patches: the margin follows the patch (a fixed 28 failed assemble()'s
+    # own check `ring_z >= thick + 2 rad + 2 (pz - 1) + 4` for 11^3 and 13^3)
+    for p in (11, 13):
+        rr = tiling.plan_ring((384, 384, 384), (p, p, p), 120e9, safety=0.92, copies=2.0)
+        if rr is not None:
+            t = max(b - a for a, b in tiling.plan_slabs(384, rr[0]))
+            assert rr[3] >= t + 2 * (p // 2) + 2 * (p - 1) + 4
     # the ring of the column's pairs box fits the budget
     assert 2.0 * tiling.cons_cache_bytes((1, 1, 1), ps) * ring * tiling.pairs_box_voxels((1, 512, 512), (1, 9, 9), 1, ny, nx) <= 0.92 * 80e9
     assert tiling.consensus_work((512,) * 3, ps, n, ny, nx, ring=True) < 0.9 * tiling.consensus_work((512,) * 3, ps, *plain)
