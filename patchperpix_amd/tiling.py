@@ -94,6 +94,87 @@ class LocalComm:
     def all_gather_slabs(self, vol, ranges):
         return vol
 
+    def sendrecv(self, sends, recvs):
+        if sends or recvs:
+            raise ValueError("a single process has no peer")
+
+
+def exchange_halo(own, own_range, need_range, comm, z_axis=0, chunk_bytes=1 << 30):
+    """The halo exchange of the north star ("patch-radius halo exchanged over RCCL/xGMI"): a rank
+    holds the slices [own_range) of a volume along `z_axis` -- its part of a RESIDENT prediction
+    (C, z, Y, X), the U-Net's output as it stands on the GPU, or of a per-voxel field (z, Y, X) --
+    and needs [need_range) (its slabs grown by halo(patchshape), clipped).  Every rank's two ranges
+    are all-gathered; each pair of ranks moves the slices one owns and the other needs point to
+    point (`comm.sendrecv`: batch_isend_irecv -- xGMI links are pairwise, a halo concerns the two
+    or three ranks next to a boundary), `chunk_bytes` of the leading axes at a time (a z-range of
+    a channel-major block is strided: the staging copy stays bounded).  Returns the tensor of
+    [need_range) -- `own` itself when nothing is missing anywhere (no collective beyond the range
+    gather).  Reference analogue: block + margin loading, stitch_patch_graph.py:553-669."""
+    import torch
+    a, b = [int(v) for v in own_range]
+    na, nb = [int(v) for v in need_range]
+    if int(own.shape[z_axis]) != b - a:
+        raise ValueError("`own` holds %d slices, own_range says %d" % (int(own.shape[z_axis]), b - a))
+    if comm.world == 1:
+        if (na, nb) != (a, b):
+            raise ValueError("a single rank must hold all it needs")
+        return own
+    mine = torch.tensor([a, b, na, nb], dtype=torch.int64, device=own.device)
+    ranges = [tuple(int(v) for v in r) for r in comm.all_gather(mine).cpu().numpy()]
+    if all(r[2] >= r[0] and r[3] <= r[1] for r in ranges):
+        return own
+    if na > a or nb < b:
+        raise ValueError("need_range must contain own_range")
+    full_shape = list(own.shape)
+    full_shape[z_axis] = nb - na
+    full = torch.empty(full_shape, dtype=own.dtype, device=own.device)
+    full.narrow(z_axis, a - na, b - a).copy_(own)
+    covered = b - a
+    # (peer, global z0, z1) of what I send / receive, every rank deriving the same lists
+    sends, recvs = [], []
+    for r, (ra, rb, rna, rnb) in enumerate(ranges):
+        if r == comm.rank:
+            continue
+        for (lo, hi) in ((rna, min(rnb, ra)), (max(rna, rb), rnb)):       # what r misses, below / above its own
+            s0, s1 = max(lo, a), min(hi, b)
+            if s0 < s1:
+                sends.append((r, s0, s1))
+        for (lo, hi) in ((na, min(nb, a)), (max(na, b), nb)):             # what I miss ...
+            s0, s1 = max(lo, ra), min(hi, rb)                              # ... and r owns
+            if s0 < s1:
+                recvs.append((r, s0, s1))
+                covered += s1 - s0
+    if covered != nb - na:
+        raise ValueError("the ranks' own ranges do not cover [%d, %d)" % (na, nb))
+    lead = int(np.prod(own.shape[:z_axis])) if z_axis else 1
+    tail_bytes = int(np.prod(own.shape[z_axis + 1:])) * own.element_size()
+    # the thickest piece ANY pair of ranks moves: every rank cuts the channel axis into the same steps
+    thick = 1
+    for (ra, rb, _, _) in ranges:
+        for (_, _, qna, qnb) in ranges:
+            thick = max(thick, min(qnb, rb) - max(qna, ra))
+    thick = min(thick, max(rb - ra for ra, rb, _, _ in ranges))
+    if z_axis == 0:
+        steps = [(0, 1)]
+    else:
+        if z_axis != 1:
+            raise NotImplementedError("exchange_halo: z_axis 0 or 1")
+        per = max(1, int(chunk_bytes // max(1, thick * tail_bytes)))
+        steps = [(c0, min(lead, c0 + per)) for c0 in range(0, lead, per)]
+    moved = 0
+    for (c0, c1) in steps:
+        def cut(t, z0, z1, base):
+            v = t.narrow(z_axis, z0 - base, z1 - z0)
+            return v if z_axis == 0 else v[c0:c1]
+        out = [(r, cut(own, s0, s1, a).contiguous()) for r, s0, s1 in sends]
+        inn = [(r, torch.empty(cut(full, s0, s1, na).shape, dtype=own.dtype, device=own.device)) for r, s0, s1 in recvs]
+        comm.sendrecv(out, inn)
+        for (r, s0, s1), (_, buf) in zip(recvs, inn):
+            cut(full, s0, s1, na).copy_(buf)
+            moved += buf.numel() * buf.element_size()
+    backend.note_add("halo_exchange_bytes_received", moved)
+    return full
+
 
 def gather_lists(comm, t):
     """[t of rank 0, t of rank 1, ...] for 1-d (or [n, k]) tensors whose length differs between
@@ -247,6 +328,30 @@ class TorchDistComm:
             if r != self.rank:
                 vol[ra:rb] = recv[r, :rb - ra]
         return vol
+
+    def sendrecv(self, sends, recvs):
+        """sends / recvs: [(peer rank, contiguous tensor)] -- one batch of point-to-point transfers
+        (batch_isend_irecv; over RCCL a grouped ncclSend / ncclRecv on the xGMI link of each pair).
+        Both sides order a pair's messages by ascending global position, which the callers
+        guarantee by building both lists from the same all-gathered ranges."""
+        import torch
+        if not sends and not recvs:
+            return
+        if any(str(t.dtype) not in self._WIRE_OK for _, t in list(sends) + list(recvs)):
+            as_bytes = lambda items: [(p, t.view(torch.uint8)) for p, t in items]       # noqa: E731
+            return self.sendrecv(as_bytes(sends), as_bytes(recvs))
+        host = self.via_host and any(t.is_cuda for _, t in list(sends) + list(recvs))
+        to_dev = (not self.via_host) and any(not t.is_cuda for _, t in list(sends) + list(recvs))
+        conv = (lambda t: t.cpu()) if host else ((lambda t: t.cuda()) if to_dev else (lambda t: t))
+        s_buf = [(p, conv(t)) for p, t in sends]
+        r_buf = [(p, torch.empty_like(conv(t))) if (host or to_dev) else (p, t) for p, t in recvs]
+        ops = [self.dist.P2POp(self.dist.isend, t, p, self.group) for p, t in s_buf]
+        ops += [self.dist.P2POp(self.dist.irecv, t, p, self.group) for p, t in r_buf]
+        for w in self.dist.batch_isend_irecv(ops):
+            w.wait()
+        if host or to_dev:
+            for (_, dst), (_, src) in zip(recvs, r_buf):
+                dst.copy_(src.to(dst.device))
 
     def neighbour_min(self, items):
         """items: [(peer rank, tensor)].  Every tensor is replaced by the element-wise minimum
@@ -756,6 +861,34 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     oz0, oz1 = int(my_slabs[0][0]), int(my_slabs[-1][1])       # hull of the own slabs
     contiguous = all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
     need_lo, need_hi = max(0, oz0 - H), min(Z, oz1 + H)
+    if comm.world > 1 and contiguous and kw.get("_exchange_halo", True):
+        # A RESIDENT slab (and local fields) that lack the halo -- the U-Net's output as it stands on
+        # each GPU -- get it from the ranks that own it (exchange_halo: point to point over RCCL / xGMI).
+        # Every rank takes part in the decision: one MAX all-reduce of "I miss slices".
+        miss_p = (not provider) and (lo_p > need_lo or hi < need_hi)
+        miss_f = local_fields and (flo > need_lo or fhi < need_hi)
+        flag = torch.tensor([int(miss_p), int(miss_f)], dtype=torch.int32, device=ops.device)
+        any_p, any_f = [int(v) for v in comm.all_reduce_max(flag).cpu()]
+        if any_p and provider:
+            raise ValueError("halo exchange: every rank must hold a resident prediction slab")
+        with backend.host_timer("halo_exchange"):
+            if any_p:
+                own = pred_local.narrow(1, oz0 - lo, oz1 - oz0)
+                pred_local = exchange_halo(own, (oz0, oz1), (need_lo, need_hi), comm, z_axis=1)
+                lo = lo_p = need_lo
+                hi = need_hi
+            if any_f:
+                def with_halo(f):
+                    t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(_plain(f)))
+                    t = t.to(ops.device).narrow(0, oz0 - flo, oz1 - oz0)
+                    if t.dtype == torch.bool:
+                        t = t.to(torch.uint8)
+                    return exchange_halo(t, (oz0, oz1), (need_lo, need_hi), comm, z_axis=0)
+                foreground, mask_to_cover, numinst = with_halo(foreground), with_halo(mask_to_cover), with_halo(numinst)
+                flo, fhi = need_lo, need_hi
+                Zf = fhi - flo
+        if local_fields and not provider and (flo, fhi) != (lo, hi):
+            raise ValueError("local fields must cover the slices of pred_local")
     if flo > need_lo or fhi < need_hi or lo_p > need_lo or hi < need_hi:
         raise ValueError("this rank's slabs [%d, %d) need the slices [%d, %d)" % (oz0, oz1, need_lo, need_hi))
     fg_d = _field_u8(foreground, dev, torch)

@@ -216,9 +216,16 @@ Z = c["pred"].shape[1]
 slabs = tiling.plan_slabs(Z, int(os.environ.get("PPP_TEST_SLABS", "4")))
 mine = tiling.slabs_of_rank(slabs, rank, world)
 lo, hi = tiling.local_range(mine, Z, ps)
+fields = [c["foreground"].copy(), c["foreground"].copy(), c["numinst"]]
+no_halo = os.environ.get("PPP_TEST_NO_HALO", "0")
+if no_halo != "0":
+    # the U-Net's output as it stands on each rank: the OWN slices only; assemble() fetches the
+    # halo from the neighbours (tiling.exchange_halo).  "2": the per-voxel fields are local too
+    lo, hi = mine[0][0], mine[-1][1]
+    if no_halo == "2":
+        fields = [f[lo:hi].copy() for f in fields]
 pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi]))   # halo'd slab only
-inst, fg = tiling.assemble(pred_local, lo, c["foreground"].shape, c["foreground"].copy(),
-                           c["foreground"].copy(), c["numinst"], ps, mine,
+inst, fg = tiling.assemble(pred_local, lo, c["foreground"].shape, fields[0], fields[1], fields[2], ps, mine,
                            comm=tiling.TorchDistComm(), ops=OracleOps(**kw), _cover_chunk=700, **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 from patchperpix_amd import backend
@@ -236,12 +243,18 @@ dist.destroy_process_group()
     (2, 2, {"select_patches_for_sparse_data": False, "skipThinCover": False}),
     (2, 2, {"_empty_top": True}),
     # every rank fills a consensus cache over its own block + halo (two tiles per rank)
-    (4, 2, {"_cons_cache": True})])
+    (4, 2, {"_cons_cache": True}),
+    # round 6, the north star's halo exchange: every rank holds its OWN slices of the prediction
+    # only and receives the patch-radius halo from its neighbours point to point; three ranks
+    # (the middle one has two neighbours); local per-voxel fields as well
+    (2, 2, {"_no_halo": "1"}), (3, 3, {"_no_halo": "1"}), (3, 3, {"_no_halo": "2"})])
 def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypatch):
     import json
     extra = dict(extra)
     if extra.pop("_empty_top", False):
         monkeypatch.setenv("PPP_TEST_EMPTY_TOP", "1")     # (inherited by the workers)
+    no_halo = extra.pop("_no_halo", "0")
+    monkeypatch.setenv("PPP_TEST_NO_HALO", no_halo)
     c, ps, kw = make_case()
     kw.update(extra)
     ref = whole_volume(c, ps, kw)
@@ -260,6 +273,45 @@ def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypa
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
         assert notes[0] == world and notes[1] > 0
         assert notes[3] == (1 if extra.get("_cons_cache") else 0)
+
+
+HALO_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from patchperpix_amd import tiling
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+comm = tiling.TorchDistComm()
+Z, H = 23, 7
+cuts = [0, 3, 9, 12, 23][:world] + [Z]
+a, b = cuts[rank], cuts[rank + 1]
+na, nb = max(0, a - H), min(Z, b + H)
+vol = torch.arange(5 * Z * 4 * 6, dtype=torch.float32).reshape(5, Z, 4, 6).to(torch.float16)
+got = tiling.exchange_halo(vol[:, a:b].contiguous(), (a, b), (na, nb), comm, z_axis=1, chunk_bytes=600)
+assert got.shape == (5, nb - na, 4, 6) and torch.equal(got, vol[:, na:nb]), rank
+fld = (torch.arange(Z * 4 * 6) % 251).to(torch.int16).reshape(Z, 4, 6)          # (no wire type: bytes)
+got = tiling.exchange_halo(fld[a:b].contiguous(), (a, b), (na, nb), comm, z_axis=0)
+assert torch.equal(got, fld[na:nb]), rank
+# nothing missing anywhere: the tensor itself comes back
+same = tiling.exchange_halo(vol[:, na:nb].contiguous(), (na, nb), (na, nb), comm, z_axis=1)
+assert same.shape[1] == nb - na
+open(os.path.join({out!r}, "ok%d" % rank), "w").write("ok")
+dist.destroy_process_group()
+"""
+
+
+def test_exchange_halo_gloo(tmp_path):
+    """tiling.exchange_halo on four ranks whose slabs (3, 6, 3 and 11 slices) are thinner than the
+    halo of 7: a rank receives from up to three others, channel-chunked (600-byte budget: one
+    channel per step), for a float16 (C, z, Y, X) block and an int16 field (moved as bytes)."""
+    script = tmp_path / "halo_worker.py"
+    script.write_text(HALO_WORKER.format(repo=REPO, out=str(tmp_path)))
+    _port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+                           "--master-addr", "127.0.0.1", "--master-port", _port, str(script)], env=env, timeout=600)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(4))
 
 
 @pytest.mark.gpu
