@@ -405,7 +405,18 @@ class Workload:
             labels_e = device_labels(torch, eshape, cell, seed=0, z_offset=glo)
             pred = backend.synth_pred(labels_e, Pe, seed=0, f16=True,
                                       voxel_offset=glo * shape[1] * shape[2])
+            # PPP_BENCH_HALO=exchange (default): a rank PRODUCES its own slices only -- the U-Net's output
+            # written into the middle of a halo-sized buffer -- and every step fetches the patch-radius
+            # halo from its neighbours, in place, inside tiling.assemble (`_refresh_halo`:
+            # exchange_halo, grouped point-to-point sends / receives over RCCL / xGMI; the north star's
+            # wording).  The halo slices start out as zeros.  "generate": every rank generates its slab
+            # with the halo (no prediction traffic; up to round 5)
+            self.halo_mode = os.environ.get("PPP_BENCH_HALO", "exchange")
             self.pred = pred[:, lo - glo:hi - glo].contiguous()
+            if self.halo_mode == "exchange":
+                self.pred[:, :mine[0][0] - lo] = 0
+                self.pred[:, mine[-1][1] - lo:] = 0
+                extra["_refresh_halo"] = True
             del labels_e, pred
             # the fields of the rank's own slices only: the global stage runs sharded
             fg = (device_labels(torch, (hi - lo, shape[1], shape[2]), cell, seed=0, z_offset=lo) != 0).to(torch.uint8)
@@ -438,6 +449,13 @@ class Workload:
                          "z_slabs": [list(m) for m in mine], "yx_tiles": list(yx), "cons_cache": bool(use_cache),
                          "ring_z": ring_z}
             self.tiles = (len(mine), yx[0], yx[1])
+            self.plan["prediction_halo"] = self.halo_mode
+            # the result stays where it is made: every rank returns its own z-range (the instance map
+            # of 1024^3 as uint32 is 4.3 GB per rank and all-gather); the line's checksum is the
+            # partition-independent crc of the per-slice crcs.  PPP_BENCH_GATHER=1: whole map everywhere
+            self.own_range = (oz0, oz1)
+            self.gather = os.environ.get("PPP_BENCH_GATHER", "0") == "1"
+            extra.setdefault("_gather_result", self.gather)
 
             def step(flag_kw=kw):
                 inst, _ = tiling.assemble(self.pred, lo, gshape, fg, fg.clone(), fg, ps, mine,
@@ -478,7 +496,19 @@ def main():
                     help="force the number of z-slabs of the single-GPU tiled path")
     ap.add_argument("--yx", type=int, nargs=2, default=None, metavar=("NY", "NX"),
                     help="cut every z-slab into NY x NX tiles (single-GPU tiled path)")
+    ap.add_argument("--dry-run-plan", action="store_true",
+                    help="no GPU needed: print what --gpus N ranks would hold and move for the workload "
+                         "(z-ranges, halo, tile / ring / cache plan, bytes per collective) and exit")
     args = ap.parse_args()
+    if args.dry_run_plan:
+        from patchperpix_amd import tiling
+        name = args.workload or DEFAULT_WORKLOAD
+        shape, ps, _cell = WORKLOADS[name]
+        plan = tiling.dry_run_plan(shape, ps, args.gpus, provider=name in PROVIDER_WORKLOADS,
+                                   halo_mode=os.environ.get("PPP_BENCH_HALO", "exchange"),
+                                   result_gather=os.environ.get("PPP_BENCH_GATHER", "0") == "1")
+        print(json.dumps(dict(plan, workload=name)))
+        return
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -608,9 +638,12 @@ def main():
     backend.EVENTS = {}
     backend.NOTES.clear()
     barrier()
+    # The timed loop runs WITHOUT per-stage device syncs (round 6): the stage breakdown
+    # (`stage_wall_ms`) comes from ONE extra step after it, with a sync around every stage.
+    # PPP_BENCH_STAGES=inline: the syncs inside the timed loop, as up to round 5; =0: no breakdown.
+    stages_mode = os.environ.get("PPP_BENCH_STAGES", "1")
     host_times = None
-    if os.environ.get("PPP_BENCH_STAGES", "1") == "1":
-        # per-stage wall clock (adds a device sync around every stage)
+    if stages_mode == "inline":
         backend.HOST_TIMES = host_times = {}
     t0 = time.perf_counter()
     step_ends = []
@@ -625,6 +658,20 @@ def main():
     notes = dict(backend.NOTES)
     backend.EVENTS = None
     backend.HOST_TIMES = None
+    stage_steps = args.steps
+    staged_step_ms = None
+    if stages_mode not in ("0", "inline"):
+        backend.HOST_TIMES = host_times = {}
+        keep_notes = dict(backend.NOTES)
+        barrier()
+        t1 = time.perf_counter()
+        inst = step()
+        barrier()
+        staged_step_ms = agree_max(time.perf_counter() - t1) * 1e3
+        backend.HOST_TIMES = None
+        backend.NOTES.clear()
+        backend.NOTES.update(keep_notes)
+        stage_steps = 1
 
     C = int(np.prod(ps))
     # per-rank HBM footprint: the allocator's peak (prediction / tile, consensus pool, lists, work
@@ -699,12 +746,35 @@ def main():
     # returns its own z-range only and the per-slice values are gathered.
     arr = np.ascontiguousarray(inst)
     slice_crc = np.array([zlib.crc32(arr[z].tobytes()) for z in range(arr.shape[0])], dtype=np.int64)
-    if dist is not None and getattr(wl, "mode", "") == "provider" and arr.shape[0] != gshape[0]:
+    if dist is not None and getattr(wl, "own_range", None) is not None and arr.shape[0] != gshape[0]:
         sizes = [None] * world
         dist.all_gather_object(sizes, (int(wl.own_range[0]), slice_crc.tolist()))
         slice_crc = np.array([c for _, cs in sorted(sizes) for c in cs], dtype=np.int64)
     volume_crc = int(zlib.crc32(slice_crc.tobytes())) if len(slice_crc) == gshape[0] else None
+    n_found = count_instances(torch, inst)
+    own_only = dist is not None and arr.shape[0] != gshape[0]
+    if own_only:
+        # distinct ids over all ranks (ids are global; a rank's slab holds a few thousand)
+        ids = torch.unique(torch.from_numpy(arr.astype(np.int64)).cuda()).cpu().tolist()
+        all_ids = [None] * world
+        dist.all_gather_object(all_ids, ids)
+        n_found = len(set(i for part in all_ids for i in part if i != 0))
+    # per-rank wall clock of every stage (the extra staged step): max / min over the ranks, so that
+    # a scaling curve explains itself -- the replicated stages show as max = min = the 1-rank time
+    stage_ranks = None
+    if dist is not None and host_times is not None:
+        mine_ms = {k: float(np.sum(v) / stage_steps * 1e3) for k, v in host_times.items()}
+        every = [None] * world
+        dist.all_gather_object(every, mine_ms)
+        keys = sorted(set(k for d in every for k in d))
+        stage_ranks = {k: {"max": round(max(d.get(k, 0.0) for d in every), 1),
+                           "min": round(min(d.get(k, 0.0) for d in every), 1)} for k in keys}
     plan = getattr(wl, "plan", None)
+    if plan is None and world == 1 and backend.LAST_PLAN is not None:
+        # N = 1: the plan to_instance_seg made for the timed steps (tiles, ring, cache, free HBM)
+        plan = dict(backend.LAST_PLAN, rank=0, ring_z_used=notes.get("ring_z", 0),
+                    ring_z_scores_pass=notes.get("ring_z_scores", 0), rank_group=notes.get("rank_group", 0),
+                    cons_cache_gb=notes.get("cons_cache_gb"))
     if dist is not None and plan is not None:
         plans = [None] * world
         dist.all_gather_object(plans, plan)
@@ -724,8 +794,8 @@ def main():
                        "pred_dtype": "f16 resident, widened to f32 in registers",
                        "flag_set": args.flags, "flags": flagsets.describe(kw),
                        "instance_ids": wl.ids, "foreground_fraction": wl.fg_fraction,
-                       "instances_found": count_instances(torch, inst),
-                       "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())),
+                       "instances_found": n_found,
+                       "instances_crc32": int(zlib.crc32(np.ascontiguousarray(inst).tobytes())) if not own_only else None,
                        "instances_slice_crc32": volume_crc,
                        "global_volume": list(gshape),
                        "parallelism": ("z-ranges x%d ranks" % n_gpus) + (
@@ -739,8 +809,9 @@ def main():
                                           "head as float32 library GEMMs, tail as the fused MFMA kernel")
                                       if wl.mode == "decode" else
                                       "generated tile by tile (provider): largest tile %.1f GB" % (wl.provider.bytes_max / 1e9)),
-                       "result": "whole instance map on every rank" if wl.mode != "provider" else
-                                 "own z-range per rank (instances_found / crc32: rank 0's range %s)" % (list(wl.own_range),),
+                       "result": "whole instance map on every rank" if not own_only else
+                                 "own z-range per rank (instances_slice_crc32: crc of the per-slice crcs of all ranks; "
+                                 "instances_found: distinct ids over all ranks)",
                        "per_rank_peak_hbm_gb": peak_gb,
                        "ranks": world, "rccl_ranks": collective_ranks if not one_gpu else None,
                        "collective_ranks": collective_ranks, "transport": transport,
@@ -753,8 +824,14 @@ def main():
             **({"stage_lists_ms": {k: [1e3 * x for x in v] for k, v in (host_times or {}).items()}}
                if os.environ.get("PPP_BENCH_DUMP_STAGES") else {}),
             "kernel_ms": {k: float(np.sum(v) / args.steps) for k, v in ev.items()},
-            "stage_wall_ms": {k: float(np.sum(v) / args.steps * 1e3)
+            "stage_wall_ms": {k: float(np.sum(v) / stage_steps * 1e3)
                               for k, v in (host_times or {}).items()},
+            "stage_wall_ms_ranks": stage_ranks,
+            "stage_wall_from": ("the timed steps (a device sync around every stage inside the timed loop)"
+                                if stages_mode == "inline" else
+                                "one extra step after the timed loop with a device sync around every stage "
+                                "(%.0f ms; the timed steps run without those syncs)" % staged_step_ms
+                                if staged_step_ms is not None else None),
             "workload_stats": {k: (v // args.steps if k in per_step else v) for k, v in notes.items()},
         }
         if config2 is not None:

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define PPP_ABI_VERSION 4
+#define PPP_ABI_VERSION 5
 
 enum ppp_error {
     PPP_OK = 0,
@@ -102,6 +102,11 @@ typedef struct ppp_params {
                               tile still needs; read by ppp_rank_patches_vm and
                               ppp_patch_graph_by_patch*.  (The reference holds the whole array in
                               managed memory: consensus_array.py:99-106.)                         */
+    int32_t pred_clean;    /* 1: the caller KNOWS (ppp_pred_check said so for the buffer it passes as
+                              d_pred) that every prediction value lies in [0, 1] and none falls
+                              between the two class tests (with the shipped rule: none equals TH);
+                              S1 then takes a shorter classification of its operands -- same bits.
+                              0 (or anything else): not known; every kernel serves any input.      */
 } ppp_params;
 
 /* --- library / device ------------------------------------------------------------- */
@@ -573,6 +578,16 @@ int ppp_synth_pred(const int32_t *d_labels, void *d_pred, int pred_dtype, uint32
  * (kernels calib_read_kernel / calib_write_kernel).                                          */
 int ppp_counter_calibration(const void *d_src, int src_dtype, int64_t n_read, float *d_dst, int64_t n_write,
                             void *stream);
+
+/* Is a prediction buffer "clean" (ppp_params.pred_clean)?  One streaming read of n_values
+ * contiguous values: *d_unclean (device int32, overwritten) = 0 when every value lies in [0, 1]
+ * (as a bit pattern: no negative zero, inf or nan) and is either > TH or < BG of p (the two class
+ * tests of fillConsensusArray.cu:44-47, 94-124; with the shipped rule the only value in between is
+ * TH itself); bit 0 set: a value outside [0, 1]; bit 1: a value in the dead zone.  The caller reads
+ * the flag and sets p->pred_clean = 1 for calls on THAT buffer while its contents stay unchanged.
+ * The reference has no such notion: its kernels branch per operand (fillConsensusArray.cu:44-60). */
+int ppp_pred_check(const void *d_pred, int pred_dtype, int64_t n_values, int32_t *d_unclean, const ppp_params *p,
+                   void *stream);
 
 /* The same generator for a BOX of a larger volume (tile-wise generation, BASELINE config [3]:
  * a rank of the 1024^3 workload holds one tile + halo of the prediction at a time).

@@ -17,7 +17,7 @@ F32, F16 = 0, 1
 BG_INV_TH, BG_HALF_TH, BG_LESS_THAN_TH = 0, 1, 2
 VAL_COUNT, VAL_PROB_PRODUCT, VAL_NORM_PROB_PRODUCT = 0, 1, 2
 CONS_COMPACT, CONS_REFERENCE, CONS_VOXEL_MAJOR = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 NONE_KEY = 0xFFFFFFFF
 NONE_KEY64 = 1 << 62      # PPP_LABEL_NONE_KEY (streaming labels, int64 keys)
 PAIR_KEY_FAR = 0x7FFFFFFFFFFFFFFF   # PPP_PAIR_KEY_FAR
@@ -41,7 +41,10 @@ class Params(ctypes.Structure):
                 ("norm_aff", ctypes.c_int32), ("cons_layout", ctypes.c_int32),
                 ("cons_box", Box),
                 ("origin_z", ctypes.c_int32), ("origin_y", ctypes.c_int32),
-                ("origin_x", ctypes.c_int32), ("ring_z", ctypes.c_int32)]
+                ("origin_x", ctypes.c_int32), ("ring_z", ctypes.c_int32),
+                # 1: ppp_pred_check found the buffer passed as `pred` clean (S1's short classification);
+                # 2 (this layer only; the library reads "not 1"): checked, not clean; 0: not checked
+                ("pred_clean", ctypes.c_int32)]
 
     @property
     def shape(self):
@@ -61,6 +64,8 @@ _LIB = None
 _SIGNATURES = {
     # name: (restype, argtypes)
     "ppp_abi_version": (ctypes.c_int, []),
+    "ppp_pred_check": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_last_error": (ctypes.c_char_p, []),
     "ppp_consensus_kernel_name": (ctypes.c_char_p, []),
     "ppp_reload_env": (None, []),
@@ -409,6 +414,7 @@ class host_timer:
 
 
 NOTES = {}
+LAST_PLAN = None    # the memory plan of the last to_instance_seg call that made one (vote_instances.py)
 
 
 def note(key, value):
@@ -503,6 +509,41 @@ def to_device_pred(pred, device="cuda", keep_f16=True):
 # ----------------------------------------------------------------------------------------
 # device stages
 # ----------------------------------------------------------------------------------------
+_CHECK_FLAG = {}
+
+
+def pred_check(pred, P):
+    """ppp_pred_check over the whole (contiguous) prediction tensor: 1 when every value lies in [0, 1]
+    and none sits between the two class tests of P (with the shipped rule: none equals the threshold),
+    2 otherwise -- the value of ppp_params.pred_clean for calls on THIS tensor while it is unchanged.
+    One streaming read (196 GB at 512^3 / 9^3: 50 ms per volume) and one device -> host copy of the
+    flag.  PPP_S1_CLEAN=0: never asked (returns 2)."""
+    torch = _torch()
+    if os.environ.get("PPP_S1_CLEAN", "1") == "0" or not torch.is_tensor(pred) or not pred.is_cuda \
+            or not pred.is_contiguous():
+        return 2
+    key = str(pred.device)
+    if key not in _CHECK_FLAG:
+        _CHECK_FLAG[key] = torch.zeros((1,), dtype=torch.int32, device=pred.device)
+    flag = _CHECK_FLAG[key]
+    with _timed("pred_check"):
+        check(lib().ppp_pred_check(_dev_ptr(pred), pred_dtype_code(pred), int(pred.numel()), _dev_ptr(flag),
+                                   ctypes.byref(P), _stream()))
+    bad = int(flag.item())
+    note("pred_unclean_bits", bad)
+    return 1 if bad == 0 else 2
+
+
+def with_pred_clean(pred, P):
+    """P with pred_clean decided (a copy when it was not): callers that pass the same tensor to many
+    S1 launches (tiling.assemble: once per frame) decide once; a direct call decides per call."""
+    if P.pred_clean != 0:
+        return P
+    Q = P.copy()
+    Q.pred_clean = pred_check(pred, P)
+    return Q
+
+
 def consensus(pred, overlap, P, want_count=False, out=None, open_rows=False):
     """S1.  Returns cons (and count) as device float32 tensors shaped
     [planes, bz, by, bx] (compact), [bz, by, bx, W] (voxel-major) or [NSZ, NSY, NSX, Z, Y, X]
@@ -511,6 +552,7 @@ def consensus(pred, overlap, P, want_count=False, out=None, open_rows=False):
     caching allocator until a tile that fits on paper no longer does)."""
     torch = _torch()
     L = lib()
+    P = with_pred_clean(pred, P)
     if P.cons_layout == CONS_REFERENCE:
         shape = (2 * P.pz if P.pz > 1 else 1, 2 * P.py, 2 * P.px, P.Z, P.Y, P.X)
     elif P.cons_layout == CONS_VOXEL_MAJOR:
@@ -1059,6 +1101,7 @@ def consensus_part(pred, overlap, P, part, out):
     `out`, a buffer indexed by the whole P.cons_box (COMPACT planes or open VOXEL_MAJOR rows)."""
     b = Box(*[int(v) for v in part])
     note_add("s1_base_voxels", int(np.prod(b.shape())))
+    P = with_pred_clean(pred, P)
     with _timed("consensus"):
         check(lib().ppp_consensus_part(_dev_ptr(pred), pred_dtype_code(pred), _dev_ptr(overlap), _dev_ptr(out),
                                        ctypes.byref(P), ctypes.byref(b), _stream()))

@@ -97,6 +97,7 @@ int make_geo(const ppp_params *p, ppp::Geo *G) {
     if (p->ring_z < 0 || (p->ring_z > 0 && (g.layout != PPP_CONS_VOXEL_MAJOR || g.bZ > p->ring_z || p->origin_z < 0)))
         return fail(PPP_ERR_INVALID_ARG, "ring_z: VOXEL_MAJOR rows only, cons_box at most ring_z slices thick");
     g.ring = p->ring_z;
+    g.pred_clean = p->pred_clean == 1 ? 1 : 0;
     *G = g;
     return PPP_OK;
 }
@@ -713,6 +714,17 @@ int ppp_counter_calibration(const void *d_src, int src_dtype, int64_t n_read, fl
     PPP_TRY(need_device());
     hipError_t e = ppp::launch_counter_calibration(d_src, src_dtype, n_read, d_dst, n_write, (hipStream_t)stream);
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_counter_calibration");
+}
+
+int ppp_pred_check(const void *d_pred, int pred_dtype, int64_t n_values, int32_t *d_unclean, const ppp_params *p,
+                   void *stream) {
+    ppp::Geo G;
+    PPP_TRY(make_geo(p, &G));
+    PPP_TRY(check_dtype(pred_dtype));
+    if (!d_unclean || n_values < 0 || (n_values > 0 && !d_pred)) return fail(PPP_ERR_INVALID_ARG, "bad argument");
+    PPP_TRY(need_device());
+    hipError_t e = ppp::launch_pred_check(d_pred, pred_dtype, n_values, G, d_unclean, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_pred_check");
 }
 
 int ppp_decode_tail(const float *d_x, int64_t n, int32_t fmaps, int32_t side, const float *d_w1, float b1,

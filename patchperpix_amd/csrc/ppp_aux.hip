@@ -203,4 +203,72 @@ hipError_t launch_counter_calibration(const void *src, int dtype, long long n_re
     return hipGetLastError();
 }
 
+// ---- ppp_pred_check: is the prediction "clean" for S1's short classification? -------------------
+// One streaming pass (16-byte loads) over a contiguous prediction buffer: *unclean |= 1 when a value
+// lies outside [0, 1] as a bit pattern (negative, -0, > 1, inf, nan), |= 2 when a value is neither
+// > TH nor < BG (with the shipped rule: exactly 0.5 -- an operand that votes nowhere,
+// fillConsensusArray.cu:44-47, 94-124).
+template <typename T> struct PredBits;
+template <> struct PredBits<__half> {
+    static constexpr int PER16 = 8;
+    static __device__ __forceinline__ unsigned bits(unsigned short h) { return h; }
+    static constexpr unsigned ONE = 0x3C00u;
+    static __device__ __forceinline__ float val(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+};
+template <typename T>
+__device__ __forceinline__ unsigned pred_check_one(float v, unsigned bits, unsigned one, float th_gt, float bg_lt) {
+    return (bits > one ? 1u : 0u) | ((!(v > th_gt) && !(v < bg_lt)) ? 2u : 0u);
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+    pred_check_kernel(const T *__restrict__ src, const long long n, const float th_gt, const float bg_lt,
+                      int *__restrict__ unclean) {
+    unsigned bad = 0u;
+    const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    if constexpr (sizeof(T) == 2) {
+        // head up to the first 16-byte boundary, body as uint4, tail
+        const long long head = min(n, (long long)(((16 - ((uintptr_t)src & 15)) & 15) / 2));
+        const unsigned short *s16 = reinterpret_cast<const unsigned short *>(src);
+        for (long long i = tid; i < head; i += nth) bad |= pred_check_one<T>(PredBits<__half>::val(s16[i]), s16[i], 0x3C00u, th_gt, bg_lt);
+        const long long nv = (n - head) / 8;
+        const uint4 *s128 = reinterpret_cast<const uint4 *>(s16 + head);
+        for (long long i = tid; i < nv; i += nth) {
+            const uint4 q = s128[i];
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned short a = (unsigned short)(w[k] & 0xFFFFu), b = (unsigned short)(w[k] >> 16);
+                bad |= pred_check_one<T>(PredBits<__half>::val(a), a, 0x3C00u, th_gt, bg_lt);
+                bad |= pred_check_one<T>(PredBits<__half>::val(b), b, 0x3C00u, th_gt, bg_lt);
+            }
+        }
+        for (long long i = head + nv * 8 + tid; i < n; i += nth) bad |= pred_check_one<T>(PredBits<__half>::val(s16[i]), s16[i], 0x3C00u, th_gt, bg_lt);
+    } else {
+        const long long head = min(n, (long long)(((16 - ((uintptr_t)src & 15)) & 15) / 4));
+        const unsigned *s32 = reinterpret_cast<const unsigned *>(src);
+        for (long long i = tid; i < head; i += nth) bad |= pred_check_one<T>(__uint_as_float(s32[i]), s32[i], 0x3F800000u, th_gt, bg_lt);
+        const long long nv = (n - head) / 4;
+        const uint4 *s128 = reinterpret_cast<const uint4 *>(s32 + head);
+        for (long long i = tid; i < nv; i += nth) {
+            const uint4 q = s128[i];
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= pred_check_one<T>(__uint_as_float(w[k]), w[k], 0x3F800000u, th_gt, bg_lt);
+        }
+        for (long long i = head + nv * 4 + tid; i < n; i += nth) bad |= pred_check_one<T>(__uint_as_float(s32[i]), s32[i], 0x3F800000u, th_gt, bg_lt);
+    }
+    if (__ballot(bad != 0u) != 0ull) {
+        for (int o = 32; o > 0; o >>= 1) bad |= (unsigned)__shfl_xor((int)bad, o);
+        if ((threadIdx.x & 63) == 0) atomicOr(unclean, (int)bad);
+    }
+}
+hipError_t launch_pred_check(const void *pred, int dtype, long long n, const Geo &G, int *unclean, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(unclean, 0, sizeof(int), s);
+    if (e != hipSuccess || n <= 0) return e;
+    const dim3 grid(256 * 16), block(256);
+    if (dtype == PPP_F16) pred_check_kernel<__half><<<grid, block, 0, s>>>((const __half *)pred, n, G.th_gt, G.bg_lt, unclean);
+    else pred_check_kernel<float><<<grid, block, 0, s>>>((const float *)pred, n, G.th_gt, G.bg_lt, unclean);
+    return hipGetLastError();
+}
+
 }  // namespace ppp

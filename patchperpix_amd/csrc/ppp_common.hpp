@@ -39,6 +39,7 @@ struct Geo {
     // box the output buffer is indexed by); the whole cons box unless ppp_consensus_part asks
     int cz0, cy0, cx0, cZ, cY, cX;
     int ring;           // voxel-major rows in a ring of `ring` z-slices (0: the plain box), ppp_params.ring_z
+    int pred_clean;     // 1: every prediction value in [0, 1] and != TH (ppp_params.pred_clean, ppp_pred_check)
 };
 
 // A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch

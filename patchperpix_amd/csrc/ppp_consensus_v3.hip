@@ -316,7 +316,13 @@ __device__ __forceinline__ float ldf_at3(const T *base, unsigned byte_off) {
     return ldf(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off), 0);
 }
 
-template <typename T, int PX, bool FLAT>
+// CLEAN (ppp_params.pred_clean, established by ppp_pred_check): every prediction value lies in
+// [0, 1] (as a bit pattern: no negative zero, no nan) and none equals the threshold 0.5.  Then
+// [v > 0.5] + [v < 0.5] = 1 and the classification of an operand is t = v - [v < 0.5], its code
+// 1 + 255 [v < 0.5]: two packed operations per "about u" pair and three per "about w" pair instead
+// of four and five, no range check of the staged values (four integer maxima per staging iteration)
+// and no exact path in the kernel -- 12 instead of 24 vector instructions per staging iteration.
+template <typename T, int PX, bool FLAT, bool CLEAN>
 __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX))
     consensus_v3_kernel(const T *__restrict__ pred, const uint8_t *__restrict__ ov,
                         float *__restrict__ cons, float *__restrict__ cnt_out, const Geo G,
@@ -547,6 +553,37 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
 #pragma unroll
             for (int it = 0; it < NIT; ++it)       // (the widening stays here, not next to the load)
                 asm volatile("" : "+v"(ra[0][it]), "+v"(ra[1][it]), "+v"(rb[0][it]), "+v"(rb[1][it]));
+            bool any_big = false;
+            if constexpr (CLEAN) {
+                const v2f c255 = splat(255.0f), one = splat(1.0f);
+#pragma unroll
+                for (int i0 = 0; i0 < NIT; i0 += CG) {
+                    v2f va[CG], vb[CG], ha[CG], hbb[CG], ta[CG], tb[CG], cc[CG];
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) {
+                        va[q] = (v2f){widen<T>(ra[0][i0 + q]), widen<T>(ra[1][i0 + q])};
+                        vb[q] = (v2f){widen<T>(rb[0][i0 + q]), widen<T>(rb[1][i0 + q])};
+                    }
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) ha[q] = pk_fma_clamp(va[q], nbig26, hb);
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) hbb[q] = pk_fma_clamp(vb[q], nbig26, hb);
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) ta[q] = va[q] - ha[q];
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) tb[q] = vb[q] - hbb[q];
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) cc[q] = pk_fma(hbb[q], c255, one);
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) if (i0 + q < NIT) {
+                        const int e = (i0 + q) * 64 + lane;
+                        const uint32_t code = (uint32_t)cc[q].x | ((uint32_t)cc[q].y << 16);
+                        at[e] = ta[q];
+                        if constexpr (SPLIT) { bt2[e] = tb[q]; ct[e] = code; }
+                        else bt[e] = (v4f){tb[q].x, tb[q].y, __uint_as_float(code), 0.0f};
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i0 = 0; i0 < NIT; i0 += CG) {
                 v2f va[CG], vb[CG], ga[CG], ha[CG], gb[CG], hbb[CG], sa[CG], sbb[CG], ta[CG], tb[CG], cc[CG];
@@ -587,7 +624,7 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             // a value outside [0, 1] (as an unsigned bit pattern: > 1.0f, negative, inf, nan) sends
             // the tile down the exact path: classification by compares (nan -> unclassified, no
             // 0 * inf), votes with compares and the double division
-            const bool any_big = __ballot(bigmax > 0x3F800000u) != 0ull;
+            any_big = __ballot(bigmax > 0x3F800000u) != 0ull;
             if (any_big) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -607,6 +644,7 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
                     else bt[e] = (v4f){tb.x, tb.y, __uint_as_float(code), 0.0f};
                 }
             }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- prefetch the next tile; its latency hides behind this tile's votes
@@ -618,10 +656,10 @@ __global__ void __launch_bounds__(64 * PPP_S1V3_WAVES(PX), PPP_S1V3_MINWAVES(PX)
             const v2f *ib2 = bt2 + (SPLIT ? pos_l : 0);
             const uint32_t *ic = ct + (SPLIT ? pos_l : 0);
             const v2f *icf = cf + pos_l;
-            if (!any_big) {
+            if (CLEAN || !any_big) {
                 if (row0) tile_votes3<PX, K::NC, true, false>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
                 else tile_votes3<PX, K::NC, false, false>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
-            } else {
+            } else if constexpr (!CLEAN) {
                 if (row0) tile_votes3<PX, K::NC, true, true>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
                 else tile_votes3<PX, K::NC, false, true>(ia, icf, ib, ib2, ic, G.th2, G.den, acc, tc);
             }
@@ -759,7 +797,7 @@ hipError_t launch_vm_zero_faces(float *S, const Geo &G, hipStream_t s) {
     return launch_vm_zero(S, G, (G.pz - 1) * G.wy + G.py, s);
 }
 
-template <typename T, int PX, bool FLAT>
+template <typename T, int PX, bool FLAT, bool CLEAN>
 static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, float *cnt,
                              const Geo &G, hipStream_t s) {
     const int n_rows = (G.pz - 1) * G.wy + G.py;
@@ -775,7 +813,7 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
         const hipError_t ez = launch_vm_zero(cons, G, n_rows, s);
         if (ez != hipSuccess) return ez;
     }
-    consensus_v3_kernel<T, PX, FLAT><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), 0, s>>>(
+    consensus_v3_kernel<T, PX, FLAT, CLEAN><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), 0, s>>>(
         pred, ov, cons, cnt, G, n_rows, runs_per_line, bZ2, n_waves);
     return hipGetLastError();
 }
@@ -788,8 +826,14 @@ static hipError_t launch_v3(const T *pred, const uint8_t *ov, float *cons, float
     bool flat = G.cX >= 64 && G.cX % 64 != 0 && G.py >= 3 && G.cY > 1;
     if (e && e[0] == '0') flat = false;
     if (e && e[0] == '1' && G.cX >= 64 && G.py >= 3) flat = true;
-    return flat ? launch_v3f<T, PX, true>(pred, ov, cons, cnt, G, s)
-                : launch_v3f<T, PX, false>(pred, ov, cons, cnt, G, s);
+    static EnvSwitch swc("PPP_S1_CLEAN");      // PPP_S1_CLEAN=0: the general kernel whatever the caller knows
+    const char *ec = swc.get();
+    const bool clean = G.pred_clean == 1 && !(ec && ec[0] == '0');
+    if (clean)
+        return flat ? launch_v3f<T, PX, true, true>(pred, ov, cons, cnt, G, s)
+                    : launch_v3f<T, PX, false, true>(pred, ov, cons, cnt, G, s);
+    return flat ? launch_v3f<T, PX, true, false>(pred, ov, cons, cnt, G, s)
+                : launch_v3f<T, PX, false, false>(pred, ov, cons, cnt, G, s);
 }
 
 // the shapes / rules the packed kernel serves (and with them the direct voxel-major output)

@@ -121,6 +121,7 @@ hipError_t launch_synth(const int32_t *labels, void *pred, int dtype, uint32_t s
                         float lo, float noise, unsigned long long voxel_offset, const Geo &G,
                         hipStream_t s);
 
+hipError_t launch_pred_check(const void *pred, int dtype, long long n, const Geo &G, int *unclean, hipStream_t s);
 hipError_t launch_counter_calibration(const void *src, int dtype, long long n_read, float *dst, long long n_write,
                                       hipStream_t s);
 hipError_t launch_synth_box(const int32_t *labels, const int *lb, void *pred, int dtype, uint32_t seed,

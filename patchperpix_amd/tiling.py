@@ -99,7 +99,7 @@ class LocalComm:
             raise ValueError("a single process has no peer")
 
 
-def exchange_halo(own, own_range, need_range, comm, z_axis=0, chunk_bytes=1 << 30):
+def exchange_halo(own, own_range, need_range, comm, z_axis=0, chunk_bytes=1 << 30, out=None):
     """The halo exchange of the north star ("patch-radius halo exchanged over RCCL/xGMI"): a rank
     holds the slices [own_range) of a volume along `z_axis` -- its part of a RESIDENT prediction
     (C, z, Y, X), the U-Net's output as it stands on the GPU, or of a per-voxel field (z, Y, X) --
@@ -109,7 +109,10 @@ def exchange_halo(own, own_range, need_range, comm, z_axis=0, chunk_bytes=1 << 3
     or three ranks next to a boundary), `chunk_bytes` of the leading axes at a time (a z-range of
     a channel-major block is strided: the staging copy stays bounded).  Returns the tensor of
     [need_range) -- `own` itself when nothing is missing anywhere (no collective beyond the range
-    gather).  Reference analogue: block + margin loading, stitch_patch_graph.py:553-669."""
+    gather).  out: a tensor of [need_range) to receive into; when `own` is the view of its own
+    slices the own part is not copied -- a producer that writes its slab into the middle of a
+    halo-sized buffer pays for the halo only (`_refresh_halo` of tiling.assemble).
+    Reference analogue: block + margin loading, stitch_patch_graph.py:553-669."""
     import torch
     a, b = [int(v) for v in own_range]
     na, nb = [int(v) for v in need_range]
@@ -127,8 +130,16 @@ def exchange_halo(own, own_range, need_range, comm, z_axis=0, chunk_bytes=1 << 3
         raise ValueError("need_range must contain own_range")
     full_shape = list(own.shape)
     full_shape[z_axis] = nb - na
-    full = torch.empty(full_shape, dtype=own.dtype, device=own.device)
-    full.narrow(z_axis, a - na, b - a).copy_(own)
+    if out is not None:
+        if list(out.shape) != full_shape or out.dtype != own.dtype:
+            raise ValueError("exchange_halo: `out` must hold [need_range)")
+        full = out
+        mid = full.narrow(z_axis, a - na, b - a)
+        if mid.data_ptr() != own.data_ptr() or mid.stride() != own.stride():
+            mid.copy_(own)
+    else:
+        full = torch.empty(full_shape, dtype=own.dtype, device=own.device)
+        full.narrow(z_axis, a - na, b - a).copy_(own)
     covered = b - a
     # (peer, global z0, z1) of what I send / receive, every rank deriving the same lists
     sends, recvs = [], []
@@ -498,6 +509,9 @@ class DeviceOps:
     def consensus(self, pred, ov, P):
         return backend.consensus(pred, ov if P.use_overlap else None, P)
 
+    def pred_check(self, pred, P):
+        return backend.pred_check(pred, P)
+
     def rank_patches(self, pred, cons, ov, P, score_box, out=None):
         return backend.rank_patches(pred, cons, ov if P.use_overlap else None, P,
                                     score_box=score_box, out=out)
@@ -780,10 +794,11 @@ def _field_u8(a, dev, torch):
 class _Frame:
     """A box of the volume with the prediction (and the overlap mask) of exactly that box on the
     device: what one kernel launch sees.  origin = global coordinate of local voxel (0, 0, 0)."""
-    __slots__ = ("pred", "ov", "origin", "shape")
+    __slots__ = ("pred", "ov", "origin", "shape", "clean")
 
     def __init__(self, pred, ov, origin, shape):
         self.pred, self.ov, self.origin, self.shape = pred, ov, tuple(origin), tuple(shape)
+        self.clean = 0          # ppp_params.pred_clean of this frame's tensor: decided at its first use
 
 
 def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchshape, my_slabs,
@@ -865,7 +880,10 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         # A RESIDENT slab (and local fields) that lack the halo -- the U-Net's output as it stands on
         # each GPU -- get it from the ranks that own it (exchange_halo: point to point over RCCL / xGMI).
         # Every rank takes part in the decision: one MAX all-reduce of "I miss slices".
-        miss_p = (not provider) and (lo_p > need_lo or hi < need_hi)
+        # `_refresh_halo`: pred_local is a halo-sized buffer whose OWN slices are current (the producer
+        # wrote them) and whose halo slices are stale -- fetched again, in place
+        refresh = bool(kw.get("_refresh_halo", False)) and not provider
+        miss_p = (not provider) and (lo_p > need_lo or hi < need_hi or refresh)
         miss_f = local_fields and (flo > need_lo or fhi < need_hi)
         flag = torch.tensor([int(miss_p), int(miss_f)], dtype=torch.int32, device=ops.device)
         any_p, any_f = [int(v) for v in comm.all_reduce_max(flag).cpu()]
@@ -874,7 +892,9 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         with backend.host_timer("halo_exchange"):
             if any_p:
                 own = pred_local.narrow(1, oz0 - lo, oz1 - oz0)
-                pred_local = exchange_halo(own, (oz0, oz1), (need_lo, need_hi), comm, z_axis=1)
+                in_place = refresh and lo <= need_lo and hi >= need_hi
+                pred_local = exchange_halo(own, (oz0, oz1), (need_lo, need_hi), comm, z_axis=1,
+                                           out=pred_local.narrow(1, need_lo - lo, need_hi - need_lo) if in_place else None)
                 lo = lo_p = need_lo
                 hi = need_hi
             if any_f:
@@ -1008,7 +1028,13 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
         o = fr.origin
         if box is not None:
             box = (box[0] - o[0], box[2] - o[1], box[4] - o[2], box[1] - o[0], box[3] - o[1], box[5] - o[2])
-        return backend.make_params(fr.shape, ps, cons_box=box, origin=o, **flags)
+        P = backend.make_params(fr.shape, ps, cons_box=box, origin=o, **flags)
+        if fr.clean == 0 and fr.pred is not None and hasattr(ops, "pred_check"):
+            # ONE streaming pass per frame (the resident block: once per call; a provider's box: once
+            # per box) tells every S1 launch on it whether the short classification applies
+            fr.clean = ops.pred_check(fr.pred, P)
+        P.pred_clean = fr.clean
+        return P
 
     def to_local(coords_t, fr, cols=1):
         """global (z, y, x) [x cols] -> frame coordinates"""
@@ -1845,6 +1871,77 @@ def plan_ring(own_shape, patchshape, free_bytes, safety=0.6, copies=2.0, min_thi
     if best is None or best[0][0] > gain * cost(*plain, False):
         return None
     return best[1], best[2], best[3], best[4]
+
+
+def dry_run_plan(shape, patchshape, world, hbm_gb=309.2, usable=0.985, provider=False, halo_mode="exchange",
+                 cover_frac=0.0346, thin_frac=0.00339, pairs_per_voxel=0.291, cover_rounds=700, result_gather=False):
+    """What `world` ranks would hold and move for one volume -- WITHOUT a GPU (bench.py --dry-run-plan).
+    Per rank: z-range, halo, resident prediction bytes, the tile / ring / cache plan the memory rule
+    takes for the HBM left, S1 work per owned voxel; per step and rank: bytes received in every
+    collective of tiling.assemble.  The list densities default to the measured dense synthetic
+    512^3 / 9^3 step (profiles/r05_zzg_*: 4.64 M cover patches, 454 k after thinning, 39.0 M pair rows
+    per 134 M voxels, ~700 cover rounds)."""
+    Z, Y, X = [int(v) for v in shape]
+    ps = [int(p) for p in patchshape]
+    C, H, plane = int(np.prod(ps)), halo(ps), Y * X
+    W = (2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1)
+    words = (C + 31) // 32
+    V = float(Z) * plane
+    out = {"volume": [Z, Y, X], "patchshape": ps, "ranks": int(world), "halo_slices": H,
+           "hbm_gb_assumed": hbm_gb, "usable_fraction": usable, "ranks_plan": [], "assumed_densities": {
+               "cover_patches_per_voxel": cover_frac, "thinned_patches_per_voxel": thin_frac,
+               "pair_rows_per_voxel": pairs_per_voxel, "cover_rounds": cover_rounds}}
+    slabs = plan_slabs(Z, world)
+    for r in range(world):
+        mine = slabs_of_rank(slabs, r, world)
+        if not mine:
+            continue
+        oz0, oz1 = mine[0][0], mine[-1][1]
+        lo, hi = local_range(mine, Z, ps)
+        own_v, held_v = float(oz1 - oz0) * plane, float(hi - lo) * plane
+        pred_own = 2.0 * C * own_v
+        pred_held = 0.0 if provider else 2.0 * C * held_v
+        resident = pred_held          # (halo exchange: in place, into the halo slices of the same buffer)
+        tile_pred = 2.0 * C * 180 ** 3 if provider else 0.0
+        # (the same reserves as the callers' memory plans: vote_instances.to_instance_seg on one rank,
+        # bench.py's multi-rank workloads; 288 GiB of HBM3E = 309.2 GB, ~1.5 % held by the runtime)
+        fields = (70.0 * held_v + 4e9) if world == 1 else (150.0 * held_v + 6e9)
+        free = usable * hbm_gb * 1e9 - resident - tile_pred
+        budget = max(free - fields, 0.25 * free)
+        own_shape = (oz1 - oz0, Y, X)
+        cz0, cz1 = max(0, oz0 - ps[0] // 2 - (ps[0] - 1)), min(Z, oz1 + ps[0] // 2)
+        n, ny, nx, cache = plan_tiles(own_shape, ps, budget, safety=0.92, copies=2.0,
+                                      cache_shape=None if provider else (cz1 - cz0, Y, X))
+        ring = None
+        if not cache and not provider:
+            ring = plan_ring(own_shape, ps, budget, safety=0.92, copies=2.0)
+            if ring is not None:
+                n, ny, nx = ring[:3]
+        work = consensus_work(own_shape, ps, n, ny, nx, ring=ring is not None) / own_v
+        if cache:
+            work = float(cz1 - cz0) / (oz1 - oz0)
+        nb = (1 if oz0 > 0 else 0) + (1 if oz1 < Z else 0)
+        zone = 2 * (ps[0] - 1) * plane                    # voxels of one boundary zone
+        recv = {
+            "prediction_halo": 2.0 * C * (held_v - own_v) if (halo_mode == "exchange" and not provider and world > 1) else 0.0,
+            "field_halo": 3.0 * (held_v - own_v) if (halo_mode == "exchange" and world > 1) else 0.0,
+            "sorted_scores_all_gather": 4.0 * (V - own_v) if world > 1 else 0.0,
+            # per round: rank volume (int32) after the count step, mask + dirty marks (bytes) after select
+            "cover_zones_point_to_point": float(cover_rounds) * nb * zone * (4.0 + 1.0 + 1.0),
+            "cover_selected_gather": 16.0 * cover_frac * (V - own_v) if world > 1 else 0.0,
+            "thinning_mask_and_bits_all_gather": ((V - own_v) * 1.0 + 4.0 * words * cover_frac * (V - own_v)) if world > 1 else 0.0,
+            "pair_affinities_all_reduce": 4.0 * pairs_per_voxel * V * 2.0 * (world - 1) / max(world, 1) if world > 1 else 0.0,
+            "labels_all_reduce": 4.0 * thin_frac * V * 2.0 * (world - 1) / max(world, 1) if world > 1 else 0.0,
+            "instances_all_gather": 4.0 * (V - own_v) if (result_gather and world > 1) else 0.0}
+        out["ranks_plan"].append({
+            "rank": r, "own_z": [oz0, oz1], "held_z": [lo, hi], "prediction_resident_gb": round(resident / 1e9, 2),
+            "free_for_consensus_gb": round(budget / 1e9, 2), "tiles": [n, ny, nx], "cons_cache": bool(cache),
+            "ring_z": int(ring[3]) if ring is not None else 0, "s1_work_per_owned_voxel": round(work, 3),
+            "row_bytes_per_voxel": 4 * W,
+            "received_gb_per_step": {k: round(v / 1e9, 3) for k, v in recv.items()},
+            "received_gb_per_step_total": round(sum(recv.values()) / 1e9, 3)})
+    out["replicated_per_rank"] = {"thinning_patches": int(cover_frac * V), "watershed_host_loop_rank0_edges": int(0.21 * V)}
+    return out
 
 
 def to_instance_seg_tiled(pred_affs, foreground, mask_to_cover, numinst, patchshape, n_slabs,

@@ -208,6 +208,12 @@ def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, *
                 n_slabs, ny_t, nx_t, kwargs["_ring_z"] = ring
         if yx_tiles is None and (ny_t > 1 or nx_t > 1):
             yx_tiles = (ny_t, nx_t)
+        # what was decided, and on what: read by bench.py (`config.plan`) so that a silent change of
+        # plan -- less free HBM: thinner tiles, a shorter ring -- shows next to the number it changes
+        backend.LAST_PLAN = {"tiles": [int(n_slabs), int(ny_t), int(nx_t)], "ring_z": int(kwargs.get("_ring_z") or 0),
+                             "cons_cache": bool(kwargs.get("_cons_cache")), "s1_writes_voxel_major": bool(direct),
+                             "free_hbm_gb_at_plan_time": round(avail / 1e9, 2), "reserve_gb": round(reserve / 1e9, 2),
+                             "budget_gb": round(max(avail - reserve, 0.25 * avail) / 1e9, 2)}
     # With nothing to store or load between the stages, the single-slab case takes the same
     # code path: it keeps the ranked patch list on the device instead of materialising the
     # reference's host lists between the stage functions (PPP_PIPELINE=stages keeps them).

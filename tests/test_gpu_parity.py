@@ -539,6 +539,56 @@ def test_consensus_out_of_range_operands_take_exact_divisions(torch_cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ps,shape,f16", [((9, 9, 9), (22, 24, 70), True), ((7, 7, 7), (18, 20, 90), False),
+                                          ((5, 5, 5), (14, 15, 130), True)])
+def test_clean_prediction_takes_the_short_classification(ps, shape, f16, torch_cuda, monkeypatch):
+    """ppp_pred_check + ppp_params.pred_clean (round 6): on a prediction whose values all lie in [0, 1]
+    and never equal the threshold, S1 classifies an operand as t = v - [v < 0.5] without the range
+    check or the exact path -- the same consensus bits as the general kernel (PPP_S1_CLEAN=0), in the
+    compact planes and in the voxel-major rows, and as the oracle.  A single value equal to 0.5, above
+    1, negative zero or nan makes the check say so (bits 1 / 0) and the general kernel serve the call."""
+    import ctypes
+    from oracle import ppp_oracle as orc
+    from patchperpix_amd import backend, synth
+    from tests_flags import FLYLIGHT
+    torch = torch_cuda
+    kw = dict(FLYLIGHT)
+    c = synth.make_case(shape, ps, seed=81, cell=[2 * p for p in ps], overlap_frac=0.02)
+    pred_h = c["pred"].astype(np.float16 if f16 else np.float32)
+    P = backend.make_params(shape, ps, **kw)
+    ov = _dev(torch, (c["numinst"] > 1).astype(np.uint8))
+    pred = _dev(torch, pred_h)
+    assert backend.pred_check(pred, P) == 1
+    want = orc.positive_planes(orc.consensus(pred_h.astype(np.float32), 1 * (c["numinst"] > 1), ps, **kw), ps)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PPP_S1_CLEAN", mode)
+        backend.reload_env()
+        Pm = P.copy()
+        Pm.pred_clean = 1 if mode == "1" else 0
+        cons = backend.consensus(pred, ov, Pm)
+        vm, _ = backend.consensus_voxel_major(pred, ov, Pm)
+        out[mode] = (cons.cpu().numpy(), vm.cpu().numpy())
+        assert backend.NOTES.get("s1_kernel") == "consensus_v3_kernel"
+    monkeypatch.delenv("PPP_S1_CLEAN")
+    backend.reload_env()
+    assert np.array_equal(_bits(out["1"][0]), _bits(want))
+    assert np.array_equal(_bits(out["1"][0]), _bits(out["0"][0]))
+    assert np.array_equal(_bits(out["1"][1]), _bits(out["0"][1]))
+    # what makes a prediction unclean, each on its own; the consensus stays the oracle's
+    mid = int(np.prod(ps)) // 2
+    for value, bit in ((0.5, 2), (1.0009765625, 1), (-0.0, 1), (np.nan, 1)):
+        bad_h = pred_h.copy()
+        bad_h[(mid + 3) % bad_h.shape[0], shape[0] // 2, shape[1] // 2, shape[2] // 2] = value
+        bad = _dev(torch, bad_h)
+        assert backend.pred_check(bad, P) == 2 and backend.NOTES["pred_unclean_bits"] & bit, value
+        if value == 0.5:
+            got = backend.consensus(bad, ov, P).cpu().numpy()           # (decides by itself: general kernel)
+            ref = orc.positive_planes(orc.consensus(bad_h.astype(np.float32), 1 * (c["numinst"] > 1), ps, **kw), ps)
+            assert np.array_equal(_bits(got), _bits(ref))
+
+
+@pytest.mark.gpu
 def test_paint_more_nodes_than_one_launch_holds():
     """ppp_paint_instances runs a thread per (node, patch pixel) and therefore chunks its nodes
     below the 2^32 work-items a HIP grid holds (2^31 / C nodes per launch): a node list just

@@ -218,13 +218,18 @@ mine = tiling.slabs_of_rank(slabs, rank, world)
 lo, hi = tiling.local_range(mine, Z, ps)
 fields = [c["foreground"].copy(), c["foreground"].copy(), c["numinst"]]
 no_halo = os.environ.get("PPP_TEST_NO_HALO", "0")
-if no_halo != "0":
+if no_halo in ("1", "2"):
     # the U-Net's output as it stands on each rank: the OWN slices only; assemble() fetches the
     # halo from the neighbours (tiling.exchange_halo).  "2": the per-voxel fields are local too
     lo, hi = mine[0][0], mine[-1][1]
     if no_halo == "2":
         fields = [f[lo:hi].copy() for f in fields]
 pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi]))   # halo'd slab only
+if no_halo == "3":
+    # a halo-sized buffer whose halo slices are stale (here: zeros): refreshed in place
+    pred_local[:, :mine[0][0] - lo] = 0
+    pred_local[:, mine[-1][1] - lo:] = 0
+    kw["_refresh_halo"] = True
 inst, fg = tiling.assemble(pred_local, lo, c["foreground"].shape, fields[0], fields[1], fields[2], ps, mine,
                            comm=tiling.TorchDistComm(), ops=OracleOps(**kw), _cover_chunk=700, **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
@@ -247,7 +252,8 @@ dist.destroy_process_group()
     # round 6, the north star's halo exchange: every rank holds its OWN slices of the prediction
     # only and receives the patch-radius halo from its neighbours point to point; three ranks
     # (the middle one has two neighbours); local per-voxel fields as well
-    (2, 2, {"_no_halo": "1"}), (3, 3, {"_no_halo": "1"}), (3, 3, {"_no_halo": "2"})])
+    # "3": a halo-sized buffer with stale halo slices, refreshed in place (`_refresh_halo`)
+    (2, 2, {"_no_halo": "1"}), (3, 3, {"_no_halo": "1"}), (3, 3, {"_no_halo": "2"}), (3, 3, {"_no_halo": "3"})])
 def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypatch):
     import json
     extra = dict(extra)
@@ -462,14 +468,21 @@ if sub > 1:
     a0 = mine[0][0]
     mine = [(a0 + a, a0 + b) for a, b in tiling.plan_slabs(mine[-1][1] - a0, sub)]
 kw.update(json.loads(os.environ.get("PPP_TEST_KW", "{{}}")))
+if os.environ.get("PPP_TEST_NO_HALO", "0") == "1":    # own slices only: assemble() exchanges the halo
+    lo, hi = mine[0][0], mine[-1][1]
 pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi])).cuda()
+if os.environ.get("PPP_TEST_NO_HALO", "0") == "3":    # halo-sized buffer, stale halo: refreshed in place
+    pred_local[:, :mine[0][0] - lo] = 0
+    pred_local[:, mine[-1][1] - lo:] = 0
+    kw["_refresh_halo"] = True
 inst, fg = tiling.assemble(pred_local, lo, shape, c["foreground"].copy(), c["foreground"].copy(),
                            c["numinst"], list(ps), mine, comm=tiling.TorchDistComm(), **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
         np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
                   backend.NOTES.get("cover_p2p", 0), backend.NOTES.get("ring_z", 0),
-                  1 if "cons_cache_gb" in backend.NOTES else 0]))
+                  1 if "cons_cache_gb" in backend.NOTES else 0,
+                  backend.NOTES.get("halo_exchange_bytes_received", 0)]))
 dist.destroy_process_group()
 """
 
@@ -481,7 +494,10 @@ dist.destroy_process_group()
     (3, False, (7, 7, 7), "cc", "1", 1, {}), (3, False, (5, 5, 5), "nothin_cc", "0", 1, {}),
     # a rank's range cut into three tiles: rows in a ring / a consensus cache over the rank's block
     (2, False, (5, 5, 5), "shipped", "1", 3, {"_ring_z": 40}), (2, False, (5, 5, 5), "cc", "1", 3, {"_cons_cache": True}),
-    (2, False, (7, 7, 7), "shipped", "1", 3, {"_ring_z": 40, "_yx_tiles": [1, 2]})])
+    (2, False, (7, 7, 7), "shipped", "1", 3, {"_ring_z": 40, "_yx_tiles": [1, 2]}),
+    # round 6: every rank holds its OWN slices of the prediction; the halo comes from the neighbours
+    (3, False, (7, 7, 7), "shipped", "1", 1, {"_no_halo": "1"}), (2, False, (5, 5, 5), "cc", "1", 3, {"_no_halo": "1", "_ring_z": 40}),
+    (3, False, (5, 5, 5), "shipped", "1", 1, {"_no_halo": "3"})])
 def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps, flagset, p2p, sub, extra):
     """The multi-rank path with the REAL kernels: `world` processes on the one GPU of the box,
     gloo as the transport (RCCL needs one device per rank): sharded cover with z-halo exchange,
@@ -502,7 +518,10 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
     script = tmp_path / "gpu_worker.py"
     script.write_text(GPU_WORKER.format(repo=REPO, out=str(tmp_path), shape=shape, ps=ps))
     _port = _free_port()
+    extra = dict(extra)
+    no_halo = str(extra.pop("_no_halo", "0"))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
+               PPP_TEST_NO_HALO=no_halo,
                PPP_TEST_EMPTY_TOP="1" if empty_top else "0", PPP_TEST_FLAGSET=flagset,
                PPP_COVER_P2P=p2p, PPP_TEST_SUBSLABS=str(sub), PPP_TEST_KW=__import__("json").dumps(extra))
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -515,6 +534,7 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
         assert notes[0] == world and notes[1] > 0 and notes[2] == int(p2p)
         assert notes[3] == extra.get("_ring_z", 0) and notes[4] == (1 if extra.get("_cons_cache") else 0)
+        assert (notes[5] > 0) == (no_halo != "0")
 
 
 RCCL_WORKER = r"""
@@ -532,20 +552,26 @@ kw = dict(flagsets.FLYLIGHT)
 slabs = tiling.plan_slabs(shape[0], world)
 mine = tiling.slabs_of_rank(slabs, rank, world)
 lo, hi = tiling.local_range(mine, shape[0], ps)
+if os.environ.get("PPP_TEST_NO_HALO", "0") == "1":    # own slices only: the halo travels over RCCL
+    lo, hi = mine[0][0], mine[-1][1]
 pred_local = torch.from_numpy(np.ascontiguousarray(c["pred"][:, lo:hi])).cuda()
 inst, fg = tiling.assemble(pred_local, lo, shape, c["foreground"].copy(), c["foreground"].copy(),
                            c["numinst"], list(ps), mine, comm=tiling.TorchDistComm(), **kw)
 np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
+assert (backend.NOTES.get("halo_exchange_bytes_received", 0) > 0) == (os.environ.get("PPP_TEST_NO_HALO", "0") == "1")
 dist.destroy_process_group()
 """
 
 
 @pytest.mark.gpu
-def test_two_ranks_over_rccl(tmp_path):
+@pytest.mark.parametrize("no_halo", [False, True])
+def test_two_ranks_over_rccl(tmp_path, no_halo):
     """One rank per GPU over RCCL (backend "nccl"): z-slabs with halos, sharded cover with zone
     MIN all-reduces, all-gather of owned score / instance slabs, merged label forests, replicated
     thinning and mutex watershed -- same instance map as one process.  Needs two GPUs in the box
-    (skipped on the single-GPU development boxes; the same path runs there over gloo, above)."""
+    (skipped on the single-GPU development boxes; the same path runs there over gloo, above).
+    no_halo: every rank holds its own slices of the prediction only and the patch-radius halo is
+    exchanged over RCCL (tiling.exchange_halo: grouped point-to-point sends / receives)."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
@@ -559,7 +585,7 @@ def test_two_ranks_over_rccl(tmp_path):
     script.write_text(RCCL_WORKER.format(repo=REPO, out=str(tmp_path)))
     _port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port, OMP_NUM_THREADS="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PPP_TEST_NO_HALO="1" if no_halo else "0")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                            "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", _port, str(script)], env=env, timeout=900)
     assert want.any()

@@ -29,6 +29,7 @@ def main():
     del labels
     ov = torch.zeros(shape, dtype=torch.uint8, device="cuda")
     Pb = backend.make_params(shape, ps, cons_box=tuple(args.box), **kw)
+    Pb = backend.with_pred_clean(pred, Pb)        # (decided once, outside the timed launches)
     nvox = (args.box[3] - args.box[0]) * (args.box[4] - args.box[1]) * (args.box[5] - args.box[2])
     W = 17 ** 3
     pool = torch.empty(nvox * W, dtype=torch.float32, device="cuda")
@@ -46,7 +47,7 @@ def main():
             crc = int(inner.reshape(-1).view(torch.int32).sum(dtype=torch.int64).item()) & 0xFFFFFFFF
     print(json.dumps({"tree": os.path.basename(ROOT), "shape": shape, "box": args.box, "base_voxels": nvox,
                       "ms": [round(t, 2) for t in times], "min_ms": round(min(times), 2),
-                      "Mvox_per_s": round(nvox / min(times) / 1e3, 2), "checksum": crc,
+                      "Mvox_per_s": round(nvox / min(times) / 1e3, 2), "checksum": crc, "pred_clean": int(Pb.pred_clean),
                       "kernel": backend.lib().ppp_consensus_kernel_name().decode()}))
 
 
