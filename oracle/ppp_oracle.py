@@ -370,13 +370,16 @@ def patch_pairs(sel_coords, patchshape, include_single=True, max_ps_dist=2):
     return pts, arr
 
 
-def _graph_edges(pairs, aff):
+def _graph_edges(pairs, aff, keep_zero=False):
     """Edge iteration order of ``nx.Graph.edges`` for the graph built by setAffgraph
     (aff_patch_graph.py:31-40): nodes in insertion order, per node its neighbours in
-    insertion order, an edge reported at the turn of its first-visited endpoint."""
+    insertion order, an edge reported at the turn of its first-visited endpoint.
+    keep_zero: the graph of computePatchGraph's NumPy branch (aff_patch_graph.py:264-270), which
+    adds EVERY candidate edge, also one whose votes sum to 0 -- such an edge joins nothing but its
+    endpoints take their place in the node order (found by the np_c2d_p25_crop golden, round 6)."""
     nodes, adj, val = [], {}, {}
     for i in range(len(aff)):
-        if aff[i] == 0:
+        if aff[i] == 0 and not keep_zero:
             continue
         u = tuple(int(v) for v in pairs[i, :3])
         v = tuple(int(v) for v in pairs[i, 3:6])
@@ -399,10 +402,10 @@ def _graph_edges(pairs, aff):
     return nodes, edges
 
 
-def connected_components(pairs, aff):
+def connected_components(pairs, aff, keep_zero=False):
     """graph_to_labeling.py:50-54: CCs of the aff > 0 sub-graph in networkx's
     enumeration order (order of first appearance of a member in the edge iteration)."""
-    _, edges = _graph_edges(pairs, aff)
+    _, edges = _graph_edges(pairs, aff, keep_zero)
     order, adj = [], {}
     for (u, v, a) in edges:
         if a > 0:
@@ -429,9 +432,9 @@ def connected_components(pairs, aff):
     return ccs
 
 
-def mutex_watershed(pairs, aff):
+def mutex_watershed(pairs, aff, keep_zero=False):
     """graph_mws.py:7-85, including its id re-issue and empty-CC quirks."""
-    nodes, edge_iter = _graph_edges(pairs, aff)
+    nodes, edge_iter = _graph_edges(pairs, aff, keep_zero)
     node_id = {n: i for i, n in enumerate(nodes)}
     node_cc = {i: 0 for i in range(len(nodes))}
     edges = []
@@ -520,8 +523,10 @@ def paint_per_channel(ccs, pred, patchshape, shape, th, packed, dtype=np.uint16)
     return np.stack(channels, axis=0)
 
 
-def label(pairs, aff, pred, patchshape, shape, **kw):
-    ccs = mutex_watershed(pairs, aff) if kw.get("mws") else connected_components(pairs, aff)
+def label(pairs, aff, pred, patchshape, shape, keep_zero_edges=False, **kw):
+    """keep_zero_edges: the graph came from computePatchGraph's NumPy branch (_graph_edges)."""
+    ccs = mutex_watershed(pairs, aff, keep_zero_edges) if kw.get("mws") else \
+        connected_components(pairs, aff, keep_zero_edges)
     if kw.get("one_instance_per_channel") or kw.get("no_overlap_per_channel"):
         return paint_per_channel(ccs, pred, patchshape, shape, kw["patch_threshold"],
                                  packed=not kw.get("one_instance_per_channel"))

@@ -813,7 +813,17 @@ static hipError_t launch_v3f(const T *pred, const uint8_t *ov, float *cons, floa
         const hipError_t ez = launch_vm_zero(cons, G, n_rows, s);
         if (ez != hipSuccess) return ez;
     }
-    consensus_v3_kernel<T, PX, FLAT, CLEAN><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), 0, s>>>(
+    // (experiment PPP_S1_DYNLDS=<bytes>: dynamic LDS nobody uses, to LOWER the waves a CU holds -- what a
+    // wave more or less per SIMD is worth: profiles/r06_d_s1_occupancy.txt)
+    static EnvSwitch dyn("PPP_S1_DYNLDS");
+    const char *ed = dyn.get();
+    const unsigned dyn_lds = ed ? (unsigned)atoi(ed) : 0u;
+    if (dyn_lds) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&consensus_v3_kernel<T, PX, FLAT, CLEAN>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+        if (ea != hipSuccess) return ea;
+    }
+    consensus_v3_kernel<T, PX, FLAT, CLEAN><<<dim3((unsigned)n_blocks), dim3(64 * V3_WAVES), dyn_lds, s>>>(
         pred, ov, cons, cnt, G, n_rows, runs_per_line, bZ2, n_waves);
     return hipGetLastError();
 }

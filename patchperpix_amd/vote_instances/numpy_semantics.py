@@ -152,16 +152,22 @@ def computePatchGraph(selected_sorted, pred_affs, mask_to_cover, overlap_mask, c
 def order_preserving_float32(weight):
     """The labelling stages take float32 affinities; the integer weights (up to C^2 * C) need not
     fit.  They only use the SIGN of a weight and the ORDER of the magnitudes (connected components:
-    aff > 0; mutex watershed: stable sort by |aff|, graph_mws.py:20-26), so every weight is replaced
-    by sign * (dense rank of |weight|) -- exact in float32 -- with rank 0 for weight 0 (a zero
-    edge is repulsive with the smallest magnitude: it is processed last and only adds a mutex
-    constraint, which nothing after it consults)."""
+    aff > 0; mutex watershed: stable sort by |aff|, graph_mws.py:20-26), so every non-zero weight is
+    replaced by sign * (1 + dense rank of |weight|) -- exact in float32 -- and a ZERO weight by -1:
+    the NumPy branch adds every candidate edge to its graph, also one whose votes sum to 0
+    (aff_patch_graph.py:264-270), and the labelling stages (made for setAffgraph's graph, which
+    leaves aff == 0 rows out) must see that edge -- its endpoints take their place in networkx's
+    node order, which decides the order of the components -- as what it is there: not positive, and
+    of the smallest magnitude (processed last by the mutex watershed, where it only adds a mutex
+    constraint nothing after it consults).  Found by the np_c2d_p25_crop golden (round 6): up to
+    round 5 a zero weight became 0.0 and the edge was dropped."""
+    weight = np.asarray(weight)
     mag = np.abs(weight)
-    uniq = np.unique(mag)
-    if len(uniq) >= (1 << 24):
+    uniq = np.unique(mag[mag != 0])
+    if len(uniq) + 2 >= (1 << 24):
         raise OverflowError("more than 2^24 distinct edge weights")
-    rank = np.searchsorted(uniq, mag) + (0 if len(uniq) and uniq[0] == 0 else 1)
-    return (np.sign(weight) * rank).astype(np.float32)
+    rank = (np.searchsorted(uniq, mag) + 2).astype(np.float64)
+    return np.where(weight == 0, -1.0, np.sign(weight) * rank).astype(np.float32)
 
 
 def to_instance_seg(pred_affs, foreground, mask_to_cover, numinst, patchshape, **kwargs):

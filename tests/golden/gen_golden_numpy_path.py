@@ -43,6 +43,10 @@ CASES = {
     # a threshold below 0.5: a pixel can be in the foreground AND the background set
     "c2d_p3_th04": ((1, 16, 18), (1, 3, 3), dict(kind="cells", seed=23, cell=[1, 6, 6], noise=0.45),
                     dict(patch_threshold=0.4, includeSinglePatchCCS=False)),
+    # BASELINE config [0]'s patch shape, (1, 25, 25), with the reference's own default thresholds
+    # (vote_instances.py:82-83, 488) on a crop its Python path finishes: 48 x 52 pixels, 672 centres
+    "c2d_p25_crop": ((1, 48, 52), (1, 25, 25), dict(kind="cells", seed=24, cell=[1, 13, 14], noise=0.3),
+                     dict(patch_threshold=0.9, skipThinCover=False)),
 }
 
 

@@ -91,11 +91,11 @@ def test_oracle_stages_match_the_reference(g):
                               include_single=g.kw["includeSinglePatchCCS"])
     # networkx reports the edges in its own iteration order; as sets with weights they agree, and
     # the rows' loop order reproduces that iteration order (orc._graph_edges)
-    nodes, edges = orc._graph_edges(rows, w)
+    nodes, edges = orc._graph_edges(rows, w, keep_zero=True)
     assert [list(u) + list(v) for u, v, _ in edges] == g.z["edge_rows"].tolist()
     assert [int(x) for _, _, x in edges] == g.z["edge_weight"].tolist()
     assert [list(n) for n in nodes] == g.z["node_order"].tolist()
-    inst = orc.label(rows.astype(np.uint32), w, g.pred, g.ps, g.foreground.shape, **g.kw)
+    inst = orc.label(rows.astype(np.uint32), w, g.pred, g.ps, g.foreground.shape, keep_zero_edges=True, **g.kw)
     assert np.array_equal(inst, g.z["instances"])
 
 
@@ -129,7 +129,7 @@ def test_device_stages_match_the_reference(g, f16, torch_cuda):
     assert np.array_equal(ranked.scores.astype(np.int64), g.z["ranked_scores"])
     if int(g.z["has_pairs"]):
         rows, w = ns.computePatchGraph(g.z["selected_sorted"], pred, g.mask, g.overlap, votes, g.ps, **g.kw)
-        nodes, edges = orc._graph_edges(rows, w)
+        nodes, edges = orc._graph_edges(rows, w, keep_zero=True)
         assert [list(u) + list(v) for u, v, _ in edges] == g.z["edge_rows"].tolist()
         assert [int(x) for _, _, x in edges] == g.z["edge_weight"].tolist()
 
@@ -177,15 +177,18 @@ def test_device_stages_match_the_oracle_on_fresh_inputs(shape, ps, th, seed, tor
 
 
 def test_order_preserving_weights():
+    """sign and magnitude order survive; a ZERO weight stays an edge: not positive, and of the
+    smallest magnitude (the NumPy branch's graph holds it, aff_patch_graph.py:264-270)"""
     from patchperpix_amd.vote_instances.numpy_semantics import order_preserving_float32 as f
     w = np.array([5, -5, 0, 1 << 40, -(1 << 40) - 1, 3, 0, -3], dtype=np.int64)
     r = f(w)
-    assert r.dtype == np.float32 and np.array_equal(np.sign(r), np.sign(w))
+    assert r.dtype == np.float32 and np.array_equal(np.sign(r)[w != 0], np.sign(w)[w != 0])
+    assert np.all(r[w == 0] == -1.0) and np.all(np.abs(r[w != 0]) > 1.0)
     a = np.abs(w).astype(object)
     for i in range(len(w)):
         for j in range(len(w)):
             assert (abs(r[i]) < abs(r[j])) == (a[i] < a[j]) and (abs(r[i]) == abs(r[j])) == (a[i] == a[j])
-    assert np.array_equal(f(np.array([2, 7, -7], np.int64)), np.array([1, 2, -2], np.float32))
+    assert np.array_equal(f(np.array([2, 7, -7, 0], np.int64)), np.array([2, 3, -3, -1], np.float32))
 
 
 @pytest.mark.gpu
