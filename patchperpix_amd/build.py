@@ -17,9 +17,22 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH,
          "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+# Kernels no dispatch reaches by default -- measured alternatives kept under test -- are compiled only
+# with PPP_BUILD_EXPERIMENTS=1 (which also defines the macro the dispatch sites test):
+#   ppp_consensus_v4.hip   S1 with a run's accumulators split over two waves (PPP_S1_V4=1); measured
+#                          slower than the one-wave kernel
+EXPERIMENTS = ("ppp_consensus_v4.hip",)
+
+
+def experiments():
+    return os.environ.get("PPP_BUILD_EXPERIMENTS", "0") == "1"
+
+
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + \
-        sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
+    src = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
+    if not experiments():
+        src = [f for f in src if os.path.basename(f) not in EXPERIMENTS]
+    return src
 
 
 def _toolchain(hipcc):
@@ -39,7 +52,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     # a library built with other PPP_EXTRA_FLAGS is stale too
-    want = " ".join(os.environ.get("PPP_EXTRA_FLAGS", "").split())
+    want = " ".join((os.environ.get("PPP_EXTRA_FLAGS", "") + (" -DPPP_BUILD_EXPERIMENTS" if experiments() else "")).split())
     have = open(_flags_stamp()).read() if os.path.exists(_flags_stamp()) else ""
     if want != have:
         return True
@@ -57,7 +70,7 @@ def build_library(force=False, verbose=False, relink=False):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("PPP_EXTRA_FLAGS", "").split()
+    extra = os.environ.get("PPP_EXTRA_FLAGS", "").split() + (["-DPPP_BUILD_EXPERIMENTS"] if experiments() else [])
     objdir = os.path.join(CSRC, "_obj", os.path.basename(LIB))
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"]

@@ -100,10 +100,12 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     if (G.layout == PPP_CONS_VOXEL_MAJOR) {
         // only the packed two-slice kernel writes the voxel-major rows directly
         if (!consensus_v3_supported(G)) return hipErrorNotSupported;
+#ifdef PPP_BUILD_EXPERIMENTS       // (the two-wave kernel: PPP_BUILD_EXPERIMENTS=1 builds, PPP_S1_V4=1 only)
         if (consensus_v4_supported(G)) {
             g_s1_kernel = "consensus_v4_kernel";
             return launch_consensus_v4(pred, dtype, ov, cons, cnt, G, s);
         }
+#endif
         g_s1_kernel = "consensus_v3_kernel";
         return launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
     }
@@ -123,8 +125,10 @@ hipError_t launch_consensus(const void *pred, int dtype, const uint8_t *ov, floa
     if (!force_generic) {
         // packed two-slice kernels (TH = 0.5, normalised product): accumulators split over two
         // waves (px in {5, 7, 9}) or in one wave; else the general v2
+#ifdef PPP_BUILD_EXPERIMENTS
         const hipError_t e4 = launch_consensus_v4(pred, dtype, ov, cons, cnt, G, s);
         if (e4 != hipErrorNotSupported) { g_s1_kernel = "consensus_v4_kernel"; return e4; }
+#endif
         const hipError_t e3 = launch_consensus_v3(pred, dtype, ov, cons, cnt, G, s);
         if (e3 != hipErrorNotSupported) { g_s1_kernel = "consensus_v3_kernel"; return e3; }
         const hipError_t e2 = launch_consensus_v2(pred, dtype, ov, cons, cnt, G, s);

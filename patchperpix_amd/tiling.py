@@ -413,7 +413,10 @@ class ZarrProvider:
         self.arr, self.device, self.expit = arr, device, bool(expit)
         self._pinned = [None, None]
         self._cur = 0
-        self._ahead = None            # (box, thread, buffer index, error holder)
+        self._ahead = None            # (box, thread, buffer index, error holder, host buffer, upload slot)
+        self._copy_stream = None
+        self._upload_events = [None, None]      # per pinned buffer: the last asynchronous copy out of it
+        self.boxes_uploaded_ahead = 0
         self.bytes_read = 0
         self.boxes_prefetched = 0
 
@@ -433,12 +436,39 @@ class ZarrProvider:
             buf = self._pinned[which] = torch.empty((n,), dtype=tdt, pin_memory=str(self.device).startswith("cuda"))
         return buf[:n].view(shape)
 
-    def _read(self, box, host, err):
+    def _read(self, box, host, err, upload=None, which=None):
         z0, z1, y0, y1, x0, x1 = box
         try:
+            if which is not None and self._upload_events[which] is not None:
+                self._upload_events[which].synchronize()     # the copy that last read this pinned buffer
+                self._upload_events[which] = None
             self.arr.read_into((slice(None), slice(z0, z1), slice(y0, y1), slice(x0, x1)), host.numpy())
+            if upload is not None:
+                self._upload(host, upload)
+                if which is not None:
+                    self._upload_events[which] = upload.get("event")
         except BaseException as e:          # reported by the pred_box that consumes the buffer
             err.append(e)
+
+    def _upload(self, host, slot):
+        """Worker thread (round 6): the box it has just decoded goes host -> HBM at once, on a copy
+        stream of its own, while the device still works on the tile before -- pred_box() then only
+        waits for an event.  slot: a dict that receives the device tensor and the event.  Without
+        room for a second tile on the device (the allocator says so) the copy stays where it was,
+        in pred_box()."""
+        import torch
+        if not str(self.device).startswith("cuda") or os.environ.get("PPP_ASYNC_H2D", "1") == "0":
+            return
+        oom = getattr(torch, "OutOfMemoryError", None) or torch.cuda.OutOfMemoryError
+        try:
+            dev = torch.device(self.device)
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.device(dev), torch.cuda.stream(self._copy_stream):
+                slot["dev"] = host.to(dev, non_blocking=True)
+                slot["event"] = self._copy_stream.record_event()
+        except oom:
+            slot.clear()
 
     def prefetch(self, box):
         """Start decoding `box` (None: nothing) in the background."""
@@ -451,16 +481,17 @@ class ZarrProvider:
                 return
             self._ahead[1].join()
         which = 1 - self._cur
-        host, err = self._buffer(which, self._shape(box)), []
-        th = threading.Thread(target=self._read, args=(box, host, err), daemon=True)
+        host, err, slot = self._buffer(which, self._shape(box)), [], {}
+        th = threading.Thread(target=self._read, args=(box, host, err, slot, which), daemon=True)
         th.start()
-        self._ahead = (box, th, which, err, host)
+        self._ahead = (box, th, which, err, host, slot)
 
     def pred_box(self, box):
         import torch
         box = tuple(int(v) for v in box)
         shape = self._shape(box)
         C = shape[0]
+        uploaded = None
         if self._torch_dtype() is None or not hasattr(self.arr, "read_into"):
             z0, z1, y0, y1, x0, x1 = box
             sel = (slice(None), slice(z0, z1), slice(y0, y1), slice(x0, x1))
@@ -474,18 +505,27 @@ class ZarrProvider:
                     raise ahead[3][0]
                 host, self._cur = ahead[4], ahead[2]
                 self.boxes_prefetched += 1
+                if ahead[5].get("dev") is not None:
+                    # already on its way to the device: the consumer's stream waits for the copy
+                    uploaded = ahead[5]["dev"]
+                    torch.cuda.current_stream().wait_event(ahead[5]["event"])
+                    uploaded.record_stream(torch.cuda.current_stream())
+                    self.boxes_uploaded_ahead += 1
             else:
                 host = self._buffer(self._cur, shape)
                 err = []
-                self._read(box, host, err)
+                self._read(box, host, err, which=self._cur)
                 if err:
                     raise err[0]
         self.bytes_read += host.numel() * host.element_size()
-        pred = host.to(self.device, non_blocking=True)
-        if str(self.device).startswith("cuda"):
-            torch.cuda.current_stream().synchronize()     # the pinned buffer is reused two boxes on
-        elif pred.data_ptr() == host.data_ptr():
-            pred = pred.clone()
+        if uploaded is not None:
+            pred = uploaded
+        else:
+            pred = host.to(self.device, non_blocking=True)
+            if str(self.device).startswith("cuda"):
+                torch.cuda.current_stream().synchronize()     # the pinned buffer is reused two boxes on
+            elif pred.data_ptr() == host.data_ptr():
+                pred = pred.clone()
         if self.expit:
             # loadAffinities: scipy.special.expit of the float16 array (evaluated in float64),
             # later narrowed to float32 -- the same two roundings here, a few channels at a time

@@ -828,6 +828,10 @@ def test_consensus_two_wave_kernel_equals_one_wave(ps, shape, dtype, torch_cuda,
                 backend.reload_env()
                 cons, cnt = backend.consensus(pred, ov, P, want_count=True)
                 name = backend.lib().ppp_consensus_kernel_name().decode()
+                if v4 == "1" and name == "consensus_v3_kernel":
+                    monkeypatch.delenv("PPP_S1_V4")
+                    backend.reload_env()
+                    pytest.skip("the two-wave kernel is an experiment: built with PPP_BUILD_EXPERIMENTS=1 only")
                 assert name == ("consensus_v4_kernel" if v4 == "1" else "consensus_v3_kernel")
                 rows, _ = backend.consensus_voxel_major(pred, ov, P)
                 out[v4] = (cons.cpu().numpy(), cnt.cpu().numpy(), rows)
