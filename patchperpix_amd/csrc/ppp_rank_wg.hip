@@ -357,9 +357,18 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
                    const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
                    const int tiles_x, const int n_tiles, const int *__restrict__ any_e,
-                   const int32_t *__restrict__ order) {
+                   const int32_t *__restrict__ order
+#ifdef PPP_RW_STAMPS
+                   , uint32_t *__restrict__ stamps
+#endif
+                   ) {
     // (one launch of each form per call when the one-bit masks are possible: the pre-pass decides)
     if (any_e && (*any_e != 0) == P1) return;
+#ifdef PPP_RW_STAMPS
+    // (diagnostic build -DPPP_RW_STAMPS, tools/s2_wg_times.py: when does every workgroup start and
+    // end, and on which CU -- the tile weights' array of the workspace is free once the order is made)
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     constexpr int C = PZ * PY * PX, W16 = (C + 15) / 16, RZ = PZ / 2, RY = PY / 2, RX = PX / 2;
     constexpr int W16P = P1 ? rw_p1_words(C) : rw_mask_words(C);   // mask words per centre in M
     constexpr int NMW = P1 ? (C + 31) / 32 : W16;                  // ... that hold bits
@@ -716,6 +725,17 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
             score[vox(G, c0z + lz, c0y + ly, c0x + lx)] = G.norm_rank ? acc / (float)(fg_cnt > 1u ? fg_cnt : 1u) : acc;
         }
     }
+#ifdef PPP_RW_STAMPS
+    if (tid == 0 && stamps && blockIdx.x < RW_ORDER_MAX / 4) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        stamps[4 * blockIdx.x + 0] = (uint32_t)(t_start >> 8);     // (256-cycle units: 32 bits hold minutes)
+        stamps[4 * blockIdx.x + 1] = (uint32_t)(t_end >> 8);
+        stamps[4 * blockIdx.x + 2] = hw_id;
+        stamps[4 * blockIdx.x + 3] = (uint32_t)bid;
+    }
+#endif
 }
 
 static size_t up256w(size_t v) { return (v + 255) / 256 * 256; }
@@ -793,9 +813,14 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     // (occupancy experiment: PPP_RANK_WG_DYNLDS=<bytes> of unused dynamic LDS per workgroup)
     static EnvSwitch dyn_sw("PPP_RANK_WG_DYNLDS");
     const unsigned dyn_lds = dyn_sw.get() ? (unsigned)atoi(dyn_sw.get()) : 0u;
+#ifdef PPP_RW_STAMPS
+#define PPP_RW_STAMP_ARG , (uint32_t *)weight
+#else
+#define PPP_RW_STAMP_ARG
+#endif
 #define PPP_RW_LAUNCH1(A_, D_, E_, F_, P1_)                                                                 \
     rank_wg_kernel<A_, A_, A_, D_, E_, F_, P1_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), dyn_lds, s>>>( \
-        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr, order)
+        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr, order PPP_RW_STAMP_ARG)
 #define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
     do {                                                                                                    \
         if (p1 && pass == 0) PPP_RW_LAUNCH1(A_, D_, E_, F_, true);                                          \
@@ -828,6 +853,7 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     }
 #undef PPP_RW_LAUNCH
 #undef PPP_RW_LAUNCH1
+#undef PPP_RW_STAMP_ARG
 #undef PPP_RW_CASE
     return hipGetLastError();
 }

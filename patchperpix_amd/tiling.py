@@ -34,6 +34,7 @@ of the patch-graph kernel is the only thing that depends on absolute coordinates
 import logging
 import ctypes
 import os
+import zlib
 
 import numpy as np
 
@@ -861,883 +862,970 @@ def assemble(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchsha
     ``_instances_dtype`` --, foreground uint8); with ``_gather_result=False`` the own z-range of
     both only; or (pairs, aff) with return_intermediates, with the reference's early-outs.
     """
-    import torch
-    # flags the slab pipeline does not implement are refused, never ignored (the caller --
-    # to_instance_seg -- applies skeletonize_foreground to the mask before it gets here)
-    for opt in ("skipConsensus", "skipRanking", "termAfterThinCover", "termAfterPatchGraph",
-                "save_consensus", "graphToInst", "debug", "isbiHack", "pad_with_ps",
-                "one_instance_per_channel", "no_overlap_per_channel", "sparse_labels"):
-        if kw.get(opt, False):
-            raise NotImplementedError("%s is not supported by the tiled / multi-rank assembly" % opt)
-    # the two optional branches of the greedy cover (foreground_cover.py:53-85, 141-168) leave marks
-    # anywhere in a slice: a sequential walk of the ranked list -- served on ONE rank (below)
-    seq_cover = bool(kw.get("mark_close_neighboorhood", False) or kw.get("select_patches_overlap_neighborhood", False))
-    if kw.get("aff_graph") is not None:
-        raise NotImplementedError("aff_graph input is not supported by the tiled assembly")
-    if kw.get("max_total_patch_distance_in_ps_multiples", 2) > 2:
-        raise NotImplementedError("the slab halo is sized for "
-                                  "max_total_patch_distance_in_ps_multiples <= 2")
-    if not my_slabs:
-        raise ValueError("this rank owns no z-slab (more ranks than slabs)")
-    comm = comm or LocalComm()
-    if seq_cover and comm.world > 1:
-        raise NotImplementedError("mark_close_neighboorhood / select_patches_overlap_neighborhood walk the ranked "
-                                  "list sequentially: one rank only")
-    ops = ops or DeviceOps()
-    dev = ops.device
-    Z, Y, X = [int(s) for s in shape]
-    dims = (Z, Y, X)
-    plane = Y * X
-    ps = [int(p) for p in patchshape]
-    rz = ps[0] // 2
-    rad = np.array([p // 2 for p in ps])
-    H = halo(ps)
-    provider = not torch.is_tensor(pred_local)
-    # ---- the per-voxel fields: on the device once (or already device tensors), in the "field
-    # frame" [flo, fhi) -- the whole volume, or the slices this rank was given.  Every later use
-    # (early-outs, overlap mask of the kernels, ranking, cover, thinning) is a device operation:
-    # host NumPy passes over a 512^3 volume cost 0.1-0.3 s each, and the reference's
-    # `1 * (numinst > 1)` is an int64 temporary of 8 bytes per voxel.
-    Zf = int(foreground.shape[0])
-    local_fields = Zf != Z
-    flo = lo if local_fields else 0
-    fhi = flo + Zf
-    if provider:
-        hi = fhi if local_fields else Z
-        lo_p = lo if local_fields else 0
-    else:
-        hi = lo + int(pred_local.shape[1])
-        lo_p = lo
-        if local_fields and Zf != hi - lo:
-            raise ValueError("local fields must cover the slices of pred_local")
-    for f in (mask_to_cover, numinst):
-        if tuple(int(v) for v in f.shape) != (Zf, Y, X):
-            raise ValueError("foreground / mask_to_cover / numinst differ in shape")
-    oz0, oz1 = int(my_slabs[0][0]), int(my_slabs[-1][1])       # hull of the own slabs
-    contiguous = all(my_slabs[i][1] == my_slabs[i + 1][0] for i in range(len(my_slabs) - 1))
-    need_lo, need_hi = max(0, oz0 - H), min(Z, oz1 + H)
-    if comm.world > 1 and contiguous and kw.get("_exchange_halo", True):
-        # A RESIDENT slab (and local fields) that lack the halo -- the U-Net's output as it stands on
-        # each GPU -- get it from the ranks that own it (exchange_halo: point to point over RCCL / xGMI).
-        # Every rank takes part in the decision: one MAX all-reduce of "I miss slices".
-        # `_refresh_halo`: pred_local is a halo-sized buffer whose OWN slices are current (the producer
-        # wrote them) and whose halo slices are stale -- fetched again, in place
-        refresh = bool(kw.get("_refresh_halo", False)) and not provider
-        miss_p = (not provider) and (lo_p > need_lo or hi < need_hi or refresh)
-        miss_f = local_fields and (flo > need_lo or fhi < need_hi)
-        flag = torch.tensor([int(miss_p), int(miss_f)], dtype=torch.int32, device=ops.device)
-        any_p, any_f = [int(v) for v in comm.all_reduce_max(flag).cpu()]
-        if any_p and provider:
-            raise ValueError("halo exchange: every rank must hold a resident prediction slab")
-        with backend.host_timer("halo_exchange"):
-            if any_p:
-                own = pred_local.narrow(1, oz0 - lo, oz1 - oz0)
-                in_place = refresh and lo <= need_lo and hi >= need_hi
-                pred_local = exchange_halo(own, (oz0, oz1), (need_lo, need_hi), comm, z_axis=1,
-                                           out=pred_local.narrow(1, need_lo - lo, need_hi - need_lo) if in_place else None)
-                lo = lo_p = need_lo
-                hi = need_hi
-            if any_f:
-                def with_halo(f):
-                    t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(_plain(f)))
-                    t = t.to(ops.device).narrow(0, oz0 - flo, oz1 - oz0)
-                    if t.dtype == torch.bool:
-                        t = t.to(torch.uint8)
-                    return exchange_halo(t, (oz0, oz1), (need_lo, need_hi), comm, z_axis=0)
-                foreground, mask_to_cover, numinst = with_halo(foreground), with_halo(mask_to_cover), with_halo(numinst)
-                flo, fhi = need_lo, need_hi
-                Zf = fhi - flo
-        if local_fields and not provider and (flo, fhi) != (lo, hi):
-            raise ValueError("local fields must cover the slices of pred_local")
-    if flo > need_lo or fhi < need_hi or lo_p > need_lo or hi < need_hi:
-        raise ValueError("this rank's slabs [%d, %d) need the slices [%d, %d)" % (oz0, oz1, need_lo, need_hi))
-    fg_d = _field_u8(foreground, dev, torch)
-    ni_d = numinst.to(dev) if torch.is_tensor(numinst) else \
-        torch.from_numpy(np.ascontiguousarray(_plain(numinst))).to(dev)
-    ov_d = (ni_d > 1).to(torch.uint8)
-    del ni_d
-    mask_d = _field_u8(mask_to_cover, dev, torch)
-    want_inter = kw.get("return_intermediates", False)
-    gather_result = kw.get("_gather_result", True)
-    id_dtype = np.dtype(kw.get("_instances_dtype") or np.uint16)
-    if id_dtype not in (np.dtype(np.uint16), np.dtype(np.uint32)):
-        raise ValueError("_instances_dtype must be uint16 or uint32")
+    return _Assembly(pred_local, lo, shape, foreground, mask_to_cover, numinst, patchshape, my_slabs, comm, ops, kw).run()
 
-    def own_sum(t):
-        """the same scalar on every rank: sum over ranks of a per-rank count"""
-        v = torch.tensor([int(t)], dtype=torch.int64, device=dev)
-        return int(comm.all_reduce_sum(v).item()) if comm.world > 1 else int(t)
 
-    def own_z(z0, z1):
-        """field-frame slice of the global slices [z0, z1)"""
-        return slice(z0 - flo, z1 - flo)
+class _Assembly:
+    """The state of one tiling.assemble() call; every stage is a method (round 6: up to round 5 this
+    was ONE function of 920 lines whose stages were nested closures over forty shared locals).  An
+    attribute is what more than one stage -- or a helper closure -- reads; a stage returns None to go
+    on, or the call's result (the reference's early-outs, the intermediates, the instance map)."""
 
-    def interior_count(field):
-        """voxels set in `field` (field frame) inside the interior of the WHOLE volume: counted
-        on the own slabs, summed over the ranks"""
-        n = 0
-        for (z0, z1) in my_slabs:
-            a, b = max(z0, rz), min(z1, Z - rz)
-            if a < b:
-                n += int(torch.count_nonzero(field[own_z(a, b), rad[1]:Y - rad[1], rad[2]:X - rad[2]]).item())
-        return own_sum(n)
+    def __init__(self, pred_local, lo, shape, foreground, mask_to_cover, numinst, patchshape, my_slabs, comm, ops, kw):
+        self.pred_local = pred_local
+        self.lo = lo
+        self.shape = shape
+        self.foreground = foreground
+        self.mask_to_cover = mask_to_cover
+        self.numinst = numinst
+        self.patchshape = patchshape
+        self.my_slabs = my_slabs
+        self.comm = comm
+        self.ops = ops
+        self.kw = kw
 
-    any_overlap = own_sum(int(ov_d[own_z(need_lo, need_hi)].any().item())) > 0
-    if any_overlap:
-        mask_d &= 1 - ov_d
-        if not torch.is_tensor(mask_to_cover):
-            # vote_instances.py:226 clears the caller's array as well
-            mask_to_cover[ov_d.cpu().numpy().astype(bool)] = 0
+    STAGES = ("setup", "frames", "rows_plan", "scores_pass", "select_patches", "thin_cover", "pair_affinities",
+              "label_and_paint")
 
-    def fg_out(z0=None, z1=None):
-        sl = slice(None) if z0 is None else own_z(z0, z1)
-        return fg_d[sl].cpu().numpy() if torch.is_tensor(foreground) else \
-            np.asarray(foreground[sl]).astype(np.uint8)
+    def run(self):
+        try:
+            for name in self.STAGES:
+                result = getattr(self, name)()
+                if result is not None:
+                    return result
+            raise AssertionError("the last stage returns the result")
+        finally:
+            # the helper closures hold `self` and `self` holds them: without this the tensors among the
+            # attributes (fields, node lists, an exchanged slab) would wait for the cycle collector
+            self.__dict__.clear()
 
-    def full_fg():
-        if not local_fields:
-            return fg_out()
-        g = torch.zeros(shape, dtype=torch.uint8, device=dev)
-        g[oz0:oz1] = fg_d[own_z(oz0, oz1)]
-        if rank_ranges is not None:
-            comm.all_gather_slabs(g, rank_ranges)
+    def setup(self):
+        """arguments checked, the per-voxel fields on the device, the halo exchange, the early-outs"""
+        import torch
+        # flags the slab pipeline does not implement are refused, never ignored (the caller --
+        # to_instance_seg -- applies skeletonize_foreground to the mask before it gets here)
+        for opt in ("skipConsensus", "skipRanking", "termAfterThinCover", "termAfterPatchGraph",
+                    "save_consensus", "graphToInst", "debug", "isbiHack", "pad_with_ps",
+                    "one_instance_per_channel", "no_overlap_per_channel", "sparse_labels"):
+            if self.kw.get(opt, False):
+                raise NotImplementedError("%s is not supported by the tiled / multi-rank assembly" % opt)
+        # the two optional branches of the greedy cover (foreground_cover.py:53-85, 141-168) leave marks
+        # anywhere in a slice: a sequential walk of the ranked list -- served on ONE rank (below)
+        self.seq_cover = bool(self.kw.get("mark_close_neighboorhood", False) or self.kw.get("select_patches_overlap_neighborhood", False))
+        if self.kw.get("aff_graph") is not None:
+            raise NotImplementedError("aff_graph input is not supported by the tiled assembly")
+        if self.kw.get("max_total_patch_distance_in_ps_multiples", 2) > 2:
+            raise NotImplementedError("the slab halo is sized for "
+                                      "max_total_patch_distance_in_ps_multiples <= 2")
+        if not self.my_slabs:
+            raise ValueError("this rank owns no z-slab (more ranks than slabs)")
+        self.comm = self.comm or LocalComm()
+        if self.seq_cover and self.comm.world > 1:
+            raise NotImplementedError("mark_close_neighboorhood / select_patches_overlap_neighborhood walk the ranked "
+                                      "list sequentially: one rank only")
+        self.ops = self.ops or DeviceOps()
+        self.dev = self.ops.device
+        self.Z, self.Y, self.X = [int(s) for s in self.shape]
+        self.dims = (self.Z, self.Y, self.X)
+        self.plane = self.Y * self.X
+        self.ps = [int(p) for p in self.patchshape]
+        self.rz = self.ps[0] // 2
+        self.rad = np.array([p // 2 for p in self.ps])
+        self.H = halo(self.ps)
+        self.provider = not torch.is_tensor(self.pred_local)
+        # ---- the per-voxel fields: on the device once (or already device tensors), in the "field
+        # frame" [flo, fhi) -- the whole volume, or the slices this rank was given.  Every later use
+        # (early-outs, overlap mask of the kernels, ranking, cover, thinning) is a device operation:
+        # host NumPy passes over a 512^3 volume cost 0.1-0.3 s each, and the reference's
+        # `1 * (numinst > 1)` is an int64 temporary of 8 bytes per voxel.
+        self.Zf = int(self.foreground.shape[0])
+        self.local_fields = self.Zf != self.Z
+        self.flo = self.lo if self.local_fields else 0
+        fhi = self.flo + self.Zf
+        if self.provider:
+            self.hi = fhi if self.local_fields else self.Z
+            lo_p = self.lo if self.local_fields else 0
         else:
-            comm.all_reduce_sum(g)
-        return g.cpu().numpy()
+            self.hi = self.lo + int(self.pred_local.shape[1])
+            lo_p = self.lo
+            if self.local_fields and self.Zf != self.hi - self.lo:
+                raise ValueError("local fields must cover the slices of pred_local")
+        for f in (self.mask_to_cover, self.numinst):
+            if tuple(int(v) for v in f.shape) != (self.Zf, self.Y, self.X):
+                raise ValueError("foreground / mask_to_cover / numinst differ in shape")
+        self.oz0, self.oz1 = int(self.my_slabs[0][0]), int(self.my_slabs[-1][1])       # hull of the own slabs
+        self.contiguous = all(self.my_slabs[i][1] == self.my_slabs[i + 1][0] for i in range(len(self.my_slabs) - 1))
+        self.need_lo, self.need_hi = max(0, self.oz0 - self.H), min(self.Z, self.oz1 + self.H)
+        if self.comm.world > 1 and self.contiguous and self.kw.get("_exchange_halo", True):
+            # A RESIDENT slab (and local fields) that lack the halo -- the U-Net's output as it stands on
+            # each GPU -- get it from the ranks that own it (exchange_halo: point to point over RCCL / xGMI).
+            # Every rank takes part in the decision: one MAX all-reduce of "I miss slices".
+            # `_refresh_halo`: pred_local is a halo-sized buffer whose OWN slices are current (the producer
+            # wrote them) and whose halo slices are stale -- fetched again, in place
+            refresh = bool(self.kw.get("_refresh_halo", False)) and not self.provider
+            miss_p = (not self.provider) and (lo_p > self.need_lo or self.hi < self.need_hi or refresh)
+            miss_f = self.local_fields and (self.flo > self.need_lo or fhi < self.need_hi)
+            flag = torch.tensor([int(miss_p), int(miss_f)], dtype=torch.int32, device=self.ops.device)
+            any_p, any_f = [int(v) for v in self.comm.all_reduce_max(flag).cpu()]
+            if any_p and self.provider:
+                raise ValueError("halo exchange: every rank must hold a resident prediction slab")
+            with backend.host_timer("halo_exchange"):
+                if any_p:
+                    own = self.pred_local.narrow(1, self.oz0 - self.lo, self.oz1 - self.oz0)
+                    in_place = refresh and self.lo <= self.need_lo and self.hi >= self.need_hi
+                    self.pred_local = exchange_halo(own, (self.oz0, self.oz1), (self.need_lo, self.need_hi), self.comm, z_axis=1,
+                                               out=self.pred_local.narrow(1, self.need_lo - self.lo, self.need_hi - self.need_lo) if in_place else None)
+                    self.lo = lo_p = self.need_lo
+                    self.hi = self.need_hi
+                if any_f:
+                    def with_halo(f):
+                        t = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(_plain(f)))
+                        t = t.to(self.ops.device).narrow(0, self.oz0 - self.flo, self.oz1 - self.oz0)
+                        if t.dtype == torch.bool:
+                            t = t.to(torch.uint8)
+                        return exchange_halo(t, (self.oz0, self.oz1), (self.need_lo, self.need_hi), self.comm, z_axis=0)
+                    self.foreground, self.mask_to_cover, self.numinst = with_halo(self.foreground), with_halo(self.mask_to_cover), with_halo(self.numinst)
+                    self.flo, fhi = self.need_lo, self.need_hi
+                    self.Zf = fhi - self.flo
+            if self.local_fields and not self.provider and (self.flo, fhi) != (self.lo, self.hi):
+                raise ValueError("local fields must cover the slices of pred_local")
+        if self.flo > self.need_lo or fhi < self.need_hi or lo_p > self.need_lo or self.hi < self.need_hi:
+            raise ValueError("this rank's slabs [%d, %d) need the slices [%d, %d)" % (self.oz0, self.oz1, self.need_lo, self.need_hi))
+        self.fg_d = _field_u8(self.foreground, self.dev, torch)
+        ni_d = self.numinst.to(self.dev) if torch.is_tensor(self.numinst) else \
+            torch.from_numpy(np.ascontiguousarray(_plain(self.numinst))).to(self.dev)
+        self.ov_d = (ni_d > 1).to(torch.uint8)
+        del ni_d
+        self.mask_d = _field_u8(self.mask_to_cover, self.dev, torch)
+        self.want_inter = self.kw.get("return_intermediates", False)
+        self.gather_result = self.kw.get("_gather_result", True)
+        self.id_dtype = np.dtype(self.kw.get("_instances_dtype") or np.uint16)
+        if self.id_dtype not in (np.dtype(np.uint16), np.dtype(np.uint32)):
+            raise ValueError("_instances_dtype must be uint16 or uint32")
 
-    def early():
-        if want_inter:
-            return None, None
-        if not gather_result:
-            return np.zeros((oz1 - oz0, Y, X), dtype=id_dtype), fg_out(oz0, oz1)
-        return np.zeros(shape, dtype=id_dtype), full_fg()
+        def own_sum(t):
+            """the same scalar on every rank: sum over ranks of a per-rank count"""
+            v = torch.tensor([int(t)], dtype=torch.int64, device=self.dev)
+            return int(self.comm.all_reduce_sum(v).item()) if self.comm.world > 1 else int(t)
+        self.own_sum = own_sum
 
-    flags = {k: v for k, v in kw.items()
-             if k not in ("cons_box", "cons_layout", "origin", "_yx_tiles", "_instances_dtype")}
-    ny_t, nx_t = kw.get("_yx_tiles") or (1, 1)
-    # tiles of patch centres (z0, z1, y0, y1, x0, x1): the rank's z-slabs, each cut in y / x
-    my_tiles = [(z0, z1) + t for (z0, z1) in my_slabs for t in plan_yx(Y, X, ny_t, nx_t)]
-    # every rank's contiguous z-range (None when a rank's slabs are not contiguous): the owned
-    # parts of the score / instance volumes are exchanged by ONE all-gather of slabs
-    rank_ranges = None
-    if comm.world > 1:
-        mine_r = torch.tensor([oz0, oz1 if contiguous else -1], dtype=torch.int64, device=dev)
-        rr = [tuple(int(v) for v in r) for r in comm.all_gather(mine_r).cpu().numpy()]
-        if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
-            rank_ranges = rr
-    else:
-        rank_ranges = [(oz0, oz1)] if contiguous else None
-    sharded = bool(kw.get("_sharded_global", local_fields))
-    if sharded and (rank_ranges is None or not hasattr(ops, "cover_shard")):
-        raise ValueError("the sharded global stage needs one contiguous z-range per rank")
-    if local_fields and not sharded:
-        raise ValueError("local fields need the sharded global stage")
+        def own_z(z0, z1):
+            """field-frame slice of the global slices [z0, z1)"""
+            return slice(z0 - self.flo, z1 - self.flo)
+        self.own_z = own_z
 
-    if interior_count(mask_d) == 0 or interior_count(fg_d) == 0:
-        return early()
+        def interior_count(field):
+            """voxels set in `field` (field frame) inside the interior of the WHOLE volume: counted
+            on the own slabs, summed over the ranks"""
+            n = 0
+            for (z0, z1) in self.my_slabs:
+                a, b = max(z0, self.rz), min(z1, self.Z - self.rz)
+                if a < b:
+                    n += int(torch.count_nonzero(field[self.own_z(a, b), self.rad[1]:self.Y - self.rad[1], self.rad[2]:self.X - self.rad[2]]).item())
+            return self.own_sum(n)
+        self.interior_count = interior_count
 
-    # ---- frames: what a kernel launch sees.  Resident prediction: ONE frame, the rank's whole
-    # local block.  Provider: a frame per tile and pass, the tile grown by what the pass reads.
-    def grow(t, g):
-        g = [int(v) for v in (g if np.ndim(g) else (g, g, g))]
-        return tuple(v for a in range(3) for v in (max(0, t[2 * a] - g[a]), min(dims[a], t[2 * a + 1] + g[a])))
+        self.any_overlap = self.own_sum(int(self.ov_d[self.own_z(self.need_lo, self.need_hi)].any().item())) > 0
+        if self.any_overlap:
+            self.mask_d &= 1 - self.ov_d
+            if not torch.is_tensor(self.mask_to_cover):
+                # vote_instances.py:226 clears the caller's array as well
+                self.mask_to_cover[self.ov_d.cpu().numpy().astype(bool)] = 0
 
-    def field_box(field, box):
-        z0, z1, y0, y1, x0, x1 = box
-        return field[own_z(z0, z1), y0:y1, x0:x1].contiguous()
+        def fg_out(z0=None, z1=None):
+            sl = slice(None) if z0 is None else self.own_z(z0, z1)
+            return self.fg_d[sl].cpu().numpy() if torch.is_tensor(self.foreground) else \
+                np.asarray(self.foreground[sl]).astype(np.uint8)
+        self.fg_out = fg_out
 
-    whole = None
-    if not provider:
-        whole = _Frame(pred_local, field_box(ov_d, (lo, hi, 0, Y, 0, X)), (lo, 0, 0), (hi - lo, Y, X))
-
-    def frame_for(box, next_box=None):
-        """next_box: the box that will be asked for after this one (a provider that can work
-        ahead -- ZarrProvider -- decodes it while this tile is on the device)"""
-        if whole is not None:
-            return whole
-        z0, z1, y0, y1, x0, x1 = box
-        with backend.host_timer("provider"):
-            pred_t = pred_local.pred_box(box)
-            if next_box is not None and hasattr(pred_local, "prefetch"):
-                pred_local.prefetch(next_box)
-        backend.note_add("provider_voxels", (z1 - z0) * (y1 - y0) * (x1 - x0))
-        return _Frame(pred_t, field_box(ov_d, box), (z0, y0, x0), (z1 - z0, y1 - y0, x1 - x0))
-
-    def params(fr, box=None):
-        """box: global (z0, z1, y0, y1, x0, x1) of consensus base voxels, or None."""
-        o = fr.origin
-        if box is not None:
-            box = (box[0] - o[0], box[2] - o[1], box[4] - o[2], box[1] - o[0], box[3] - o[1], box[5] - o[2])
-        P = backend.make_params(fr.shape, ps, cons_box=box, origin=o, **flags)
-        if fr.clean == 0 and fr.pred is not None and hasattr(ops, "pred_check"):
-            # ONE streaming pass per frame (the resident block: once per call; a provider's box: once
-            # per box) tells every S1 launch on it whether the short classification applies
-            fr.clean = ops.pred_check(fr.pred, P)
-        P.pred_clean = fr.clean
-        return P
-
-    def to_local(coords_t, fr, cols=1):
-        """global (z, y, x) [x cols] -> frame coordinates"""
-        sh = torch.tensor(list(fr.origin) * cols, dtype=coords_t.dtype, device=dev)
-        return (coords_t - sh).contiguous()
-
-    Pg = backend.make_params(shape, ps, **flags)          # global geometry (pairs, labels)
-    keep_cons = len(my_tiles) == 1 and kw.get("_keep_cons", True)
-    kept = {}
-
-    def bases_for_scores(t):
-        """consensus bases the scores of the centres in tile t read: t grown by the radius"""
-        return grow(t, rad)
-
-    def bases_for_pairs(t):
-        """... the pairs with patch A in t read: the voxel-major rows S[u][q], u in win(A), are
-        built from the stored (positive) offsets, S[u][q < 0] = cons[-q][u + q]; u + q lies up
-        to p-1 below u in z and up to p-1 on either side in y / x"""
-        b = []
-        for a in range(3):
-            g = ps[a] - 1
-            b += [max(0, t[2 * a] - int(rad[a]) - g),
-                  min(dims[a], t[2 * a + 1] + int(rad[a]) + (g if a > 0 else 0))]
-        return tuple(b)
-
-    words = (int(np.prod(ps)) + 31) // 32
-    can_vm = hasattr(ops, "consensus_voxel_major")
-
-    def consensus_of(fr, P, pool):
-        if can_vm and ops.rank_on_voxel_major(P):
-            # ranking and patch graph both read the voxel-major layout: S1 writes it directly
-            # where the library can (else compact planes + one re-layout, planes dropped)
-            return ops.consensus_voxel_major(fr.pred, fr.ov, P, **({"out": pool} if pool is not None else {}))
-        return ops.consensus(fr.pred, fr.ov, P), P
-
-    # ---- consensus cache (`_cons_cache`, decided by the caller's memory plan: plan_tiles).
-    # Several tiles and a resident prediction: the COMPACT planes of the rank's whole block (every
-    # tile's pairs box) are computed ONCE, tile by tile, into one array; the voxel-major rows a tile
-    # needs -- for its scores now, for its pair rows after the global stage -- are cut from it by a
-    # transpose.  S1 then runs over 1.0 x the block (+ the rank's z-halo) instead of scores pass
-    # (tile + radius) + pairs pass (tile + radius + p - 1): 2.5 x at 512^3 / 9^3.
-    cache = cache_box = None
-    if kw.get("_cons_cache") and not keep_cons and len(my_tiles) > 1 and whole is not None and contiguous \
-            and hasattr(ops, "cons_cache_alloc") \
-            and (not hasattr(ops, "rank_on_voxel_major") or ops.rank_on_voxel_major(params(whole))):
-        boxes = [bases_for_pairs(t) for t in my_tiles]
-        cache_box = tuple(f(b[i] for b in boxes) for i, f in enumerate((min, max) * 3))
-        Pc = params(whole, cache_box)
-        cache = ops.cons_cache_alloc(Pc)
-        if cache is None:
-            cache_box = None
-        else:
-            def to_frame(b):
-                o = whole.origin
-                return (b[0] - o[0], b[2] - o[1], b[4] - o[2], b[1] - o[0], b[3] - o[1], b[5] - o[2])
-            with backend.host_timer("s1_consensus"):
-                for t in my_tiles:
-                    # a tile fills its own voxels; tiles on the rim of the rank's block also the rim
-                    part = list(t)
-                    for a in range(3):
-                        lo_a, hi_a = (oz0, oz1) if a == 0 else (0, dims[a])
-                        if t[2 * a] == lo_a:
-                            part[2 * a] = cache_box[2 * a]
-                        if t[2 * a + 1] == hi_a:
-                            part[2 * a + 1] = cache_box[2 * a + 1]
-                    ops.cons_cache_fill(whole.pred, whole.ov, Pc, to_frame(part), cache)
-            backend.note("cons_cache_gb", round(cache.numel() * 4 / 1e9, 2))
-
-    def rows_from_cache(fr, cbox, pool):
-        with backend.host_timer("cons_rows"):
-            return ops.cons_from_cache(cache, to_frame(cache_box), params(fr, cbox), **({"out": pool} if pool is not None else {}))
-
-    # ---- z-sweep with the rows in a RING (`_ring_z`, decided by the caller's memory plan: plan_ring).
-    # The tiles of a (y, x) column are visited bottom-up; the row buffer is a ring of `_ring_z`
-    # slices (row of slice z in slot z mod ring).  A tile computes only the base slices its
-    # predecessor in the column has not (ppp_consensus_part) -- the rows it shares with it are still
-    # in the ring, and the mirrored entries S[u + d][-d] its predecessor's last bases wrote into
-    # rows ABOVE their own box wait there ("spill": the box of a launch reaches p - 1 slices past
-    # its last base).  So neither pass pays a z-halo: S1 runs over (tile + radius in y / x) per
-    # pass instead of (tile + radius) and (tile + radius + p - 1) in all three axes.
-    ring_z = int(kw.get("_ring_z") or 0)
-    if ring_z and (keep_cons or cache is not None or whole is None or not hasattr(ops, "ring_fill")
-                   or not ops.rank_on_voxel_major(params(whole))):
-        ring_z = 0
-    if ring_z:
-        thick = max(t[1] - t[0] for t in my_tiles)
-        if ring_z < thick + ring_margin(ps[0]) or thick < ps[0] - 1:
-            raise ValueError("_ring_z = %d is too small for tiles of %d slices (or the tiles are thinner than "
-                             "p - 1)" % (ring_z, thick))
-        # column-major order: all z-tiles of one (y, x) column, bottom-up, then the next column
-        my_tiles.sort(key=lambda t: (t[2], t[4], t[0]))
-        backend.note("ring_z", ring_z)
-    ring_state = {}
-    # the scores pass keeps a column's rows on a smaller (y, x) box than the pairs pass the pool is
-    # sized for (tile + radius instead of tile + radius + p - 1 per side): its ring is as many slices
-    # as the same pool holds of THAT box (44 -> 49 at 512^3 / 9^3 with 256^2 columns)
-    ring_sc = {"z": ring_z}
-
-    def ring_rows(fr, t, pairs_pass, pool):
-        """S1 for the new base slices of tile t into the ring; returns (pool, params of the rows the
-        consumers of t read: slices [z0 - rad, z1 + rad), the column's y / x box)."""
-        ybox = bases_for_pairs(t) if pairs_pass else bases_for_scores(t)
-        r0, r1 = bases_for_scores(t)[:2]                          # rows the consumers read
-        col = (pairs_pass,) + tuple(ybox[2:])
-        hi = ring_state.get("hi") if ring_state.get("col") == col else None
-        if hi is None or hi < r0:
-            # first tile of the column: for the pair rows also the p - 1 source slices below
-            part0 = max(bases_for_pairs(t)[0], 0) if pairs_pass else r0
-        else:
-            part0 = hi
-        o = fr.origin
-        top = min(fr.shape[0] + o[0], dims[0], r1 + ps[0] - 1)     # spill rows (inside the frame)
-        ring_len = ring_z if pairs_pass else ring_sc["z"]
-        if part0 < r1:
-            P1 = params(fr, (min(part0, r0), top) + tuple(ybox[2:]))
-            P1.cons_layout = backend.CONS_VOXEL_MAJOR
-            P1.ring_z = ring_len
-            part = (part0 - o[0], ybox[2] - o[1], ybox[4] - o[2], r1 - o[0], ybox[3] - o[1], ybox[5] - o[2])
-            ops.ring_fill(fr.pred, fr.ov, P1, part, pool)
-        ring_state.update(col=col, hi=r1)
-        Pr = params(fr, (r0, r1) + tuple(ybox[2:]))
-        Pr.cons_layout = backend.CONS_VOXEL_MAJOR
-        Pr.ring_z = ring_len
-        return pool, Pr
-
-    # ---- stage A: consensus + scores per tile ----------------------------------------------
-    # several tiles: ONE consensus buffer, sized for the largest box of either pass, serves all
-    # of them (allocated first, while the allocator's address space is still unfragmented)
-    pool = None
-    if not keep_cons and my_tiles and hasattr(ops, "voxel_major_pool"):
-        biggest = max(int(np.prod([b[2 * a + 1] - b[2 * a] for a in range(3)]))
-                      for b in (bases_for_pairs(t) for t in my_tiles))
-        if ring_z:
-            biggest = ring_z * max((b[3] - b[2]) * (b[5] - b[4]) for b in (bases_for_pairs(t) for t in my_tiles))
-        fr0 = whole if whole is not None else _Frame(None, None, (0, 0, 0), (2 * ps[0], 2 * ps[1], 2 * ps[2]))
-        P0 = params(fr0)
-        if ops.rank_on_voxel_major(P0):
-            pool = ops.voxel_major_pool(P0, biggest)
-        if ring_z and pool is not None and os.environ.get("PPP_RING_SCORES", "1") != "0":
-            area_sc = max((b[3] - b[2]) * (b[5] - b[4]) for b in (bases_for_scores(t) for t in my_tiles))
-            ring_sc["z"] = max(ring_z, int(biggest // area_sc))
-    # scores in the field frame; with a provider also the patch bits of every own voxel (the
-    # cover candidates), packed while the tile's prediction exists
-    score_f = torch.zeros((Zf, Y, X), dtype=torch.float32, device=dev)
-    bits_own = None
-    if provider:
-        bits_own = torch.zeros(((oz1 - oz0) * plane, words), dtype=torch.int32, device=dev)
-    def scores_frame_box(t):
-        return grow(bases_for_pairs(t) if keep_cons else bases_for_scores(t), 2 * rad)
-
-    # Ring sweep: ONE ranking launch serves as many consecutive tiles of a column as the ring holds
-    # rows for (their slices + the radius on both sides + the p - 1 slices S1 reaches past its last
-    # base).  A launch is as long as its slowest workgroup (the tiles of centres differ in valid
-    # rows and foreground pixels: 146 ms for one round of 1 024 workgroups, + 64 ms for every further
-    # round on a 264 x 264 column, profiles/r05_zl_s2_rounds.txt) -- a launch of 2 048 workgroups
-    # costs 0.72 of two launches of 1 024.  PPP_RANK_GROUP=1: one launch per tile.
-    rank_group = 1
-    if ring_z:
-        thick = max(t[1] - t[0] for t in my_tiles)
-        rank_group = max(1, (ring_sc["z"] - 2 * int(rad[0]) - (ps[0] - 1)) // thick)
-        rank_group = max(1, min(rank_group, int(os.environ.get("PPP_RANK_GROUP", rank_group))))
-        backend.note("rank_group", rank_group)
-        backend.note("ring_z_scores", ring_sc["z"])
-    pending = []          # tiles of the current column whose rows are in the ring, not ranked yet
-
-    for ti, t in enumerate(my_tiles):
-        z0, z1, y0, y1, x0, x1 = t
-        cbox = bases_for_pairs(t) if keep_cons else bases_for_scores(t)
-        fr = frame_for(scores_frame_box(t), scores_frame_box(my_tiles[ti + 1]) if ti + 1 < len(my_tiles) else None)
-        o = fr.origin
-        P = params(fr, cbox)
-        if cache is not None:
-            cons, P = rows_from_cache(fr, cbox, pool)
-        elif ring_z:
-            with backend.host_timer("s1_consensus"):
-                cons, P = ring_rows(fr, t, False, pool)
-            if rank_group > 1:
-                pending.append(t)
-                nxt = my_tiles[ti + 1] if ti + 1 < len(my_tiles) else None
-                if len(pending) < rank_group and nxt is not None and nxt[2:] == t[2:] and nxt[0] == t[1]:
-                    del cons, fr
-                    continue                       # ranked together with the next tile of the column
-                # the rows of every pending tile: [first z0 - rad, last z1 + rad) of the column's box
-                z0 = pending[0][0]
-                rb = bases_for_scores((z0, z1) + tuple(t[2:]))
-                P = params(fr, rb)
-                P.cons_layout = backend.CONS_VOXEL_MAJOR
-                P.ring_z = ring_sc["z"]
-                pending = []
-        else:
-            with backend.host_timer("s1_consensus"):
-                cons, P = consensus_of(fr, P, pool)
-        with backend.host_timer("s2_rank"):
-            same = fr.shape == (Zf, Y, X) and o == (flo, 0, 0)
-            sc = ops.rank_patches(fr.pred, cons, fr.ov, P, (z0 - o[0], y0 - o[1], x0 - o[2], z1 - o[0], y1 - o[1], x1 - o[2]),
-                                  **({"out": score_f} if same and hasattr(ops, "voxel_major_pool") else {}))
-            if sc is not score_f:
-                score_f[own_z(z0, z1), y0:y1, x0:x1] = sc[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
-        if provider:
-            with backend.host_timer("patch_bits"):
-                zz, yy, xx = torch.meshgrid(torch.arange(z0, z1, device=dev), torch.arange(y0, y1, device=dev),
-                                            torch.arange(x0, x1, device=dev), indexing="ij")
-                cen = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)], 1).to(torch.int32)
-                row = ((zz - oz0) * Y + yy) * X + xx
-                bits_own[row.reshape(-1)] = ops.patch_bits(fr.pred, to_local(cen, fr), kw["fc_threshold"], params(fr))
-                del zz, yy, xx, cen, row
-        if keep_cons:
-            kept[t] = (cons, P, fr)
-        del cons, sc, fr
-    if not sharded and comm.world > 1:
-        if rank_ranges is not None:
-            comm.all_gather_slabs(score_f, rank_ranges)
-        else:
-            comm.all_reduce_sum(score_f)
-    # The pooled consensus buffer stays allocated for the whole call (handing tens of GB back to
-    # the driver and asking for them again costs seconds: 2 s + 1.3 s at 512^3); the global stage
-    # carves its big temporaries -- the dense patch-bit table and the gathered candidate bits --
-    # out of it.
-    scratch = pool.view(torch.int32) if pool is not None else None
-
-    def owned(z):
-        m = torch.zeros_like(z, dtype=torch.bool)
-        for (z0, z1) in my_slabs:
-            m |= (z >= z0) & (z < z1)
-        return m
-
-    def bits_of_own(coords_own, thresh, use_scratch=False):
-        """patch bits of centres in the own slabs (global int32 [n, 3])"""
-        if provider:
-            c = coords_own.to(torch.int64)
-            return bits_own[((c[:, 0] - oz0) * Y + c[:, 1]) * X + c[:, 2]]
-        kw_s = {"scratch": scratch} if use_scratch and scratch is not None and hasattr(ops, "voxel_major_pool") else {}
-        return ops.patch_bits(whole.pred, to_local(coords_own, whole), thresh, params(whole), **kw_s)
-
-    def gathered_bits(coords_t, thresh, use_scratch=False):
-        """Patch bits of `coords_t` (global, int32 [n, 3] on the device): each rank packs those
-        centred in its own slabs, the sum over ranks is the full table."""
-        if comm.world == 1:
-            return bits_of_own(coords_t, thresh, use_scratch)       # one rank owns everything
-        bits = torch.zeros((int(coords_t.shape[0]), words), dtype=torch.int32, device=dev)
-        mine = torch.nonzero(owned(coords_t[:, 0])).reshape(-1)
-        if mine.numel():
-            bits[mine] = bits_of_own(coords_t[mine], thresh)
-        comm.all_reduce_sum(bits)
-        return bits
-
-    def coords_of(lin_g):
-        return torch.stack([lin_g // plane, (lin_g // X) % Y, lin_g % X], dim=1).to(torch.int32)
-
-    def local_params(a, b):
-        return backend.make_params((b - a, Y, X), ps, origin=(a, 0, 0), **flags)
-
-    from .vote_instances import foreground_cover as fc
-    pix_ths = fc._pix_thresholds(ps, kw)
-    thr = kw.get("score_threshold", False)
-    debug_crc = os.environ.get("PPP_DEBUG_CRC") == "1"     # development aid (tools/cover_repro.py)
-    if debug_crc:
-        import zlib
-    injected = kw.get("selected_patches") is not None
-    if injected:
-        sel_coords = np.array(list(kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
-    elif sharded:
-        # ---- stage B2: ranking and greedy cover SHARDED by z -- no rank holds a list as long as
-        # the volume.  (i) every rank sorts the patches of its own range; (ii) the position of a
-        # patch in the global ranked list = its own position + the number of patches of every
-        # other rank that precede it -- a binary search in that rank's sorted scores (all-gathered:
-        # 4 bytes per foreground voxel); ties keep raster order, i.e. lower ranks first;
-        # (iii) the cover rounds run on the own slices with the global positions as priorities
-        # (sharded_cover_own); (iv) the selected patches -- a short list -- are gathered.
-        with backend.host_timer("sort"):
-            fg_own = torch.zeros_like(fg_d)
-            fg_own[own_z(oz0, oz1)] = fg_d[own_z(oz0, oz1)]
-            lin_l, sc_own = ops.rank_order(score_f, fg_own, ps)       # field-frame indices, sorted
-            del fg_own
-            lin_own = lin_l + flo * plane
-            del lin_l
-            n_own = int(lin_own.numel())
-            rank_id = torch.arange(n_own, dtype=torch.int64, device=dev)
-            neg = -sc_own
-            for r, other in enumerate(gather_lists(comm, neg)):
-                if r != comm.rank and other.numel():
-                    rank_id += torch.searchsorted(other.contiguous(), neg, right=(r < comm.rank))
-            del neg
-            backend.note("ranked_own", n_own)
-        del score_f
-        with backend.host_timer("s3_cover"):
-            if kw.get("skipSelection", False):
-                sel_own = torch.ones(n_own, dtype=torch.bool, device=dev)
+        def full_fg():
+            if not self.local_fields:
+                return self.fg_out()
+            g = torch.zeros(self.shape, dtype=torch.uint8, device=self.dev)
+            g[self.oz0:self.oz1] = self.fg_d[self.own_z(self.oz0, self.oz1)]
+            if self.rank_ranges is not None:
+                self.comm.all_gather_slabs(g, self.rank_ranges)
             else:
-                never = torch.zeros(n_own, dtype=torch.bool, device=dev)
-                if any_overlap:
-                    never |= ov_d.reshape(-1)[lin_own - flo * plane] != 0
-                if isinstance(thr, float):
-                    never |= sc_own.double() < thr
-                h = ps[0] - 1
-                a, b = max(0, oz0 - h), min(Z, oz1 + h)
-                sel_own = sharded_cover_own(ops, comm, shape, ps, (oz0, oz1), rank_ranges,
-                                            mask_d[own_z(a, b)].clone(), a, interior_count(mask_d),
-                                            lin_own, rank_id.to(torch.int32), never,
-                                            bits_of_own(coords_of(lin_own), kw["fc_threshold"], True),
-                                            pix_ths, local_params)
-                del never
-            mine_sel = torch.stack([rank_id[sel_own], lin_own[sel_own]], 1)
-            allsel = torch.cat(gather_lists(comm, mine_sel), 0)
-            allsel = allsel[torch.argsort(allsel[:, 0])]                  # global rank order
-            sel_coords = coords_of(allsel[:, 1]).cpu().numpy()
-            del mine_sel, allsel, sel_own, lin_own, sc_own, rank_id
-    else:
-        # ---- stage B: ranking, greedy cover (global; identical on every rank) ---------------
-        # The ranked list stays on the device (it has one entry per foreground voxel of the
-        # GLOBAL volume); only the selected patches come back to the host.
-        if debug_crc:
-            backend.note("crc_scores", zlib.crc32(score_f.cpu().numpy().tobytes()))
-        with backend.host_timer("sort"):
-            lin_t, rscores_t = ops.rank_order(score_f, fg_d, ps)
-        if debug_crc:
-            backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
-        scores_host = score_f.cpu().numpy() if seq_cover and kw.get("select_patches_overlap_neighborhood") else None
-        del score_f
-        coords_t = coords_of(lin_t)
-        if kw.get("skipSelection", False):
-            sel_coords = coords_t.cpu().numpy()
-        elif seq_cover:
-            # ---- sequential native cover with marks (one rank; the ranked list goes to the host,
-            # the patch bits of a chunk of centres come from wherever the prediction lives)
-            from .vote_instances.ranked_patches import PatchList
-            with backend.host_timer("s3_cover"):
-                radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
+                self.comm.all_reduce_sum(g)
+            return g.cpu().numpy()
+        self.full_fg = full_fg
 
-                def bits_of(coords):
-                    c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.int32)).to(dev)
-                    return gathered_bits(c, kw["fc_threshold"]).cpu().numpy().view(np.uint32)
-                ranked_h = PatchList(coords_t.cpu().numpy(), rscores_t.cpu().numpy())
-                sel_list, _ = fc.cover_sequential(ov_d.cpu().numpy(), mask_d.cpu().numpy() != 0, ps, ranked_h, radslice,
-                                                  bits_of, scores_host, **kw)
-                sel_coords = np.ascontiguousarray(sel_list.coords, dtype=np.int32).reshape(-1, 3)
-            del ranked_h, scores_host
+        def early():
+            if self.want_inter:
+                return None, None
+            if not self.gather_result:
+                return np.zeros((self.oz1 - self.oz0, self.Y, self.X), dtype=self.id_dtype), self.fg_out(self.oz0, self.oz1)
+            return np.zeros(self.shape, dtype=self.id_dtype), self.full_fg()
+        self.early = early
+
+
+    def frames(self):
+        """tiles, ranks' ranges, frames (what a kernel launch sees) and their parameters"""
+        import torch
+        self.flags = {k: v for k, v in self.kw.items()
+                 if k not in ("cons_box", "cons_layout", "origin", "_yx_tiles", "_instances_dtype")}
+        self.ny_t, self.nx_t = self.kw.get("_yx_tiles") or (1, 1)
+        # tiles of patch centres (z0, z1, y0, y1, x0, x1): the rank's z-slabs, each cut in y / x
+        self.my_tiles = [(z0, z1) + t for (z0, z1) in self.my_slabs for t in plan_yx(self.Y, self.X, self.ny_t, self.nx_t)]
+        # every rank's contiguous z-range (None when a rank's slabs are not contiguous): the owned
+        # parts of the score / instance volumes are exchanged by ONE all-gather of slabs
+        self.rank_ranges = None
+        if self.comm.world > 1:
+            mine_r = torch.tensor([self.oz0, self.oz1 if self.contiguous else -1], dtype=torch.int64, device=self.dev)
+            rr = [tuple(int(v) for v in r) for r in self.comm.all_gather(mine_r).cpu().numpy()]
+            if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
+                self.rank_ranges = rr
         else:
-            # sharded over the ranks when every rank owns one contiguous z-range
-            # (PPP_COVER_SHARDED=0: every rank runs the whole cover; "force": also with one rank)
-            shard_env = os.environ.get("PPP_COVER_SHARDED", "1")
-            use_shard = (comm.world > 1 or shard_env == "force") and hasattr(ops, "cover_shard") and \
-                kw.get("_shard_cover", shard_env != "0") and rank_ranges is not None and \
-                all(r[1] - r[0] >= 2 * (ps[0] - 1) for r in rank_ranges)
-            with backend.host_timer("s3_cover"):
-                # patches the loop never looks at (foreground_cover.py:136-141): centre on an
-                # overlap voxel; everything from the first score below score_threshold on
-                never = torch.zeros(lin_t.shape, dtype=torch.bool, device=dev)
-                if any_overlap:
-                    never |= ov_d.reshape(-1)[lin_t] != 0
-                if isinstance(thr, float):
-                    below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
-                    if below.numel():
-                        never[int(below[0].item()):] = True
-                radslice = tuple(slice(int(rad[i]), shape[i] - int(rad[i])) for i in range(3))
-                if use_shard:
-                    selected = sharded_cover(ops, comm, shape, ps, rank_ranges[comm.rank], rank_ranges,
-                                             mask_d, lin_t, never, pix_ths, radslice,
-                                             lambda idx: bits_of_own(coords_t[idx], kw["fc_threshold"]),
-                                             local_params)
-                elif provider and comm.world == 1 and hasattr(ops, "voxel_major_pool"):
-                    # the per-voxel bit table of stage A serves the cover as it is (a copy in rank
-                    # order would double its 92 bytes per voxel)
-                    selected = ops.greedy_cover(mask_d, bits_own, lin_t, rscores_t, never, pix_ths, radslice,
-                                                Pg, kw, bits_first_voxel=oz0 * plane)
-                else:
-                    bits = gathered_bits(coords_t, kw["fc_threshold"], True)
-                    selected = ops.greedy_cover(mask_d, bits, lin_t, rscores_t, never, pix_ths, radslice, Pg, kw)
-                    del bits
-                del never
-                sel_coords = coords_t[selected].cpu().numpy()
-        del lin_t, rscores_t, coords_t
-    if debug_crc and not injected:
-        backend.note("crc_selected", zlib.crc32(np.ascontiguousarray(sel_coords).tobytes()))
-        if os.environ.get("PPP_STOP_AFTER_COVER") == "1":
-            return early()
-    backend.note("n_cover", len(sel_coords))
-    if not kw.get("skipThinCover") and len(sel_coords) > 0:
-        if kw.get("sample", 1.0) < 1.0:
-            raise NotImplementedError("sample < 1 uses unseeded random sampling in the reference")
-        with backend.host_timer("s4_thin"):
-            # replicated: every rank thins the same (short) global list on its own device; with
-            # local fields the mask of the whole volume is gathered for it (one byte per voxel)
-            if local_fields:
-                mask_g = torch.zeros(shape, dtype=torch.uint8, device=dev)
-                mask_g[oz0:oz1] = mask_d[own_z(oz0, oz1)]
-                comm.all_gather_slabs(mask_g, rank_ranges)
+            self.rank_ranges = [(self.oz0, self.oz1)] if self.contiguous else None
+        self.sharded = bool(self.kw.get("_sharded_global", self.local_fields))
+        if self.sharded and (self.rank_ranges is None or not hasattr(self.ops, "cover_shard")):
+            raise ValueError("the sharded global stage needs one contiguous z-range per rank")
+        if self.local_fields and not self.sharded:
+            raise ValueError("local fields need the sharded global stage")
+
+        if self.interior_count(self.mask_d) == 0 or self.interior_count(self.fg_d) == 0:
+            return self.early()
+
+        # ---- frames: what a kernel launch sees.  Resident prediction: ONE frame, the rank's whole
+        # local block.  Provider: a frame per tile and pass, the tile grown by what the pass reads.
+        def grow(t, g):
+            g = [int(v) for v in (g if np.ndim(g) else (g, g, g))]
+            return tuple(v for a in range(3) for v in (max(0, t[2 * a] - g[a]), min(self.dims[a], t[2 * a + 1] + g[a])))
+        self.grow = grow
+
+        def field_box(field, box):
+            z0, z1, y0, y1, x0, x1 = box
+            return field[self.own_z(z0, z1), y0:y1, x0:x1].contiguous()
+        self.field_box = field_box
+
+        self.whole = None
+        if not self.provider:
+            self.whole = _Frame(self.pred_local, self.field_box(self.ov_d, (self.lo, self.hi, 0, self.Y, 0, self.X)), (self.lo, 0, 0), (self.hi - self.lo, self.Y, self.X))
+
+        def frame_for(box, next_box=None):
+            """next_box: the box that will be asked for after this one (a provider that can work
+            ahead -- ZarrProvider -- decodes it while this tile is on the device)"""
+            if self.whole is not None:
+                return self.whole
+            z0, z1, y0, y1, x0, x1 = box
+            with backend.host_timer("provider"):
+                pred_t = self.pred_local.pred_box(box)
+                if next_box is not None and hasattr(self.pred_local, "prefetch"):
+                    self.pred_local.prefetch(next_box)
+            backend.note_add("provider_voxels", (z1 - z0) * (y1 - y0) * (x1 - x0))
+            return _Frame(pred_t, self.field_box(self.ov_d, box), (z0, y0, x0), (z1 - z0, y1 - y0, x1 - x0))
+        self.frame_for = frame_for
+
+        def params(fr, box=None):
+            """box: global (z0, z1, y0, y1, x0, x1) of consensus base voxels, or None."""
+            o = fr.origin
+            if box is not None:
+                box = (box[0] - o[0], box[2] - o[1], box[4] - o[2], box[1] - o[0], box[3] - o[1], box[5] - o[2])
+            P = backend.make_params(fr.shape, self.ps, cons_box=box, origin=o, **self.flags)
+            if fr.clean == 0 and fr.pred is not None and hasattr(self.ops, "pred_check"):
+                # ONE streaming pass per frame (the resident block: once per call; a provider's box: once
+                # per box) tells every S1 launch on it whether the short classification applies
+                fr.clean = self.ops.pred_check(fr.pred, P)
+            P.pred_clean = fr.clean
+            return P
+        self.params = params
+
+        def to_local(coords_t, fr, cols=1):
+            """global (z, y, x) [x cols] -> frame coordinates"""
+            sh = torch.tensor(list(fr.origin) * cols, dtype=coords_t.dtype, device=self.dev)
+            return (coords_t - sh).contiguous()
+        self.to_local = to_local
+
+        self.Pg = backend.make_params(self.shape, self.ps, **self.flags)          # global geometry (pairs, labels)
+        self.keep_cons = len(self.my_tiles) == 1 and self.kw.get("_keep_cons", True)
+        self.kept = {}
+
+        def bases_for_scores(t):
+            """consensus bases the scores of the centres in tile t read: t grown by the radius"""
+            return self.grow(t, self.rad)
+        self.bases_for_scores = bases_for_scores
+
+        def bases_for_pairs(t):
+            """... the pairs with patch A in t read: the voxel-major rows S[u][q], u in win(A), are
+            built from the stored (positive) offsets, S[u][q < 0] = cons[-q][u + q]; u + q lies up
+            to p-1 below u in z and up to p-1 on either side in y / x"""
+            b = []
+            for a in range(3):
+                g = self.ps[a] - 1
+                b += [max(0, t[2 * a] - int(self.rad[a]) - g),
+                      min(self.dims[a], t[2 * a + 1] + int(self.rad[a]) + (g if a > 0 else 0))]
+            return tuple(b)
+        self.bases_for_pairs = bases_for_pairs
+
+        self.words = (int(np.prod(self.ps)) + 31) // 32
+        self.can_vm = hasattr(self.ops, "consensus_voxel_major")
+
+        def consensus_of(fr, P, pool):
+            if self.can_vm and self.ops.rank_on_voxel_major(P):
+                # ranking and patch graph both read the voxel-major layout: S1 writes it directly
+                # where the library can (else compact planes + one re-layout, planes dropped)
+                return self.ops.consensus_voxel_major(fr.pred, fr.ov, P, **({"out": pool} if pool is not None else {}))
+            return self.ops.consensus(fr.pred, fr.ov, P), P
+        self.consensus_of = consensus_of
+
+
+    def rows_plan(self):
+        """how a tile's voxel-major rows come about: consensus cache, ring of rows, the pooled buffer"""
+        import torch
+        # ---- consensus cache (`_cons_cache`, decided by the caller's memory plan: plan_tiles).
+        # Several tiles and a resident prediction: the COMPACT planes of the rank's whole block (every
+        # tile's pairs box) are computed ONCE, tile by tile, into one array; the voxel-major rows a tile
+        # needs -- for its scores now, for its pair rows after the global stage -- are cut from it by a
+        # transpose.  S1 then runs over 1.0 x the block (+ the rank's z-halo) instead of scores pass
+        # (tile + radius) + pairs pass (tile + radius + p - 1): 2.5 x at 512^3 / 9^3.
+        self.cache = self.cache_box = None
+        if self.kw.get("_cons_cache") and not self.keep_cons and len(self.my_tiles) > 1 and self.whole is not None and self.contiguous \
+                and hasattr(self.ops, "cons_cache_alloc") \
+                and (not hasattr(self.ops, "rank_on_voxel_major") or self.ops.rank_on_voxel_major(self.params(self.whole))):
+            boxes = [self.bases_for_pairs(t) for t in self.my_tiles]
+            self.cache_box = tuple(f(b[i] for b in boxes) for i, f in enumerate((min, max) * 3))
+            Pc = self.params(self.whole, self.cache_box)
+            self.cache = self.ops.cons_cache_alloc(Pc)
+            if self.cache is None:
+                self.cache_box = None
             else:
-                mask_g = mask_d
-            sel_t = torch.from_numpy(np.ascontiguousarray(sel_coords)).to(dev)
-            bits = gathered_bits(sel_t, kw["fc_threshold"])
-            sel_lin = (sel_coords[:, 0].astype(np.int64) * Y + sel_coords[:, 1]) * X + sel_coords[:, 2]
-            if hasattr(ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
-                    and ps[2] <= 32:
-                keep = ops.thin_cover(mask_g, bits, torch.from_numpy(sel_lin).to(dev), Pg)
-                keep = keep.cpu().numpy()
+                def to_frame(b):
+                    o = self.whole.origin
+                    return (b[0] - o[0], b[2] - o[1], b[4] - o[2], b[1] - o[0], b[3] - o[1], b[5] - o[2])
+                self.to_frame = to_frame
+                with backend.host_timer("s1_consensus"):
+                    for t in self.my_tiles:
+                        # a tile fills its own voxels; tiles on the rim of the rank's block also the rim
+                        part = list(t)
+                        for a in range(3):
+                            lo_a, hi_a = (self.oz0, self.oz1) if a == 0 else (0, self.dims[a])
+                            if t[2 * a] == lo_a:
+                                part[2 * a] = self.cache_box[2 * a]
+                            if t[2 * a + 1] == hi_a:
+                                part[2 * a + 1] = self.cache_box[2 * a + 1]
+                        self.ops.cons_cache_fill(self.whole.pred, self.whole.ov, Pc, self.to_frame(part), self.cache)
+                backend.note("cons_cache_gb", round(self.cache.numel() * 4 / 1e9, 2))
+
+        def rows_from_cache(fr, cbox, pool):
+            with backend.host_timer("cons_rows"):
+                return self.ops.cons_from_cache(self.cache, self.to_frame(self.cache_box), self.params(fr, cbox), **({"out": pool} if pool is not None else {}))
+        self.rows_from_cache = rows_from_cache
+
+        # ---- z-sweep with the rows in a RING (`_ring_z`, decided by the caller's memory plan: plan_ring).
+        # The tiles of a (y, x) column are visited bottom-up; the row buffer is a ring of `_ring_z`
+        # slices (row of slice z in slot z mod ring).  A tile computes only the base slices its
+        # predecessor in the column has not (ppp_consensus_part) -- the rows it shares with it are still
+        # in the ring, and the mirrored entries S[u + d][-d] its predecessor's last bases wrote into
+        # rows ABOVE their own box wait there ("spill": the box of a launch reaches p - 1 slices past
+        # its last base).  So neither pass pays a z-halo: S1 runs over (tile + radius in y / x) per
+        # pass instead of (tile + radius) and (tile + radius + p - 1) in all three axes.
+        self.ring_z = int(self.kw.get("_ring_z") or 0)
+        if self.ring_z and (self.keep_cons or self.cache is not None or self.whole is None or not hasattr(self.ops, "ring_fill")
+                       or not self.ops.rank_on_voxel_major(self.params(self.whole))):
+            self.ring_z = 0
+        if self.ring_z:
+            thick = max(t[1] - t[0] for t in self.my_tiles)
+            if self.ring_z < thick + ring_margin(self.ps[0]) or thick < self.ps[0] - 1:
+                raise ValueError("_ring_z = %d is too small for tiles of %d slices (or the tiles are thinner than "
+                                 "p - 1)" % (self.ring_z, thick))
+            # column-major order: all z-tiles of one (y, x) column, bottom-up, then the next column
+            self.my_tiles.sort(key=lambda t: (t[2], t[4], t[0]))
+            backend.note("ring_z", self.ring_z)
+        self.ring_state = {}
+        # the scores pass keeps a column's rows on a smaller (y, x) box than the pairs pass the pool is
+        # sized for (tile + radius instead of tile + radius + p - 1 per side): its ring is as many slices
+        # as the same pool holds of THAT box (44 -> 49 at 512^3 / 9^3 with 256^2 columns)
+        self.ring_sc = {"z": self.ring_z}
+
+        def ring_rows(fr, t, pairs_pass, pool):
+            """S1 for the new base slices of tile t into the ring; returns (pool, params of the rows the
+            consumers of t read: slices [z0 - rad, z1 + rad), the column's y / x box)."""
+            ybox = self.bases_for_pairs(t) if pairs_pass else self.bases_for_scores(t)
+            r0, r1 = self.bases_for_scores(t)[:2]                          # rows the consumers read
+            col = (pairs_pass,) + tuple(ybox[2:])
+            hi = self.ring_state.get("hi") if self.ring_state.get("col") == col else None
+            if hi is None or hi < r0:
+                # first tile of the column: for the pair rows also the p - 1 source slices below
+                part0 = max(self.bases_for_pairs(t)[0], 0) if pairs_pass else r0
             else:
-                keep = backend.host_thin_cover(np.ascontiguousarray(mask_g.cpu().numpy()),
-                                               ps, np.ascontiguousarray(sel_lin),
-                                               bits.cpu().numpy().view(np.uint32))
-            sel_coords = sel_coords[keep]
-            del bits, sel_t, mask_g
-    bits_own = None
+                part0 = hi
+            o = fr.origin
+            top = min(fr.shape[0] + o[0], self.dims[0], r1 + self.ps[0] - 1)     # spill rows (inside the frame)
+            ring_len = self.ring_z if pairs_pass else self.ring_sc["z"]
+            if part0 < r1:
+                P1 = self.params(fr, (min(part0, r0), top) + tuple(ybox[2:]))
+                P1.cons_layout = backend.CONS_VOXEL_MAJOR
+                P1.ring_z = ring_len
+                part = (part0 - o[0], ybox[2] - o[1], ybox[4] - o[2], r1 - o[0], ybox[3] - o[1], ybox[5] - o[2])
+                self.ops.ring_fill(fr.pred, fr.ov, P1, part, pool)
+            self.ring_state.update(col=col, hi=r1)
+            Pr = self.params(fr, (r0, r1) + tuple(ybox[2:]))
+            Pr.cons_layout = backend.CONS_VOXEL_MAJOR
+            Pr.ring_z = ring_len
+            return pool, Pr
+        self.ring_rows = ring_rows
 
-    # ---- pairs (global coordinates; replicated, it is cheap) -------------------------------
-    order = np.argsort(sel_coords[:, 2], kind="stable")
-    nodes = np.ascontiguousarray(sel_coords[order].astype(np.int32))
-    nodes_dev = torch.from_numpy(nodes).to(dev)
-    max_ps = kw.get("max_total_patch_distance_in_ps_multiples", 2)
-    streaming = not want_inter and not kw.get("mws") and kw.get("selected_patch_pairs") is None \
-        and kw.get("_stream_pairs", os.environ.get("PPP_STREAM_PAIRS", "1") != "0") \
-        and hasattr(ops, "label_state")
+        # ---- stage A: consensus + scores per tile ----------------------------------------------
+        # several tiles: ONE consensus buffer, sized for the largest box of either pass, serves all
+        # of them (allocated first, while the allocator's address space is still unfragmented)
+        self.pool = None
+        if not self.keep_cons and self.my_tiles and hasattr(self.ops, "voxel_major_pool"):
+            biggest = max(int(np.prod([b[2 * a + 1] - b[2 * a] for a in range(3)]))
+                          for b in (self.bases_for_pairs(t) for t in self.my_tiles))
+            if self.ring_z:
+                biggest = self.ring_z * max((b[3] - b[2]) * (b[5] - b[4]) for b in (self.bases_for_pairs(t) for t in self.my_tiles))
+            fr0 = self.whole if self.whole is not None else _Frame(None, None, (0, 0, 0), (2 * self.ps[0], 2 * self.ps[1], 2 * self.ps[2]))
+            P0 = self.params(fr0)
+            if self.ops.rank_on_voxel_major(P0):
+                self.pool = self.ops.voxel_major_pool(P0, biggest)
+            if self.ring_z and self.pool is not None and os.environ.get("PPP_RING_SCORES", "1") != "0":
+                area_sc = max((b[3] - b[2]) * (b[5] - b[4]) for b in (self.bases_for_scores(t) for t in self.my_tiles))
+                self.ring_sc["z"] = max(self.ring_z, int(biggest // area_sc))
 
-    def pairs_frame_box(t):
-        # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
-        # to 2 p away) and their windows: the tile grown by the halo
-        return grow(t, (H, 2 * ps[1] + int(rad[1]), 2 * ps[2] + int(rad[2])))
+    def scores_pass(self):
+        """stage A: consensus + scores per tile"""
+        import torch
+        # scores in the field frame; with a provider also the patch bits of every own voxel (the
+        # cover candidates), packed while the tile's prediction exists
+        self.score_f = torch.zeros((self.Zf, self.Y, self.X), dtype=torch.float32, device=self.dev)
+        self.bits_own = None
+        if self.provider:
+            self.bits_own = torch.zeros(((self.oz1 - self.oz0) * self.plane, self.words), dtype=torch.int32, device=self.dev)
+        def scores_frame_box(t):
+            return self.grow(self.bases_for_pairs(t) if self.keep_cons else self.bases_for_scores(t), 2 * self.rad)
 
-    def next_of(t):
-        i = my_tiles.index(t)
-        return my_tiles[i + 1] if i + 1 < len(my_tiles) else None
+        # Ring sweep: ONE ranking launch serves as many consecutive tiles of a column as the ring holds
+        # rows for (their slices + the radius on both sides + the p - 1 slices S1 reaches past its last
+        # base).  A launch is as long as its slowest workgroup (the tiles of centres differ in valid
+        # rows and foreground pixels: 146 ms for one round of 1 024 workgroups, + 64 ms for every further
+        # round on a 264 x 264 column, profiles/r05_zl_s2_rounds.txt) -- a launch of 2 048 workgroups
+        # costs 0.72 of two launches of 1 024.  PPP_RANK_GROUP=1: one launch per tile.
+        rank_group = 1
+        if self.ring_z:
+            thick = max(t[1] - t[0] for t in self.my_tiles)
+            rank_group = max(1, (self.ring_sc["z"] - 2 * int(self.rad[0]) - (self.ps[0] - 1)) // thick)
+            rank_group = max(1, min(rank_group, int(os.environ.get("PPP_RANK_GROUP", rank_group))))
+            backend.note("rank_group", rank_group)
+            backend.note("ring_z_scores", self.ring_sc["z"])
+        pending = []          # tiles of the current column whose rows are in the ring, not ranked yet
 
-    def tile_consensus(t):
-        """(frame, cons, P) for the pairs whose patch A lies in tile t"""
-        if keep_cons:
-            cons, P, fr = kept.pop(t)
-            return fr, cons, P
-        cbox = bases_for_pairs(t)
-        if cache is not None:
-            cons, P = rows_from_cache(whole, cbox, pool)
-            return whole, cons, P
-        if ring_z:
-            cons, P = ring_rows(whole, t, True, pool)
-            return whole, cons, P
-        nxt = next_of(t)
-        fr = frame_for(pairs_frame_box(t), pairs_frame_box(nxt) if nxt is not None else None)
-        cons, P = consensus_of(fr, params(fr, cbox), pool)
-        return fr, cons, P
-
-    state = None
-    if streaming:
-        # ---- stage C (streaming): the pair rows of a tile are enumerated, scored and fed to
-        # the union-find while the tile's consensus is alive; they are never gathered.  A row
-        # belongs to the tile (hence the rank) of its first patch; its GLOBAL row id -- the
-        # position it would have in the canonical list -- comes from the exclusive scan of the
-        # per-patch partner counts, which every rank computes for its own patches only.
-        def tile_subset(t):
+        for ti, t in enumerate(self.my_tiles):
             z0, z1, y0, y1, x0, x1 = t
-            own = (nodes_dev[:, 0] >= z0) & (nodes_dev[:, 0] < z1)
-            if ny_t > 1 or nx_t > 1:
-                own &= (nodes_dev[:, 1] >= y0) & (nodes_dev[:, 1] < y1) & \
-                       (nodes_dev[:, 2] >= x0) & (nodes_dev[:, 2] < x1)
-            return torch.nonzero(own).reshape(-1)
+            cbox = self.bases_for_pairs(t) if self.keep_cons else self.bases_for_scores(t)
+            fr = self.frame_for(scores_frame_box(t), scores_frame_box(self.my_tiles[ti + 1]) if ti + 1 < len(self.my_tiles) else None)
+            o = fr.origin
+            P = self.params(fr, cbox)
+            if self.cache is not None:
+                cons, P = self.rows_from_cache(fr, cbox, self.pool)
+            elif self.ring_z:
+                with backend.host_timer("s1_consensus"):
+                    cons, P = self.ring_rows(fr, t, False, self.pool)
+                if rank_group > 1:
+                    pending.append(t)
+                    nxt = self.my_tiles[ti + 1] if ti + 1 < len(self.my_tiles) else None
+                    if len(pending) < rank_group and nxt is not None and nxt[2:] == t[2:] and nxt[0] == t[1]:
+                        del cons, fr
+                        continue                       # ranked together with the next tile of the column
+                    # the rows of every pending tile: [first z0 - rad, last z1 + rad) of the column's box
+                    z0 = pending[0][0]
+                    rb = self.bases_for_scores((z0, z1) + tuple(t[2:]))
+                    P = self.params(fr, rb)
+                    P.cons_layout = backend.CONS_VOXEL_MAJOR
+                    P.ring_z = self.ring_sc["z"]
+                    pending = []
+            else:
+                with backend.host_timer("s1_consensus"):
+                    cons, P = self.consensus_of(fr, P, self.pool)
+            with backend.host_timer("s2_rank"):
+                same = fr.shape == (self.Zf, self.Y, self.X) and o == (self.flo, 0, 0)
+                sc = self.ops.rank_patches(fr.pred, cons, fr.ov, P, (z0 - o[0], y0 - o[1], x0 - o[2], z1 - o[0], y1 - o[1], x1 - o[2]),
+                                      **({"out": self.score_f} if same and hasattr(self.ops, "voxel_major_pool") else {}))
+                if sc is not self.score_f:
+                    self.score_f[self.own_z(z0, z1), y0:y1, x0:x1] = sc[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
+            if self.provider:
+                with backend.host_timer("patch_bits"):
+                    zz, yy, xx = torch.meshgrid(torch.arange(z0, z1, device=self.dev), torch.arange(y0, y1, device=self.dev),
+                                                torch.arange(x0, x1, device=self.dev), indexing="ij")
+                    cen = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)], 1).to(torch.int32)
+                    row = ((zz - self.oz0) * self.Y + yy) * self.X + xx
+                    self.bits_own[row.reshape(-1)] = self.ops.patch_bits(fr.pred, self.to_local(cen, fr), self.kw["fc_threshold"], self.params(fr))
+                    del zz, yy, xx, cen, row
+            if self.keep_cons:
+                self.kept[t] = (cons, P, fr)
+            del cons, sc, fr
+        if not self.sharded and self.comm.world > 1:
+            if self.rank_ranges is not None:
+                self.comm.all_gather_slabs(self.score_f, self.rank_ranges)
+            else:
+                self.comm.all_reduce_sum(self.score_f)
+        # The pooled consensus buffer stays allocated for the whole call (handing tens of GB back to
+        # the driver and asking for them again costs seconds: 2 s + 1.3 s at 512^3); the global stage
+        # carves its big temporaries -- the dense patch-bit table and the gathered candidate bits --
+        # out of it.
+        self.scratch = self.pool.view(torch.int32) if self.pool is not None else None
 
-        subsets = [tile_subset(t) for t in my_tiles]
-        with backend.host_timer("pairs"):
-            counts = ops.pair_counts(nodes_dev, torch.cat(subsets) if subsets else
-                                     torch.zeros((0,), dtype=torch.int64, device=dev), Pg, max_ps)
-            comm.all_reduce_sum(counts)
-            ends = torch.cumsum(counts, 0)
-            n_pair_rows = int(ends[-1].item()) if len(nodes) else 0
-            goffsets = (ends - counts).contiguous()
-            del ends
-        n_rows = n_pair_rows + (len(nodes) if kw["includeSinglePatchCCS"] else 0)
-        if n_rows == 0:
-            return early()
-        backend.note("n_selected", len(nodes))
-        backend.note("n_pairs", n_rows)
-        state = ops.label_state(nodes_dev, Pg)
+
+    def select_patches(self):
+        """stage B: ranking and greedy cover (replicated, or sharded over the ranks by z)"""
+        import torch
+        def owned(z):
+            m = torch.zeros_like(z, dtype=torch.bool)
+            for (z0, z1) in self.my_slabs:
+                m |= (z >= z0) & (z < z1)
+            return m
+        self.owned = owned
+
+        def bits_of_own(coords_own, thresh, use_scratch=False):
+            """patch bits of centres in the own slabs (global int32 [n, 3])"""
+            if self.provider:
+                c = coords_own.to(torch.int64)
+                return self.bits_own[((c[:, 0] - self.oz0) * self.Y + c[:, 1]) * self.X + c[:, 2]]
+            kw_s = {"scratch": self.scratch} if use_scratch and self.scratch is not None and hasattr(self.ops, "voxel_major_pool") else {}
+            return self.ops.patch_bits(self.whole.pred, self.to_local(coords_own, self.whole), thresh, self.params(self.whole), **kw_s)
+        self.bits_of_own = bits_of_own
+
+        def gathered_bits(coords_t, thresh, use_scratch=False):
+            """Patch bits of `coords_t` (global, int32 [n, 3] on the device): each rank packs those
+            centred in its own slabs, the sum over ranks is the full table."""
+            if self.comm.world == 1:
+                return self.bits_of_own(coords_t, thresh, use_scratch)       # one rank owns everything
+            bits = torch.zeros((int(coords_t.shape[0]), self.words), dtype=torch.int32, device=self.dev)
+            mine = torch.nonzero(self.owned(coords_t[:, 0])).reshape(-1)
+            if mine.numel():
+                bits[mine] = self.bits_of_own(coords_t[mine], thresh)
+            self.comm.all_reduce_sum(bits)
+            return bits
+        self.gathered_bits = gathered_bits
+
+        def coords_of(lin_g):
+            return torch.stack([lin_g // self.plane, (lin_g // self.X) % self.Y, lin_g % self.X], dim=1).to(torch.int32)
+
+        def local_params(a, b):
+            return backend.make_params((b - a, self.Y, self.X), self.ps, origin=(a, 0, 0), **self.flags)
+
+        from .vote_instances import foreground_cover as fc
+        pix_ths = fc._pix_thresholds(self.ps, self.kw)
+        thr = self.kw.get("score_threshold", False)
+        self.debug_crc = os.environ.get("PPP_DEBUG_CRC") == "1"     # development aid (tools/cover_repro.py)
+        self.injected = self.kw.get("selected_patches") is not None
+        if self.injected:
+            self.sel_coords = np.array(list(self.kw["selected_patches"]), dtype=np.int32).reshape(-1, 3)
+        elif self.sharded:
+            # ---- stage B2: ranking and greedy cover SHARDED by z -- no rank holds a list as long as
+            # the volume.  (i) every rank sorts the patches of its own range; (ii) the position of a
+            # patch in the global ranked list = its own position + the number of patches of every
+            # other rank that precede it -- a binary search in that rank's sorted scores (all-gathered:
+            # 4 bytes per foreground voxel); ties keep raster order, i.e. lower ranks first;
+            # (iii) the cover rounds run on the own slices with the global positions as priorities
+            # (sharded_cover_own); (iv) the selected patches -- a short list -- are gathered.
+            with backend.host_timer("sort"):
+                fg_own = torch.zeros_like(self.fg_d)
+                fg_own[self.own_z(self.oz0, self.oz1)] = self.fg_d[self.own_z(self.oz0, self.oz1)]
+                lin_l, sc_own = self.ops.rank_order(self.score_f, fg_own, self.ps)       # field-frame indices, sorted
+                del fg_own
+                lin_own = lin_l + self.flo * self.plane
+                del lin_l
+                n_own = int(lin_own.numel())
+                rank_id = torch.arange(n_own, dtype=torch.int64, device=self.dev)
+                neg = -sc_own
+                for r, other in enumerate(gather_lists(self.comm, neg)):
+                    if r != self.comm.rank and other.numel():
+                        rank_id += torch.searchsorted(other.contiguous(), neg, right=(r < self.comm.rank))
+                del neg
+                backend.note("ranked_own", n_own)
+            del self.score_f
+            with backend.host_timer("s3_cover"):
+                if self.kw.get("skipSelection", False):
+                    sel_own = torch.ones(n_own, dtype=torch.bool, device=self.dev)
+                else:
+                    never = torch.zeros(n_own, dtype=torch.bool, device=self.dev)
+                    if self.any_overlap:
+                        never |= self.ov_d.reshape(-1)[lin_own - self.flo * self.plane] != 0
+                    if isinstance(thr, float):
+                        never |= sc_own.double() < thr
+                    h = self.ps[0] - 1
+                    a, b = max(0, self.oz0 - h), min(self.Z, self.oz1 + h)
+                    sel_own = sharded_cover_own(self.ops, self.comm, self.shape, self.ps, (self.oz0, self.oz1), self.rank_ranges,
+                                                self.mask_d[self.own_z(a, b)].clone(), a, self.interior_count(self.mask_d),
+                                                lin_own, rank_id.to(torch.int32), never,
+                                                self.bits_of_own(coords_of(lin_own), self.kw["fc_threshold"], True),
+                                                pix_ths, local_params)
+                    del never
+                mine_sel = torch.stack([rank_id[sel_own], lin_own[sel_own]], 1)
+                allsel = torch.cat(gather_lists(self.comm, mine_sel), 0)
+                allsel = allsel[torch.argsort(allsel[:, 0])]                  # global rank order
+                self.sel_coords = coords_of(allsel[:, 1]).cpu().numpy()
+                del mine_sel, allsel, sel_own, lin_own, sc_own, rank_id
+        else:
+            # ---- stage B: ranking, greedy cover (global; identical on every rank) ---------------
+            # The ranked list stays on the device (it has one entry per foreground voxel of the
+            # GLOBAL volume); only the selected patches come back to the host.
+            if self.debug_crc:
+                backend.note("crc_scores", zlib.crc32(self.score_f.cpu().numpy().tobytes()))
+            with backend.host_timer("sort"):
+                lin_t, rscores_t = self.ops.rank_order(self.score_f, self.fg_d, self.ps)
+            if self.debug_crc:
+                backend.note("crc_ranked", zlib.crc32(lin_t.cpu().numpy().tobytes()))
+            scores_host = self.score_f.cpu().numpy() if self.seq_cover and self.kw.get("select_patches_overlap_neighborhood") else None
+            del self.score_f
+            self.coords_t = coords_of(lin_t)
+            if self.kw.get("skipSelection", False):
+                self.sel_coords = self.coords_t.cpu().numpy()
+            elif self.seq_cover:
+                # ---- sequential native cover with marks (one rank; the ranked list goes to the host,
+                # the patch bits of a chunk of centres come from wherever the prediction lives)
+                from .vote_instances.ranked_patches import PatchList
+                with backend.host_timer("s3_cover"):
+                    radslice = tuple(slice(int(self.rad[i]), self.shape[i] - int(self.rad[i])) for i in range(3))
+
+                    def bits_of(coords):
+                        c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.int32)).to(self.dev)
+                        return self.gathered_bits(c, self.kw["fc_threshold"]).cpu().numpy().view(np.uint32)
+                    ranked_h = PatchList(self.coords_t.cpu().numpy(), rscores_t.cpu().numpy())
+                    sel_list, _ = fc.cover_sequential(self.ov_d.cpu().numpy(), self.mask_d.cpu().numpy() != 0, self.ps, ranked_h, radslice,
+                                                      bits_of, scores_host, **self.kw)
+                    self.sel_coords = np.ascontiguousarray(sel_list.coords, dtype=np.int32).reshape(-1, 3)
+                del ranked_h, scores_host
+            else:
+                # sharded over the ranks when every rank owns one contiguous z-range
+                # (PPP_COVER_SHARDED=0: every rank runs the whole cover; "force": also with one rank)
+                shard_env = os.environ.get("PPP_COVER_SHARDED", "1")
+                use_shard = (self.comm.world > 1 or shard_env == "force") and hasattr(self.ops, "cover_shard") and \
+                    self.kw.get("_shard_cover", shard_env != "0") and self.rank_ranges is not None and \
+                    all(r[1] - r[0] >= 2 * (self.ps[0] - 1) for r in self.rank_ranges)
+                with backend.host_timer("s3_cover"):
+                    # patches the loop never looks at (foreground_cover.py:136-141): centre on an
+                    # overlap voxel; everything from the first score below score_threshold on
+                    never = torch.zeros(lin_t.shape, dtype=torch.bool, device=self.dev)
+                    if self.any_overlap:
+                        never |= self.ov_d.reshape(-1)[lin_t] != 0
+                    if isinstance(thr, float):
+                        below = torch.nonzero(rscores_t.double() < thr).reshape(-1)
+                        if below.numel():
+                            never[int(below[0].item()):] = True
+                    radslice = tuple(slice(int(self.rad[i]), self.shape[i] - int(self.rad[i])) for i in range(3))
+                    if use_shard:
+                        selected = sharded_cover(self.ops, self.comm, self.shape, self.ps, self.rank_ranges[self.comm.rank], self.rank_ranges,
+                                                 self.mask_d, lin_t, never, pix_ths, radslice,
+                                                 lambda idx: self.bits_of_own(self.coords_t[idx], self.kw["fc_threshold"]),
+                                                 local_params)
+                    elif self.provider and self.comm.world == 1 and hasattr(self.ops, "voxel_major_pool"):
+                        # the per-voxel bit table of stage A serves the cover as it is (a copy in rank
+                        # order would double its 92 bytes per voxel)
+                        selected = self.ops.greedy_cover(self.mask_d, self.bits_own, lin_t, rscores_t, never, pix_ths, radslice,
+                                                    self.Pg, self.kw, bits_first_voxel=self.oz0 * self.plane)
+                    else:
+                        bits = self.gathered_bits(self.coords_t, self.kw["fc_threshold"], True)
+                        selected = self.ops.greedy_cover(self.mask_d, bits, lin_t, rscores_t, never, pix_ths, radslice, self.Pg, self.kw)
+                        del bits
+                    del never
+                    self.sel_coords = self.coords_t[selected].cpu().numpy()
+            del lin_t, rscores_t, self.coords_t
+
+    def thin_cover(self):
+        """set-cover thinning of the selected patches (replicated)"""
+        import torch
+        if self.debug_crc and not self.injected:
+            backend.note("crc_selected", zlib.crc32(np.ascontiguousarray(self.sel_coords).tobytes()))
+            if os.environ.get("PPP_STOP_AFTER_COVER") == "1":
+                return self.early()
+        backend.note("n_cover", len(self.sel_coords))
+        if not self.kw.get("skipThinCover") and len(self.sel_coords) > 0:
+            if self.kw.get("sample", 1.0) < 1.0:
+                raise NotImplementedError("sample < 1 uses unseeded random sampling in the reference")
+            with backend.host_timer("s4_thin"):
+                # replicated: every rank thins the same (short) global list on its own device; with
+                # local fields the mask of the whole volume is gathered for it (one byte per voxel)
+                if self.local_fields:
+                    mask_g = torch.zeros(self.shape, dtype=torch.uint8, device=self.dev)
+                    mask_g[self.oz0:self.oz1] = self.mask_d[self.own_z(self.oz0, self.oz1)]
+                    self.comm.all_gather_slabs(mask_g, self.rank_ranges)
+                else:
+                    mask_g = self.mask_d
+                sel_t = torch.from_numpy(np.ascontiguousarray(self.sel_coords)).to(self.dev)
+                bits = self.gathered_bits(sel_t, self.kw["fc_threshold"])
+                sel_lin = (self.sel_coords[:, 0].astype(np.int64) * self.Y + self.sel_coords[:, 1]) * self.X + self.sel_coords[:, 2]
+                if hasattr(self.ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
+                        and self.ps[2] <= 32:
+                    keep = self.ops.thin_cover(mask_g, bits, torch.from_numpy(sel_lin).to(self.dev), self.Pg)
+                    keep = keep.cpu().numpy()
+                else:
+                    keep = backend.host_thin_cover(np.ascontiguousarray(mask_g.cpu().numpy()),
+                                                   self.ps, np.ascontiguousarray(sel_lin),
+                                                   bits.cpu().numpy().view(np.uint32))
+                self.sel_coords = self.sel_coords[keep]
+                del bits, sel_t, mask_g
+        self.bits_own = None
+
+
+    def pair_affinities(self):
+        """pair enumeration and stage C: the pair affinities, per tile"""
+        import torch
+        # ---- pairs (global coordinates; replicated, it is cheap) -------------------------------
+        order = np.argsort(self.sel_coords[:, 2], kind="stable")
+        self.nodes = np.ascontiguousarray(self.sel_coords[order].astype(np.int32))
+        self.nodes_dev = torch.from_numpy(self.nodes).to(self.dev)
+        max_ps = self.kw.get("max_total_patch_distance_in_ps_multiples", 2)
+        streaming = not self.want_inter and not self.kw.get("mws") and self.kw.get("selected_patch_pairs") is None \
+            and self.kw.get("_stream_pairs", os.environ.get("PPP_STREAM_PAIRS", "1") != "0") \
+            and hasattr(self.ops, "label_state")
+
+        def pairs_frame_box(t):
+            # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
+            # to 2 p away) and their windows: the tile grown by the halo
+            return self.grow(t, (self.H, 2 * self.ps[1] + int(self.rad[1]), 2 * self.ps[2] + int(self.rad[2])))
+        self.pairs_frame_box = pairs_frame_box
+
+        def next_of(t):
+            i = self.my_tiles.index(t)
+            return self.my_tiles[i + 1] if i + 1 < len(self.my_tiles) else None
+        self.next_of = next_of
+
+        def tile_consensus(t):
+            """(frame, cons, P) for the pairs whose patch A lies in tile t"""
+            if self.keep_cons:
+                cons, P, fr = self.kept.pop(t)
+                return fr, cons, P
+            cbox = self.bases_for_pairs(t)
+            if self.cache is not None:
+                cons, P = self.rows_from_cache(self.whole, cbox, self.pool)
+                return self.whole, cons, P
+            if self.ring_z:
+                cons, P = self.ring_rows(self.whole, t, True, self.pool)
+                return self.whole, cons, P
+            nxt = self.next_of(t)
+            fr = self.frame_for(self.pairs_frame_box(t), self.pairs_frame_box(nxt) if nxt is not None else None)
+            cons, P = self.consensus_of(fr, self.params(fr, cbox), self.pool)
+            return fr, cons, P
+
+        self.state = None
+        if streaming:
+            # ---- stage C (streaming): the pair rows of a tile are enumerated, scored and fed to
+            # the union-find while the tile's consensus is alive; they are never gathered.  A row
+            # belongs to the tile (hence the rank) of its first patch; its GLOBAL row id -- the
+            # position it would have in the canonical list -- comes from the exclusive scan of the
+            # per-patch partner counts, which every rank computes for its own patches only.
+            def tile_subset(t):
+                z0, z1, y0, y1, x0, x1 = t
+                own = (self.nodes_dev[:, 0] >= z0) & (self.nodes_dev[:, 0] < z1)
+                if self.ny_t > 1 or self.nx_t > 1:
+                    own &= (self.nodes_dev[:, 1] >= y0) & (self.nodes_dev[:, 1] < y1) & \
+                           (self.nodes_dev[:, 2] >= x0) & (self.nodes_dev[:, 2] < x1)
+                return torch.nonzero(own).reshape(-1)
+
+            subsets = [tile_subset(t) for t in self.my_tiles]
+            with backend.host_timer("pairs"):
+                counts = self.ops.pair_counts(self.nodes_dev, torch.cat(subsets) if subsets else
+                                         torch.zeros((0,), dtype=torch.int64, device=self.dev), self.Pg, max_ps)
+                self.comm.all_reduce_sum(counts)
+                ends = torch.cumsum(counts, 0)
+                n_pair_rows = int(ends[-1].item()) if len(self.nodes) else 0
+                goffsets = (ends - counts).contiguous()
+                del ends
+            n_rows = n_pair_rows + (len(self.nodes) if self.kw["includeSinglePatchCCS"] else 0)
+            if n_rows == 0:
+                return self.early()
+            backend.note("n_selected", len(self.nodes))
+            backend.note("n_pairs", n_rows)
+            self.state = self.ops.label_state(self.nodes_dev, self.Pg)
+            with backend.host_timer("s5_patch_graph"):
+                for t, subset in zip(self.my_tiles, subsets):
+                    with backend.host_timer("s5a_select_rows"):
+                        rows_t, gid_t = self.ops.pairs_subset(self.nodes_dev, subset, counts, goffsets, n_pair_rows,
+                                                         self.Pg, max_ps, self.kw["includeSinglePatchCCS"])
+                        if rows_t is None:
+                            continue
+                    with backend.host_timer("s5b_consensus"):
+                        fr, cons, P = tile_consensus(t)
+                    with backend.host_timer("s5c_patch_graph"):
+                        a = self.ops.patch_graph(fr.pred, cons, self.to_local(rows_t, fr, 2), P)
+                    with backend.host_timer("s6_label_paint"):
+                        self.state.add(rows_t, a, gid_t)
+                    del cons, rows_t, gid_t, a, fr
+            self.kept.clear()
+            del counts, goffsets, subsets
+            if self.comm.world > 1:
+                # boundary-label merge: every rank's forest (node -> parent) is gathered and united
+                # with the own one; first appearances / "has a positive edge" are reduced
+                par, fp, hp = self.state.export()
+                self.state.merge(self.comm.all_gather(par), self.comm.all_reduce_min(fp), self.comm.all_reduce_max(hp))
+                del par, fp, hp
+            self.rows = None
+        elif self.kw.get("selected_patch_pairs") is not None:
+            rows_host = np.ascontiguousarray(
+                np.array(self.kw["selected_patch_pairs"], dtype=np.uint32).reshape(-1, 6))
+            self.rows = torch.from_numpy(rows_host.view(np.int32)).to(self.dev) if len(rows_host) else None
+        else:
+            with backend.host_timer("pairs"):
+                self.rows = self.ops.patch_pairs(self.nodes_dev, self.Pg, max_ps, self.kw["includeSinglePatchCCS"])
+        if self.state is None and self.rows is None:
+            return self.early()
+        if self.state is None:
+            n_rows = int(self.rows.shape[0])
+            backend.note("n_selected", len(self.nodes))
+            backend.note("n_pairs", n_rows)
+
+        # ---- stage C (materialised list: intermediates wanted, injected pairs, mutex watershed):
+        # pair affinities, each pair on the rank / tile that owns patch A
+        self.aff = None if self.state is not None else torch.zeros((n_rows,), dtype=torch.float32, device=self.dev)
         with backend.host_timer("s5_patch_graph"):
-            for t, subset in zip(my_tiles, subsets):
+            rows_of_tile = None
+            if self.state is None and len(self.my_tiles) > 1:
                 with backend.host_timer("s5a_select_rows"):
-                    rows_t, gid_t = ops.pairs_subset(nodes_dev, subset, counts, goffsets, n_pair_rows,
-                                                     Pg, max_ps, kw["includeSinglePatchCCS"])
-                    if rows_t is None:
+                    rows_of_tile = rows_by_tile(self.rows, self.my_tiles)
+            for n_t, t in enumerate(self.my_tiles if self.state is None else []):
+                z0, z1, y0, y1, x0, x1 = t
+                with backend.host_timer("s5a_select_rows"):
+                    if rows_of_tile is not None:
+                        idx = rows_of_tile.pop(n_t)
+                    else:
+                        own = (self.rows[:, 0] >= z0) & (self.rows[:, 0] < z1)
+                        if self.ny_t > 1 or self.nx_t > 1:
+                            own &= (self.rows[:, 1] >= y0) & (self.rows[:, 1] < y1) & \
+                                   (self.rows[:, 2] >= x0) & (self.rows[:, 2] < x1)
+                        idx = torch.nonzero(own).reshape(-1)
+                        del own
+                    if idx.numel() == 0:
                         continue
                 with backend.host_timer("s5b_consensus"):
                     fr, cons, P = tile_consensus(t)
                 with backend.host_timer("s5c_patch_graph"):
-                    a = ops.patch_graph(fr.pred, cons, to_local(rows_t, fr, 2), P)
-                with backend.host_timer("s6_label_paint"):
-                    state.add(rows_t, a, gid_t)
-                del cons, rows_t, gid_t, a, fr
-        kept.clear()
-        del counts, goffsets, subsets
-        if comm.world > 1:
-            # boundary-label merge: every rank's forest (node -> parent) is gathered and united
-            # with the own one; first appearances / "has a positive edge" are reduced
-            par, fp, hp = state.export()
-            state.merge(comm.all_gather(par), comm.all_reduce_min(fp), comm.all_reduce_max(hp))
-            del par, fp, hp
-        rows = None
-    elif kw.get("selected_patch_pairs") is not None:
-        rows_host = np.ascontiguousarray(
-            np.array(kw["selected_patch_pairs"], dtype=np.uint32).reshape(-1, 6))
-        rows = torch.from_numpy(rows_host.view(np.int32)).to(dev) if len(rows_host) else None
-    else:
-        with backend.host_timer("pairs"):
-            rows = ops.patch_pairs(nodes_dev, Pg, max_ps, kw["includeSinglePatchCCS"])
-    if state is None and rows is None:
-        return early()
-    if state is None:
-        n_rows = int(rows.shape[0])
-        backend.note("n_selected", len(nodes))
-        backend.note("n_pairs", n_rows)
+                    a = self.ops.patch_graph(fr.pred, cons, self.to_local(self.rows[idx], fr, 2), P)
+                with backend.host_timer("s5d_scatter"):
+                    self.aff[idx] = a
+                del cons, idx, a, fr
+        self.kept.clear()
+        self.pool = self.scratch = self.cache = None
+        if self.state is None:
+            self.comm.all_reduce_sum(self.aff)
+        if self.want_inter:
+            return self.rows.cpu().numpy().view(np.uint32), self.aff.cpu().numpy()
 
-    # ---- stage C (materialised list: intermediates wanted, injected pairs, mutex watershed):
-    # pair affinities, each pair on the rank / tile that owns patch A
-    aff = None if state is not None else torch.zeros((n_rows,), dtype=torch.float32, device=dev)
-    with backend.host_timer("s5_patch_graph"):
-        rows_of_tile = None
-        if state is None and len(my_tiles) > 1:
-            with backend.host_timer("s5a_select_rows"):
-                rows_of_tile = rows_by_tile(rows, my_tiles)
-        for n_t, t in enumerate(my_tiles if state is None else []):
-            z0, z1, y0, y1, x0, x1 = t
-            with backend.host_timer("s5a_select_rows"):
-                if rows_of_tile is not None:
-                    idx = rows_of_tile.pop(n_t)
-                else:
-                    own = (rows[:, 0] >= z0) & (rows[:, 0] < z1)
-                    if ny_t > 1 or nx_t > 1:
-                        own &= (rows[:, 1] >= y0) & (rows[:, 1] < y1) & \
-                               (rows[:, 2] >= x0) & (rows[:, 2] < x1)
-                    idx = torch.nonzero(own).reshape(-1)
-                    del own
-                if idx.numel() == 0:
-                    continue
-            with backend.host_timer("s5b_consensus"):
-                fr, cons, P = tile_consensus(t)
-            with backend.host_timer("s5c_patch_graph"):
-                a = ops.patch_graph(fr.pred, cons, to_local(rows[idx], fr, 2), P)
-            with backend.host_timer("s5d_scatter"):
-                aff[idx] = a
-            del cons, idx, a, fr
-    kept.clear()
-    pool = scratch = cache = None
-    if state is None:
-        comm.all_reduce_sum(aff)
-    if want_inter:
-        return rows.cpu().numpy().view(np.uint32), aff.cpu().numpy()
 
-    # ---- stage D: components (replicated) and painting of the own slabs ---------------------
-    with backend.host_timer("s6_label_paint"):
-        if kw.get("mws") and kw.get("selected_patch_pairs") is None and hasattr(ops, "mws_labels"):
-            # the library's own pair list never repeats a node pair: edge order and |aff| sort on
-            # the device, only the sequential loop on the host -- on rank 0 alone (the loop is one
-            # host thread; N copies of it on one node's memory system run slower than one), the
-            # labels reach the others as one SUM all-reduce of 4 bytes per selected patch
-            if comm.world > 1 and os.environ.get("PPP_MWS_RANK0", "1") != "0":
-                if comm.rank == 0:
-                    lab_all, n_labels = ops.mws_labels(rows, aff, nodes_dev, Pg)
-                    lab_all = torch.cat([lab_all.to(torch.int32),
-                                         torch.tensor([n_labels], dtype=torch.int32, device=dev)])
+    def label_and_paint(self):
+        """stage D: components / mutex watershed and the painting of the own slabs"""
+        import torch
+        # ---- stage D: components (replicated) and painting of the own slabs ---------------------
+        with backend.host_timer("s6_label_paint"):
+            if self.kw.get("mws") and self.kw.get("selected_patch_pairs") is None and hasattr(self.ops, "mws_labels"):
+                # the library's own pair list never repeats a node pair: edge order and |aff| sort on
+                # the device, only the sequential loop on the host -- on rank 0 alone (the loop is one
+                # host thread; N copies of it on one node's memory system run slower than one), the
+                # labels reach the others as one SUM all-reduce of 4 bytes per selected patch
+                if self.comm.world > 1 and os.environ.get("PPP_MWS_RANK0", "1") != "0":
+                    if self.comm.rank == 0:
+                        lab_all, n_labels = self.ops.mws_labels(self.rows, self.aff, self.nodes_dev, self.Pg)
+                        lab_all = torch.cat([lab_all.to(torch.int32),
+                                             torch.tensor([n_labels], dtype=torch.int32, device=self.dev)])
+                    else:
+                        lab_all = torch.zeros((len(self.nodes) + 1,), dtype=torch.int32, device=self.dev)
+                    self.comm.all_reduce_sum(lab_all)
+                    n_labels = int(lab_all[-1].item())
+                    lab_all = lab_all[:-1]
                 else:
-                    lab_all = torch.zeros((len(nodes) + 1,), dtype=torch.int32, device=dev)
-                comm.all_reduce_sum(lab_all)
-                n_labels = int(lab_all[-1].item())
-                lab_all = lab_all[:-1]
+                    lab_all, n_labels = self.ops.mws_labels(self.rows, self.aff, self.nodes_dev, self.Pg)
+                held = lab_all > 0
+                lab_nodes, labels = self.nodes_dev[held], lab_all[held]
+                del lab_all, held
+            elif self.kw.get("mws"):
+                lab_nodes, labels, n_labels = backend.host_mws(self.rows.cpu().numpy().view(np.uint32),
+                                                               self.aff.cpu().numpy(), self.shape)
+                lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(self.dev)
+                labels = torch.from_numpy(labels.astype(np.int32)).to(self.dev)
             else:
-                lab_all, n_labels = ops.mws_labels(rows, aff, nodes_dev, Pg)
-            held = lab_all > 0
-            lab_nodes, labels = nodes_dev[held], lab_all[held]
-            del lab_all, held
-        elif kw.get("mws"):
-            lab_nodes, labels, n_labels = backend.host_mws(rows.cpu().numpy().view(np.uint32),
-                                                           aff.cpu().numpy(), shape)
-            lab_nodes = torch.from_numpy(np.ascontiguousarray(lab_nodes)).to(dev)
-            labels = torch.from_numpy(labels.astype(np.int32)).to(dev)
-        else:
-            if state is not None:
-                keys = state.finish()
-                valid = keys != backend.NONE_KEY64
-                state = None
+                if self.state is not None:
+                    keys = self.state.finish()
+                    valid = keys != backend.NONE_KEY64
+                    self.state = None
+                else:
+                    keys = self.ops.label_components(self.rows, self.aff, self.nodes_dev, self.Pg)
+                    valid = keys != backend.NONE_KEY
+                # component ids in the order of their keys (= networkx's component order)
+                uniq, inverse = torch.unique(keys[valid], sorted=True, return_inverse=True)
+                lab_nodes = self.nodes_dev[valid]
+                labels = (inverse + 1).to(torch.int32)
+                n_labels = int(uniq.numel())
+                del keys, valid, uniq, inverse
+            del self.rows, self.aff
+            # ids are uint16 in the whole-volume entry (vote_instances.py:230; its np.seterr(over=
+            # 'raise') makes an id above 65 535 an error) and uint32 in the blockwise / stitched one
+            # (stitch_patch_graph.py:120), which the caller asks for with _instances_dtype
+            if n_labels > np.iinfo(self.id_dtype).max:
+                raise OverflowError("%d instance ids do not fit %s (the blockwise entry, "
+                                    "stitch_patch_graph.main, carries uint32 ids)" % (n_labels, self.id_dtype.name))
+            backend.note("ids_issued", n_labels)
+            # painted on the own slabs only; `inst_g` is the whole map when it is gathered
+            gz0, gz1 = (0, self.Z) if self.gather_result else (self.oz0, self.oz1)
+            inst_g = torch.zeros((gz1 - gz0, self.Y, self.X), dtype=torch.int32, device=self.dev)
+            if self.whole is not None:
+                Pl = self.params(self.whole)
+                for (z0, z1) in self.my_slabs:
+                    near = torch.nonzero((lab_nodes[:, 0] >= z0 - self.rz) & (lab_nodes[:, 0] < z1 + self.rz)).reshape(-1)
+                    if near.numel() == 0:
+                        continue
+                    inst_l = torch.zeros(self.whole.shape, dtype=torch.int32, device=self.dev)
+                    self.ops.paint(self.whole.pred, self.to_local(lab_nodes[near], self.whole), labels[near].contiguous(), inst_l, Pl)
+                    inst_g[z0 - gz0:z1 - gz0] = inst_l[z0 - self.lo:z1 - self.lo]
+                    del inst_l
             else:
-                keys = ops.label_components(rows, aff, nodes_dev, Pg)
-                valid = keys != backend.NONE_KEY
-            # component ids in the order of their keys (= networkx's component order)
-            uniq, inverse = torch.unique(keys[valid], sorted=True, return_inverse=True)
-            lab_nodes = nodes_dev[valid]
-            labels = (inverse + 1).to(torch.int32)
-            n_labels = int(uniq.numel())
-            del keys, valid, uniq, inverse
-        del rows, aff
-        # ids are uint16 in the whole-volume entry (vote_instances.py:230; its np.seterr(over=
-        # 'raise') makes an id above 65 535 an error) and uint32 in the blockwise / stitched one
-        # (stitch_patch_graph.py:120), which the caller asks for with _instances_dtype
-        if n_labels > np.iinfo(id_dtype).max:
-            raise OverflowError("%d instance ids do not fit %s (the blockwise entry, "
-                                "stitch_patch_graph.main, carries uint32 ids)" % (n_labels, id_dtype.name))
-        backend.note("ids_issued", n_labels)
-        # painted on the own slabs only; `inst_g` is the whole map when it is gathered
-        gz0, gz1 = (0, Z) if gather_result else (oz0, oz1)
-        inst_g = torch.zeros((gz1 - gz0, Y, X), dtype=torch.int32, device=dev)
-        if whole is not None:
-            Pl = params(whole)
-            for (z0, z1) in my_slabs:
-                near = torch.nonzero((lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)).reshape(-1)
-                if near.numel() == 0:
-                    continue
-                inst_l = torch.zeros(whole.shape, dtype=torch.int32, device=dev)
-                ops.paint(whole.pred, to_local(lab_nodes[near], whole), labels[near].contiguous(), inst_l, Pl)
-                inst_g[z0 - gz0:z1 - gz0] = inst_l[z0 - lo:z1 - lo]
-                del inst_l
-        else:
-            # nodes sorted by z once: a tile looks at the nodes of its own z-range (+ radius) only
-            # instead of scanning the whole list (640 tiles x 3.6 M nodes at 1024^3); the painting
-            # keeps the largest label per voxel, so the order of the nodes does not matter
-            if len(my_tiles) > 1 and lab_nodes.shape[0] > 0:
-                z_order = torch.argsort(lab_nodes[:, 0].contiguous(), stable=True)
-                lab_nodes, labels = lab_nodes[z_order].contiguous(), labels[z_order].contiguous()
-                node_z = lab_nodes[:, 0].contiguous()
-                del z_order
+                # nodes sorted by z once: a tile looks at the nodes of its own z-range (+ radius) only
+                # instead of scanning the whole list (640 tiles x 3.6 M nodes at 1024^3); the painting
+                # keeps the largest label per voxel, so the order of the nodes does not matter
+                if len(self.my_tiles) > 1 and lab_nodes.shape[0] > 0:
+                    z_order = torch.argsort(lab_nodes[:, 0].contiguous(), stable=True)
+                    lab_nodes, labels = lab_nodes[z_order].contiguous(), labels[z_order].contiguous()
+                    node_z = lab_nodes[:, 0].contiguous()
+                    del z_order
+                else:
+                    node_z = None
+                for t in self.my_tiles:
+                    z0, z1, y0, y1, x0, x1 = t
+                    if node_z is not None:
+                        za = int(torch.searchsorted(node_z, torch.tensor([z0 - self.rz], dtype=node_z.dtype, device=self.dev)).item())
+                        zb = int(torch.searchsorted(node_z, torch.tensor([z1 + self.rz], dtype=node_z.dtype, device=self.dev)).item())
+                        part = lab_nodes[za:zb]
+                        near = (part[:, 1] >= y0 - int(self.rad[1])) & (part[:, 1] < y1 + int(self.rad[1]))
+                        near &= (part[:, 2] >= x0 - int(self.rad[2])) & (part[:, 2] < x1 + int(self.rad[2]))
+                        near = torch.nonzero(near).reshape(-1) + za
+                        del part
+                    else:
+                        near = (lab_nodes[:, 0] >= z0 - self.rz) & (lab_nodes[:, 0] < z1 + self.rz)
+                        near &= (lab_nodes[:, 1] >= y0 - int(self.rad[1])) & (lab_nodes[:, 1] < y1 + int(self.rad[1]))
+                        near &= (lab_nodes[:, 2] >= x0 - int(self.rad[2])) & (lab_nodes[:, 2] < x1 + int(self.rad[2]))
+                        near = torch.nonzero(near).reshape(-1)
+                    if near.numel() == 0:
+                        continue
+                    nxt = self.next_of(t)
+                    fr = self.frame_for(self.grow(t, self.rad), self.grow(nxt, self.rad) if nxt is not None else None)
+                    o = fr.origin
+                    inst_l = torch.zeros(fr.shape, dtype=torch.int32, device=self.dev)
+                    self.ops.paint(fr.pred, self.to_local(lab_nodes[near], fr), labels[near].contiguous(), inst_l, self.params(fr))
+                    inst_g[z0 - gz0:z1 - gz0, y0:y1, x0:x1] = \
+                        inst_l[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
+                    del inst_l, fr
+            if not self.gather_result:
+                instances = inst_g.cpu().numpy().view(np.uint32).astype(self.id_dtype, copy=False)
+                return instances, self.fg_out(self.oz0, self.oz1)
+            if self.id_dtype == np.uint32:
+                if self.comm.world > 1:
+                    if self.rank_ranges is not None:
+                        self.comm.all_gather_slabs(inst_g, self.rank_ranges)
+                    else:
+                        self.comm.all_reduce_sum(inst_g)
+                instances = inst_g.cpu().numpy().view(np.uint32)
             else:
-                node_z = None
-            for t in my_tiles:
-                z0, z1, y0, y1, x0, x1 = t
-                if node_z is not None:
-                    za = int(torch.searchsorted(node_z, torch.tensor([z0 - rz], dtype=node_z.dtype, device=dev)).item())
-                    zb = int(torch.searchsorted(node_z, torch.tensor([z1 + rz], dtype=node_z.dtype, device=dev)).item())
-                    part = lab_nodes[za:zb]
-                    near = (part[:, 1] >= y0 - int(rad[1])) & (part[:, 1] < y1 + int(rad[1]))
-                    near &= (part[:, 2] >= x0 - int(rad[2])) & (part[:, 2] < x1 + int(rad[2]))
-                    near = torch.nonzero(near).reshape(-1) + za
-                    del part
-                else:
-                    near = (lab_nodes[:, 0] >= z0 - rz) & (lab_nodes[:, 0] < z1 + rz)
-                    near &= (lab_nodes[:, 1] >= y0 - int(rad[1])) & (lab_nodes[:, 1] < y1 + int(rad[1]))
-                    near &= (lab_nodes[:, 2] >= x0 - int(rad[2])) & (lab_nodes[:, 2] < x1 + int(rad[2]))
-                    near = torch.nonzero(near).reshape(-1)
-                if near.numel() == 0:
-                    continue
-                nxt = next_of(t)
-                fr = frame_for(grow(t, rad), grow(nxt, rad) if nxt is not None else None)
-                o = fr.origin
-                inst_l = torch.zeros(fr.shape, dtype=torch.int32, device=dev)
-                ops.paint(fr.pred, to_local(lab_nodes[near], fr), labels[near].contiguous(), inst_l, params(fr))
-                inst_g[z0 - gz0:z1 - gz0, y0:y1, x0:x1] = \
-                    inst_l[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
-                del inst_l, fr
-        if not gather_result:
-            instances = inst_g.cpu().numpy().view(np.uint32).astype(id_dtype, copy=False)
-            return instances, fg_out(oz0, oz1)
-        if id_dtype == np.uint32:
-            if comm.world > 1:
-                if rank_ranges is not None:
-                    comm.all_gather_slabs(inst_g, rank_ranges)
-                else:
-                    comm.all_reduce_sum(inst_g)
-            instances = inst_g.cpu().numpy().view(np.uint32)
-        else:
-            # ids fit 16 bits (checked above): half the bytes on the wire and to the host
-            inst16 = inst_g.to(torch.int16)
-            del inst_g
-            if comm.world > 1:
-                if rank_ranges is not None:
-                    comm.all_gather_slabs(inst16, rank_ranges)
-                else:
-                    inst32 = inst16.to(torch.int32) & 0xFFFF
-                    comm.all_reduce_sum(inst32)
-                    inst16 = inst32.to(torch.int16)
-            instances = inst16.cpu().numpy().view(np.uint16)
-    return instances, full_fg()
+                # ids fit 16 bits (checked above): half the bytes on the wire and to the host
+                inst16 = inst_g.to(torch.int16)
+                del inst_g
+                if self.comm.world > 1:
+                    if self.rank_ranges is not None:
+                        self.comm.all_gather_slabs(inst16, self.rank_ranges)
+                    else:
+                        inst32 = inst16.to(torch.int32) & 0xFFFF
+                        self.comm.all_reduce_sum(inst32)
+                        inst16 = inst32.to(torch.int16)
+                instances = inst16.cpu().numpy().view(np.uint16)
+        return instances, self.full_fg()
 
 
 def slabs_needed(shape, patchshape, free_bytes, safety=0.6, copies=3.0):
