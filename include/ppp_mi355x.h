@@ -448,6 +448,34 @@ int ppp_cover_zone(int32_t import, void *d_work, int32_t z_lo, int32_t z_hi, int
                    int32_t own_hi, int32_t *d_rank, uint8_t *d_mask, uint8_t *d_clean,
                    const ppp_params *p, void *stream);
 
+/* The set-cover thinning (ppp_thin_cover, foreground_cover.py:183-256) one round step at a time, SHARDED
+ * over ranks by z like the cover above (round 6): every rank holds its own slices + p-1 halo slices
+ * (local coordinates, origin_z = first global slice) and thins its OWN selected patches.
+ *   ppp_thin_open    d_lin int64[n]: LOCAL linear index of the own selected patches, d_index int32[n]:
+ *                    their positions in the GLOBAL selected list (the tie-break of the loop's argmax,
+ *                    :210); d_state / d_count / d_cleared int32[n] are zeroed here and filled by the
+ *                    steps: state 1 = kept in some round, 2 = retired with nothing left to cover;
+ *                    count = voxels it covered when it was kept; cleared = interior voxels among them
+ *   ppp_thin_step    PPP_COVER_COUNT / _FILTER / _SELECT (d_bits u32[n][words], the own patches' bits)
+ *   ppp_thin_alive   *alive = some own patch was undecided at the last count (host sync)
+ *   ppp_thin_zone    export / import of the local slices [z_lo, z_hi) around a slab boundary: d_key
+ *                    int64 (own slices [own_lo, own_hi), INT64_MAX elsewhere -> MIN over ranks),
+ *                    d_mask / d_clean as in ppp_cover_zone
+ *   ppp_thin_close   the running mask back into d_mask
+ * The loop's stop rule ("interior empty", tested before every pick) is the caller's: the kept patches
+ * of all ranks in the order of their keys (count descending, index ascending), cut where the cumulative
+ * cleared interior voxels reach the interior voxels the mask held at the start.
+ * Workspace: ppp_thin_shard_workspace_bytes of the LOCAL geometry.                             */
+int64_t ppp_thin_shard_workspace_bytes(const ppp_params *p);
+int ppp_thin_open(const uint8_t *d_mask, const int64_t *d_lin, const int32_t *d_index, int64_t n, int32_t *d_state,
+                  int32_t *d_count, int32_t *d_cleared, void *d_work, const ppp_params *p, void *stream);
+int ppp_thin_step(int32_t what, const uint32_t *d_bits, int32_t *d_state, int32_t *d_count, int32_t *d_cleared,
+                  void *d_work, int32_t global_z, const ppp_params *p, void *stream);
+int ppp_thin_alive(void *d_work, const ppp_params *p, void *stream, int32_t *alive);
+int ppp_thin_close(uint8_t *d_mask, void *d_work, const ppp_params *p, void *stream);
+int ppp_thin_zone(int32_t import, void *d_work, int32_t z_lo, int32_t z_hi, int32_t own_lo, int32_t own_hi,
+                  int64_t *d_key, uint8_t *d_mask, uint8_t *d_clean, const ppp_params *p, void *stream);
+
 /* --- patch pairs on the device ---------------------------------------------------------
  * replaces computeAndStorePatchPairs (aff_patch_graph.py:43-110).  d_sorted_zyx int32[n][3]
  * is the selected list stably sorted by x (aff_patch_graph.py:45).  Two calls: count the

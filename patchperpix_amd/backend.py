@@ -217,6 +217,19 @@ _SIGNATURES = {
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_thin_shard_workspace_bytes": (ctypes.c_int64, [ctypes.POINTER(Params)]),
+    "ppp_thin_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_thin_step": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(Params),
+                                     ctypes.c_void_p]),
+    "ppp_thin_alive": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_int32)]),
+    "ppp_thin_close": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
+    "ppp_thin_zone": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.POINTER(Params), ctypes.c_void_p]),
     "ppp_synth_pred": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_uint64, ctypes.POINTER(Params),
@@ -1286,6 +1299,53 @@ class CoverShard:
         with _timed("cover"):
             check(lib().ppp_cover_close(_dev_ptr(self.mask), _dev_ptr(self.work), ctypes.byref(self.P),
                                         _stream()))
+
+
+class ThinShard:
+    """One rank's share of the set-cover thinning rounds (ppp_thin_open / _step / _zone / _close; round 6):
+    local mask uint8 (Zl, Y, X) device tensor (own slices + halo), the own selected patches (local linear
+    indices, positions in the global selected list, local bit table), local params with origin_z = first
+    slice.  After the rounds: state (1 = kept), count (voxels covered when kept), cleared (interior ones)."""
+    COUNT, FILTER, SELECT = 0, 1, 2
+
+    def __init__(self, mask, lin_local, index_global, bits, P, global_z):
+        torch = _torch()
+        self.P, self.mask, self.bits = P, mask, bits
+        self.lin, self.index = lin_local.contiguous(), index_global.to(torch.int32).contiguous()
+        self.n = int(lin_local.numel())
+        self.gz = int(global_z)
+        nbytes = int(lib().ppp_thin_shard_workspace_bytes(ctypes.byref(P)))
+        check(min(nbytes, 0))
+        dev = mask.device
+        self.work = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.state = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        self.count = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        self.cleared = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        with _timed("thin_cover"):
+            check(lib().ppp_thin_open(_dev_ptr(self.mask), _dev_ptr(self.lin), _dev_ptr(self.index), self.n,
+                                      _dev_ptr(self.state), _dev_ptr(self.count), _dev_ptr(self.cleared),
+                                      _dev_ptr(self.work), ctypes.byref(self.P), _stream()))
+
+    def step(self, what):
+        with _timed("thin_cover"):
+            check(lib().ppp_thin_step(int(what), _dev_ptr(self.bits), _dev_ptr(self.state), _dev_ptr(self.count),
+                                      _dev_ptr(self.cleared), _dev_ptr(self.work), self.gz, ctypes.byref(self.P),
+                                      _stream()))
+
+    def alive(self):
+        a = ctypes.c_int32(0)
+        check(lib().ppp_thin_alive(_dev_ptr(self.work), ctypes.byref(self.P), _stream(), ctypes.byref(a)))
+        return a.value != 0
+
+    def zone(self, imp, z_lo, z_hi, own, key=None, mask=None, clean=None):
+        with _timed("thin_cover"):
+            check(lib().ppp_thin_zone(1 if imp else 0, _dev_ptr(self.work), int(z_lo), int(z_hi), int(own[0]),
+                                      int(own[1]), _dev_ptr(key), _dev_ptr(mask), _dev_ptr(clean),
+                                      ctypes.byref(self.P), _stream()))
+
+    def close(self):
+        with _timed("thin_cover"):
+            check(lib().ppp_thin_close(_dev_ptr(self.mask), _dev_ptr(self.work), ctypes.byref(self.P), _stream()))
 
 
 def synth_pred(labels, P, seed=0, hi=0.95, lo=0.05, noise=0.04, f16=True, voxel_offset=0):

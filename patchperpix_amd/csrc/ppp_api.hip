@@ -918,4 +918,62 @@ int ppp_cover_zone(int32_t import, void *d_work, int32_t z_lo, int32_t z_hi, int
     return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_cover_zone");
 }
 
+/* ---- sharded thinning: the rounds of ppp_thin_cover one step at a time on a rank's z-range ---- */
+int64_t ppp_thin_shard_workspace_bytes(const ppp_params *p) {
+    ppp::Geo G;
+    if (make_geo(p, &G) != PPP_OK) return -1;
+    return (int64_t)ppp::thin_shard_workspace_bytes(G);
+}
+
+int ppp_thin_open(const uint8_t *d_mask, const int64_t *d_lin, const int32_t *d_index, int64_t n, int32_t *d_state,
+                  int32_t *d_count, int32_t *d_cleared, void *d_work, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_mask || !d_work || (n > 0 && (!d_lin || !d_index || !d_state || !d_count || !d_cleared)))
+        return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e = ppp::thin_open(d_mask, (const long long *)d_lin, d_index, n, d_state, d_count, d_cleared, d_work, G,
+                                  (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_thin_open");
+}
+
+int ppp_thin_step(int32_t what, const uint32_t *d_bits, int32_t *d_state, int32_t *d_count, int32_t *d_cleared,
+                  void *d_work, int32_t global_z, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e;
+    if (what == PPP_COVER_COUNT) e = ppp::thin_step_count(d_bits, d_state, d_work, G, (hipStream_t)stream);
+    else if (what == PPP_COVER_FILTER) e = ppp::thin_step_filter(d_work, G, (hipStream_t)stream);
+    else if (what == PPP_COVER_SELECT) e = ppp::thin_step_select(d_bits, d_state, d_count, d_cleared, d_work, global_z, G, (hipStream_t)stream);
+    else return fail(PPP_ERR_INVALID_ARG, "unknown thinning step %d", what);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_thin_step");
+}
+
+int ppp_thin_alive(void *d_work, const ppp_params *p, void *stream, int32_t *alive) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_work || !alive) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e = ppp::thin_alive(d_work, G, alive, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_thin_alive");
+}
+
+int ppp_thin_close(uint8_t *d_mask, void *d_work, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_mask || !d_work) return fail(PPP_ERR_INVALID_ARG, "NULL pointer argument");
+    hipError_t e = ppp::thin_close(d_mask, d_work, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_thin_close");
+}
+
+int ppp_thin_zone(int32_t import, void *d_work, int32_t z_lo, int32_t z_hi, int32_t own_lo, int32_t own_hi,
+                  int64_t *d_key, uint8_t *d_mask, uint8_t *d_clean, const ppp_params *p, void *stream) {
+    ppp::Geo G;
+    PPP_TRY(cover_geo(p, &G));
+    if (!d_work || z_lo < 0 || z_hi > G.Z || z_lo > z_hi || ((d_mask == nullptr) != (d_clean == nullptr)))
+        return fail(PPP_ERR_INVALID_ARG, "bad zone");
+    hipError_t e = import ? ppp::thin_zone_import(d_work, z_lo, z_hi, (const long long *)d_key, d_mask, d_clean, G, (hipStream_t)stream)
+                          : ppp::thin_zone_export(d_work, z_lo, z_hi, own_lo, own_hi, (long long *)d_key, d_mask, d_clean, G, (hipStream_t)stream);
+    return e == hipSuccess ? PPP_OK : hip_fail(e, "ppp_thin_zone");
+}
+
 }  // extern "C"

@@ -627,7 +627,8 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(COUNT_THREADS)
     thin_count_kernel(const uint32_t *__restrict__ mbits, const uint32_t *__restrict__ bits,
                       uint8_t *__restrict__ dirty, int32_t *__restrict__ state,
-                      long long *__restrict__ key_vol, int32_t *__restrict__ n_alive, const Geo G) {
+                      long long *__restrict__ key_vol, int32_t *__restrict__ n_alive,
+                      const int32_t *__restrict__ loc_vol, const Geo G) {
     __shared__ uint16_t s_list[COUNT_THREADS];
     __shared__ int s_n;
     if (threadIdx.x == 0) s_n = 0;
@@ -636,7 +637,9 @@ __global__ void __launch_bounds__(COUNT_THREADS)
     {
         const long long v = v0 + threadIdx.x;
         const bool in = v < G.V;
-        const bool alive = in && key_vol[v] != THIN_NONE;
+        // (sharded: loc_vol = local list index of an OWN centre, -1 elsewhere -- the keys a rank sees in
+        // its halo slices belong to patches their owner counts)
+        const bool alive = in && key_vol[v] != THIN_NONE && (!loc_vol || loc_vol[v] >= 0);
         const bool marked = in && dirty[v] != 0;
         if (marked) dirty[v] = 0;
         const unsigned long long m = __ballot(alive && marked);
@@ -654,11 +657,12 @@ __global__ void __launch_bounds__(COUNT_THREADS)
     const int n = s_n;
     for (int t = threadIdx.x; t < n; t += blockDim.x) {
         const long long v = v0 + s_list[t];
-        const int k = (int)(key_vol[v] & 0xFFFFFFFFll);
+        const int k = (int)(key_vol[v] & 0xFFFFFFFFll);          // position in the (global) list: the key's tie-break
+        const int kl = loc_vol ? loc_vol[v] : k;                 // row of `bits` / `state`
         const int words = (G.C + 31) / 32, XW = row_words(G);
         int cz, cy, cx;
         centre_of(G, v, cz, cy, cx);
-        const uint32_t *b = bits + (long long)k * words;
+        const uint32_t *b = bits + (long long)kl * words;
         const int start = cx - G.rx, wi = start >> 5, sh = start & 31;
         const bool two = sh + G.px > 32;
         const uint32_t pmask = G.px >= 32 ? 0xFFFFFFFFu : ((1u << G.px) - 1u);
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(COUNT_THREADS)
             }
         }
         if (hits == 0) {
-            state[k] = 2;
+            state[kl] = 2;
             key_vol[v] = THIN_NONE;
         } else {
             key_vol[v] = ((THIN_MAXC - (long long)hits) << 32) | (long long)k;
@@ -696,14 +700,15 @@ __global__ void __launch_bounds__(256)
                        const long long *__restrict__ nbr_min, int32_t *__restrict__ state,
                        long long *__restrict__ key_vol, int32_t *__restrict__ sel_count,
                        int32_t *__restrict__ cleared_interior, uint8_t *__restrict__ dirty,
-                       const Geo G) {
+                       const int32_t *__restrict__ loc_vol, const int oz, const int gZ, const Geo G) {
     const long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const long long key = v < G.V ? key_vol[v] : THIN_NONE;
-    const bool ready = is_zmin<long long>(nbr_min, v, key, key != THIN_NONE, G);      // (xy-filtered keys)
+    bool ready = is_zmin<long long>(nbr_min, v, key, key != THIN_NONE, G);      // (xy-filtered keys)
+    int k = (int)(key & 0xFFFFFFFFll);
+    if (loc_vol && ready) { k = loc_vol[v]; ready = k >= 0; }                   // own centres only; local index
     unsigned long long todo = __ballot(ready);
     const int words = (G.C + 31) / 32, XW = row_words(G);
-    const int k = (int)(key & 0xFFFFFFFFll);
     while (todo) {
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -724,7 +729,8 @@ __global__ void __launch_bounds__(256)
             if (cl) {
                 atomicAnd(row + (start >> 5), ~(cl << sh));
                 if (sh && (cl >> (32 - sh))) atomicAnd(row + (start >> 5) + 1, ~(cl >> (32 - sh)));
-                if (z >= G.rz && z < G.Z - G.rz && y >= G.ry && y < G.Y - G.ry)
+                // (interior of the WHOLE volume: gZ slices, this buffer starts at its slice oz)
+                if (z + oz >= G.rz && z + oz < gZ - G.rz && y >= G.ry && y < G.Y - G.ry)
                     cleared += __popc(cl & xin);
             }
         }
@@ -773,10 +779,10 @@ hipError_t run_thin_cover(const uint8_t *mask, const uint32_t *bits, const long 
         if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
         for (int r = 0; r < COVER_BATCH; ++r) {
             thin_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
-                W.mbits, bits, W.dirty, W.state, W.key_vol, W.counters + r, G);
+                W.mbits, bits, W.dirty, W.state, W.key_vol, W.counters + r, nullptr, G);
             minfilter_xy<long long>(W.key_vol, W.tmp, W.nbr_min, G, s);
             thin_select_kernel<<<vgrid, block, 0, s>>>(W.mbits, bits, W.nbr_min, W.state, W.key_vol,
-                                                       W.sel_count, W.cleared, W.dirty, G);
+                                                       W.sel_count, W.cleared, W.dirty, nullptr, 0, G.Z, G);
         }
         *rounds += COVER_BATCH;
         if ((e = hipMemcpyAsync(&n_alive, W.counters + COVER_BATCH - 1, 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
@@ -943,6 +949,154 @@ hipError_t cover_zone_import(void *work, int z_lo, int z_hi, const int32_t *in_r
     if (n <= 0) return hipSuccess;
     cover_zone_import_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
         W.rank_vol, W.mbits, W.dirty, z_lo, z_hi, in_rank, in_mask, in_clean, G);
+    return hipGetLastError();
+}
+
+// ---- set-cover thinning, one round step at a time on the z-range of one rank (round 6) --------
+//
+// The same rounds as run_thin_cover with the volume split by z, after the pattern of the sharded greedy
+// cover above: every rank keeps key volume, bit mask and dirty marks for its own slices + p-1 halo slices
+// and decides its OWN patches; the caller makes the zones of 2(p-1) slices around every slab boundary
+// consistent twice per round -- keys after the count step (every slice has one owner, the others
+// contribute "none", MIN combines), mask and dirty marks after the select step.  A key's low word is the
+// patch's position in the GLOBAL selected list (the sequential loop's tie-break, foreground_cover.py:210);
+// loc_vol maps an own centre to its row in the rank's own lists.  The stop rule (foreground_cover.py:
+// 206-216) needs every rank's kept patches: the caller gathers (key at selection, cleared interior voxels).
+struct ThinShardWork {
+    long long *key_vol, *nbr_min, *tmp;  // [V] each
+    uint8_t *dirty;                      // [V]
+    uint32_t *mbits;                     // [Z*Y][XW]
+    int32_t *counters;                   // [COVER_BATCH]
+    int32_t *loc_vol;                    // [V]
+};
+size_t thin_shard_workspace_bytes(const Geo &G) {
+    return 3 * up256((size_t)G.V * 8) + up256((size_t)G.V) + up256((size_t)G.Z * G.Y * row_words(G) * 4) + 256 +
+           up256((size_t)G.V * 4);
+}
+static ThinShardWork carve_thin_shard(void *work, const Geo &G) {
+    ThinShardWork W;
+    char *p = (char *)work;
+    W.key_vol = (long long *)p; p += up256((size_t)G.V * 8);
+    W.nbr_min = (long long *)p; p += up256((size_t)G.V * 8);
+    W.tmp = (long long *)p;     p += up256((size_t)G.V * 8);
+    W.dirty = (uint8_t *)p;     p += up256((size_t)G.V);
+    W.mbits = (uint32_t *)p;    p += up256((size_t)G.Z * G.Y * row_words(G) * 4);
+    W.counters = (int32_t *)p;  p += 256;
+    W.loc_vol = (int32_t *)p;
+    return W;
+}
+__global__ void __launch_bounds__(256)
+    thin_init_local_kernel(const long long *__restrict__ lin, const int32_t *__restrict__ gidx, int n,
+                           long long *__restrict__ key_vol, int32_t *__restrict__ loc_vol) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key_vol[lin[i]] = (THIN_MAXC << 32) | (long long)gidx[i];     // (count not known yet; centres are distinct)
+    loc_vol[lin[i]] = i;
+}
+hipError_t thin_open(const uint8_t *mask, const long long *lin, const int32_t *gidx, long long n, int32_t *state,
+                     int32_t *sel_count, int32_t *cleared, void *work, const Geo &G, hipStream_t s) {
+    if (n >= (1ll << 31) || G.C >= THIN_MAXC) return hipErrorInvalidValue;
+    PPP_GRID_CHECK((G.V + 255) / 256, 256);
+    ThinShardWork W = carve_thin_shard(work, G);
+    hipError_t e;
+    if ((e = hipMemsetD32Async((hipDeviceptr_t)W.key_vol, 0x7F7F7F7F, (size_t)G.V * 2, s)) != hipSuccess) return e;
+    if ((e = hipMemsetD32Async((hipDeviceptr_t)W.loc_vol, 0xFFFFFFFF, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.dirty, 1, (size_t)G.V, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(W.counters, 0, COVER_BATCH * 4, s)) != hipSuccess) return e;
+    if (n) {
+        if ((e = hipMemsetAsync(state, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(sel_count, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(cleared, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    }
+    const dim3 block(256);
+    const long long n_words = (long long)G.Z * G.Y * row_words(G);
+    cover_pack_kernel<<<dim3((unsigned)((n_words + 255) / 256)), block, 0, s>>>(mask, W.mbits, G);
+    if (n) thin_init_local_kernel<<<dim3((unsigned)((n + 255) / 256)), block, 0, s>>>(lin, gidx, (int)n, W.key_vol, W.loc_vol);
+    return hipGetLastError();
+}
+hipError_t thin_step_count(const uint32_t *bits, int32_t *state, void *work, const Geo &G, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    hipError_t e;
+    if ((e = hipMemsetAsync(W.counters, 0, 4, s)) != hipSuccess) return e;
+    thin_count_kernel<<<dim3((unsigned)((G.V + COUNT_THREADS - 1) / COUNT_THREADS)), dim3(COUNT_THREADS), 0, s>>>(
+        W.mbits, bits, W.dirty, state, W.key_vol, W.counters, W.loc_vol, G);
+    return hipGetLastError();
+}
+hipError_t thin_step_filter(void *work, const Geo &G, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    minfilter_xy<long long>(W.key_vol, W.tmp, W.nbr_min, G, s);
+    return hipGetLastError();
+}
+hipError_t thin_step_select(const uint32_t *bits, int32_t *state, int32_t *sel_count, int32_t *cleared, void *work,
+                            int gZ, const Geo &G, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    thin_select_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(
+        W.mbits, bits, W.nbr_min, state, W.key_vol, sel_count, cleared, W.dirty, W.loc_vol, G.oz, gZ, G);
+    return hipGetLastError();
+}
+hipError_t thin_alive(void *work, const Geo &G, int32_t *alive, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    hipError_t e;
+    if ((e = hipMemcpyAsync(alive, W.counters, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
+hipError_t thin_close(uint8_t *mask, void *work, const Geo &G, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    cover_unpack_kernel<<<dim3((unsigned)((G.V + 255) / 256)), dim3(256), 0, s>>>(W.mbits, mask, G);
+    return hipGetLastError();
+}
+static constexpr long long THIN_ZONE_NONE = 0x7FFFFFFFFFFFFFFFll;      // "not my slice" in an exported zone of keys
+__global__ void __launch_bounds__(256)
+    thin_zone_export_kernel(const long long *__restrict__ key_vol, const uint32_t *__restrict__ mbits,
+                            const uint8_t *__restrict__ dirty, const int z_lo, const int z_hi, const int own_lo,
+                            const int own_hi, long long *__restrict__ out_key, uint8_t *__restrict__ out_mask,
+                            uint8_t *__restrict__ out_clean, const Geo G) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long plane = (long long)G.Y * G.X;
+    if (t >= (long long)(z_hi - z_lo) * plane) return;
+    const int z = z_lo + (int)(t / plane);
+    const long long v = (long long)z * plane + t % plane;
+    const int x = (int)(v % G.X);
+    const long long row = v / G.X;
+    if (out_key) out_key[t] = (z >= own_lo && z < own_hi) ? key_vol[v] : THIN_ZONE_NONE;
+    if (out_mask) {
+        out_mask[t] = (mbits[row * row_words(G) + (x >> 5)] >> (x & 31)) & 1u;
+        out_clean[t] = dirty[v] ? 0 : 1;
+    }
+}
+__global__ void __launch_bounds__(256)
+    thin_zone_import_kernel(long long *__restrict__ key_vol, uint32_t *__restrict__ mbits, uint8_t *__restrict__ dirty,
+                            const int z_lo, const int z_hi, const long long *__restrict__ in_key,
+                            const uint8_t *__restrict__ in_mask, const uint8_t *__restrict__ in_clean, const Geo G) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long plane = (long long)G.Y * G.X;
+    if (t >= (long long)(z_hi - z_lo) * plane) return;
+    const int z = z_lo + (int)(t / plane);
+    const long long v = (long long)z * plane + t % plane;
+    const int x = (int)(v % G.X);
+    const long long row = v / G.X;
+    if (in_key) key_vol[v] = in_key[t] == THIN_ZONE_NONE ? THIN_NONE : in_key[t];
+    if (in_mask) {
+        if (!in_mask[t]) atomicAnd(&mbits[row * row_words(G) + (x >> 5)], ~(1u << (x & 31)));
+        if (!in_clean[t]) dirty[v] = 1;
+    }
+}
+hipError_t thin_zone_export(void *work, int z_lo, int z_hi, int own_lo, int own_hi, long long *out_key,
+                            uint8_t *out_mask, uint8_t *out_clean, const Geo &G, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    const long long n = (long long)(z_hi - z_lo) * G.Y * G.X;
+    if (n <= 0) return hipSuccess;
+    thin_zone_export_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        W.key_vol, W.mbits, W.dirty, z_lo, z_hi, own_lo, own_hi, out_key, out_mask, out_clean, G);
+    return hipGetLastError();
+}
+hipError_t thin_zone_import(void *work, int z_lo, int z_hi, const long long *in_key, const uint8_t *in_mask,
+                            const uint8_t *in_clean, const Geo &G, hipStream_t s) {
+    ThinShardWork W = carve_thin_shard(work, G);
+    const long long n = (long long)(z_hi - z_lo) * G.Y * G.X;
+    if (n <= 0) return hipSuccess;
+    thin_zone_import_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        W.key_vol, W.mbits, W.dirty, z_lo, z_hi, in_key, in_mask, in_clean, G);
     return hipGetLastError();
 }
 

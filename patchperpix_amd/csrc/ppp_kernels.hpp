@@ -163,5 +163,19 @@ hipError_t cover_zone_export(void *work, int z_lo, int z_hi, int own_lo, int own
 hipError_t cover_zone_import(void *work, int z_lo, int z_hi, const int32_t *in_rank,
                              const uint8_t *in_mask, const uint8_t *in_clean, const Geo &G,
                              hipStream_t s);
+// set-cover thinning sharded over ranks by z (round 6)
+size_t thin_shard_workspace_bytes(const Geo &G);
+hipError_t thin_open(const uint8_t *mask, const long long *lin, const int32_t *gidx, long long n, int32_t *state,
+                     int32_t *sel_count, int32_t *cleared, void *work, const Geo &G, hipStream_t s);
+hipError_t thin_step_count(const uint32_t *bits, int32_t *state, void *work, const Geo &G, hipStream_t s);
+hipError_t thin_step_filter(void *work, const Geo &G, hipStream_t s);
+hipError_t thin_step_select(const uint32_t *bits, int32_t *state, int32_t *sel_count, int32_t *cleared, void *work,
+                            int gZ, const Geo &G, hipStream_t s);
+hipError_t thin_alive(void *work, const Geo &G, int32_t *alive, hipStream_t s);
+hipError_t thin_close(uint8_t *mask, void *work, const Geo &G, hipStream_t s);
+hipError_t thin_zone_export(void *work, int z_lo, int z_hi, int own_lo, int own_hi, long long *out_key,
+                            uint8_t *out_mask, uint8_t *out_clean, const Geo &G, hipStream_t s);
+hipError_t thin_zone_import(void *work, int z_lo, int z_hi, const long long *in_key, const uint8_t *in_mask,
+                            const uint8_t *in_clean, const Geo &G, hipStream_t s);
 
 }  // namespace ppp

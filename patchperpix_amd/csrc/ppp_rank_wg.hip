@@ -291,15 +291,34 @@ __global__ void __launch_bounds__(256)
 // tiles (neighbours share rows in its L2) and walks it in descending order of weight.
 // order[slot] = tile, or -1 for the padding slots.
 static constexpr int RW_ORDER_MAX = 16384;
+// Tile number -> (tz, ty, tx).  Round 6: Y-MAJOR numbering (y_major = 1).  Every XCD takes a contiguous range
+// of tile numbers; numbered z-major, XCD 0 held the launch's lowest z-tiles and XCD 7 its highest, and a
+// launch's z-edge tiles run ~20 % longer than its inner ones -- per-workgroup start / end stamps
+// (tools/s2_wg_times.py, profiles/r06_h*): the XCDs of a 2 048-tile launch finished between 134 and 178 ms.
+// Numbered y-major an XCD's range is a slab of y-tiles with EVERY z-tile in it (and z-neighbours, which
+// share half of their rows, still meet in one L2).  PPP_RANK_TILE_MAJOR=z: the old numbering.
+__device__ __forceinline__ void rw_tile_decode(int bid, int n_tiles, int tiles_y, int tiles_x, int y_major,
+                                               int &tz_i, int &ty_i, int &tx_i) {
+    tx_i = bid % tiles_x;
+    if (y_major) {
+        const int tiles_z = n_tiles / (tiles_y * tiles_x);
+        tz_i = (bid / tiles_x) % tiles_z;
+        ty_i = bid / (tiles_x * tiles_z);
+    } else {
+        ty_i = (bid / tiles_x) % tiles_y;
+        tz_i = bid / (tiles_x * tiles_y);
+    }
+}
 // weight of a tile = the chunks of 64 items its workgroup walks: over the VALID voxels u of the tile
 // grown by the radius, ceil(items of u / 64) (+ 1 for the row's staging and barriers); 0 without an
 // active centre (the workgroup leaves at once).  PPP_RANK_ORDER=centres: the active centres instead.
 __global__ void __launch_bounds__(256)
     rank_tile_weight_kernel(const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid, const ppp_box sb,
                             const int TZ, const int TY, const int TX, const int tiles_y, const int tiles_x,
-                            const int by_centres, int32_t *__restrict__ weight, const Geo G) {
+                            const int by_centres, const int y_major, int32_t *__restrict__ weight, const Geo G) {
     const int bid = blockIdx.x;
-    const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
+    int tx_i, ty_i, tz_i;
+    rw_tile_decode(bid, (int)gridDim.x, tiles_y, tiles_x, y_major, tz_i, ty_i, tx_i);
     const int sX = sb.x1 - sb.x0, sY = sb.y1 - sb.y0, sZ = sb.z1 - sb.z0;
     int c = 0, w = 0;
     for (int cl = threadIdx.x; cl < TZ * TY * TX; cl += blockDim.x) {
@@ -357,7 +376,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
                    const uint32_t *__restrict__ info, const uint8_t *__restrict__ valid,
                    float *__restrict__ score, const ppp_box sb, const Geo G, const int tiles_y,
                    const int tiles_x, const int n_tiles, const int *__restrict__ any_e,
-                   const int32_t *__restrict__ order
+                   const int32_t *__restrict__ order, const int y_major
 #ifdef PPP_RW_STAMPS
                    , uint32_t *__restrict__ stamps
 #endif
@@ -400,7 +419,8 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
     // (heavy tiles first within the XCD's range when the launcher made an order)
     const int bid = order ? order[slot] : slot;
     if (bid < 0 || bid >= n_tiles) return;
-    const int tx_i = bid % tiles_x, ty_i = (bid / tiles_x) % tiles_y, tz_i = bid / (tiles_x * tiles_y);
+    int tx_i, ty_i, tz_i;
+    rw_tile_decode(bid, n_tiles, tiles_y, tiles_x, y_major, tz_i, ty_i, tx_i);
     const int c0z = sb.z0 + tz_i * TZ, c0y = sb.y0 + ty_i * TY, c0x = sb.x0 + tx_i * TX;
     const int tz = min(TZ, sb.z1 - c0z), ty = min(TY, sb.y1 - c0y), tx = min(TX, sb.x1 - c0x);
     if (tz <= 0 || ty <= 0 || tx <= 0) return;
@@ -730,10 +750,12 @@ __global__ void __launch_bounds__(64 * RW_WAVES, PPP_RW_MINWAVES(PX))
         const unsigned long long t_end = __builtin_readcyclecounter();
         unsigned hw_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        unsigned xcc_id;          // (s_memtime is a counter per XCD: the tool needs to know whose clock a stamp is)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
         stamps[4 * blockIdx.x + 0] = (uint32_t)(t_start >> 8);     // (256-cycle units: 32 bits hold minutes)
         stamps[4 * blockIdx.x + 1] = (uint32_t)(t_end >> 8);
         stamps[4 * blockIdx.x + 2] = hw_id;
-        stamps[4 * blockIdx.x + 3] = (uint32_t)bid;
+        stamps[4 * blockIdx.x + 3] = (uint32_t)bid | ((xcc_id & 0xFu) << 24);
     }
 #endif
 }
@@ -810,6 +832,8 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     int32_t *weight = (int32_t *)((char *)any_e + 256), *order = weight + RW_ORDER_MAX;
     if (n_tiles > RW_ORDER_MAX || (order_sw.get() && order_sw.get()[0] == '0')) order = nullptr;
     const bool by_centres = order_sw.get() && order_sw.get()[0] == 'c';
+    static EnvSwitch major_sw("PPP_RANK_TILE_MAJOR");
+    const int y_major = (major_sw.get() && major_sw.get()[0] == 'z') ? 0 : 1;
     // (occupancy experiment: PPP_RANK_WG_DYNLDS=<bytes> of unused dynamic LDS per workgroup)
     static EnvSwitch dyn_sw("PPP_RANK_WG_DYNLDS");
     const unsigned dyn_lds = dyn_sw.get() ? (unsigned)atoi(dyn_sw.get()) : 0u;
@@ -820,7 +844,7 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
 #endif
 #define PPP_RW_LAUNCH1(A_, D_, E_, F_, P1_)                                                                 \
     rank_wg_kernel<A_, A_, A_, D_, E_, F_, P1_><<<dim3((unsigned)n_blocks), dim3(64 * RW_WAVES), dyn_lds, s>>>( \
-        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr, order PPP_RW_STAMP_ARG)
+        S, M, info, valid, score, sb, G, tiles_y, tiles_x, (int)n_tiles, p1 ? any_e : nullptr, order, y_major PPP_RW_STAMP_ARG)
 #define PPP_RW_LAUNCH(A_, D_, E_, F_)                                                                       \
     do {                                                                                                    \
         if (p1 && pass == 0) PPP_RW_LAUNCH1(A_, D_, E_, F_, true);                                          \
@@ -840,9 +864,12 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
                                                                                               p1 ? any_e : nullptr, G);
         if (order && pass == (p1 ? 0 : 1)) {      // (`info` is the same from either pre-pass)
             rank_tile_weight_kernel<<<dim3((unsigned)n_tiles), dim3(256), 0, s>>>(info, valid, sb, TZ, TY, TX, tiles_y, tiles_x,
-                                                                                  by_centres ? 1 : 0, weight, G);
+                                                                                  by_centres ? 1 : 0, y_major, weight, G);
             rank_tile_order_kernel<<<dim3(8), dim3(256), 0, s>>>(weight, (int)n_tiles, (int)(n_blocks / 8), order);
         }
+#ifdef PPP_RW_STAMPS
+        (void)hipMemsetAsync(weight, 0, (size_t)RW_ORDER_MAX * 4, s);      // (the weights are spent: room for the stamps)
+#endif
         switch (G.px) {
             PPP_RW_CASE(5)
             PPP_RW_CASE(7)

@@ -655,6 +655,9 @@ class DeviceOps:
     def thin_cover(self, mask_to_cover, bits, lin, P):
         return backend.thin_cover_device(mask_to_cover, bits, lin, P)
 
+    def thin_shard(self, mask_local, lin_local, index_global, bits, P_local, global_z):
+        return backend.ThinShard(mask_local, lin_local, index_global, bits, P_local, global_z)
+
     def mws_labels(self, rows, aff, nodes, P):
         return backend.mws_labels_device(rows, aff, nodes, P)
 
@@ -670,6 +673,7 @@ class DeviceOps:
 # ------------------------------------------------------------------------------------------
 COVER_BATCH = 8          # rounds between two "is anybody still undecided" all-reduces
 INT32_MAX = 0x7FFFFFFF
+INT64_MAX = 0x7FFFFFFFFFFFFFFF
 
 
 def sharded_cover(ops, comm, shape, ps, my_range, ranges, mask_to_cover, lin_t, never, pix_ths,
@@ -811,6 +815,103 @@ def sharded_cover_own(ops, comm, shape, ps, my_range, ranges, mask_ab, a, remain
     backend.note("cover_sharded", comm.world)
     backend.note("cover_p2p", 1 if pairwise else 0)
     return selected
+
+
+THIN_MAXC = 1 << 20          # csrc/ppp_cover.hip: key = (THIN_MAXC - count) << 32 | index
+
+
+def sharded_thin_own(ops, comm, shape, ps, my_range, ranges, mask_ab, a, interior_total, lin_own, index_own,
+                     bits_own, make_local_params):
+    """The set-cover thinning (foreground_cover.py:183-256; priority-parallel rounds, csrc/ppp_cover.hip) with
+    the volume split by z, after the pattern of sharded_cover_own: every rank runs the rounds on its own
+    slices + pz - 1 halo slices and decides its OWN selected patches; twice per round the 2(pz - 1) slices
+    around every slab boundary are made consistent -- the 64-bit keys (count, position in the global list)
+    after the count step, mask and dirty marks after the select step -- point to point between the two
+    neighbours (or by MIN all-reduces when slabs are thinner than the zones).
+
+    mask_ab  uint8 device tensor, the mask on the global slices [a, b) = own +- (pz - 1) (clipped; cleared in
+             place); interior_total: interior mask voxels of the WHOLE volume before the thinning (the loop
+             stops when they are used up); lin_own int64 [m]: GLOBAL linear indices of the own selected
+             patches, index_own int64 [m]: their positions in the global selected list; bits_own [m, words].
+    Returns (kept_index int64 [k] -- the positions in the global list of ALL kept patches, ascending, the same
+    on every rank --, rounds)."""
+    import torch
+    dev = ops.device
+    Z, Y, X = [int(v) for v in shape]
+    h = int(ps[0]) - 1
+    z0, z1 = my_range
+    b = a + int(mask_ab.shape[0])
+    plane = Y * X
+    m_own = int(lin_own.numel())
+    shard = ops.thin_shard(mask_ab, (lin_own - a * plane).contiguous(), index_own, bits_own, make_local_params(a, b), Z)
+    bounds = [int(r[1]) for r in ranges[:-1]]
+    zones = [(max(0, zb - h), min(Z, zb + h)) for zb in bounds]
+    mine = [i for i, zb in enumerate(bounds) if zb == z0 or zb == z1]
+    zlen = 2 * h * plane
+    key_buf = torch.empty((max(len(zones), 1), zlen), dtype=torch.int64, device=dev)
+    mask_buf = torch.empty((max(len(zones), 1), 2, zlen), dtype=torch.uint8, device=dev)
+    own_loc = (z0 - a, z1 - a)
+    pairwise = hasattr(comm, "neighbour_min") and os.environ.get("PPP_COVER_P2P", "1") != "0" and \
+        all(r[1] - r[0] >= 2 * h for r in ranges)
+
+    def zone_io(imp, i, with_key):
+        lo_z, hi_z = zones[i][0] - a, zones[i][1] - a
+        if with_key:
+            shard.zone(imp, lo_z, hi_z, own_loc, key=key_buf[i])
+        else:
+            shard.zone(imp, lo_z, hi_z, own_loc, mask=mask_buf[i, 0], clean=mask_buf[i, 1])
+
+    def exchange(with_key):
+        if not zones:
+            return
+        buf = key_buf if with_key else mask_buf
+        if pairwise:
+            for i in mine:
+                zone_io(False, i, with_key)
+            comm.neighbour_min([(comm.rank + 1 if bounds[i] == z1 else comm.rank - 1, buf[i]) for i in mine])
+        else:
+            buf.fill_(INT64_MAX if with_key else 1)
+            for i in mine:
+                zone_io(False, i, with_key)
+            comm.all_reduce_min(buf)
+        for i in mine:
+            zone_io(True, i, with_key)
+
+    rounds, alive = 0, True
+    while alive:
+        for _ in range(COVER_BATCH):
+            shard.step(shard.COUNT)
+            exchange(True)
+            shard.step(shard.FILTER)
+            shard.step(shard.SELECT)
+            exchange(False)
+        rounds += COVER_BATCH
+        flag = torch.tensor([1 if shard.alive() else 0], dtype=torch.int32, device=dev)
+        alive = int(comm.all_reduce_max(flag).item()) > 0
+    shard.close()
+    # ---- the stop rule over ALL ranks' kept patches: the order the sequential loop picks them in is the
+    # order of their keys when they were kept (count descending, index ascending); it stops at the first
+    # pick that leaves no interior voxel uncovered
+    kept = torch.nonzero(shard.state[:m_own] == 1).reshape(-1) if m_own else torch.zeros((0,), dtype=torch.int64, device=dev)
+    key = ((THIN_MAXC - shard.count[:m_own][kept].to(torch.int64)) << 32) | index_own[kept].to(torch.int64)
+    mine_kc = torch.stack([key, shard.cleared[:m_own][kept].to(torch.int64)], 1) if m_own else \
+        torch.zeros((0, 2), dtype=torch.int64, device=dev)
+    allkc = torch.cat(gather_lists(comm, mine_kc), 0)
+    keep_idx = torch.zeros((0,), dtype=torch.int64, device=dev)
+    remaining = int(interior_total)
+    if allkc.shape[0]:
+        order = torch.argsort(allkc[:, 0])
+        left = remaining - torch.cumsum(allkc[order, 1], 0)
+        done = torch.nonzero(left <= 0).reshape(-1)
+        n_keep = int(done[0].item()) + 1 if done.numel() else int(order.numel())
+        remaining = int(left[n_keep - 1].item())
+        keep_idx = allkc[order[:n_keep], 0] & 0xFFFFFFFF
+    if remaining > 0:
+        # every count is 0 with voxels left: np.argmax picks patch 0 once more (foreground_cover.py:210-216)
+        keep_idx = torch.cat([keep_idx, torch.zeros((1,), dtype=torch.int64, device=dev)])
+    backend.note("thin_rounds", rounds)
+    backend.note("thin_sharded", comm.world)
+    return torch.unique(keep_idx), rounds
 
 
 # ------------------------------------------------------------------------------------------
@@ -1533,28 +1634,52 @@ class _Assembly:
         if not self.kw.get("skipThinCover") and len(self.sel_coords) > 0:
             if self.kw.get("sample", 1.0) < 1.0:
                 raise NotImplementedError("sample < 1 uses unseeded random sampling in the reference")
-            with backend.host_timer("s4_thin"):
-                # replicated: every rank thins the same (short) global list on its own device; with
-                # local fields the mask of the whole volume is gathered for it (one byte per voxel)
-                if self.local_fields:
-                    mask_g = torch.zeros(self.shape, dtype=torch.uint8, device=self.dev)
-                    mask_g[self.oz0:self.oz1] = self.mask_d[self.own_z(self.oz0, self.oz1)]
-                    self.comm.all_gather_slabs(mask_g, self.rank_ranges)
-                else:
-                    mask_g = self.mask_d
-                sel_t = torch.from_numpy(np.ascontiguousarray(self.sel_coords)).to(self.dev)
-                bits = self.gathered_bits(sel_t, self.kw["fc_threshold"])
-                sel_lin = (self.sel_coords[:, 0].astype(np.int64) * self.Y + self.sel_coords[:, 1]) * self.X + self.sel_coords[:, 2]
-                if hasattr(self.ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
-                        and self.ps[2] <= 32:
-                    keep = self.ops.thin_cover(mask_g, bits, torch.from_numpy(sel_lin).to(self.dev), self.Pg)
-                    keep = keep.cpu().numpy()
-                else:
-                    keep = backend.host_thin_cover(np.ascontiguousarray(mask_g.cpu().numpy()),
-                                                   self.ps, np.ascontiguousarray(sel_lin),
-                                                   bits.cpu().numpy().view(np.uint32))
-                self.sel_coords = self.sel_coords[keep]
-                del bits, sel_t, mask_g
+            h_t = self.ps[0] - 1
+            shard_thin = self.comm.world > 1 and self.rank_ranges is not None and self.contiguous and \
+                hasattr(self.ops, "thin_shard") and self.ps[2] <= 32 and \
+                self.kw.get("_shard_thin", os.environ.get("PPP_THIN_SHARDED", "1") != "0") and \
+                all(r[1] - r[0] >= 2 * h_t for r in self.rank_ranges)
+            if shard_thin:
+                # ---- sharded by z (round 6): every rank thins the selected patches of its own slices; the
+                # slab-boundary zones travel point to point every round, nothing of the volume's size is
+                # gathered (sharded_thin_own)
+                with backend.host_timer("s4_thin"):
+                    idx_own = np.flatnonzero((self.sel_coords[:, 0] >= self.oz0) & (self.sel_coords[:, 0] < self.oz1))
+                    c_own = torch.from_numpy(np.ascontiguousarray(self.sel_coords[idx_own])).to(self.dev)
+                    lin_own = (c_own[:, 0].to(torch.int64) * self.Y + c_own[:, 1]) * self.X + c_own[:, 2]
+                    bits = self.bits_of_own(c_own, self.kw["fc_threshold"]) if len(idx_own) else \
+                        torch.zeros((0, self.words), dtype=torch.int32, device=self.dev)
+                    a_t, b_t = max(0, self.oz0 - h_t), min(self.Z, self.oz1 + h_t)
+                    keep_idx, _ = sharded_thin_own(
+                        self.ops, self.comm, self.shape, self.ps, (self.oz0, self.oz1), self.rank_ranges,
+                        self.mask_d[self.own_z(a_t, b_t)].clone(), a_t, self.interior_count(self.mask_d),
+                        lin_own, torch.from_numpy(idx_own.astype(np.int64)).to(self.dev), bits,
+                        lambda a, b: backend.make_params((b - a, self.Y, self.X), self.ps, origin=(a, 0, 0), **self.flags))
+                    self.sel_coords = self.sel_coords[keep_idx.cpu().numpy()]
+                    del bits, c_own, lin_own, keep_idx
+            else:
+                with backend.host_timer("s4_thin"):
+                    # replicated: every rank thins the same (short) global list on its own device; with
+                    # local fields the mask of the whole volume is gathered for it (one byte per voxel)
+                    if self.local_fields:
+                        mask_g = torch.zeros(self.shape, dtype=torch.uint8, device=self.dev)
+                        mask_g[self.oz0:self.oz1] = self.mask_d[self.own_z(self.oz0, self.oz1)]
+                        self.comm.all_gather_slabs(mask_g, self.rank_ranges)
+                    else:
+                        mask_g = self.mask_d
+                    sel_t = torch.from_numpy(np.ascontiguousarray(self.sel_coords)).to(self.dev)
+                    bits = self.gathered_bits(sel_t, self.kw["fc_threshold"])
+                    sel_lin = (self.sel_coords[:, 0].astype(np.int64) * self.Y + self.sel_coords[:, 1]) * self.X + self.sel_coords[:, 2]
+                    if hasattr(self.ops, "thin_cover") and os.environ.get("PPP_THIN", "device") != "host" \
+                            and self.ps[2] <= 32:
+                        keep = self.ops.thin_cover(mask_g, bits, torch.from_numpy(sel_lin).to(self.dev), self.Pg)
+                        keep = keep.cpu().numpy()
+                    else:
+                        keep = backend.host_thin_cover(np.ascontiguousarray(mask_g.cpu().numpy()),
+                                                       self.ps, np.ascontiguousarray(sel_lin),
+                                                       bits.cpu().numpy().view(np.uint32))
+                    self.sel_coords = self.sel_coords[keep]
+                    del bits, sel_t, mask_g
         self.bits_own = None
 
 

@@ -147,6 +147,9 @@ class OracleOps:
     def label_state(self, nodes, P):
         return OracleLabelState(nodes.numpy(), (P.Z, P.Y, P.X))
 
+    def thin_shard(self, mask_local, lin_local, index_global, bits, P_local, global_z):
+        return OracleThinShard(mask_local, lin_local, index_global, bits, P_local, global_z)
+
     def cover_shard(self, mask_local, lin_local, rank_id, bits, P_local, global_z):
         return OracleCoverShard(mask_local, lin_local, rank_id, bits, P_local, global_z)
 
@@ -390,6 +393,122 @@ class OracleCoverShard:
             if rank is not None:
                 r = rank.numpy()[:n].astype(np.int64).reshape((z_hi - z_lo,) + self.shape[1:])
                 self.rank_vol[z_lo:z_hi] = np.where(r == self.IMAX, self.NONE, r)
+            if mask is not None:
+                m = mask.numpy()[:n].reshape((z_hi - z_lo,) + self.shape[1:]) != 0
+                cln = clean.numpy()[:n].reshape((z_hi - z_lo,) + self.shape[1:]) != 0
+                self.run[z_lo:z_hi] &= m
+                self.dirty[z_lo:z_hi] |= ~cln
+
+    def close(self):
+        self.mask_t.numpy()[~self.run] = 0
+
+
+class OracleThinShard:
+    """backend.ThinShard in NumPy: the count / filter / select steps of the sharded set-cover thinning
+    (csrc/ppp_cover.hip, thin_* kernels) on a rank's local buffer, with the zone export / import."""
+    COUNT, FILTER, SELECT = 0, 1, 2
+    MAXC = 1 << 20
+    NONE = 0x7F7F7F7F7F7F7F7F
+    ZNONE = 0x7FFFFFFFFFFFFFFF
+
+    def __init__(self, mask, lin_local, index_global, bits, P, global_z):
+        self.mask_t = mask
+        self.shape = (P.Z, P.Y, P.X)
+        self.ps = (P.pz, P.py, P.px)
+        self.oz, self.gz = P.origin_z, int(global_z)
+        self.lin = lin_local.numpy().astype(np.int64)
+        self.index = index_global.numpy().astype(np.int64)
+        self.n = len(self.lin)
+        C = int(np.prod(self.ps))
+        b = bits.numpy().view(np.uint32).reshape(self.n, -1) if self.n else np.zeros((0, 1), np.uint32)
+        self.pbits = np.zeros((self.n, C), dtype=bool)
+        for r in range(C):
+            self.pbits[:, r] = (b[:, r // 32] >> np.uint32(r % 32)) & 1
+        self.pbits = self.pbits.reshape((self.n,) + self.ps)
+        self.state = torch.zeros(max(self.n, 1), dtype=torch.int32)
+        self.count = torch.zeros(max(self.n, 1), dtype=torch.int32)
+        self.cleared = torch.zeros(max(self.n, 1), dtype=torch.int32)
+        self.run = self.mask_t.numpy() != 0
+        self.key_vol = np.full(self.shape, self.NONE, dtype=np.int64)
+        self.loc_vol = np.full(self.shape, -1, dtype=np.int64)
+        self.dirty = np.ones(self.shape, dtype=bool)
+        self.centres = np.stack(np.unravel_index(self.lin, self.shape), axis=1) if self.n else np.zeros((0, 3), int)
+        for i in range(self.n):
+            c = tuple(self.centres[i])
+            self.loc_vol[c] = i
+            self.key_vol[c] = (self.MAXC << 32) | int(self.index[i])
+        self._alive = False
+
+    def _win(self, c):
+        rad = [p // 2 for p in self.ps]
+        return tuple(slice(c[i] - rad[i], c[i] + rad[i] + 1) for i in range(3))
+
+    def step(self, what):
+        st, cnt, cl = self.state.numpy(), self.count.numpy(), self.cleared.numpy()
+        if what == self.COUNT:
+            alive = False
+            for i in range(self.n):
+                c = tuple(self.centres[i])
+                if self.key_vol[c] == self.NONE:
+                    continue
+                if self.dirty[c]:
+                    hits = int(np.count_nonzero(self.run[self._win(c)] & self.pbits[i]))
+                    if hits == 0:
+                        st[i] = 2
+                        self.key_vol[c] = self.NONE
+                        continue
+                    self.key_vol[c] = ((self.MAXC - hits) << 32) | int(self.index[i])
+                alive = True
+            self.dirty[:] = False
+            self._alive = alive
+        elif what == self.FILTER:
+            from scipy import ndimage
+            self.nbr_min = ndimage.minimum_filter(self.key_vol, size=[2 * p - 1 for p in self.ps],
+                                                  mode="constant", cval=self.NONE)
+        else:
+            rad = [p // 2 for p in self.ps]
+            ready = [i for i in range(self.n)
+                     if self.key_vol[tuple(self.centres[i])] != self.NONE and
+                     self.nbr_min[tuple(self.centres[i])] == self.key_vol[tuple(self.centres[i])]]
+            for i in ready:
+                c = self.centres[i]
+                w = self._win(c)
+                hit = self.run[w] & self.pbits[i]
+                zz, yy, xx = np.nonzero(hit)
+                gz_ = zz + c[0] - rad[0] + self.oz
+                gy, gx = yy + c[1] - rad[1], xx + c[2] - rad[2]
+                inside = (gz_ >= rad[0]) & (gz_ < self.gz - rad[0]) & (gy >= rad[1]) & \
+                    (gy < self.shape[1] - rad[1]) & (gx >= rad[2]) & (gx < self.shape[2] - rad[2])
+                cl[i] = int(np.count_nonzero(inside))
+                cnt[i] = self.MAXC - int(self.key_vol[tuple(c)] >> 32)
+                self.run[w] &= ~hit
+                box = tuple(slice(max(c[k] - (self.ps[k] - 1), 0), min(c[k] + self.ps[k], self.shape[k]))
+                            for k in range(3))
+                self.dirty[box] = True
+                st[i] = 1
+                self.key_vol[tuple(c)] = self.NONE
+
+    def alive(self):
+        return bool(self._alive)
+
+    def zone(self, imp, z_lo, z_hi, own, key=None, mask=None, clean=None):
+        n = (z_hi - z_lo) * self.shape[1] * self.shape[2]
+        if n <= 0:
+            return
+        if not imp:
+            if key is not None:
+                r = np.full((z_hi - z_lo,) + self.shape[1:], self.ZNONE, dtype=np.int64)
+                for z in range(z_lo, z_hi):
+                    if own[0] <= z < own[1]:
+                        r[z - z_lo] = self.key_vol[z]
+                key.numpy()[:n] = r.reshape(-1)
+            if mask is not None:
+                mask.numpy()[:n] = self.run[z_lo:z_hi].reshape(-1)
+                clean.numpy()[:n] = ~self.dirty[z_lo:z_hi].reshape(-1)
+        else:
+            if key is not None:
+                r = key.numpy()[:n].astype(np.int64).reshape((z_hi - z_lo,) + self.shape[1:])
+                self.key_vol[z_lo:z_hi] = np.where(r == self.ZNONE, self.NONE, r)
             if mask is not None:
                 m = mask.numpy()[:n].reshape((z_hi - z_lo,) + self.shape[1:]) != 0
                 cln = clean.numpy()[:n].reshape((z_hi - z_lo,) + self.shape[1:]) != 0

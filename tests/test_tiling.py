@@ -236,7 +236,8 @@ np.save(os.path.join({out!r}, "inst_rank%d.npy" % rank), inst)
 from patchperpix_amd import backend
 np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
         np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
-                  backend.NOTES.get("cover_p2p", 0), 1 if "cons_cache_gb" in backend.NOTES else 0]))
+                  backend.NOTES.get("cover_p2p", 0), 1 if "cons_cache_gb" in backend.NOTES else 0,
+                  backend.NOTES.get("thin_sharded", 0), backend.NOTES.get("thin_rounds", 0)]))
 dist.destroy_process_group()
 """
 
@@ -279,6 +280,9 @@ def test_ranks_gloo_equal_whole_volume(tmp_path, n_slabs, world, extra, monkeypa
         notes = np.load(tmp_path / ("notes_rank%d.npy" % r))
         assert notes[0] == world and notes[1] > 0
         assert notes[3] == (1 if extra.get("_cons_cache") else 0)
+        # the set-cover thinning ran sharded too (round 6), when the flags ask for it at all
+        thin_on = not dict(kw).get("skipThinCover", False)
+        assert notes[4] == (world if thin_on else 0) and (notes[5] > 0) == thin_on
 
 
 HALO_WORKER = r"""
@@ -482,7 +486,7 @@ np.save(os.path.join({out!r}, "notes_rank%d.npy" % rank),
         np.array([backend.NOTES.get("cover_sharded", 0), backend.NOTES.get("cover_rounds", 0),
                   backend.NOTES.get("cover_p2p", 0), backend.NOTES.get("ring_z", 0),
                   1 if "cons_cache_gb" in backend.NOTES else 0,
-                  backend.NOTES.get("halo_exchange_bytes_received", 0)]))
+                  backend.NOTES.get("halo_exchange_bytes_received", 0), backend.NOTES.get("thin_sharded", 0)]))
 dist.destroy_process_group()
 """
 
@@ -535,6 +539,7 @@ def test_ranks_sharing_one_gpu_equal_whole_volume(tmp_path, world, empty_top, ps
         assert notes[0] == world and notes[1] > 0 and notes[2] == int(p2p)
         assert notes[3] == extra.get("_ring_z", 0) and notes[4] == (1 if extra.get("_cons_cache") else 0)
         assert (notes[5] > 0) == (no_halo != "0")
+        assert notes[6] == (world if not FLYLIGHT.get("skipThinCover", False) else 0)      # thinning sharded too
 
 
 RCCL_WORKER = r"""
