@@ -2127,7 +2127,8 @@ def plan_ring(own_shape, patchshape, free_bytes, safety=0.6, copies=2.0, min_thi
 
 
 def dry_run_plan(shape, patchshape, world, hbm_gb=309.2, usable=0.985, provider=False, halo_mode="exchange",
-                 cover_frac=0.0346, thin_frac=0.00339, pairs_per_voxel=0.291, cover_rounds=700, result_gather=False):
+                 cover_frac=0.0346, thin_frac=0.00339, pairs_per_voxel=0.291, cover_rounds=700, thin_rounds=40,
+                 result_gather=False):
     """What `world` ranks would hold and move for one volume -- WITHOUT a GPU (bench.py --dry-run-plan).
     Per rank: z-range, halo, resident prediction bytes, the tile / ring / cache plan the memory rule
     takes for the HBM left, S1 work per owned voxel; per step and rank: bytes received in every
@@ -2143,7 +2144,7 @@ def dry_run_plan(shape, patchshape, world, hbm_gb=309.2, usable=0.985, provider=
     out = {"volume": [Z, Y, X], "patchshape": ps, "ranks": int(world), "halo_slices": H,
            "hbm_gb_assumed": hbm_gb, "usable_fraction": usable, "ranks_plan": [], "assumed_densities": {
                "cover_patches_per_voxel": cover_frac, "thinned_patches_per_voxel": thin_frac,
-               "pair_rows_per_voxel": pairs_per_voxel, "cover_rounds": cover_rounds}}
+               "pair_rows_per_voxel": pairs_per_voxel, "cover_rounds": cover_rounds, "thin_rounds": thin_rounds}}
     slabs = plan_slabs(Z, world)
     for r in range(world):
         mine = slabs_of_rank(slabs, r, world)
@@ -2182,7 +2183,8 @@ def dry_run_plan(shape, patchshape, world, hbm_gb=309.2, usable=0.985, provider=
             # per round: rank volume (int32) after the count step, mask + dirty marks (bytes) after select
             "cover_zones_point_to_point": float(cover_rounds) * nb * zone * (4.0 + 1.0 + 1.0),
             "cover_selected_gather": 16.0 * cover_frac * (V - own_v) if world > 1 else 0.0,
-            "thinning_mask_and_bits_all_gather": ((V - own_v) * 1.0 + 4.0 * words * cover_frac * (V - own_v)) if world > 1 else 0.0,
+            # sharded thinning: per round the keys (int64) after count, mask + dirty marks after select
+            "thinning_zones_point_to_point": float(thin_rounds) * nb * zone * (8.0 + 1.0 + 1.0),
             "pair_affinities_all_reduce": 4.0 * pairs_per_voxel * V * 2.0 * (world - 1) / max(world, 1) if world > 1 else 0.0,
             "labels_all_reduce": 4.0 * thin_frac * V * 2.0 * (world - 1) / max(world, 1) if world > 1 else 0.0,
             "instances_all_gather": 4.0 * (V - own_v) if (result_gather and world > 1) else 0.0}
@@ -2193,7 +2195,7 @@ def dry_run_plan(shape, patchshape, world, hbm_gb=309.2, usable=0.985, provider=
             "row_bytes_per_voxel": 4 * W,
             "received_gb_per_step": {k: round(v / 1e9, 3) for k, v in recv.items()},
             "received_gb_per_step_total": round(sum(recv.values()) / 1e9, 3)})
-    out["replicated_per_rank"] = {"thinning_patches": int(cover_frac * V), "watershed_host_loop_rank0_edges": int(0.21 * V)}
+    out["replicated"] = {"watershed_host_loop_rank0_edges": int(0.21 * V), "pair_enumeration_patches": int(thin_frac * V)}
     return out
 
 
