@@ -186,6 +186,27 @@ def test_plan_ring(monkeypatch):
     assert tiling.plan_ring((512, 512, 512), ps, 80e9, safety=0.92, copies=2.0) is None
 
 
+def test_dry_run_plan():
+    """bench.py --dry-run-plan (tiling.dry_run_plan): no GPU.  At N = 1 it reproduces the plan the real
+    512^3 / 9^3 run takes (16 x 2 x 2 tiles, a ring of 60 slices: profiles/r06_g_bench_default.json,
+    config.plan); at N = 8 every rank owns 64 slices, holds 22 halo slices per inner side, takes the
+    consensus cache, and the collectives' byte counts are there."""
+    one = tiling.dry_run_plan((512, 512, 512), (9, 9, 9), 1)["ranks_plan"][0]
+    assert one["tiles"] == [16, 2, 2] and one["ring_z"] == 60 and not one["cons_cache"]
+    assert 2.0 < one["s1_work_per_owned_voxel"] < 2.2 and one["received_gb_per_step_total"] == 0
+    eight = tiling.dry_run_plan((512, 512, 512), (9, 9, 9), 8)
+    assert eight["halo_slices"] == 22 and len(eight["ranks_plan"]) == 8
+    for r in eight["ranks_plan"]:
+        assert r["own_z"][1] - r["own_z"][0] == 64 and r["cons_cache"] and r["s1_work_per_owned_voxel"] < 1.3
+        inner = (r["own_z"][0] > 0) + (r["own_z"][1] < 512)
+        assert r["held_z"][1] - r["held_z"][0] == 64 + 22 * inner
+        got = r["received_gb_per_step"]
+        assert abs(got["prediction_halo"] - inner * 22 * 729 * 512 * 512 * 2 / 1e9) < 0.01
+        assert got["cover_zones_point_to_point"] > got["thinning_zones_point_to_point"] > 0 and got["instances_all_gather"] == 0
+    big = tiling.dry_run_plan((1024, 1024, 1024), (9, 9, 9), 8, provider=True)
+    assert all(r["received_gb_per_step"]["prediction_halo"] == 0 and r["prediction_resident_gb"] == 0 for r in big["ranks_plan"])
+
+
 def test_tiles_needed():
     # fits whole: one tile
     assert tiling.tiles_needed((140, 140, 140), (7, 7, 7), 250e9) == (1, 1, 1)
@@ -306,6 +327,12 @@ assert torch.equal(got, fld[na:nb]), rank
 # nothing missing anywhere: the tensor itself comes back
 same = tiling.exchange_halo(vol[:, na:nb].contiguous(), (na, nb), (na, nb), comm, z_axis=1)
 assert same.shape[1] == nb - na
+# in place: a halo-sized buffer whose own slices are current and whose halo slices are stale
+buf = torch.full((5, nb - na, 4, 6), -1.0, dtype=torch.float16)
+buf[:, a - na:b - na] = vol[:, a:b]
+own_view = buf.narrow(1, a - na, b - a)
+got = tiling.exchange_halo(own_view, (a, b), (na, nb), comm, z_axis=1, out=buf)
+assert got.data_ptr() == buf.data_ptr() and torch.equal(buf, vol[:, na:nb]), rank
 open(os.path.join({out!r}, "ok%d" % rank), "w").write("ok")
 dist.destroy_process_group()
 """

@@ -19,6 +19,7 @@ python3 tools/summarize_prof.py $out/stats $out/kernel_stats.txt > /dev/null
 # written with the access widths of the hot kernels -- MI355X_MICROARCH.md, "calibrate on a known
 # byte count in your own access pattern")
 export PPP_BENCH_CALIBRATE=1
+export PPP_BENCH_STAGES=0        # (no extra staged step in the counter passes)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-north-star --no-variants > $out/bench_pmc_$c.json 2>> $out/bench.err
 done
@@ -65,5 +66,6 @@ json.dump({"src_sha16": bench.source_sha16(), "command": "python3 bench.py $*",
           open("$out/meta.json", "w"), indent=1)
 PY
 rm -rf $out/pmc_all $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/stats/*/*kernel_trace.csv $out/bench_pmc_*.json
+unset PPP_BENCH_STAGES
 head -12 $out/kernel_stats.txt
 cat $out/bench.json
