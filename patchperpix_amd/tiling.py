@@ -1402,18 +1402,32 @@ class _Assembly:
         # round on a 264 x 264 column, profiles/r05_zl_s2_rounds.txt) -- a launch of 2 048 workgroups
         # costs 0.72 of two launches of 1 024.  PPP_RANK_GROUP=1: one launch per tile.
         rank_group = 1
+        tiles = self.my_tiles
+        split = int(self.kw.get("_scores_split", os.environ.get("PPP_SCORES_SPLIT", "1")))
+        if self.ring_z and split > 1 and self.pool is not None:
+            # Round 6 (experiment, PPP_SCORES_SPLIT=2): the scores pass on NARROWER columns than the pairs
+            # pass.  A ranking launch gets more efficient with its size (7.7 / 10.3 / 11.8 workgroups per ms
+            # at 1 024 / 2 048 / 4 096, profiles/r06_e_*) and the ring holds what the pool holds of a
+            # column's box: columns of half the width in y and x hold four times the slices, so one launch
+            # ranks several tiles of a column -- for a larger y / x halo in this pass's S1.
+            z_ranges = sorted(set((t[0], t[1]) for t in self.my_tiles))
+            tiles = [(z0, z1) + c for c in plan_yx(self.Y, self.X, self.ny_t * split, self.nx_t * split) for (z0, z1) in z_ranges]
+            W_row = int(np.prod([2 * p - 1 for p in self.ps]))
+            area_sc = max((b[3] - b[2]) * (b[5] - b[4]) for b in (self.bases_for_scores(t) for t in tiles))
+            self.ring_sc["z"] = max(self.ring_z, int(self.pool.numel() // W_row // area_sc))
+            backend.note("scores_columns", self.ny_t * split * self.nx_t * split)
         if self.ring_z:
-            thick = max(t[1] - t[0] for t in self.my_tiles)
+            thick = max(t[1] - t[0] for t in tiles)
             rank_group = max(1, (self.ring_sc["z"] - 2 * int(self.rad[0]) - (self.ps[0] - 1)) // thick)
             rank_group = max(1, min(rank_group, int(os.environ.get("PPP_RANK_GROUP", rank_group))))
             backend.note("rank_group", rank_group)
             backend.note("ring_z_scores", self.ring_sc["z"])
         pending = []          # tiles of the current column whose rows are in the ring, not ranked yet
 
-        for ti, t in enumerate(self.my_tiles):
+        for ti, t in enumerate(tiles):
             z0, z1, y0, y1, x0, x1 = t
             cbox = self.bases_for_pairs(t) if self.keep_cons else self.bases_for_scores(t)
-            fr = self.frame_for(scores_frame_box(t), scores_frame_box(self.my_tiles[ti + 1]) if ti + 1 < len(self.my_tiles) else None)
+            fr = self.frame_for(scores_frame_box(t), scores_frame_box(tiles[ti + 1]) if ti + 1 < len(tiles) else None)
             o = fr.origin
             P = self.params(fr, cbox)
             if self.cache is not None:
@@ -1423,7 +1437,7 @@ class _Assembly:
                     cons, P = self.ring_rows(fr, t, False, self.pool)
                 if rank_group > 1:
                     pending.append(t)
-                    nxt = self.my_tiles[ti + 1] if ti + 1 < len(self.my_tiles) else None
+                    nxt = tiles[ti + 1] if ti + 1 < len(tiles) else None
                     if len(pending) < rank_group and nxt is not None and nxt[2:] == t[2:] and nxt[0] == t[1]:
                         del cons, fr
                         continue                       # ranked together with the next tile of the column
