@@ -107,6 +107,12 @@ typedef struct ppp_params {
                               between the two class tests (with the shipped rule: none equals TH);
                               S1 then takes a shorter classification of its operands -- same bits.
                               0 (or anything else): not known; every kernel serves any input.      */
+    int32_t rank_tile;     /* ppp_rank_patches_vm, cubic 5 / 7 / 9 patches: the tile of centres a workgroup
+                              takes -- 0: the library's rule; 1: 8 x 8 x 16; 2: 8 x 16 x 16; 3: 16 x 8 x 16
+                              (z, y, x).  Same scores whichever; larger tiles stage fewer rows per centre
+                              (4.5 instead of 6 times) and win where the memory system is the slower part
+                              (measured per box: profiles/r06_l_*), smaller ones where it is not -- a
+                              caller with many launches times one of each and keeps the faster.            */
 } ppp_params;
 
 /* --- library / device ------------------------------------------------------------- */

@@ -40,7 +40,7 @@ class Params(ctypes.Structure):                       # struct ppp_params (inclu
                 ("norm_aff", ctypes.c_int32), ("cons_layout", ctypes.c_int32),
                 ("cons_box", Box),
                 ("origin_z", ctypes.c_int32), ("origin_y", ctypes.c_int32),
-                ("origin_x", ctypes.c_int32), ("ring_z", ctypes.c_int32), ("pred_clean", ctypes.c_int32)]
+                ("origin_x", ctypes.c_int32), ("ring_z", ctypes.c_int32), ("pred_clean", ctypes.c_int32), ("rank_tile", ctypes.c_int32)]
 
 
 def _check(rc):

@@ -44,7 +44,10 @@ class Params(ctypes.Structure):
                 ("origin_x", ctypes.c_int32), ("ring_z", ctypes.c_int32),
                 # 1: ppp_pred_check found the buffer passed as `pred` clean (S1's short classification);
                 # 2 (this layer only; the library reads "not 1"): checked, not clean; 0: not checked
-                ("pred_clean", ctypes.c_int32)]
+                ("pred_clean", ctypes.c_int32),
+                # tile of centres per workgroup of the ranking kernel: 0 = the library's rule,
+                # 1 / 2 / 3 = 8 x 8 x 16 / 8 x 16 x 16 / 16 x 8 x 16 (same scores; tiling.assemble times them)
+                ("rank_tile", ctypes.c_int32)]
 
     @property
     def shape(self):

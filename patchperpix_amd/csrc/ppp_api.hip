@@ -98,6 +98,8 @@ int make_geo(const ppp_params *p, ppp::Geo *G) {
         return fail(PPP_ERR_INVALID_ARG, "ring_z: VOXEL_MAJOR rows only, cons_box at most ring_z slices thick");
     g.ring = p->ring_z;
     g.pred_clean = p->pred_clean == 1 ? 1 : 0;
+    if (p->rank_tile < 0 || p->rank_tile > 3) return fail(PPP_ERR_INVALID_ARG, "rank_tile must be 0 .. 3");
+    g.rank_tile = p->rank_tile;
     *G = g;
     return PPP_OK;
 }

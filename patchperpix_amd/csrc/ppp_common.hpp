@@ -40,6 +40,7 @@ struct Geo {
     int cz0, cy0, cx0, cZ, cY, cX;
     int ring;           // voxel-major rows in a ring of `ring` z-slices (0: the plain box), ppp_params.ring_z
     int pred_clean;     // 1: every prediction value in [0, 1] and != TH (ppp_params.pred_clean, ppp_pred_check)
+    int rank_tile;      // ppp_params.rank_tile: 0 = the launcher's rule, 1 / 2 / 3 = 8x8x16 / 8x16x16 / 16x8x16
 };
 
 // A HIP grid is limited to 2^32 - 1 work-items per dimension (blocks x threads): a larger launch

@@ -821,7 +821,11 @@ static hipError_t launch_rwg(const T *pred, const float *S, const uint8_t *ov, f
     // the size of the 512^3 tiles: 256 ms against 265 ms for 8 x 16 x 16 -- and for a 16 x 8 x 16 tile,
     // which has half of its items in conflict-free rows: profiles/r04_k_s2_tiles*.txt)
     if (G.px == 9 && PPP_RW_ZRUNS(9) && !tile_sw.get()) big = false;
-    const bool tall = tile_sw.get() && strcmp(tile_sw.get(), "16x8x16") == 0;
+    bool tall = tile_sw.get() && strcmp(tile_sw.get(), "16x8x16") == 0;
+    // the caller's choice (ppp_params.rank_tile; the environment switch, a development aid, wins): which
+    // shape is faster depends on the box -- 8 x 8 x 16 by 3 % where the ranking kernel runs at 161 ms per
+    // 2 048-tile launch, 16 x 8 x 16 by 12 % where it runs at 215 ms (profiles/r06_l_bench_ab_tiles.txt)
+    if (G.rank_tile && !tile_sw.get()) { big = G.rank_tile == 2; tall = G.rank_tile == 3; }
     const int TZ = tall ? 16 : 8, TY = tall ? 8 : (big ? 16 : 8), TX = 16;
     const int tiles_z = (sZ + TZ - 1) / TZ, tiles_y = (sY + TY - 1) / TY, tiles_x = (sX + TX - 1) / TX;
     const long long n_tiles = (long long)tiles_z * tiles_y * tiles_x;

@@ -658,6 +658,8 @@ class DeviceOps:
     def thin_shard(self, mask_local, lin_local, index_global, bits, P_local, global_z):
         return backend.ThinShard(mask_local, lin_local, index_global, bits, P_local, global_z)
 
+    times_rank_tiles = True       # (the ranking kernel's tile shape is chosen by timing: _Assembly.scores_pass)
+
     def mws_labels(self, rows, aff, nodes, P):
         return backend.mws_labels_device(rows, aff, nodes, P)
 
@@ -1423,6 +1425,17 @@ class _Assembly:
             backend.note("rank_group", rank_group)
             backend.note("ring_z_scores", self.ring_sc["z"])
         pending = []          # tiles of the current column whose rows are in the ring, not ranked yet
+        # Which tile of centres a ranking workgroup takes (ppp_params.rank_tile) is decided per CALL by
+        # measurement (round 6): 8 x 8 x 16 is 3 % faster where a 2 048-tile launch takes 161 ms, 16 x 8 x 16 is
+        # 12 % faster on the boxes where it takes 215 ms (the kernel follows the memory system's speed, the
+        # boxes differ; profiles/r06_l_bench_ab_tiles.txt) -- the scores are the same bits either way.  With
+        # enough launches ahead the first two are timed, one of each shape, and the faster serves the rest.
+        # PPP_RANK_TILE=0..3 fixes the choice (0: the library's rule).
+        n_launches = -(-len(tiles) // rank_group)
+        tile_env = os.environ.get("PPP_RANK_TILE", "auto")
+        rank_tile = int(tile_env) if tile_env.isdigit() else 0
+        trials = [1, 3] if (tile_env == "auto" and n_launches >= 6 and getattr(self.ops, "times_rank_tiles", False)) else []
+        timed = []            # (shape, start event, stop event, centres)
 
         for ti, t in enumerate(tiles):
             z0, z1, y0, y1, x0, x1 = t
@@ -1453,8 +1466,23 @@ class _Assembly:
                     cons, P = self.consensus_of(fr, P, self.pool)
             with backend.host_timer("s2_rank"):
                 same = fr.shape == (self.Zf, self.Y, self.X) and o == (self.flo, 0, 0)
+                trial = trials.pop(0) if trials else 0
+                P.rank_tile = trial or rank_tile
+                if trial:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(torch.cuda.current_stream())
                 sc = self.ops.rank_patches(fr.pred, cons, fr.ov, P, (z0 - o[0], y0 - o[1], x0 - o[2], z1 - o[0], y1 - o[1], x1 - o[2]),
                                       **({"out": self.score_f} if same and hasattr(self.ops, "voxel_major_pool") else {}))
+                if trial:
+                    ev[1].record(torch.cuda.current_stream())
+                    timed.append((trial, ev[0], ev[1], (z1 - z0) * (y1 - y0) * (x1 - x0)))
+                    if not trials:
+                        torch.cuda.synchronize()
+                        per_centre = {shape: a.elapsed_time(b) / max(1, n) for shape, a, b, n in timed}
+                        rank_tile = min(per_centre, key=per_centre.get)
+                        backend.note("rank_tile", rank_tile)
+                        backend.note("rank_tile_trial_ns_per_centre",
+                                     " ".join("%d:%.1f" % (k, 1e6 * v) for k, v in sorted(per_centre.items())))
                 if sc is not self.score_f:
                     self.score_f[self.own_z(z0, z1), y0:y1, x0:x1] = sc[z0 - o[0]:z1 - o[0], y0 - o[1]:y1 - o[1], x0 - o[2]:x1 - o[2]]
             if self.provider:

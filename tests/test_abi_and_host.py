@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_params_struct_matches_header_size():
     # int32 x7, pad, double x2, int32 x8, box 6 x int32  (natural C alignment)
-    # (+ origin x3, ring_z, pred_clean, tail padding to the doubles' alignment)
+    # (+ origin x3, ring_z, pred_clean, rank_tile)
     assert ctypes.sizeof(backend.Params) == 8 * 4 + 2 * 8 + 8 * 4 + 6 * 4 + 4 * 4 + 2 * 4
     P = backend.make_params((4, 5, 6), (3, 3, 3), patch_threshold=0.9)
     assert (P.bg_rule, P.thi) == (backend.BG_INV_TH, 1.0 - 0.9)
