@@ -472,6 +472,78 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+def rooflines(ev, notes, wl, ps, args, rank, world):
+    """The three roofline blocks of the JSON line from the HIP-event times of the timed steps (`ev`) and the
+    workload statistics (`notes`): S1 -- the contract's `roofline` (HBM-read fraction, counter traffic from the
+    committed profile of these sources) and `roofline_valu` (the bound that holds) --, and the secondary
+    figures of S2 and S5 (`roofline_other_kernels`)."""
+    C = int(np.prod(ps))
+    roofline = roofline_valu = None
+    if ev.get("consensus"):
+        s1_kernel = notes.get("s1_kernel", "consensus_v3_kernel")
+        roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C, kernel=s1_kernel)
+        roofline["workload"] = wl.name
+        if rank == 0 and world == 1 and not args.slabs and not args.yx:
+            roofline.update(pmc_traffic(s1_kernel, wl.name))
+        if notes.get("s1_output_bytes"):
+            # the algorithmic figure counts the INPUT (SURVEY 8d); the launch also writes the whole
+            # consensus -- most of the measured traffic
+            roofline["output_bytes_per_launch"] = notes["s1_output_bytes"] / max(1, len(ev["consensus"]))
+            roofline["traffic_reading"] = (
+                "writes = the consensus output (symmetric voxel-major rows, 2x the stored planes); "
+                "reads = the f16 prediction (re-read across the offset rows of a run) + the "
+                "read-for-ownership of partially written lines")
+        # "bound" keeps the contract's vocabulary and the north star's figure (HBM-read fraction);
+        # what limits the kernel is vector-instruction issue: roofline_valu below
+        roofline["limited_by"] = "valu-issue (see roofline_valu)"
+        n_l = max(1, len(ev["consensus"]))
+        fgf = float(getattr(wl, "fg_fraction", 1.0))
+        roofline_valu = valu_roofline(s1_kernel, wl.name, float(np.sum(ev["consensus"])) / n_l,
+                                      C * (C - 1) / 2.0 * fgf * notes.get("s1_base_voxels", 0) / n_l)
+    # Secondary figures for the other two big kernels.  S2 (ranking): the voxel-major consensus
+    # rows it reads once + the prediction block once: 4 (2p-1)^3 + 2 C bytes per base voxel.
+    # S5 (patch graph): both patches' channel vectors per dispatched pair row, SURVEY 8(d)'s
+    # bound without `visited`.
+    roofline_other = {}
+    if ev.get("rank_patches"):
+        W_vm = (2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1)
+        ms = float(np.sum(ev["rank_patches"]))
+        b = (4.0 * W_vm + 2.0 * C) * notes.get("s2_base_voxels", notes.get("s1_base_voxels", 0))
+        roofline_other["rank_patches"] = {
+            "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["rank_patches"]),
+            "launches": len(ev["rank_patches"]),
+            "bytes": "voxel-major consensus rows of the launch's box once + the prediction block once",
+            "algorithmic_bytes_per_launch": b / len(ev["rank_patches"])}
+        if rank == 0 and world == 1 and not args.slabs and not args.yx:
+            t = pmc_traffic("rank_wg_kernel", wl.name, read_width="float")
+            if t.get("traffic") is not None:
+                rd = t.get("traffic_read_corrected", t["traffic_read"])
+                roofline_other["rank_patches"].update(
+                    traffic_read=t["traffic_read"], traffic_read_corrected=t.get("traffic_read_corrected"),
+                    counter_over_true_bytes=t.get("counter_over_true_bytes"), traffic_source=t["traffic_source"],
+                    traffic_over_algorithmic=rd / (b / len(ev["rank_patches"])),
+                    fabric_gb_per_s=rd / (ms / len(ev["rank_patches"]) * 1e-3) / 1e9)
+    if ev.get("patch_graph") and notes.get("n_pairs"):
+        ms = float(np.sum(ev["patch_graph"]))
+        rows = float(notes.get("s5_rows_dispatched", notes["n_pairs"] * args.steps))
+        b = rows * 2.0 * C * 2.0
+        roofline_other["patch_graph"] = {
+            "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["patch_graph"]),
+            "launches": len(ev["patch_graph"]), "pair_rows_per_s": rows / (ms * 1e-3),
+            "pair_rows_in_list_per_step": notes["n_pairs"]}
+        if rank == 0 and world == 1 and not args.slabs and not args.yx:
+            t = pmc_traffic("patch_graph_pa_kernel", wl.name, read_width="float")
+            if t.get("traffic") is not None:
+                rd = t.get("traffic_read_corrected", t["traffic_read"])
+                roofline_other["patch_graph"].update(
+                    traffic_read=t["traffic_read"], traffic_read_corrected=t.get("traffic_read_corrected"),
+                    counter_over_true_bytes=t.get("counter_over_true_bytes"), traffic_source=t["traffic_source"],
+                    fabric_gb_per_s=rd / (ms / len(ev["patch_graph"]) * 1e-3) / 1e9)
+    return roofline, roofline_valu, roofline_other
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -678,69 +750,7 @@ def main():
     # space) -- the maximum over the ranks
     peak_gb = agree_max(torch.cuda.max_memory_allocated() / 1e9)
     value = float(np.prod(gshape)) * args.steps / dt / 1e6
-    roofline = roofline_valu = None
-    if ev.get("consensus"):
-        s1_kernel = notes.get("s1_kernel", "consensus_v3_kernel")
-        roofline = s1_roofline(ev["consensus"], notes.get("s1_base_voxels", 0), C, kernel=s1_kernel)
-        roofline["workload"] = wl.name
-        if rank == 0 and world == 1 and not args.slabs and not args.yx:
-            roofline.update(pmc_traffic(s1_kernel, wl.name))
-        if notes.get("s1_output_bytes"):
-            # the algorithmic figure counts the INPUT; the launch also writes the whole
-            # consensus -- most of the measured traffic
-            roofline["output_bytes_per_launch"] = notes["s1_output_bytes"] / max(1, len(ev["consensus"]))
-            roofline["traffic_reading"] = (
-                "writes = the consensus output (symmetric voxel-major rows, 2x the stored planes); "
-                "reads = the f16 prediction (re-read across the offset rows of a run) + the "
-                "read-for-ownership of partially written lines")
-        # "bound" keeps the contract's vocabulary and the north star's figure (HBM-read fraction);
-        # what limits the kernel is vector-instruction issue: roofline_valu below
-        roofline["limited_by"] = "valu-issue (see roofline_valu)"
-        n_l = max(1, len(ev["consensus"]))
-        fgf = float(getattr(wl, "fg_fraction", 1.0))
-        roofline_valu = valu_roofline(s1_kernel, wl.name, float(np.sum(ev["consensus"])) / n_l,
-                                      C * (C - 1) / 2.0 * fgf * notes.get("s1_base_voxels", 0) / n_l)
-    # Secondary figures for the other two big kernels.  S2 (ranking): the voxel-major consensus
-    # rows it reads once + the prediction block once: 4 (2p-1)^3 + 2 C bytes per base voxel.
-    # S5 (patch graph): both patches' channel vectors per dispatched pair row, SURVEY 8(d)'s
-    # bound without `visited`.
-    roofline_other = {}
-    if ev.get("rank_patches"):
-        W_vm = (2 * ps[0] - 1) * (2 * ps[1] - 1) * (2 * ps[2] - 1)
-        ms = float(np.sum(ev["rank_patches"]))
-        b = (4.0 * W_vm + 2.0 * C) * notes.get("s2_base_voxels", notes.get("s1_base_voxels", 0))
-        roofline_other["rank_patches"] = {
-            "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["rank_patches"]),
-            "launches": len(ev["rank_patches"]),
-            "bytes": "voxel-major consensus rows of the launch's box once + the prediction block once",
-            "algorithmic_bytes_per_launch": b / len(ev["rank_patches"])}
-        if rank == 0 and world == 1 and not args.slabs and not args.yx:
-            t = pmc_traffic("rank_wg_kernel", wl.name, read_width="float")
-            if t.get("traffic") is not None:
-                rd = t.get("traffic_read_corrected", t["traffic_read"])
-                roofline_other["rank_patches"].update(
-                    traffic_read=t["traffic_read"], traffic_read_corrected=t.get("traffic_read_corrected"),
-                    counter_over_true_bytes=t.get("counter_over_true_bytes"), traffic_source=t["traffic_source"],
-                    traffic_over_algorithmic=rd / (b / len(ev["rank_patches"])),
-                    fabric_gb_per_s=rd / (ms / len(ev["rank_patches"]) * 1e-3) / 1e9)
-    if ev.get("patch_graph") and notes.get("n_pairs"):
-        ms = float(np.sum(ev["patch_graph"]))
-        rows = float(notes.get("s5_rows_dispatched", notes["n_pairs"] * args.steps))
-        b = rows * 2.0 * C * 2.0
-        roofline_other["patch_graph"] = {
-            "bound": "hbm", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_ms": ms / len(ev["patch_graph"]),
-            "launches": len(ev["patch_graph"]), "pair_rows_per_s": rows / (ms * 1e-3),
-            "pair_rows_in_list_per_step": notes["n_pairs"]}
-        if rank == 0 and world == 1 and not args.slabs and not args.yx:
-            t = pmc_traffic("patch_graph_pa_kernel", wl.name, read_width="float")
-            if t.get("traffic") is not None:
-                rd = t.get("traffic_read_corrected", t["traffic_read"])
-                roofline_other["patch_graph"].update(
-                    traffic_read=t["traffic_read"], traffic_read_corrected=t.get("traffic_read_corrected"),
-                    counter_over_true_bytes=t.get("counter_over_true_bytes"), traffic_source=t["traffic_source"],
-                    fabric_gb_per_s=rd / (ms / len(ev["patch_graph"]) * 1e-3) / 1e9)
+    roofline, roofline_valu, roofline_other = rooflines(ev, notes, wl, ps, args, rank, world)
     # A checksum that does not depend on how the volume was split: crc32 of the per-slice crc32s
     # in z order.  With the result gathered every rank holds all slices; in provider mode a rank
     # returns its own z-range only and the per-slice values are gathered.
