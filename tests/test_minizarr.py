@@ -200,6 +200,32 @@ def test_zarr_provider_works_ahead(tmp_path):
     assert np.array_equal(np.asarray(got), np.asarray(want))
 
 
+@pytest.mark.gpu
+def test_zarr_provider_uploads_ahead_on_the_gpu(tmp_path):
+    """ZarrProvider with a device (round 6): the worker thread that decodes the announced box also uploads it
+    on a copy stream of its own; pred_box() of that box waits for an event instead of copying -- same bytes
+    as a box read on demand, also when the pinned buffers are reused a few boxes later."""
+    import torch
+    from patchperpix_amd import synth, tiling
+    ps = (3, 3, 3)
+    c = synth.make_case((20, 22, 24), ps, seed=43, cell=[6, 6, 6])
+    a = c["pred"].astype(np.float16)
+    g = mz.open(str(tmp_path / "u.zarr"), "w")
+    g.create_dataset("volumes/pred_affs", data=a, chunks=(27, 5, 6, 7))
+    arr = mz.open(str(tmp_path / "u.zarr"), "r")["volumes/pred_affs"]
+    prov = tiling.ZarrProvider(arr, device="cuda")
+    boxes = [(0, 9, 0, 22, 0, 12), (5, 20, 2, 20, 4, 24), (1, 14, 1, 15, 1, 16), (0, 20, 0, 22, 0, 24), (3, 8, 3, 9, 3, 10)]
+    got = []
+    for i, b in enumerate(boxes):
+        t = prov.pred_box(b)
+        if i + 1 < len(boxes):
+            prov.prefetch(boxes[i + 1])
+        got.append((t * 1).cpu().numpy())        # (a kernel on the consumer's stream reads the uploaded tensor)
+    for t, b in zip(got, boxes):
+        assert np.array_equal(t, a[:, b[0]:b[1], b[2]:b[3], b[4]:b[5]])
+    assert prov.boxes_prefetched == len(boxes) - 1 and prov.boxes_uploaded_ahead == len(boxes) - 1
+
+
 def test_reference_example_store():
     """The reference's own example store (experiments/flylight/JRC_SS05008-20160318_24_B2_crop.zip:
     zarr v2 written by a real zarr / numcodecs, gzip level-1 chunks, `|u1` and `<u2`, an edge chunk on
