@@ -784,7 +784,10 @@ def main():
         # N = 1: the plan to_instance_seg made for the timed steps (tiles, ring, cache, free HBM)
         plan = dict(backend.LAST_PLAN, rank=0, ring_z_used=notes.get("ring_z", 0),
                     ring_z_scores_pass=notes.get("ring_z_scores", 0), rank_group=notes.get("rank_group", 0),
-                    cons_cache_gb=notes.get("cons_cache_gb"))
+                    cons_cache_gb=notes.get("cons_cache_gb"),
+                    # S2's tile of centres per workgroup, chosen per call by timing (1 = 8x8x16, 3 = 16x8x16;
+                    # None: the library's rule) and the two trial launches' ns per centre
+                    rank_tile=notes.get("rank_tile"), rank_tile_trial_ns_per_centre=notes.get("rank_tile_trial_ns_per_centre"))
     if dist is not None and plan is not None:
         plans = [None] * world
         dist.all_gather_object(plans, plan)
