@@ -16,8 +16,9 @@ PARITY UNPINNED for the decoder arithmetic: the reference builds it from
 ``funlib.learn.torch`` (``ConvPass``, ``Upsample``; git dependency, branch ``ppp``, not vendored
 and not importable here) and ships no checkpoint.  ``PatchDecoder`` restates the published
 structure of those blocks (conv stack with "same" padding and an activation after every conv;
-``resize_conv`` = nearest-neighbour upsampling followed by one conv pass); the gather / scatter
-semantics are tested against a literal restatement of the reference loop.
+``resize_conv`` = nearest-neighbour upsampling followed by one conv pass).  The gather / scatter
+semantics ARE pinned: tests/golden/ds_*.npz hold outputs of the reference's own ``decode_sample``
+run with a PatchDecoder as ``model.decoder`` (tests/golden/gen_golden_decode_sample.py).
 """
 import logging
 import os

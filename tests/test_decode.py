@@ -292,3 +292,47 @@ def test_decode_2d_25_then_vote():
         inst, _ = vi.to_instance_seg(p16, f.copy(), f.copy(), f.astype(np.uint8), ps, **kw)
         ref = orc.to_instance_seg(p16.float().cpu().numpy(), f, f.copy(), f.astype(np.uint8), ps, **kw)
         assert np.array_equal(inst, ref["instances"]) and inst.max() > 0
+
+
+def _golden_decode_sample(name):
+    import json
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    ae = json.loads(str(f["ae_json"]))
+    ae["input_shape_squeezed"] = tuple(ae["input_shape_squeezed"])
+    d = dec.PatchDecoder(ae).eval()
+    d.load_state_dict({k[2:]: torch.as_tensor(f[k]) for k in f.files if k.startswith("w:")}, strict=True)
+    return f, d
+
+
+DECODE_SAMPLE_CASES = ["ds_p7_numinst3", "ds_p7_fg1", "ds_p5x5_numinst3"]
+
+
+@pytest.mark.parametrize("name", DECODE_SAMPLE_CASES)
+def test_decode_volume_equals_the_references_decode_sample(name):
+    """The reference's OWN decode_sample (setup01/decode.py:16-66), run in the development container by
+    tests/golden/gen_golden_decode_sample.py with this decoder (weights in the fixture) as
+    ``model.decoder``: foreground rule, visiting order, (B, 1, units) batches and the layout of the
+    (prod(patchshape), Z, Y, X) block are the reference's.  Same network and same batch size on both
+    sides, float32 on the CPU: equal to rounding of the convolutions (tolerance 1e-6 absolute)."""
+    f, d = _golden_decode_sample(name)
+    fg = dec.foreground_from_numinst(f["numinst"], float(f["fg_thresh"]))
+    want = f["output"]
+    assert fg.shape == want.shape[1:]
+    assert np.array_equal(fg != 0, np.any(want != 0, axis=0))          # decoded exactly on the foreground
+    got = dec.decode_volume(d, f["code"], fg, batch_size=int(f["batch"]), device="cpu", fused=False).numpy()
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.allclose(got, want, rtol=0, atol=1e-6)
+    assert not got[:, fg == 0].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DECODE_SAMPLE_CASES)
+def test_decode_volume_on_the_gpu_equals_the_references_decode_sample(name):
+    """The same fixtures through the device path (GEMM / MIOpen head, torch or fused tail): float32
+    accumulation in another order, tolerance 1e-4 absolute on logits of magnitude ~1."""
+    f, d = _golden_decode_sample(name)
+    fg = dec.foreground_from_numinst(f["numinst"], float(f["fg_thresh"]))
+    got = dec.decode_volume(d, f["code"], fg, batch_size=int(f["batch"]), device="cuda").cpu().numpy()
+    assert np.allclose(got, f["output"], rtol=0, atol=1e-4)
+    assert not got[:, fg == 0].any()
