@@ -17,6 +17,10 @@ Import-time stubs only (none of them is called): ``toml``, ``h5py``, the sibling
 module and ``PatchPerPix.visualize``; ``zarr.open`` is replaced by a reader of in-memory arrays, the
 one container access ``decode_sample`` makes.
 
+A second kind of fixture (``ae_forward_*``) runs the reference's ``Autoencoder.forward``
+(setup01/torch_model.py:523-544) with the real ``PatchPerPix.util.crop`` on an instance carrying this
+repository's layers: see ``autoencoder_forward``.
+
   python tests/golden/gen_golden_decode_sample.py [case ...]
 """
 import importlib.util
@@ -31,6 +35,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF_DECODE = "/root/reference/experiments/flylight/setups/setup01/decode.py"
+REF_MODEL = "/root/reference/experiments/flylight/setups/setup01/torch_model.py"
+REF_TRAIN_UTIL = "/root/reference/PatchPerPix/util/train_util.py"
 sys.path.insert(0, REPO)
 
 from patchperpix_amd import decode as dec  # noqa: E402
@@ -85,10 +91,72 @@ class Model:
         self.decoder = decoder
 
 
+def load_reference_autoencoder():
+    """The reference's ``Autoencoder`` class (setup01/torch_model.py:452-544) with the REAL
+    ``PatchPerPix.util.crop`` (util/train_util.py:55-69).  Import-time stubs, never called: monai,
+    torchinfo, gunpowder and the NAMES torch_model imports from funlib.learn.torch.models."""
+    def unused(*a, **k):
+        raise RuntimeError("stubbed name used")
+    _stub("gunpowder")
+    spec = importlib.util.spec_from_file_location("ppp_ref_train_util", REF_TRAIN_UTIL)
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    names = ("crop crop_to_factor gather_nd_torch gather_nd_torch_no_batch "
+             "seg_to_affgraph_3d_multi_torch_code seg_to_affgraph_2d_multi_torch_code "
+             "seg_to_affgraph_3d_multi_torch seg_to_affgraph_2d_multi_torch seg_to_affgraph_3d_torch "
+             "seg_to_affgraph_2d_torch seg_to_affgraph_3d_torch_code seg_to_affgraph_2d_torch_code").split()
+    _stub("PatchPerPix")
+    _stub("PatchPerPix.util", **{n: getattr(tu, n) for n in names})
+    _stub("monai")
+    _stub("torchinfo")
+    _stub("funlib")
+    _stub("funlib.learn")
+    _stub("funlib.learn.torch")
+    _stub("funlib.learn.torch.models", UNet=unused, ConvPass=unused, Downsample=unused, Upsample=unused)
+    spec = importlib.util.spec_from_file_location("ppp_ref_torch_model", REF_MODEL)
+    tm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tm)
+    return tm.Autoencoder
+
+
+AE_FORWARD_CASES = {
+    # name: (decoder config, batch, seed) -- 2^3 -> 4^3 -> 8^3 -> crop 7^3;  2^2 -> 4^2 -> 8^2 -> crop 5^2
+    "ae_forward_p7": (AE3, 5, 21),
+    "ae_forward_p5x5": (AE2, 6, 22),
+}
+
+
+def autoencoder_forward(names):
+    """``Autoencoder.forward`` of the reference on an instance whose LAYERS are this repository's
+    (``__init__`` builds them from funlib's ConvPass / Upsample, which the image lacks, so it is not
+    run): the reshape to ``code_shape``, the order from_code -> [up_i -> up_conv_i] and the centre
+    crop (which of the 8 planes per axis is dropped for a 7-wide patch) are the reference's."""
+    Autoencoder = load_reference_autoencoder()
+    for name in names:
+        ae, batch, seed = AE_FORWARD_CASES[name]
+        torch.manual_seed(seed)
+        mine = dec.PatchDecoder(dict(ae)).eval()
+        ref = Autoencoder.__new__(Autoencoder)
+        torch.nn.Module.__init__(ref)
+        ref.config = dict(ae)
+        ref.code_shape = mine.code_shape
+        ref.from_code, ref.up, ref.up_conv = mine.from_code, mine.up, mine.up_conv
+        code = torch.randn(batch, 1, ae["code_units"])       # (B, 1, units): what decode_sample hands over
+        with torch.no_grad():
+            out = Autoencoder.forward(ref, code)
+        weights = {"w:" + k: v.numpy() for k, v in mine.state_dict().items()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), code=code.numpy(), output=out.numpy(),
+                            ae_json=np.array(json.dumps(ae)), **weights)
+        print("%-20s code %s -> %s" % (name, tuple(code.shape), tuple(out.shape)))
+
+
 def main(argv):
+    fwd = [n for n in (argv or list(AE_FORWARD_CASES)) if n in AE_FORWARD_CASES]
+    if fwd:
+        autoencoder_forward(fwd)
     store = {}
     ref = load_reference_decode(store)
-    for name in argv or list(CASES):
+    for name in [n for n in (argv or list(CASES)) if n in CASES]:
         ae, ps, shape, nch, fg_thresh, batch, seed = CASES[name]
         torch.manual_seed(seed)
         rng = np.random.default_rng(seed)

@@ -336,3 +336,18 @@ def test_decode_volume_on_the_gpu_equals_the_references_decode_sample(name):
     got = dec.decode_volume(d, f["code"], fg, batch_size=int(f["batch"]), device="cuda").cpu().numpy()
     assert np.allclose(got, f["output"], rtol=0, atol=1e-4)
     assert not got[:, fg == 0].any()
+
+
+@pytest.mark.parametrize("name", ["ae_forward_p7", "ae_forward_p5x5"])
+def test_patch_decoder_forward_equals_the_references_autoencoder_forward(name):
+    """``Autoencoder.forward`` of the reference (setup01/torch_model.py:523-544, with the real
+    ``PatchPerPix.util.crop``, util/train_util.py:55-69) run in the development container on an instance
+    carrying THIS decoder's layers (gen_golden_decode_sample.py: its ``__init__`` needs funlib): the
+    reshape of the (B, 1, units) code, the order of the stages and the centre crop -- which plane of the
+    8 per axis a 7-wide patch drops -- are the reference's.  Same layers, same batch, float32 on the CPU:
+    bit-identical."""
+    f, d = _golden_decode_sample(name)
+    with torch.no_grad():
+        got = d(torch.as_tensor(f["code"])).numpy()
+    assert got.shape == f["output"].shape
+    assert np.array_equal(got, f["output"])
