@@ -183,7 +183,9 @@ int ppp_rank_patches(const void *d_pred, int pred_dtype, const float *d_cons,
  * consensus row is staged in LDS once per tile of centres and serves all centres of the tile
  * whose window holds its voxel (csrc/ppp_rank_vm.hip) -- the gather form above re-fetches each
  * entry ~50 times from HBM.  Cubic patches of 3 / 5 / 7 / 9, count_pos_neg = 0; otherwise
- * PPP_ERR_UNSUPPORTED (ppp_rank_workspace_bytes returns 0).  d_work: ppp_rank_workspace_bytes. */
+ * PPP_ERR_UNSUPPORTED (ppp_rank_workspace_bytes returns 0).  d_work: ppp_rank_workspace_bytes.
+ * Rows in a RING (p->ring_z) are read by the workgroup-per-tile kernel only (patches of 5 / 7 / 9):
+ * ppp_rank_workspace_bytes with ring_z set returns 0 for any other shape -- ask before planning a ring. */
 int64_t ppp_rank_workspace_bytes(const ppp_box *score_box, const ppp_params *p);
 int ppp_rank_patches_vm(const void *d_pred, int pred_dtype, const float *d_cons_vm,
                         const uint8_t *d_overlap, float *d_score, const ppp_box *score_box,

@@ -646,7 +646,9 @@ def rank_vm_available(P):
         return False
     Pv = P.copy()
     Pv.cons_layout = CONS_VOXEL_MAJOR
-    Pv.cons_box = Box(0, 0, 0, P.Z, P.Y, P.X)     # (the question is about the configuration, not a tile)
+    # (the question is about the configuration, not a tile; with ring_z set -- "from a RING of rows?", which
+    # only the workgroup-per-tile kernel reads -- the box is as thick as a ring may hold)
+    Pv.cons_box = Box(0, 0, 0, min(P.Z, P.ring_z) if P.ring_z else P.Z, P.Y, P.X)
     return int(lib().ppp_rank_workspace_bytes(None, ctypes.byref(Pv))) > 0
 
 

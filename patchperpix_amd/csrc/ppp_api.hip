@@ -263,6 +263,8 @@ int64_t ppp_rank_workspace_bytes(const ppp_box *score_box, const ppp_params *p) 
     ppp::Geo G;
     if (make_geo(p, &G) != PPP_OK) return -1;
     if (!ppp::rank_vm_supported(G)) return 0;
+    // (rows in a ring: the workgroup-per-tile kernel only -- a caller planning a ring asks with ring_z set)
+    if (G.ring && !ppp::rank_wg_supported(G)) return 0;
     ppp_box sb;
     if (rank_box(score_box, p, G, &sb) != PPP_OK) return -1;
     return (int64_t)ppp::rank_vm_workspace_bytes(sb, G);

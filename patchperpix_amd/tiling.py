@@ -1043,6 +1043,10 @@ class _Assembly:
         # `1 * (numinst > 1)` is an int64 temporary of 8 bytes per voxel.
         self.Zf = int(self.foreground.shape[0])
         self.local_fields = self.Zf != self.Z
+        # "some rank holds local fields": what every COLLECTIVE decision below asks (frames() settles it over
+        # the ranks) -- on a short volume a middle rank's slices + halo can be the whole volume while its
+        # neighbours' are not, and the ranks must still take the same path
+        self.any_local = self.local_fields
         self.flo = self.lo if self.local_fields else 0
         fhi = self.flo + self.Zf
         if self.provider:
@@ -1142,7 +1146,7 @@ class _Assembly:
         self.fg_out = fg_out
 
         def full_fg():
-            if not self.local_fields:
+            if not self.any_local:
                 return self.fg_out()
             g = torch.zeros(self.shape, dtype=torch.uint8, device=self.dev)
             g[self.oz0:self.oz1] = self.fg_d[self.own_z(self.oz0, self.oz1)]
@@ -1174,16 +1178,18 @@ class _Assembly:
         # parts of the score / instance volumes are exchanged by ONE all-gather of slabs
         self.rank_ranges = None
         if self.comm.world > 1:
-            mine_r = torch.tensor([self.oz0, self.oz1 if self.contiguous else -1], dtype=torch.int64, device=self.dev)
+            mine_r = torch.tensor([self.oz0, self.oz1 if self.contiguous else -1, int(self.local_fields)], dtype=torch.int64, device=self.dev)
             rr = [tuple(int(v) for v in r) for r in self.comm.all_gather(mine_r).cpu().numpy()]
+            self.any_local = any(r[2] for r in rr)
+            rr = [r[:2] for r in rr]
             if all(r[1] >= 0 for r in rr) and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)):
                 self.rank_ranges = rr
         else:
             self.rank_ranges = [(self.oz0, self.oz1)] if self.contiguous else None
-        self.sharded = bool(self.kw.get("_sharded_global", self.local_fields))
+        self.sharded = bool(self.kw.get("_sharded_global", self.any_local))
         if self.sharded and (self.rank_ranges is None or not hasattr(self.ops, "cover_shard")):
             raise ValueError("the sharded global stage needs one contiguous z-range per rank")
-        if self.local_fields and not self.sharded:
+        if self.any_local and not self.sharded:
             raise ValueError("local fields need the sharded global stage")
 
         if self.interior_count(self.mask_d) == 0 or self.interior_count(self.fg_d) == 0:
@@ -1327,6 +1333,12 @@ class _Assembly:
                        or not self.ops.rank_on_voxel_major(self.params(self.whole))):
             self.ring_z = 0
         if self.ring_z:
+            # (a patch shape whose ranking kernel reads plain boxes only -- 3^3 -- sweeps plain tiles)
+            Pq = self.params(self.whole)
+            Pq.ring_z = self.ring_z
+            if not self.ops.rank_on_voxel_major(Pq):
+                self.ring_z = 0
+        if self.ring_z:
             thick = max(t[1] - t[0] for t in self.my_tiles)
             if self.ring_z < thick + ring_margin(self.ps[0]) or thick < self.ps[0] - 1:
                 raise ValueError("_ring_z = %d is too small for tiles of %d slices (or the tiles are thinner than "
@@ -1345,7 +1357,9 @@ class _Assembly:
             consumers of t read: slices [z0 - rad, z1 + rad), the column's y / x box)."""
             ybox = self.bases_for_pairs(t) if pairs_pass else self.bases_for_scores(t)
             r0, r1 = self.bases_for_scores(t)[:2]                          # rows the consumers read
-            col = (pairs_pass,) + tuple(ybox[2:])
+            # (the TILE's y / x range names the column, not only the box of its rows: on a narrow axis two
+            # columns grow to the same clipped box, and the second one must start its sweep from the bottom)
+            col = (pairs_pass,) + tuple(t[2:]) + tuple(ybox[2:])
             hi = self.ring_state.get("hi") if self.ring_state.get("col") == col else None
             if hi is None or hi < r0:
                 # first tile of the column: for the pair rows also the p - 1 source slices below
@@ -1394,8 +1408,16 @@ class _Assembly:
         self.bits_own = None
         if self.provider:
             self.bits_own = torch.zeros(((self.oz1 - self.oz0) * self.plane, self.words), dtype=torch.int32, device=self.dev)
+        def pairs_frame_box(t):
+            # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
+            # to 2 p away) and their windows: the tile grown by the halo
+            return self.grow(t, (self.H, 2 * self.ps[1] + int(self.rad[1]), 2 * self.ps[2] + int(self.rad[2])))
+        self.pairs_frame_box = pairs_frame_box
+
         def scores_frame_box(t):
-            return self.grow(self.bases_for_pairs(t) if self.keep_cons else self.bases_for_scores(t), 2 * self.rad)
+            # (a kept consensus keeps its frame for the patch-graph stage, which looks at the windows of
+            # partners up to 2 p away: the larger box -- it holds the bases of the pair rows + 2 rad)
+            return pairs_frame_box(t) if self.keep_cons else self.grow(self.bases_for_scores(t), 2 * self.rad)
 
         # Ring sweep: ONE ranking launch serves as many consecutive tiles of a column as the ring holds
         # rows for (their slices + the radius on both sides + the p - 1 slices S1 reaches past its last
@@ -1703,7 +1725,7 @@ class _Assembly:
                 with backend.host_timer("s4_thin"):
                     # replicated: every rank thins the same (short) global list on its own device; with
                     # local fields the mask of the whole volume is gathered for it (one byte per voxel)
-                    if self.local_fields:
+                    if self.any_local:
                         mask_g = torch.zeros(self.shape, dtype=torch.uint8, device=self.dev)
                         mask_g[self.oz0:self.oz1] = self.mask_d[self.own_z(self.oz0, self.oz1)]
                         self.comm.all_gather_slabs(mask_g, self.rank_ranges)
@@ -1737,11 +1759,7 @@ class _Assembly:
             and self.kw.get("_stream_pairs", os.environ.get("PPP_STREAM_PAIRS", "1") != "0") \
             and hasattr(self.ops, "label_state")
 
-        def pairs_frame_box(t):
-            # S1 reads the prediction 2 rad around its bases; the partner patches B of the rows (up
-            # to 2 p away) and their windows: the tile grown by the halo
-            return self.grow(t, (self.H, 2 * self.ps[1] + int(self.rad[1]), 2 * self.ps[2] + int(self.rad[2])))
-        self.pairs_frame_box = pairs_frame_box
+        pairs_frame_box = self.pairs_frame_box
 
         def next_of(t):
             i = self.my_tiles.index(t)

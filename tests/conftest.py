@@ -19,12 +19,13 @@ def pytest_configure(config):
 
 def golden_names():
     # (bw_*.npz: goldens of the blockwise driver, tests/test_blockwise.py loads them itself;
+    # ds_* / ae_forward_*.npz: the reference's decode_sample / Autoencoder.forward, tests/test_decode.py;
     # scale_*.npz: the oracle's benchmark-scale fixtures, tests/test_gpu_parity.py; np_*.npz: the
     # reference's NumPy-semantics path, tests/test_numpy_semantics.py; large_*.npz: the larger
     # reference-made case whose input is regenerated, tests/test_large_golden.py)
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0]
                               for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-                  if not n.startswith(("bw_", "scale_", "np_", "large_")))
+                  if not n.startswith(("bw_", "scale_", "np_", "large_", "ds_", "ae_forward_")))
 
 
 class Golden:

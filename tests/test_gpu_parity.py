@@ -1024,8 +1024,10 @@ def test_consensus_cache_equals_recomputation(ps, shape, cell, flags, torch_cuda
         assert np.array_equal(want, got) and want.max() > 5
 
 
+# (the last case, found by tools/fuzz_tiling.py: axes so narrow that the columns of tiles grow to the same
+# clipped box -- the sweep mistook the second column for the continuation of the first)
 @pytest.mark.parametrize("ps,shape,cell,flags", [((9, 9, 9), (70, 48, 60), 24, "shipped"), ((7, 7, 7), (64, 52, 56), 18, "shipped"),
-                                                 ((5, 5, 5), (50, 44, 48), 12, "cc")])
+                                                 ((5, 5, 5), (50, 44, 48), 12, "cc"), ((7, 7, 7), (46, 18, 17), 9, "shipped")])
 def test_ring_sweep_equals_plain_tiles(ps, shape, cell, flags, torch_cuda, monkeypatch):
     """Tiled path with the rows in a ring (`_ring_z`: the tiles of a column bottom-up, every base
     slice computed once per pass by ppp_consensus_part, ranking and patch-graph kernels addressing
@@ -1060,6 +1062,32 @@ def test_ring_sweep_equals_plain_tiles(ps, shape, cell, flags, torch_cuda, monke
         assert not np.isnan(got_aff).any()
         assert np.array_equal(_bits(want_aff), _bits(got_aff))
         assert np.array_equal(want, got) and want.max() > 5
+
+
+def test_ring_request_falls_back_where_no_kernel_reads_a_ring(torch_cuda):
+    """3^3 patches are ranked by the one-wave kernel, which reads plain boxes only (ppp_rank_workspace_bytes
+    with ring_z set answers 0): a plan that asks for a ring sweeps plain tiles instead of failing in the
+    first ranking launch (found by tools/fuzz_tiling.py)."""
+    from patchperpix_amd import backend, synth, tiling
+    from patchperpix_amd import flags as F
+    from patchperpix_amd.vote_instances import vote_instances as vi
+    torch = torch_cuda
+    ps, shape = (3, 3, 3), (40, 30, 28)
+    kw = dict(F.FLYLIGHT, _instances_dtype=np.uint32, _cons_cache=False)
+    P = backend.make_params(shape, ps, **kw)
+    lab = synth.cell_labels(shape, [8] * 3, seed=9)
+    pred = backend.synth_pred(_dev(torch, lab.astype(np.int32)), P, seed=9, f16=True)
+    fg = lab != 0
+    args = lambda: (fg.copy(), fg.copy(), fg.astype(np.uint8), list(ps))     # noqa: E731
+    grid = dict(_n_slabs=4, _yx_tiles=(1, 2))
+    want = vi.to_instance_seg(pred, *args(), **dict(kw, **grid))[0]
+    backend.NOTES.pop("ring_z", None)
+    got = vi.to_instance_seg(pred, *args(), **dict(kw, _ring_z=10 + tiling.ring_margin(3) + 2, **grid))[0]
+    assert "ring_z" not in backend.NOTES
+    assert np.array_equal(want, got) and want.max() > 5
+    Pq = backend.make_params(shape, (5, 5, 5), **kw)
+    Pq.ring_z = 24
+    assert backend.rank_vm_available(Pq)          # 5^3: the workgroup-per-tile kernel reads a ring
 
 
 @pytest.mark.parametrize("ps,shape", [((9, 9, 9), (20, 30, 44)), ((7, 7, 7), (18, 26, 40)), ((5, 5, 5), (14, 20, 36))])
