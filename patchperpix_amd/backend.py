@@ -648,7 +648,12 @@ def rank_vm_available(P):
     Pv.cons_layout = CONS_VOXEL_MAJOR
     # (the question is about the configuration, not a tile; with ring_z set -- "from a RING of rows?", which
     # only the workgroup-per-tile kernel reads -- the box is as thick as a ring may hold)
-    Pv.cons_box = Box(0, 0, 0, min(P.Z, P.ring_z) if P.ring_z else P.Z, P.Y, P.X)
+    Pv.cons_box = Box(0, 0, 0, P.Z, P.Y, P.X)
+    if P.ring_z and P.ring_z < P.Z:
+        # (a ring holds fewer slices than the volume: ask about centres whose rows fit into it)
+        Pv.cons_box = Box(0, 0, 0, P.ring_z, P.Y, P.X)
+        sb = Box(0, 0, 0, max(1, P.ring_z - P.pz // 2), P.Y, P.X)
+        return int(lib().ppp_rank_workspace_bytes(ctypes.byref(sb), ctypes.byref(Pv))) > 0
     return int(lib().ppp_rank_workspace_bytes(None, ctypes.byref(Pv))) > 0
 
 
