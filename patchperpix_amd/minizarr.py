@@ -192,6 +192,10 @@ def blosc_encode(data, typesize, cname="zstd", clevel=3, shuffle="bit", blocksiz
     """uint8 array -> Blosc-1 frame (bytes): one stream per block (flag "do not split")."""
     data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
     nbytes = len(data)
+    if cname not in ("zstd", "zlib"):
+        # (frames of the other codecs are READ -- blosc_decode -- but the writers of the reference only
+        # ever ask for zstd, stitch_patch_graph.py:36)
+        raise NotImplementedError("minizarr writes Blosc frames with zstd or zlib, not %r" % (cname,))
     codec_id = {"zstd": 4, "zlib": 3}[cname]
     if blocksize is None:
         blocksize = max(typesize, min(nbytes, 1 << 18) // typesize * typesize) if nbytes else typesize

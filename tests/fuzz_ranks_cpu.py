@@ -38,6 +38,9 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 ps = cfg["ps"]
 c = synth.make_case(tuple(cfg["shape"]), tuple(ps), seed=cfg["seed"], cell=cfg["cell"], overlap_frac=cfg["overlap"])
+if cfg.get("empty_top"):
+    z = cfg["empty_top"]
+    c["pred"][:, z:] = 0.05; c["foreground"][z:] = False; c["numinst"][z:] = 0
 kw = dict(FLYLIGHT_NOTHIN_CC)
 kw.update(cfg["flags"])
 Z = c["pred"].shape[1]
@@ -103,7 +106,7 @@ def main():
             cfg = json.loads(args.cfg)
             world, shape, ps, flags, extra = args.world, cfg["shape"], cfg["ps"], cfg["flags"], cfg["extra"]
         else:
-            world = int(rng.integers(2, 5))
+            world = int(rng.integers(2, 6))
             per_rank = int(rng.integers(1, 3))
             ps = [3, 3, 3] if rng.integers(0, 5) else [int(v) for v in rng.choice([[3, 5, 3], [3, 3, 5], [5, 3, 3]])]
             lo_z = max(4 * ps[0], (ps[0] + 1) * world * per_rank)
@@ -121,9 +124,19 @@ def main():
                 extra["_cover_chunk"] = int(rng.integers(100, 900))
             if rng.integers(0, 3) == 0:
                 extra["_gather_result"] = False
+            if rng.integers(0, 4) == 0 and "local_fields" not in mode:
+                extra["_sharded_global"] = True
             cfg = dict(shape=shape, ps=ps, seed=int(rng.integers(1, 10000)), cell=[int(rng.integers(3, 8))] * 3,
-                       overlap=float(rng.choice([0.0, 0.02, 0.05])), flags=flags, n_slabs=world * per_rank, mode=mode, extra=extra)
+                       overlap=float(rng.choice([0.0, 0.02, 0.05])), flags=flags, n_slabs=world * per_rank, mode=mode, extra=extra,
+                       p2p=str(rng.choice(["1", "1", "0"])))
+            if rng.integers(0, 6) == 0:
+                cfg["empty_top"] = int(shape[0] * 0.6)       # nothing above: ranks whose slabs hold no patch
         c = synth.make_case(tuple(shape), tuple(ps), seed=cfg["seed"], cell=cfg["cell"], overlap_frac=cfg["overlap"])
+        if cfg.get("empty_top"):
+            z = cfg["empty_top"]
+            c["pred"][:, z:] = 0.05
+            c["foreground"][z:] = False
+            c["numinst"][z:] = 0
         kw = dict(FLYLIGHT_NOTHIN_CC)
         kw.update(flags)
         ref = orc.to_instance_seg(c["pred"], c["foreground"], c["foreground"].copy(), c["numinst"], ps, **kw)["instances"]
@@ -132,7 +145,8 @@ def main():
             script = os.path.join(tmp, "worker.py")
             open(script, "w").write(WORKER.format(repo=REPO, out=tmp))
             port = free_port()
-            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1", PPP_FUZZ_CFG=json.dumps(cfg))
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1", PPP_FUZZ_CFG=json.dumps(cfg),
+                       PPP_COVER_P2P=cfg.get("p2p", "1"))
             r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
                                 "--master-addr", "127.0.0.1", "--master-port", port, script], env=env, timeout=1200,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
