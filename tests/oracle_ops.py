@@ -301,7 +301,7 @@ class OracleCoverShard:
         self.rank_id = rank_id.numpy().astype(np.int64)
         self.n = len(self.lin)
         C = int(np.prod(self.ps))
-        b = bits.numpy().view(np.uint32).reshape(self.n, -1) if self.n else np.zeros((0, 1), np.uint32)
+        b = bits.numpy().view(np.uint32).reshape(self.n, -1) if self.n else np.zeros((0, (C + 31) // 32), np.uint32)
         self.pbits = np.zeros((self.n, C), dtype=bool)
         for r in range(C):
             self.pbits[:, r] = (b[:, r // 32] >> np.uint32(r % 32)) & 1
@@ -420,7 +420,7 @@ class OracleThinShard:
         self.index = index_global.numpy().astype(np.int64)
         self.n = len(self.lin)
         C = int(np.prod(self.ps))
-        b = bits.numpy().view(np.uint32).reshape(self.n, -1) if self.n else np.zeros((0, 1), np.uint32)
+        b = bits.numpy().view(np.uint32).reshape(self.n, -1) if self.n else np.zeros((0, (C + 31) // 32), np.uint32)
         self.pbits = np.zeros((self.n, C), dtype=bool)
         for r in range(C):
             self.pbits[:, r] = (b[:, r // 32] >> np.uint32(r % 32)) & 1
