@@ -590,5 +590,9 @@ def to_instance_seg(pred, foreground, mask_to_cover, numinst, patchshape, **kw):
     out["pairs"] = pairs
     aff = patch_graph(pred, cons, pairs, patchshape, **kw)
     out["aff"] = aff
+    if kw.get("return_intermediates", False):
+        # vote_instances.py:435-440: (pairs, aff) go back before anything is labelled or painted -- the
+        # blockwise driver injects patches of a neighbouring block whose windows may leave this one
+        return out
     out["instances"] = label(pairs, aff, pred, patchshape, foreground.shape, **kw)
     return out
