@@ -101,6 +101,7 @@ def test_label_task_on_reference_layout_zarr(tmp_path):
     kw = dict(cfg["vote_instances"], **cfg["model"])
     kw.pop("patchshape")
     kw["blockwise"] = False
+    kw["return_intermediates"] = False    # (the config's `true` serves the blockwise driver; the oracle is asked for the map)
     # what the loaders derive (utilVoteInstances.py:254-303): numinst from the thresholds,
     # foreground = numinst > 0
     ni = np.zeros(numinst.shape, dtype=np.uint8)
