@@ -92,14 +92,18 @@ def free_port():
         return str(sk.getsockname()[1])
 
 
-def draw(rng):
+def draw(rng, aniso=False):
     from patchperpix_amd import tiling
     world = int(rng.integers(2, 5))
     p = int(rng.choice([3, 5, 7, 9], p=[0.1, 0.35, 0.35, 0.2]))
+    pp = [p, p, p]
+    if aniso and rng.integers(0, 2) == 0:
+        pp = [int(v) for v in rng.choice([3, 5, 7, 9], size=3, p=[0.35, 0.3, 0.2, 0.15])]
+        p = pp[0]
     sub = int(rng.integers(1, 4))
     zmin = world * sub * max(p - 1, 2) + 2
-    shape = [int(rng.integers(max(zmin, 2 * p + 2), max(zmin, 2 * p + 2) + 40)), int(rng.integers(2 * p + 2, 44)), int(rng.integers(2 * p + 2, 44))]
-    if p == 9:
+    shape = [int(rng.integers(max(zmin, 2 * p + 2), max(zmin, 2 * p + 2) + 40)), int(rng.integers(2 * pp[1] + 2, 44)), int(rng.integers(2 * pp[2] + 2, 44))]
+    if max(pp) == 9:
         shape = [shape[0]] + [min(s, 36) for s in shape[1:]]
     mode = str(rng.choice(["halo", "own", "own_local_fields", "refresh", "provider", "provider_local_fields"]))
     extra = {}
@@ -117,7 +121,7 @@ def draw(rng):
             extra["_ring_z"] = thick + tiling.ring_margin(p) + int(rng.integers(0, 5))
     if rng.integers(0, 3) == 0:
         extra["_gather_result"] = False
-    cfg = dict(shape=shape, ps=[p, p, p], seed=int(rng.integers(1, 10000)), cell=[int(rng.integers(max(4, p), 2 * p + 3))] * 3,
+    cfg = dict(shape=shape, ps=pp, seed=int(rng.integers(1, 10000)), cell=[int(rng.integers(max(4, max(pp)), 2 * max(pp) + 3))] * 3,
                overlap=float(rng.choice([0.0, 0.02])), flagset=str(rng.choice(["shipped", "cc", "nothin_cc"])), sub=sub, mode=mode,
                extra=extra, p2p=str(rng.choice(["1", "1", "0"])))
     if rng.integers(0, 6) == 0:
@@ -131,6 +135,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cfg")
     ap.add_argument("--world", type=int)
+    ap.add_argument("--aniso", action="store_true", help="half of the trials with anisotropic patch shapes")
     args = ap.parse_args()
     from patchperpix_amd import synth, tiling
     from patchperpix_amd import flags as flagsets
@@ -139,7 +144,7 @@ def main():
     bad = 0
     t0 = time.time()
     for trial in range(1 if args.cfg else args.trials):
-        world, cfg = (args.world, json.loads(args.cfg)) if args.cfg else draw(rng)
+        world, cfg = (args.world, json.loads(args.cfg)) if args.cfg else draw(rng, args.aniso)
         shape, ps = tuple(cfg["shape"]), cfg["ps"]
         c = synth.make_case(shape, tuple(ps), seed=cfg["seed"], cell=cfg["cell"], overlap_frac=cfg["overlap"])
         if cfg.get("empty_top"):

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max", type=int, default=64, help="largest extent of an axis")
     ap.add_argument("--plans", type=int, default=3, help="random plans per trial")
+    ap.add_argument("--aniso", action="store_true", help="half of the trials with anisotropic patch shapes")
     args = ap.parse_args()
     import torch
     from patchperpix_amd import backend, synth, tiling
@@ -39,14 +40,17 @@ def main():
     for trial in range(args.trials):
         p = int(rng.choice([3, 5, 7, 9], p=[0.15, 0.3, 0.3, 0.25]))
         ps = (p, p, p)
-        lo = 2 * p + 2
-        shape = tuple(int(rng.integers(lo, max(lo + 1, args.max + 1))) for _ in range(3))
-        if p == 9:      # (keeps a trial in seconds)
+        if args.aniso and rng.integers(0, 2) == 0:
+            # anisotropic patches: compact planes, the gather ranking kernel, no ring / cache (the plans fall back)
+            ps = tuple(int(v) for v in rng.choice([3, 5, 7, 9], size=3, p=[0.35, 0.3, 0.2, 0.15]))
+            p = ps[0]
+        shape = tuple(int(rng.integers(2 * q + 2, max(2 * q + 3, args.max + 1))) for q in ps)
+        if max(ps) == 9:      # (keeps a trial in seconds)
             shape = tuple(min(s, 56) for s in shape)
         flagset = str(rng.choice(["shipped", "cc"]))
         f16 = bool(rng.integers(0, 2))
         seed = int(rng.integers(1, 10000))
-        cell = int(rng.integers(max(4, p + 1), 3 * p + 2))
+        cell = int(rng.integers(max(4, max(ps) + 1), 3 * max(ps) + 2))
         kw = dict(F.FLYLIGHT if flagset == "shipped" else F.FLYLIGHT_CC, _instances_dtype=np.uint32)
         P = backend.make_params(shape, ps, **kw)
         lab = synth.cell_labels(shape, [cell] * 3, seed=seed)
@@ -57,7 +61,7 @@ def main():
             ov = (rng.uniform(size=shape) < 0.02) & fg
             numinst[ov] = 2
         fargs = lambda: (fg.copy(), fg.copy(), numinst.copy(), list(ps))     # noqa: E731
-        desc = "trial %d: shape %s p %d %s f16 %d seed %d cell %d" % (trial, shape, p, flagset, f16, seed, cell)
+        desc = "trial %d: shape %s ps %s %s f16 %d seed %d cell %d" % (trial, shape, "x".join(str(q) for q in ps), flagset, f16, seed, cell)
         try:
             one = dict(kw, _n_slabs=1, _cons_cache=False)
             want = vi.to_instance_seg(pred, *fargs(), **one)[0]
