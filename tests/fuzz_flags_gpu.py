@@ -38,12 +38,16 @@ def draw(rng):
     # the oracle visits C^2 pixel pairs per foreground voxel: bound the volume by that
     budget = 2e9
     vmax = max(int(budget / (C * C)), 2 * int(np.prod([q + 1 for q in ps])))
+    long_x = bool(rng.integers(0, 4) == 0)      # lines of more than one 64-voxel run (the packed S1 kernel's flattened runs)
     while True:
         shape = tuple(1 if q == 1 else int(rng.integers(q + 1, q + 28)) for q in ps)
         if kind == "2d":
             shape = (1, int(rng.integers(ps[1] + 4, 90)), int(rng.integers(ps[2] + 4, 90)))
+        if long_x:
+            shape = shape[:2] + (int(rng.integers(60, 200)),)
         if int(np.prod(shape)) <= vmax:
             break
+        long_x = long_x and rng.integers(0, 4) != 0
     th = float(rng.choice([0.5, 0.5, 0.5, 0.6, 0.8, 0.9]))
     bg = str(rng.choice(["less", "inv", "half"]))
     flags = dict(patch_threshold=th, fc_threshold=float(rng.choice([0.5, 0.5, 0.7])),
@@ -60,7 +64,7 @@ def draw(rng):
     cell = [1 if q == 1 else int(rng.integers(max(3, q // 2 + 1), 2 * q + 4)) for q in ps]
     return dict(shape=list(shape), ps=list(ps), seed=int(rng.integers(1, 100000)), cell=cell,
                 overlap=float(rng.choice([0.0, 0.02, 0.05])), noise=float(rng.choice([0.0, 0.2, 0.35])),
-                perturb=str(rng.choice(["f16", "f32", "pinned"])), flags=flags)
+                perturb=str(rng.choice(["f16", "f32", "pinned"])), half_input=bool(rng.integers(0, 2)), flags=flags)
 
 
 def make_pred(cfg, synth):
@@ -80,6 +84,9 @@ def make_pred(cfg, synth):
         pred[(r >= 0.02) & (r < 0.04)] = 0.0
         pred[(r >= 0.04) & (r < 0.06)] = 1.0
         pred[(r >= 0.06) & (r < 0.07)] = np.float32(1.0) - th
+    if cfg.get("half_input") and cfg["perturb"] != "f32":
+        # float16-exact values: the oracle sees their widening
+        pred = pred.astype(np.float16).astype(np.float32)
     return c, pred
 
 
@@ -111,11 +118,14 @@ def main():
         t_or = time.time() - t1
         status = "ok"
         try:
-            inst, _ = vi.to_instance_seg(pred.copy(), c["foreground"].copy(), c["foreground"].copy(), c["numinst"].copy(), ps, **kw)
+            # (half of the float16-exact cases enter as float16 arrays: the __half instantiations of the kernels)
+            as16 = bool(cfg.get("half_input")) and cfg["perturb"] != "f32"
+            pred_in = pred.astype(np.float16) if as16 else pred
+            inst, _ = vi.to_instance_seg(pred_in.copy(), c["foreground"].copy(), c["foreground"].copy(), c["numinst"].copy(), ps, **kw)
             if not np.array_equal(inst, ref["instances"]):
                 d = np.argwhere(inst != ref["instances"])
                 status = "INSTANCES DIFFER: %d voxels" % len(d)
-            inter = vi.to_instance_seg(pred.copy(), c["foreground"].copy(), c["foreground"].copy(), c["numinst"].copy(), ps,
+            inter = vi.to_instance_seg(pred_in.copy(), c["foreground"].copy(), c["foreground"].copy(), c["numinst"].copy(), ps,
                                        **dict(kw, return_intermediates=True))
             if "pairs" in ref and ref["pairs"] is not None and len(ref["pairs"]):
                 if inter[0] is None or not np.array_equal(inter[0], ref["pairs"]):
