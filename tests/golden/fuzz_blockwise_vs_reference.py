@@ -92,7 +92,12 @@ def main():
             t1 = time.time()
             ref_dir = os.path.join(work, "ref")
             os.makedirs(ref_dir)
-            spg.main(pred_file, result_folder=ref_dir, **kw)
+            try:
+                spg.main(pred_file, result_folder=ref_dir, **kw)
+            except Exception as e:       # noqa: BLE001
+                # (e.g. no block with a pair anywhere: stitch_patch_graph.py:369 reads affgraph.nodes of None)
+                print(desc, "REFERENCE RAISED %r (not counted)" % (e,), flush=True)
+                continue
             t_ref = time.time() - t1
             want_inst = recorded.get("vote_instances")
             a = stored(os.path.join(ref_dir, "sample.zarr"))
