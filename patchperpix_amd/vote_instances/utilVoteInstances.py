@@ -20,7 +20,12 @@ logger = logging.getLogger(__name__)
 def setKernelBuildOptions(step=None, **kwargs):
     """Kept for API parity (utilVoteInstances.py:389-449): returns the -D style flag list the
     reference would pass to nvcc; the same decisions are taken by backend.make_params."""
-    P = backend.make_params((1, 1, 1), (1, 1, 1), **dict(kwargs))
+    kw = dict(kwargs)
+    if step != "consensus":
+        # the reference looks at the value rule (and asserts that counted votes are not normalised) for the
+        # consensus kernel only (:412-427); the other steps' switches do not depend on it
+        kw.update(consensus_norm_prob_product=True)
+    P = backend.make_params((1, 1, 1), (1, 1, 1), **kw)
     opts = [{backend.BG_INV_TH: "-DUSE_INV_TH", backend.BG_HALF_TH: "-DUSE_HALF_TH",
              backend.BG_LESS_THAN_TH: "-DUSE_LESS_THAN_TH"}[P.bg_rule]]
     if P.use_overlap:

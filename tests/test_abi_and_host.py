@@ -399,3 +399,24 @@ def test_lcg_mask_plan_cuts_the_groups_into_batches_that_fit(budget_words, max_b
     assert np.array_equal(seen, served)
     if max_batches >= len(cuts) - 1:
         assert np.array_equal(served, words > 0)
+
+
+def test_kernel_build_options_mirror_the_references_decisions():
+    """setKernelBuildOptions (utilVoteInstances.py:389-449) as the list of -D switches the reference would compile
+    with, derived from the SAME decisions the kernels run with (backend.make_params): precedence of the background
+    rules with the defaults of absent keys (inv_th is on unless switched off), the th < 0.5 switch, the value rule,
+    and -- found by tests/golden/fuzz_build_options_vs_reference.py, 6 000 random flag sets against the reference's
+    own function -- the 'counted votes are not normalised' assertion belongs to the consensus step alone."""
+    from patchperpix_amd.vote_instances import utilVoteInstances as util
+    assert util.setKernelBuildOptions(step="consensus", patch_threshold=0.9) == ["-DUSE_INV_TH", "-DNORM_PROB_PRODUCT"]
+    assert util.setKernelBuildOptions(step="consensus", patch_threshold=0.3, overlapping_inst=True,
+                                      consensus_norm_prob_product=False) == ["-DUSE_LESS_THAN_TH", "-DOVERLAP", "-DPROB_PRODUCT"]
+    assert util.setKernelBuildOptions(step="rank", patch_threshold=0.5, vi_bg_use_inv_th=False, vi_bg_use_half_th=True,
+                                      rank_int_counter=True) == ["-DUSE_HALF_TH", "-DNORM_PATCH_RANK", "-DCOUNT_POS_NEG"]
+    assert util.setKernelBuildOptions(step="patch_graph", patch_threshold=0.5) == ["-DNORM_PATCH_AFFINITY"]
+    counted = dict(patch_threshold=0.5, consensus_norm_prob_product=False, consensus_prob_product=False, consensus_norm_aff=True)
+    with pytest.raises(AssertionError):
+        util.setKernelBuildOptions(step="consensus", **counted)
+    assert util.setKernelBuildOptions(step="rank", **counted) == ["-DUSE_INV_TH", "-DNORM_PATCH_RANK"]
+    with pytest.raises(RuntimeError):
+        util.setKernelBuildOptions(patch_threshold=0.5, vi_bg_use_inv_th=False)
