@@ -1017,6 +1017,9 @@ class _Assembly:
         self.seq_cover = bool(self.kw.get("mark_close_neighboorhood", False) or self.kw.get("select_patches_overlap_neighborhood", False))
         if self.kw.get("aff_graph") is not None:
             raise NotImplementedError("aff_graph input is not supported by the tiled assembly")
+        if self.kw.get("consensus_interleaved_cnt", True):
+            # consensus_array.py:131-133, where the reference launches its consensus kernel
+            assert self.kw.get("consensus_norm_aff", True), "consensus aff not normalized so no computation required"
         if self.kw.get("max_total_patch_distance_in_ps_multiples", 2) > 2:
             raise NotImplementedError("the slab halo is sized for "
                                       "max_total_patch_distance_in_ps_multiples <= 2")

@@ -55,6 +55,21 @@ def draw(rng):
     flags.update(consensus_norm_prob_product=value == "norm_prob", consensus_prob_product=value in ("norm_prob", "prob"))
     if value == "count":
         flags["consensus_norm_aff"] = False
+    # the rarer switches (each in a few of the goldens): interleaved count, flipped consensus axes, the two optional
+    # branches of the cover, one instance per channel / no overlap per channel
+    if rng.integers(0, 4) == 0:
+        flags["consensus_interleaved_cnt"] = True
+    if rng.integers(0, 6) == 0:
+        flags["flip_cons_arr_axes"] = True
+    if rng.integers(0, 5) == 0:
+        flags["mark_close_neighboorhood"] = True
+    if rng.integers(0, 5) == 0:
+        flags["select_patches_overlap_neighborhood"] = True
+    r = rng.integers(0, 8)
+    if r == 0:
+        flags["one_instance_per_channel"] = True
+    elif r == 1:
+        flags["no_overlap_per_channel"] = True
     cell = [1 if q == 1 else int(rng.integers(3, 8)) for q in ps]
     return dict(shape=list(shape), ps=list(ps), seed=int(rng.integers(1, 100000)), cell=cell,
                 overlap=float(rng.choice([0.0, 0.03])), noise=float(rng.choice([0.0, 0.25])), flags=flags)

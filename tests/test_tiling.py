@@ -462,6 +462,20 @@ def test_tiles_vs_oracle_p7_gpu():
     assert np.array_equal(got, ref["instances"]) and got.any()
 
 
+def test_fused_path_asserts_like_the_references_consensus_stage():
+    """consensus_array.py:131-133: counts interleaved with values that are not normalised -- the reference
+    asserts where it launches the consensus kernel; the fused assembly (which never calls that stage function)
+    must refuse too.  (35 of 300 random flag sets of tests/golden/fuzz_oracle_vs_reference.py were refused by the
+    reference; the oracle refused all of them, the fused path missed this assertion.)"""
+    import torch
+    from oracle_ops import OracleOps
+    c, ps, kw = make_case(seed=63, shape=(12, 9, 10))
+    kw.update(consensus_interleaved_cnt=True, consensus_norm_aff=False)
+    with pytest.raises(AssertionError, match="not normalized"):
+        tiling.assemble(torch.from_numpy(c["pred"]), 0, c["foreground"].shape, c["foreground"].copy(), c["foreground"].copy(),
+                        c["numinst"], ps, tiling.plan_slabs(12, 1), ops=OracleOps(**dict(kw, consensus_interleaved_cnt=False)), **kw)
+
+
 def test_tiled_path_refuses_flags_it_does_not_honour():
     """the tiled dispatch must not silently drop flags."""
     import torch
