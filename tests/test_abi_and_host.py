@@ -420,3 +420,15 @@ def test_kernel_build_options_mirror_the_references_decisions():
     assert util.setKernelBuildOptions(step="rank", **counted) == ["-DUSE_INV_TH", "-DNORM_PATCH_RANK"]
     with pytest.raises(RuntimeError):
         util.setKernelBuildOptions(patch_threshold=0.5, vi_bg_use_inv_th=False)
+
+
+def test_host_stage_fuzzer_runs_clean_on_a_few_trials():
+    """tests/fuzz_host_stages.py (native host stages against the oracle's Python on random tiny cases; 1 650 clean
+    trials in round 6) as a smoke test: twenty trials."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_host_stages.py"), "--trials", "20", "--seed", "11"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "20 trials, 0 failures" in out, out[-2000:]
